@@ -1,0 +1,131 @@
+/*
+ * fhe_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the ciphertext arithmetic that the reference
+ * (wfus/Fully-Homomorphic-Image-Processing) drives through Microsoft SEAL v2.3:
+ * the Evaluator calls made by homo/fhe_image.h:196-325, homo/fhe_resize.h:143-204
+ * and homo/fhe_decode.h:48-242.
+ *
+ * SEAL itself is an un-vendored, unpinned git submodule of the reference
+ * (.gitmodules:1-3, README.md:70; SEAL/ is empty) and the reference holds no
+ * golden ciphertexts, so:
+ *
+ *        ***  PARITY UNPINNED at the SEAL boundary  ***
+ *
+ * What pins this oracle instead (see DESIGN.md "Oracle"):
+ *   - add/sub/negate/add_plain/sub_plain/multiply_plain are exact operations in
+ *     R_q = Z_q[x]/(x^n+1); their fully reduced residues are mathematically
+ *     unique.  oracle/bigint_model.py re-derives them with Python big integers
+ *     (CRT + Kronecker-substitution product) and tests/golden/ holds its output.
+ *   - multiply/square follow the published full-RNS BEHZ algorithm
+ *     (Bajard-Eynard-Hasan-Zucca, SAC 2016) with SEAL 2.3's conventions
+ *     (m_tilde = 2^32, centred small-Montgomery remainder, fast floor,
+ *     Shenoy-Kumaresan back conversion); the integer-level definition is
+ *     re-computed by bigint_model.py without any auxiliary base.
+ *   - decrypt(circuit(encrypt(x))) equals the plaintext models restated from
+ *     homo/fhe_image.h:400-484 (dct) and the closed forms in fhe_resize.h.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link
+ * or call this library.  The shipped path is the HIP library behind
+ * include/fhe_hip.h and never falls back to this code.
+ *
+ * Ciphertext memory layout everywhere: u64 [poly j][prime i][coeff c], every
+ * residue fully reduced to [0, q_i).
+ */
+#ifndef FHE_ORACLE_H
+#define FHE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FO_MAX_K 8
+
+typedef struct fo_ctx fo_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+fo_ctx *fo_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t);
+void fo_ctx_destroy(fo_ctx *c);
+uint32_t fo_ctx_n(const fo_ctx *c);
+uint32_t fo_ctx_k(const fo_ctx *c);
+uint64_t fo_ctx_t(const fo_ctx *c);
+uint64_t fo_ctx_q(const fo_ctx *c, uint32_t i);
+/* auxiliary BEHZ base: index 0..k-1 = B primes, index k = m_sk */
+uint64_t fo_ctx_aux(const fo_ctx *c, uint32_t i);
+
+/* deterministic synthetic input generator shared with the HIP side:
+ * value = splitmix64(seed ^ linear_index) mod q_i   */
+uint64_t fo_splitmix64(uint64_t x);
+void fo_fill_random_ct(const fo_ctx *c, uint64_t *ct, uint64_t n_polys, uint64_t seed,
+                       uint64_t first_linear_index);
+
+/* ---- negacyclic NTT over one residue polynomial (in place) ------------- */
+/* base = 0: q-base prime i; base = 1: aux base prime i (i == k -> m_sk)    */
+void fo_ntt_fwd(const fo_ctx *c, int base, uint32_t i, uint64_t *a);
+void fo_ntt_inv(const fo_ctx *c, int base, uint32_t i, uint64_t *a);
+
+/* ---- exact ring ops (SEAL Evaluator semantics, in place on `a`) -------- */
+/* add/sub of unequal sizes: `a` must have room for max(size_a,size_b) polys;
+ * return value = resulting size. */
+uint32_t fo_add(const fo_ctx *c, uint64_t *a, uint32_t size_a, const uint64_t *b, uint32_t size_b);
+uint32_t fo_sub(const fo_ctx *c, uint64_t *a, uint32_t size_a, const uint64_t *b, uint32_t size_b);
+void fo_negate(const fo_ctx *c, uint64_t *a, uint32_t size);
+/* plaintext = plain_len coefficients in [0,t) */
+void fo_add_plain(const fo_ctx *c, uint64_t *a, const uint64_t *plain, uint32_t plain_len);
+void fo_sub_plain(const fo_ctx *c, uint64_t *a, const uint64_t *plain, uint32_t plain_len);
+void fo_multiply_plain(const fo_ctx *c, uint64_t *a, uint32_t size, const uint64_t *plain,
+                       uint32_t plain_len);
+/* lift a plaintext to the q-base (centred representative), coefficient form */
+void fo_plain_lift(const fo_ctx *c, const uint64_t *plain, uint32_t plain_len, uint64_t *out_kn);
+
+/* ---- ct x ct (BEHZ full-RNS), out has size_a+size_b-1 polys ------------ */
+uint32_t fo_multiply(const fo_ctx *c, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                     uint32_t size_b, uint64_t *out);
+uint32_t fo_square(const fo_ctx *c, const uint64_t *a, uint32_t size_a, uint64_t *out);
+
+/* ---- FractionalEncoder (base 2) ---------------------------------------- */
+/* returns significant coefficient count; plain must hold n coefficients */
+uint32_t fo_frac_encode(const fo_ctx *c, double v, int int_coeffs, int frac_coeffs, uint64_t *plain);
+double fo_frac_decode(const fo_ctx *c, const uint64_t *plain, int int_coeffs, int frac_coeffs);
+
+/* ---- keys / encrypt / decrypt (test scaffolding) ----------------------- */
+/* sk: [k][n] coefficient form; pk: [2][k][n] */
+void fo_keygen(const fo_ctx *c, uint64_t seed, uint64_t *sk, uint64_t *pk);
+void fo_encrypt(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t plain_len,
+                uint64_t seed, uint64_t *ct /* [2][k][n] */);
+/* phase = [sum_j c_j s^j]_{q_i}, [k][n]; CRT + rounding is done by the caller */
+void fo_decrypt_phase(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size,
+                      uint64_t *phase);
+/* exact decryption: plain[n] = round(t * phase / q) mod t; returns invariant noise budget in bits */
+int fo_decrypt(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain);
+
+/* evaluation keys for relinearising s^2: layout [k (prime idx)][n_digits][2][k][n], NTT form.
+ * n_digits = ceil(bits(q_i)/dbc) computed per context as max over primes. */
+uint32_t fo_evk_digits(const fo_ctx *c, uint32_t dbc);
+void fo_evk_gen(const fo_ctx *c, const uint64_t *sk, uint32_t dbc, uint64_t seed, uint64_t *evk);
+/* relinearise a size-3 ciphertext to size 2 (in place, first two polys) */
+void fo_relinearize3(const fo_ctx *c, uint64_t *ct, const uint64_t *evk, uint32_t dbc);
+
+/* ---- circuits, op-at-a-time exactly as the reference issues them ------- */
+/* data: 64 ct(2), row-major 8x8 (homo/fhe_image.h:196-288) */
+void fo_encrypted_dct(const fo_ctx *c, uint64_t *data64);
+/* data[i] *= encode(1/quant[i])  (homo/fhe_image.h:294-305) */
+void fo_quantize(const fo_ctx *c, uint64_t *data64, const double *quant64);
+/* (r,g,b) -> (y,cb,cr) in place (homo/fhe_image.h:310-325) */
+void fo_rgb_to_ycc(const fo_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b);
+/* Cubic (homo/fhe_resize.h:143-189): A..D size s, t size 2, result size s+2 */
+uint32_t fo_cubic(const fo_ctx *c, const uint64_t *A, const uint64_t *B, const uint64_t *C,
+                  const uint64_t *D, uint32_t s, const uint64_t *t2ct, uint64_t *result);
+/* Linear (homo/fhe_resize.h:191-204): A,B size s, t size 2, result size s+1 */
+uint32_t fo_linear(const fo_ctx *c, const uint64_t *A, const uint64_t *B, uint32_t s,
+                   const uint64_t *t2ct, uint64_t *result);
+
+/* 64-bit digest of a buffer of u64 (order-sensitive), for large-size comparisons */
+uint64_t fo_digest(const uint64_t *p, uint64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+"""ctypes binding of the CPU ORACLE (oracle/libfhe_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+See oracle/fhe_oracle.h for what it restates and the "parity unpinned" statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfhe_oracle.so")
+
+# Parameter presets.  S3 is what BASELINE.json configs 2/5 name
+# ("n=4096, 3 coeff moduli"); SEAL23_* are the SEAL 2.3.1 coeff_modulus_128 defaults.
+PRESETS = {
+    "P4096": dict(n=4096, q=[0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001], t=1 << 14),
+    "P8192": dict(n=8192, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),
+    "SEAL23_4096": dict(n=4096, q=[0x7FFFFFFF380001, 0x3FFFFFFF000001], t=1 << 14),
+    "SEAL23_2048": dict(n=2048, q=[0x3FFFFFFF000001], t=1 << 14),
+    "SEAL3_8192": dict(n=8192, q=[0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001, 0xFFFFFEBC001], t=1 << 14),
+}
+
+YQT = [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+       14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+       49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99]  # homo/fhe_image.h:99
+
+SEED = 0x5EA12026
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "fhe_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+u64p = C.POINTER(C.c_uint64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.fo_ctx_create.restype = C.c_void_p
+        L.fo_ctx_create.argtypes = [C.c_uint32, u64p, C.c_uint32, C.c_uint64]
+        L.fo_ctx_destroy.argtypes = [C.c_void_p]
+        L.fo_ctx_aux.restype = C.c_uint64
+        L.fo_ctx_aux.argtypes = [C.c_void_p, C.c_uint32]
+        L.fo_splitmix64.restype = C.c_uint64
+        L.fo_splitmix64.argtypes = [C.c_uint64]
+        L.fo_fill_random_ct.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        for name in ("fo_ntt_fwd", "fo_ntt_inv"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+        for name in ("fo_add", "fo_sub"):
+            getattr(L, name).restype = C.c_uint32
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.fo_negate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        for name in ("fo_add_plain", "fo_sub_plain"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fo_multiply_plain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.fo_plain_lift.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_multiply.restype = C.c_uint32
+        L.fo_multiply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_square.restype = C.c_uint32
+        L.fo_square.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_frac_encode.restype = C.c_uint32
+        L.fo_frac_encode.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        L.fo_frac_decode.restype = C.c_double
+        L.fo_frac_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.fo_keygen.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.fo_encrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.fo_decrypt_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_decrypt.restype = C.c_int
+        L.fo_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_evk_digits.restype = C.c_uint32
+        L.fo_evk_digits.argtypes = [C.c_void_p, C.c_uint32]
+        L.fo_evk_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.fo_relinearize3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fo_encrypted_dct.argtypes = [C.c_void_p, C.c_void_p]
+        L.fo_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fo_rgb_to_ycc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fo_cubic.restype = C.c_uint32
+        L.fo_cubic.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.fo_linear.restype = C.c_uint32
+        L.fo_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.fo_digest.restype = C.c_uint64
+        L.fo_digest.argtypes = [C.c_void_p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """SEAL-Evaluator-shaped CPU oracle over numpy u64 arrays laid out [size][k][n]."""
+
+    INT_COEFFS = 100   # FractionalEncoder(t, poly, 100, 100, 2): homo/server_jpeg.cpp:100
+    FRAC_COEFFS = 100
+
+    def __init__(self, n, q, t):
+        self.n, self.q, self.t, self.k = int(n), [int(x) for x in q], int(t), len(q)
+        arr = (C.c_uint64 * self.k)(*self.q)
+        self.h = lib().fo_ctx_create(self.n, arr, self.k, self.t)
+        if not self.h:
+            raise ValueError("invalid encryption parameters")
+        self.aux = [int(lib().fo_ctx_aux(self.h, i)) for i in range(self.k + 1)]
+
+    @classmethod
+    def preset(cls, name):
+        p = PRESETS[name]
+        return cls(p["n"], p["q"], p["t"])
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fo_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- helpers --------------------------------------------------------
+    def ct_words(self, size=2):
+        return size * self.k * self.n
+
+    def random_ct(self, n_cts, size=2, seed=SEED, first_index=0):
+        out = np.empty((n_cts, size, self.k, self.n), dtype=np.uint64)
+        lib().fo_fill_random_ct(self.h, _p(out), n_cts * size, seed, first_index)
+        return out
+
+    # -- ntt ------------------------------------------------------------
+    def ntt_fwd(self, a, prime, base=0):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        lib().fo_ntt_fwd(self.h, base, prime, _p(a))
+        return a
+
+    def ntt_inv(self, a, prime, base=0):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        lib().fo_ntt_inv(self.h, base, prime, _p(a))
+        return a
+
+    # -- evaluator --------------------------------------------------------
+    def _grow(self, a, size):
+        if a.shape[0] >= size:
+            return np.ascontiguousarray(a).copy()
+        out = np.zeros((size,) + a.shape[1:], dtype=np.uint64)
+        out[: a.shape[0]] = a
+        return out
+
+    def add(self, a, b):
+        s = max(a.shape[0], b.shape[0])
+        out = self._grow(a, s)
+        lib().fo_add(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
+        return out
+
+    def sub(self, a, b):
+        s = max(a.shape[0], b.shape[0])
+        out = self._grow(a, s)
+        lib().fo_sub(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
+        return out
+
+    def negate(self, a):
+        out = np.ascontiguousarray(a).copy()
+        lib().fo_negate(self.h, _p(out), a.shape[0])
+        return out
+
+    def _plain(self, plain):
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        return p, len(p)
+
+    def add_plain(self, a, plain):
+        out = np.ascontiguousarray(a).copy()
+        p, ln = self._plain(plain)
+        lib().fo_add_plain(self.h, _p(out), _p(p), ln)
+        return out
+
+    def sub_plain(self, a, plain):
+        out = np.ascontiguousarray(a).copy()
+        p, ln = self._plain(plain)
+        lib().fo_sub_plain(self.h, _p(out), _p(p), ln)
+        return out
+
+    def multiply_plain(self, a, plain):
+        out = np.ascontiguousarray(a).copy()
+        p, ln = self._plain(plain)
+        lib().fo_multiply_plain(self.h, _p(out), a.shape[0], _p(p), ln)
+        return out
+
+    def plain_lift(self, plain):
+        p, ln = self._plain(plain)
+        out = np.zeros((self.k, self.n), dtype=np.uint64)
+        lib().fo_plain_lift(self.h, _p(p), ln, _p(out))
+        return out
+
+    def multiply(self, a, b):
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        out = np.zeros((a.shape[0] + b.shape[0] - 1, self.k, self.n), dtype=np.uint64)
+        lib().fo_multiply(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+        return out
+
+    def square(self, a):
+        a = np.ascontiguousarray(a)
+        out = np.zeros((2 * a.shape[0] - 1, self.k, self.n), dtype=np.uint64)
+        lib().fo_square(self.h, _p(a), a.shape[0], _p(out))
+        return out
+
+    # -- encoder ----------------------------------------------------------
+    def encode(self, v):
+        out = np.zeros(self.n, dtype=np.uint64)
+        lib().fo_frac_encode(self.h, float(v), self.INT_COEFFS, self.FRAC_COEFFS, _p(out))
+        return out
+
+    def decode(self, plain):
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        return float(lib().fo_frac_decode(self.h, _p(p), self.INT_COEFFS, self.FRAC_COEFFS))
+
+    # -- keys -------------------------------------------------------------
+    def keygen(self, seed=1):
+        sk = np.zeros((self.k, self.n), dtype=np.uint64)
+        pk = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        lib().fo_keygen(self.h, seed, _p(sk), _p(pk))
+        return sk, pk
+
+    def encrypt(self, pk, plain, seed=7):
+        p, ln = self._plain(plain)
+        ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        lib().fo_encrypt(self.h, _p(pk), _p(p), ln, seed, _p(ct))
+        return ct
+
+    def decrypt(self, sk, ct):
+        ct = np.ascontiguousarray(ct)
+        plain = np.zeros(self.n, dtype=np.uint64)
+        budget = lib().fo_decrypt(self.h, _p(sk), _p(ct), ct.shape[0], _p(plain))
+        return plain, int(budget)
+
+    def decrypt_phase(self, sk, ct):
+        ct = np.ascontiguousarray(ct)
+        ph = np.zeros((self.k, self.n), dtype=np.uint64)
+        lib().fo_decrypt_phase(self.h, _p(sk), _p(ct), ct.shape[0], _p(ph))
+        return ph
+
+    def evk_gen(self, sk, dbc=30, seed=11):
+        nd = int(lib().fo_evk_digits(self.h, dbc))
+        evk = np.zeros((self.k, nd, 2, self.k, self.n), dtype=np.uint64)
+        lib().fo_evk_gen(self.h, _p(sk), dbc, seed, _p(evk))
+        return evk
+
+    def relinearize(self, ct, evk, dbc=30):
+        assert ct.shape[0] == 3
+        out = np.ascontiguousarray(ct).copy()
+        lib().fo_relinearize3(self.h, _p(out), _p(evk), dbc)
+        return out[:2].copy()
+
+    # -- circuits ---------------------------------------------------------
+    def encrypted_dct(self, block):
+        out = np.ascontiguousarray(block).copy()
+        assert out.shape == (64, 2, self.k, self.n)
+        lib().fo_encrypted_dct(self.h, _p(out))
+        return out
+
+    def quantize(self, block, quant=YQT):
+        out = np.ascontiguousarray(block).copy()
+        qv = (C.c_double * 64)(*[float(x) for x in quant])
+        lib().fo_quantize(self.h, _p(out), qv)
+        return out
+
+    def dct_quant(self, block, quant=YQT):
+        return self.quantize(self.encrypted_dct(block), quant)
+
+    def rgb_to_ycc(self, r, g, b):
+        r, g, b = (np.ascontiguousarray(x).copy() for x in (r, g, b))
+        lib().fo_rgb_to_ycc(self.h, _p(r), _p(g), _p(b))
+        return r, g, b
+
+    def cubic(self, A, B, Cc, D, t):
+        s = A.shape[0]
+        out = np.zeros((s + 2, self.k, self.n), dtype=np.uint64)
+        A, B, Cc, D, t = (np.ascontiguousarray(x) for x in (A, B, Cc, D, t))
+        lib().fo_cubic(self.h, _p(A), _p(B), _p(Cc), _p(D), s, _p(t), _p(out))
+        return out
+
+    def linear(self, A, B, t):
+        s = A.shape[0]
+        out = np.zeros((s + 1, self.k, self.n), dtype=np.uint64)
+        A, B, t = (np.ascontiguousarray(x) for x in (A, B, t))
+        lib().fo_linear(self.h, _p(A), _p(B), s, _p(t), _p(out))
+        return out
+
+
+def digest(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return int(lib().fo_digest(_p(a), a.size))
