@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: encrypted 8x8 blocks/sec for homomorphic DCT+quant.
+
+Workload (BASELINE.json configs[1]): 1024 ciphertext blocks ("256x256 gray") per GPU,
+poly_modulus_degree 4096, 3 coefficient moduli {0xffffee001, 0xffffc4001, 0x1ffffe0001}, t = 2^14;
+one step = encrypted_dct (homo/fhe_image.h:196-288) + quantize_fhe (:294-305) over every block,
+inputs already resident in HBM (synthetic random-residue ciphertexts).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Multi-GPU: blocks are sharded, one process per GPU, no data-path
+collective (weak scaling: 1024 blocks per GPU); RCCL is used for the barrier, the max-over-ranks
+time and an all-reduce of the output digests.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_BLOCK = 128 * 2 * 3 * 4096 * 8   # read 64 ct + write 64 ct, ct = 2*3*4096*8 B  
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(n_blocks_sample):
+    """The CPU oracle (op-at-a-time port of the SEAL path) timed on this host, 1 thread."""
+    from oracle import oracle as om
+    om.build()
+    orc = om.Oracle.preset("P4096")
+    blocks = orc.random_ct(n_blocks_sample * 64, seed=om.SEED).reshape(n_blocks_sample, 64, 2, orc.k, orc.n)
+    t0 = time.perf_counter()
+    digs = []
+    for b in range(n_blocks_sample):
+        digs.append(om.digest(orc.dct_quant(blocks[b], om.YQT)))
+    dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": n_blocks_sample / dt, "unit": "blocks/s", "cores": 1, "kind": "port",
+        "sample": "%d blocks of the same workload (n=4096,k=3), oracle/libfhe_oracle.so op-at-a-time, 1 thread of %d on %s"
+                  % (n_blocks_sample, os.cpu_count() or 0, cpu),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU per step")
+    ap.add_argument("--cpu-blocks", type=int, default=4, help="CPU baseline sample size (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import fhip_amd as fhe
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = fhe.SEALContext.preset("P4096", device=local_rank)
+    ev = fhe.Evaluator(ctx)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    B = args.blocks
+    words_per_block = 64 * 2 * ctx.k * ctx.n
+    # global block index g = rank * B + b: any GPU count generates the same bytes for block g
+    first_index = rank * B * words_per_block
+    blocks = ctx.random_ct(B, 64, seed=fhe.SEED, first_index=first_index)
+    out = torch.empty_like(blocks)
+    torch.cuda.synchronize()
+
+    def step():
+        ev.dct8x8_quant(plan, blocks, out=out)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()                      # same stream the C ABI launches on (torch current stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    if dist is not None:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    # ---- verification: sampled blocks against the CPU oracle, digest over everything -----------------
+    digest = ctx.digest(out.view(-1), index0=first_index)
+    if dist is not None:
+        dg = torch.tensor([digest & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device="cuda")
+        dist.all_reduce(dg, op=dist.ReduceOp.BXOR)
+        digest_all = int(dg.item())
+    else:
+        digest_all = digest & 0x7FFFFFFFFFFFFFFF
+    verified = None
+    if rank == 0 and not args.no_verify:
+        from oracle import oracle as om
+        om.build()
+        orc = om.Oracle.preset("P4096")
+        sample = [0, B - 1] if B > 1 else [0]
+        ok = True
+        for b in sample:
+            ref = orc.dct_quant(fhe.to_host(blocks[b]), om.YQT)
+            ok &= bool(np.array_equal(fhe.to_host(out[b]), ref))
+        verified = ok
+
+    if rank == 0:
+        total_blocks = B * world * args.steps
+        value = total_blocks / wall
+        achieved = B * BYTES_PER_BLOCK / (dev_ms_per_step * 1e-3) / 1e9
+        res = {
+            "metric": "encrypted 8x8 blocks/sec (homomorphic DCT+quant)",
+            "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=4096, 3 coeff moduli, t=2^14" % B,
+                       "blocks_per_gpu": B, "poly_modulus_degree": 4096, "coeff_moduli": [hex(x) for x in ctx.q],
+                       "sharding": "blocks x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fhe_dct8x8_quant (all launches of one step, HIP events on the launch stream)",
+                         "algorithmic_bytes_per_block": BYTES_PER_BLOCK, "ms_per_launch": dev_ms_per_step},
+            "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
+        }
+        if world == 1 and args.cpu_blocks > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,840 @@
+// fhe_hip.hip -- libfhe_hip.so: HIP kernels (gfx950) + the C ABI of include/fhe_hip.h.
+//
+// Product code.  Never includes, links or calls anything under oracle/.
+#include "../../include/fhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_math.h"
+#include "modarith.h"
+#include "ntt_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+#define KERNEL_CHECK()                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *fhe_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t fhe_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct BaseTables {
+    std::vector<u64> primes;
+    ulonglong2 *d_tw = nullptr, *d_itw = nullptr;
+    Modulus *d_mod = nullptr;
+    std::vector<Modulus> h_mod;
+    RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size()}; }
+};
+
+struct fhe_ctx {
+    u32 n = 0, logn = 0, k = 0;
+    u64 t = 0;
+    int device = 0;
+    BaseTables qb;     // q-base
+    // plaintext lifting (SEAL 2.3 multiply_plain / preencrypt semantics)
+    u64 upper_half_threshold = 0;
+    u64 plain_upper_half_increment[FHE_MAX_K] = {0};   // (q - t) mod q_i
+    u64 delta_mod[FHE_MAX_K] = {0};                    // floor(q/t) mod q_i
+    u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
+};
+
+static int build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn) {
+    using namespace hostmath;
+    const size_t cnt = primes.size();
+    B.primes = primes;
+    std::vector<ulonglong2> tw(cnt * n), itw(cnt * n);
+    B.h_mod.resize(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+        const u64 q = primes[i];
+        const u64 psi = primitive_2n_root(q, n);
+        if (!psi) return fail(FHE_ERR_PARAM, "no primitive 2n-th root modulo %llu", (unsigned long long)q);
+        const u64 ipsi = invmod(psi, q), ninv = invmod(n % q, q);
+        u64 p = 1, ip = 1;
+        for (u32 j = 0; j < n; ++j) {
+            const u32 r = bit_reverse(j, (int)logn);
+            tw[i * n + r] = make_ulonglong2(p, shoup(p, q));
+            itw[i * n + r] = make_ulonglong2(ip, shoup(ip, q));
+            p = mulmod(p, psi, q);
+            ip = mulmod(ip, ipsi, q);
+        }
+        // entry 0 is never indexed by a butterfly: it carries n^-1; the last inverse stage
+        // (twiddle index 1) is pre-multiplied by n^-1 so the scaling costs nothing extra.
+        itw[i * n + 0] = make_ulonglong2(ninv, shoup(ninv, q));
+        const u64 w1 = mulmod(itw[i * n + 1].x, ninv, q);
+        itw[i * n + 1] = make_ulonglong2(w1, shoup(w1, q));
+        Modulus m;
+        m.q = q;
+        const int b = bit_length(q);
+        m.mu = (u64)((((u128)1) << (2 * b)) / q);
+        m.s1 = (u32)(b - 1);
+        m.s2 = (u32)(b + 1);
+        B.h_mod[i] = m;
+    }
+    HIP_TRY(hipMalloc(&B.d_tw, sizeof(ulonglong2) * cnt * n));
+    HIP_TRY(hipMalloc(&B.d_itw, sizeof(ulonglong2) * cnt * n));
+    HIP_TRY(hipMalloc(&B.d_mod, sizeof(Modulus) * cnt));
+    HIP_TRY(hipMemcpy(B.d_tw, tw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B.d_itw, itw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B.d_mod, B.h_mod.data(), sizeof(Modulus) * cnt, hipMemcpyHostToDevice));
+    return FHE_OK;
+}
+static void free_base(BaseTables &B) {
+    if (B.d_tw) (void)hipFree(B.d_tw);
+    if (B.d_itw) (void)hipFree(B.d_itw);
+    if (B.d_mod) (void)hipFree(B.d_mod);
+    B.d_tw = B.d_itw = nullptr;
+    B.d_mod = nullptr;
+}
+
+extern "C" int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out) {
+    // preset 0: small (36..44-bit) prime sets, 109/218 bits total (BASELINE.json "3 coeff moduli" at 4096)
+    // preset 1: SEAL 2.3.1 coeff_modulus_128 defaults
+    static const u64 s3_4096[] = {0xffffee001ULL, 0xffffc4001ULL, 0x1ffffe0001ULL};
+    static const u64 s3_8192[] = {0x7fffffd8001ULL, 0x7fffffc8001ULL, 0xfffffffc001ULL, 0xffffff6c001ULL, 0xfffffebc001ULL};
+    static const u64 s23_2048[] = {0x3fffffff000001ULL};
+    static const u64 s23_4096[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL};
+    static const u64 s23_8192[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x3fffffff000001ULL, 0x3ffffffef40001ULL};
+    const u64 *src = nullptr;
+    int cnt = 0;
+#define PICK(a) do { src = a; cnt = (int)(sizeof(a) / sizeof(a[0])); } while (0)
+    if (preset == 0) {
+        if (n == 4096) PICK(s3_4096);
+        else if (n == 8192) PICK(s3_8192);
+        else if (n == 2048 || n == 1024) PICK(s23_2048);
+    } else if (preset == 1) {
+        if (n == 2048 || n == 1024) PICK(s23_2048);
+        else if (n == 4096) PICK(s23_4096);
+        else if (n == 8192) PICK(s23_8192);
+    }
+#undef PICK
+    if (!src) return fail(FHE_ERR_PARAM, "no default coefficient modulus for n=%u preset=%d", n, preset);
+    for (int i = 0; i < cnt; ++i) q_out[i] = src[i];
+    return cnt;
+}
+
+extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int device, fhe_ctx **out) {
+    using namespace hostmath;
+    if (!out || !q) return fail(FHE_ERR_PARAM, "null argument");
+    *out = nullptr;
+    if (k == 0 || k > FHE_MAX_K) return fail(FHE_ERR_PARAM, "coeff modulus count %u out of range", k);
+    if (n < 1024 || n > 16384 || (n & (n - 1))) return fail(FHE_ERR_PARAM, "poly_modulus_degree %u unsupported", n);
+    if (t < 2) return fail(FHE_ERR_PARAM, "plain modulus too small");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FHE_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FHE_ERR_PARAM, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<u64> primes(k);
+    for (u32 i = 0; i < k; ++i) primes[i] = q[i];
+    for (u32 i = 0; i < k; ++i) {
+        if (primes[i] >> 61) return fail(FHE_ERR_PARAM, "modulus %u exceeds 61 bits", i);
+        if (!is_prime(primes[i]) || (primes[i] - 1) % (2ULL * n)) return fail(FHE_ERR_PARAM, "modulus %u is not an NTT prime for n=%u", i, n);
+        if (t >= primes[i]) return fail(FHE_ERR_PARAM, "plain modulus must be below every coefficient modulus");
+        for (u32 j = 0; j < i; ++j)
+            if (primes[j] == primes[i]) return fail(FHE_ERR_PARAM, "duplicate modulus");
+    }
+    fhe_ctx *c = new fhe_ctx();
+    c->n = n;
+    c->k = k;
+    c->t = t;
+    c->device = device;
+    while ((1u << c->logn) < n) ++c->logn;
+    int rc = build_base(c->qb, primes, n, c->logn);
+    if (rc) { delete c; return rc; }
+    // plaintext lifting constants
+    BigUInt Q(1);
+    for (u32 i = 0; i < k; ++i) Q.mul_small(primes[i]);
+    const u64 q_mod_t = Q.mod_small(t);
+    c->upper_half_threshold = (t + 1) >> 1;
+    for (u32 i = 0; i < k; ++i) {
+        const u64 qi = primes[i];
+        c->plain_upper_half_increment[i] = submod(0, t % qi, qi);
+        c->upper_half_increment[i] = q_mod_t % qi;
+        c->delta_mod[i] = mulmod(submod(0, q_mod_t % qi, qi), invmod(t % qi, qi), qi);
+    }
+    *out = c;
+    return FHE_OK;
+}
+
+extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
+    if (!c) return FHE_OK;
+    free_base(c->qb);
+    delete c;
+    return FHE_OK;
+}
+extern "C" uint32_t fhe_ctx_n(const fhe_ctx *c) { return c->n; }
+extern "C" uint32_t fhe_ctx_k(const fhe_ctx *c) { return c->k; }
+extern "C" uint64_t fhe_ctx_t(const fhe_ctx *c) { return c->t; }
+extern "C" uint64_t fhe_ctx_q(const fhe_ctx *c, uint32_t i) { return i < c->k ? c->qb.primes[i] : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int fhe_dev_alloc(size_t bytes, void **dptr) {
+    if (!dptr) return fail(FHE_ERR_PARAM, "null argument");
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e == hipErrorOutOfMemory) return fail(FHE_ERR_NOMEM, "hipMalloc(%zu) out of memory", bytes);
+    if (e != hipSuccess) return fail(FHE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    return FHE_OK;
+}
+extern "C" int fhe_dev_free(void *p) { if (p) HIP_TRY(hipFree(p)); return FHE_OK; }
+extern "C" int fhe_upload(void *d, const void *h, size_t bytes, fhe_stream s) {
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    return FHE_OK;
+}
+extern "C" int fhe_download(void *h, const void *d, size_t bytes, fhe_stream s) {
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+    return FHE_OK;
+}
+extern "C" int fhe_copy(void *dst, const void *src, size_t bytes, fhe_stream s) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return FHE_OK;
+}
+extern "C" int fhe_stream_sync(fhe_stream s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return FHE_OK; }
+
+// ------------------------------------------------------------------------------------------------
+// FractionalEncoder (host)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fhe_frac_encode(uint32_t n, uint64_t t, double value, int int_coeffs, int frac_coeffs, uint64_t *plain) {
+    if (!plain || int_coeffs < 0 || frac_coeffs < 0 || (uint32_t)(int_coeffs + frac_coeffs) > n)
+        return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");
+    if (!std::isfinite(value) || std::fabs(value) >= 9.0e18) return fail(FHE_ERR_PARAM, "value out of range");
+    memset(plain, 0, sizeof(uint64_t) * n);
+    const int64_t whole = (int64_t)value;              // truncation toward zero
+    double frac = value - (double)whole;
+    uint64_t mag = whole < 0 ? (uint64_t)(-whole) : (uint64_t)whole;
+    for (int d = 0; mag; ++d, mag >>= 1) {
+        if (!(mag & 1)) continue;
+        if (d >= int_coeffs) return fail(FHE_ERR_PARAM, "integer part needs more than %d coefficients", int_coeffs);
+        plain[d] = whole < 0 ? t - 1 : 1;
+    }
+    if (frac != 0.0) {
+        const bool negative = value < 0;
+        for (int i = 1; i <= frac_coeffs; ++i) {       // digit of weight 2^-i sits at x^(n-i) with flipped sign
+            frac *= 2.0;
+            const int64_t bit = (int64_t)frac;
+            frac -= (double)bit;
+            if (bit) plain[n - i] = negative ? 1 : t - 1;
+        }
+    }
+    int len = (int)n;
+    while (len > 0 && plain[len - 1] == 0) --len;
+    return len;
+}
+
+extern "C" double fhe_frac_decode(uint32_t n, uint64_t t, const uint64_t *plain, int int_coeffs, int frac_coeffs) {
+    (void)frac_coeffs;   // every coefficient above the integer part is fractional (products push digits down)
+    const uint64_t half = (t + 1) >> 1;
+    auto centred = [&](uint64_t m) { return m >= half ? -(double)(t - m) : (double)m; };
+    double whole = 0.0, frac = 0.0;
+    for (int d = int_coeffs - 1; d >= 0; --d) whole = whole * 2.0 + centred(plain[d]);
+    for (uint32_t i = (uint32_t)int_coeffs; i < n; ++i) frac = (frac + centred(plain[i])) * 0.5;
+    return whole - frac;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise kernels
+// ------------------------------------------------------------------------------------------------
+enum { OP_ADD = 0, OP_SUB = 1, OP_NEG = 2 };
+
+// One thread handles two adjacent coefficients (16-byte accesses).  grid.y walks residue
+// polynomials so the modulus is uniform per block.
+template <int OP>
+__global__ __launch_bounds__(256) void k_eltwise(const ulonglong2 *__restrict__ a, const ulonglong2 *__restrict__ b,
+                                                 ulonglong2 *__restrict__ out, const Modulus *__restrict__ mods,
+                                                 u32 k, u32 half_n, u64 n_res_polys) {
+    for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
+        const u64 q = mods[rp % k].q;
+        const u64 base = rp * half_n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < half_n; i += gridDim.x * blockDim.x) {
+            ulonglong2 x = a[base + i], r;
+            if (OP == OP_NEG) {
+                r.x = negmod(x.x, q);
+                r.y = negmod(x.y, q);
+            } else {
+                ulonglong2 y = b[base + i];
+                r.x = OP == OP_ADD ? addmod(x.x, y.x, q) : submod(x.x, y.x, q);
+                r.y = OP == OP_ADD ? addmod(x.y, y.y, q) : submod(x.y, y.y, q);
+            }
+            out[base + i] = r;
+        }
+    }
+}
+
+static int launch_eltwise(int op, const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out,
+                          uint64_t n_polys, fhe_stream s) {
+    if (!c || !a || !out || (op != OP_NEG && !b)) return fail(FHE_ERR_PARAM, "null argument");
+    if (n_polys == 0) return FHE_OK;
+    const u64 nrp = n_polys * c->k;
+    const u32 half_n = c->n / 2;
+    dim3 grid((half_n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+    auto A = (const ulonglong2 *)a;
+    auto B = (const ulonglong2 *)b;
+    auto O = (ulonglong2 *)out;
+    hipStream_t st = (hipStream_t)s;
+    if (op == OP_ADD) k_eltwise<OP_ADD><<<grid, 256, 0, st>>>(A, B, O, c->qb.d_mod, c->k, half_n, nrp);
+    else if (op == OP_SUB) k_eltwise<OP_SUB><<<grid, 256, 0, st>>>(A, B, O, c->qb.d_mod, c->k, half_n, nrp);
+    else k_eltwise<OP_NEG><<<grid, 256, 0, st>>>(A, B, O, c->qb.d_mod, c->k, half_n, nrp);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+extern "C" int fhe_add(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    return launch_eltwise(OP_ADD, c, a, b, out, n_polys, s);
+}
+extern "C" int fhe_sub(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    return launch_eltwise(OP_SUB, c, a, b, out, n_polys, s);
+}
+extern "C" int fhe_negate(const fhe_ctx *c, const uint64_t *a, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    return launch_eltwise(OP_NEG, c, a, nullptr, out, n_polys, s);
+}
+
+// c_0[i] += / -= v[i] for `count` ciphertexts (add_plain / sub_plain)
+__global__ void k_add_plain(u64 *ct, u64 stride_words, u64 count, const u64 *__restrict__ vals, u32 len,
+                            const Modulus *__restrict__ mods, u32 k, u32 n, int sign) {
+    const u32 prime = blockIdx.y;
+    const u64 q = mods[prime].q;
+    for (u64 cidx = blockIdx.z; cidx < count; cidx += gridDim.z) {
+        u64 *p = ct + cidx * stride_words + (u64)prime * n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+            const u64 v = vals[(u64)prime * len + i];
+            p[i] = sign > 0 ? addmod(p[i], v, q) : submod(p[i], v, q);
+        }
+    }
+}
+
+extern "C" int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, uint64_t count, const uint64_t *plain,
+                             uint32_t len, int sign, fhe_stream s) {
+    using namespace hostmath;
+    if (!c || !ct || (!plain && len)) return fail(FHE_ERR_PARAM, "null argument");
+    if (len > c->n) return fail(FHE_ERR_PARAM, "plaintext longer than the polynomial");
+    if (sign != 1 && sign != -1) return fail(FHE_ERR_PARAM, "sign must be +1 or -1");
+    if (len == 0 || count == 0) return FHE_OK;
+    std::vector<u64> vals((size_t)c->k * len);
+    for (u32 i = 0; i < c->k; ++i) {
+        const u64 qi = c->qb.primes[i];
+        for (u32 j = 0; j < len; ++j) {
+            const u64 m = plain[j];
+            if (m >= c->t) return fail(FHE_ERR_PARAM, "plaintext coefficient %u not below the plain modulus", j);
+            u64 v = mulmod(c->delta_mod[i], m % qi, qi);
+            if (m >= c->upper_half_threshold) v = addmod(v, c->upper_half_increment[i], qi);
+            vals[(size_t)i * len + j] = v;
+        }
+    }
+    hipStream_t st = (hipStream_t)s;
+    u64 *d_vals = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&d_vals, vals.size() * sizeof(u64), st));
+    HIP_TRY(hipMemcpyAsync(d_vals, vals.data(), vals.size() * sizeof(u64), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // vals is a stack-lifetime host buffer
+    dim3 grid((len + 255) / 256, c->k, (unsigned)(count < 16384 ? count : 16384));
+    k_add_plain<<<grid, 256, 0, st>>>((u64 *)ct, stride, count, d_vals, len, c->qb.d_mod, c->k, c->n, sign);
+    KERNEL_CHECK();
+    HIP_TRY(hipFreeAsync(d_vals, st));
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT kernels: one workgroup per residue polynomial
+// ------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP) void k_ntt_fwd(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const u64 rp = blockIdx.x;
+    const u32 prime = (u32)(rp % base.count);
+    const u64 q = base.mod[prime].q;
+    u64 x[16];
+    load_coeff<L>(x, in + rp * NttShape<L>::N, tid);
+    ntt_fwd_regs<L>(x, base.tw + (size_t)prime * NttShape<L>::N, q, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
+    store_slots<L>(x, out + rp * NttShape<L>::N, tid);
+}
+
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP) void k_ntt_inv(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const u64 rp = blockIdx.x;
+    const u32 prime = (u32)(rp % base.count);
+    const u64 q = base.mod[prime].q;
+    u64 x[16];
+    load_slots<L>(x, in + rp * NttShape<L>::N, tid);
+    ntt_inv_regs<L>(x, base.itw + (size_t)prime * NttShape<L>::N, q, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = csub(x[r], q);
+    store_coeff<L>(x, out + rp * NttShape<L>::N, tid);
+}
+
+// multiply_plain: NTT -> dyadic product with a prepared plaintext (Shoup pairs) -> inverse NTT
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP) void k_mulplain(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                               const ulonglong2 *__restrict__ plain, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u64 rp = blockIdx.x;
+    const u32 prime = (u32)(rp % base.count);
+    const u64 q = base.mod[prime].q;
+    u64 x[16];
+    load_coeff<L>(x, in + rp * N, tid);
+    ntt_fwd_regs<L>(x, base.tw + (size_t)prime * N, q, lds, tid);
+    const ulonglong2 *pl = plain + (size_t)prime * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const ulonglong2 w = pl[r * TP + tid];
+        x[r] = mul_shoup_lazy(x[r], w.x, w.y, q);
+    }
+    ntt_inv_regs<L>(x, base.itw + (size_t)prime * N, q, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = csub(x[r], q);
+    store_coeff<L>(x, out + rp * N, tid);
+}
+
+#define DISPATCH_L(logn, ...)                                                    \
+    switch (logn) {                                                              \
+        case 10: { constexpr int L = 10; __VA_ARGS__; } break;                          \
+        case 11: { constexpr int L = 11; __VA_ARGS__; } break;                          \
+        case 12: { constexpr int L = 12; __VA_ARGS__; } break;                          \
+        case 13: { constexpr int L = 13; __VA_ARGS__; } break;                          \
+        case 14: { constexpr int L = 14; __VA_ARGS__; } break;                          \
+        default: return fail(FHE_ERR_PARAM, "unsupported log2(n)=%u", logn);     \
+    }
+
+static int ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st) {
+    if (n_res_polys == 0) return FHE_OK;
+    if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    const RnsBase base = B.dev();
+    DISPATCH_L(c->logn, {
+        if (inverse) k_ntt_inv<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        else k_ntt_fwd<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+    });
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
+    return ntt_launch(false, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
+}
+extern "C" int fhe_ntt_inverse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
+    return ntt_launch(true, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
+}
+
+extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                                  const uint64_t *d_plain_ntt, fhe_stream s) {
+    if (!c || !in || !out || !d_plain_ntt) return fail(FHE_ERR_PARAM, "null argument");
+    const u64 nrp = n_polys * c->k;
+    if (nrp == 0) return FHE_OK;
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    const RnsBase base = c->qb.dev();
+    hipStream_t st = (hipStream_t)s;
+    DISPATCH_L(c->logn, (k_mulplain<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plaintext preparation
+// ------------------------------------------------------------------------------------------------
+// in: [k][n] NTT-form values; out: [k][n] (value, Shoup companion) pairs.  in may alias the first
+// half of out only if processed back to front -- callers pass a separate buffer.
+__global__ void k_make_shoup(const u64 *__restrict__ in, ulonglong2 *__restrict__ out, const Modulus *__restrict__ mods, u32 n, u32 total) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 q = mods[i / n].q;
+    const u64 w = in[i];
+    out[i] = make_ulonglong2(w, shoup_companion(w, q));
+}
+
+extern "C" size_t fhe_plain_ntt_words(const fhe_ctx *c) { return c ? (size_t)2 * c->k * c->n : 0; }
+
+static int lift_plain_host(const fhe_ctx *c, const uint64_t *plain, uint32_t len, std::vector<u64> &out) {
+    if (len > c->n) return fail(FHE_ERR_PARAM, "plaintext longer than the polynomial");
+    out.assign((size_t)c->k * c->n, 0);
+    for (u32 j = 0; j < len; ++j) {
+        const u64 m = plain[j];
+        if (m >= c->t) return fail(FHE_ERR_PARAM, "plaintext coefficient %u not below the plain modulus", j);
+        for (u32 i = 0; i < c->k; ++i) {
+            const u64 qi = c->qb.primes[i];
+            out[(size_t)i * c->n + j] = m >= c->upper_half_threshold ? (m + c->plain_upper_half_increment[i]) % qi : m % qi;
+        }
+    }
+    return FHE_OK;
+}
+
+extern "C" int fhe_plain_prepare(const fhe_ctx *c, const uint64_t *plain, uint32_t len, uint64_t *d_out, fhe_stream s) {
+    if (!c || (!plain && len) || !d_out) return fail(FHE_ERR_PARAM, "null argument");
+    std::vector<u64> lifted;
+    int rc = lift_plain_host(c, plain, len, lifted);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)s;
+    const size_t words = (size_t)c->k * c->n;
+    u64 *tmp = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&tmp, 2 * words * sizeof(u64), st));
+    HIP_TRY(hipMemcpyAsync(tmp, lifted.data(), words * sizeof(u64), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rc = ntt_launch(false, c, c->qb, tmp, tmp + words, c->k, st);
+    if (rc) return rc;
+    k_make_shoup<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(tmp + words, (ulonglong2 *)d_out, c->qb.d_mod, c->n, (u32)words);
+    KERNEL_CHECK();
+    HIP_TRY(hipFreeAsync(tmp, st));
+    return FHE_OK;
+}
+
+__global__ void k_plain_ntt_mul(const ulonglong2 *__restrict__ a, const ulonglong2 *__restrict__ b, ulonglong2 *__restrict__ out,
+                                const Modulus *__restrict__ mods, u32 n, u32 total) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Modulus m = mods[i / n];
+    const u64 w = mul_barrett(a[i].x, b[i].x, m);
+    out[i] = make_ulonglong2(w, shoup_companion(w, m.q));
+}
+extern "C" int fhe_plain_ntt_mul(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, fhe_stream s) {
+    if (!c || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
+    const u32 total = c->k * c->n;
+    k_plain_ntt_mul<<<(total + 255) / 256, 256, 0, (hipStream_t)s>>>((const ulonglong2 *)a, (const ulonglong2 *)b, (ulonglong2 *)out, c->qb.d_mod, c->n, total);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// dyadic product of two NTT-form operands
+__global__ __launch_bounds__(256) void k_dyadic(const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out,
+                                                const Modulus *__restrict__ mods, u32 k, u32 n, u64 n_res_polys) {
+    for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
+        const Modulus m = mods[rp % k];
+        const u64 base = rp * n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+            out[base + i] = mul_barrett(a[base + i], b[base + i], m);
+    }
+}
+extern "C" int fhe_dyadic_multiply(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys, fhe_stream s) {
+    if (!c || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
+    const u64 nrp = n_polys * c->k;
+    if (!nrp) return FHE_OK;
+    dim3 grid((c->n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+    k_dyadic<<<grid, 256, 0, (hipStream_t)s>>>((const u64 *)a, (const u64 *)b, (u64 *)out, c->qb.d_mod, c->k, c->n, nrp);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DCT + quantisation block circuit
+// ------------------------------------------------------------------------------------------------
+// Constant table: [cid][prime][n] Shoup pairs in slot order.
+//   cid 0..11  : the twelve LL&M constants of homo/fhe_image.h:221-236, in order of first use
+//   cid 12..75 : per-output scale = encode(0.125) [* encode(1/quant[i])], i = row-major output index
+static const double kDctConst[12] = {0.541196100, 0.765366865, -1.847759065, 1.175875602, 0.298631336, 2.053119869,
+                                     3.072711026, 1.501321110, -0.899976223, -2.562915447, -1.961570560, -0.390180644};
+#define DCT_NCONST 76
+
+struct fhe_dct_plan {
+    ulonglong2 *d_consts = nullptr;   // [DCT_NCONST][k][n]
+    u32 k = 0, n = 0;
+    bool has_quant = false;
+};
+
+// One 1-D LL&M pass on eight fully reduced residues (same dataflow as homo/fhe_image.h:207-242).
+// C(cid) yields the Shoup pair of constant cid at this thread's slot.
+template <typename CF>
+__device__ __forceinline__ void dct_line_u64(u64 &d0, u64 &d1, u64 &d2, u64 &d3, u64 &d4, u64 &d5, u64 &d6, u64 &d7, const u64 q, CF C) {
+    auto MUL = [&](u64 x, int cid) { const ulonglong2 w = C(cid); return mul_shoup(x, w.x, w.y, q); };
+    u64 tmp0 = addmod(d0, d7, q), tmp7 = submod(d0, d7, q);
+    u64 tmp1 = addmod(d1, d6, q), tmp6 = submod(d1, d6, q);
+    u64 tmp2 = addmod(d2, d5, q), tmp5 = submod(d2, d5, q);
+    u64 tmp3 = addmod(d3, d4, q), tmp4 = submod(d3, d4, q);
+    const u64 tmp10 = addmod(tmp0, tmp3, q), tmp13 = submod(tmp0, tmp3, q);
+    const u64 tmp11 = addmod(tmp1, tmp2, q), tmp12 = submod(tmp1, tmp2, q);
+    d0 = addmod(tmp10, tmp11, q);
+    d4 = submod(tmp10, tmp11, q);
+    u64 z1 = MUL(addmod(tmp12, tmp13, q), 0);
+    d2 = addmod(z1, MUL(tmp13, 1), q);
+    d6 = addmod(z1, MUL(tmp12, 2), q);
+    z1 = addmod(tmp4, tmp7, q);
+    u64 z2 = addmod(tmp5, tmp6, q), z3 = addmod(tmp4, tmp6, q), z4 = addmod(tmp5, tmp7, q);
+    const u64 z5 = MUL(addmod(z3, z4, q), 3);
+    tmp4 = MUL(tmp4, 4);
+    tmp5 = MUL(tmp5, 5);
+    tmp6 = MUL(tmp6, 6);
+    tmp7 = MUL(tmp7, 7);
+    z1 = MUL(z1, 8);
+    z2 = MUL(z2, 9);
+    z3 = addmod(MUL(z3, 10), z5, q);
+    z4 = addmod(MUL(z4, 11), z5, q);
+    d7 = addmod(addmod(tmp4, z1, q), z3, q);
+    d5 = addmod(addmod(tmp5, z2, q), z4, q);
+    d3 = addmod(addmod(tmp6, z2, q), z3, q);
+    d1 = addmod(addmod(tmp7, z1, q), z4, q);
+}
+
+// V1 slot kernel: one thread owns one NTT slot of one (block, poly, prime) unit: 64 values in,
+// row pass, column pass, per-output scale, 64 values out (in place).
+__global__ __launch_bounds__(256) void k_dct_slots(u64 *__restrict__ data, const ulonglong2 *__restrict__ consts,
+                                                   const Modulus *__restrict__ mods, u32 k, u32 n) {
+    const u32 unit = blockIdx.y;             // (block * 2 + poly) * k + prime
+    const u32 prime = unit % k;
+    const u32 bp = unit / k;                 // block * 2 + poly
+    const u32 blk = bp >> 1, poly = bp & 1;
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 q = mods[prime].q;
+    const size_t ct_stride = (size_t)2 * k * n;
+    u64 *p = data + (size_t)blk * 64 * ct_stride + ((size_t)poly * k + prime) * n + slot;
+    const ulonglong2 *cp = consts + (size_t)prime * n + slot;
+    const size_t cstride = (size_t)k * n;
+    auto C = [&](int cid) { return cp[(size_t)cid * cstride]; };
+    u64 v[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) v[i] = p[(size_t)i * ct_stride];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        dct_line_u64(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7], q, C);
+#pragma unroll
+    for (int col = 0; col < 8; col++)
+        dct_line_u64(v[col], v[col + 8], v[col + 16], v[col + 24], v[col + 32], v[col + 40], v[col + 48], v[col + 56], q, C);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const ulonglong2 w = C(12 + i);
+        p[(size_t)i * ct_stride] = mul_shoup(v[i], w.x, w.y, q);
+    }
+}
+
+extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int int_coeffs, int frac_coeffs, fhe_stream s, fhe_dct_plan **out) {
+    if (!c || !out) return fail(FHE_ERR_PARAM, "null argument");
+    *out = nullptr;
+    fhe_dct_plan *p = new fhe_dct_plan();
+    p->k = c->k;
+    p->n = c->n;
+    p->has_quant = quant64 != nullptr;
+    const size_t pw = (size_t)c->k * c->n;   // pairs per constant
+    int rc = fhe_dev_alloc(sizeof(ulonglong2) * pw * DCT_NCONST, (void **)&p->d_consts);
+    if (rc) { delete p; return rc; }
+    std::vector<uint64_t> plain(c->n);
+    ulonglong2 *d_eighth = nullptr, *d_tmp = nullptr;
+    auto cleanup = [&](int code) {
+        if (d_eighth) (void)hipFree(d_eighth);
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (code) { (void)hipFree(p->d_consts); delete p; }
+        return code;
+    };
+    auto prep = [&](double v, ulonglong2 *dst) -> int {
+        int len = fhe_frac_encode(c->n, c->t, v, int_coeffs, frac_coeffs, plain.data());
+        if (len < 0) return len;
+        return fhe_plain_prepare(c, plain.data(), (uint32_t)len, (uint64_t *)dst, s);
+    };
+    for (int i = 0; i < 12; ++i)
+        if ((rc = prep(kDctConst[i], p->d_consts + pw * i))) return cleanup(rc);
+    if (!quant64) {
+        for (int i = 0; i < 64; ++i)
+            if ((rc = prep(0.125, p->d_consts + pw * (12 + i)))) return cleanup(rc);
+    } else {
+        if ((rc = fhe_dev_alloc(sizeof(ulonglong2) * pw, (void **)&d_eighth))) return cleanup(rc);
+        if ((rc = fhe_dev_alloc(sizeof(ulonglong2) * pw, (void **)&d_tmp))) return cleanup(rc);
+        if ((rc = prep(0.125, d_eighth))) return cleanup(rc);
+        for (int i = 0; i < 64; ++i) {
+            if (!(quant64[i] != 0.0)) return cleanup(fail(FHE_ERR_PARAM, "quant[%d] is zero", i));
+            if ((rc = prep(1 / quant64[i], d_tmp))) return cleanup(rc);
+            if ((rc = fhe_plain_ntt_mul(c, (const uint64_t *)d_eighth, (const uint64_t *)d_tmp, (uint64_t *)(p->d_consts + pw * (12 + i)), s)))
+                return cleanup(rc);
+        }
+    }
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return cleanup(fail(FHE_ERR_HIP, "stream sync failed"));
+    *out = p;
+    return cleanup(FHE_OK);
+}
+extern "C" int fhe_dct_plan_destroy(fhe_dct_plan *p) {
+    if (!p) return FHE_OK;
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    delete p;
+    return FHE_OK;
+}
+extern "C" size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *, uint64_t) { return 0; }
+
+extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out, uint64_t n_blocks,
+                                void *, size_t, fhe_stream s) {
+    if (!c || !plan || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (plan->k != c->k || plan->n != c->n) return fail(FHE_ERR_PARAM, "plan was built for another context");
+    if (n_blocks == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)s;
+    // launches are chunked so that grid dimensions stay in range
+    const u64 polys_per_block = 64 * 2;   // RNS polynomials (of k residues) per block
+    const u64 max_blocks = 4096;
+    for (u64 b0 = 0; b0 < n_blocks; b0 += max_blocks) {
+        const u64 nb = (n_blocks - b0) < max_blocks ? (n_blocks - b0) : max_blocks;
+        const size_t off = (size_t)b0 * polys_per_block * c->k * c->n;
+        int rc = ntt_launch(false, c, c->qb, (const u64 *)in + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
+        if (rc) return rc;
+        dim3 grid(c->n / 256, (unsigned)(nb * 2 * c->k));
+        k_dct_slots<<<grid, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_mod, c->k, c->n);
+        KERNEL_CHECK();
+        rc = ntt_launch(true, c, c->qb, (const u64 *)out + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
+        if (rc) return rc;
+    }
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rgb_to_ycc_fhe: 9 multiply_plain + adds (homo/fhe_image.h:310-325), fused per residue polynomial
+// ------------------------------------------------------------------------------------------------
+// consts: [9][k][n] Shoup pairs (0.299, 0.587, 0.114, -0.168736, 0.331264, 0.5, 0.5, 0.418688, 0.081312);
+// y_off: [k][len] = Delta * encode(128.0) lifted, subtracted from poly 0 of Y.
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP) void k_rgb2ycc(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc,
+                                                              const ulonglong2 *__restrict__ consts, const u64 *__restrict__ yoff, u32 yoff_len,
+                                                              RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u64 rp = blockIdx.x;                 // (pixel * 2 + poly) * k + prime
+    const u32 prime = (u32)(rp % base.count);
+    const u32 poly = (u32)((rp / base.count) & 1);
+    const u64 q = base.mod[prime].q;
+    const ulonglong2 *tw = base.tw + (size_t)prime * N, *itw = base.itw + (size_t)prime * N;
+    const size_t cstride = (size_t)base.count * N;
+    const ulonglong2 *cp = consts + (size_t)prime * N;
+    u64 r[16], g[16], b[16];
+    load_coeff<L>(r, R + rp * N, tid);
+    ntt_fwd_regs<L>(r, tw, q, lds, tid);
+    load_coeff<L>(g, G + rp * N, tid);
+    ntt_fwd_regs<L>(g, tw, q, lds, tid);
+    load_coeff<L>(b, Bc + rp * N, tid);
+    ntt_fwd_regs<L>(b, tw, q, lds, tid);
+    u64 y[16], u[16], v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int pos = i * TP + tid;
+        auto M = [&](u64 x, int cid) { const ulonglong2 w = cp[cid * cstride + pos]; return mul_shoup(x, w.x, w.y, q); };
+        y[i] = addmod(addmod(M(r[i], 0), M(g[i], 1), q), M(b[i], 2), q);
+        u[i] = addmod(submod(M(r[i], 3), M(g[i], 4), q), M(b[i], 5), q);
+        v[i] = submod(submod(M(r[i], 6), M(g[i], 7), q), M(b[i], 8), q);
+    }
+    ntt_inv_regs<L>(y, itw, q, lds, tid);
+    ntt_inv_regs<L>(u, itw, q, lds, tid);
+    ntt_inv_regs<L>(v, itw, q, lds, tid);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        y[i] = csub(y[i], q);
+        u[i] = csub(u[i], q);
+        v[i] = csub(v[i], q);
+        if (poly == 0) {
+            const int j = elem_index<L - 4>(tid, i);
+            if ((u32)j < yoff_len) y[i] = submod(y[i], yoff[(size_t)prime * yoff_len + j], q);
+        }
+    }
+    store_coeff<L>(y, R + rp * N, tid);
+    store_coeff<L>(u, G + rp * N, tid);
+    store_coeff<L>(v, Bc + rp * N, tid);
+}
+
+extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int int_coeffs, int frac_coeffs, fhe_stream s) {
+    using namespace hostmath;
+    if (!c || !r || !g || !b) return fail(FHE_ERR_PARAM, "null argument");
+    if (!count) return FHE_OK;
+    static const double cc[9] = {0.299, 0.587, 0.114, -0.168736, 0.331264, 0.5, 0.5, 0.418688, 0.081312};
+    hipStream_t st = (hipStream_t)s;
+    const size_t pw = (size_t)c->k * c->n;
+    ulonglong2 *d_c = nullptr;
+    u64 *d_off = nullptr;
+    std::vector<uint64_t> plain(c->n);
+    int rc = fhe_dev_alloc(sizeof(ulonglong2) * pw * 9, (void **)&d_c);
+    if (rc) return rc;
+    auto done = [&](int code) { if (d_c) (void)hipFree(d_c); if (d_off) (void)hipFree(d_off); return code; };
+    for (int i = 0; i < 9; ++i) {
+        int len = fhe_frac_encode(c->n, c->t, cc[i], int_coeffs, frac_coeffs, plain.data());
+        if (len < 0) return done(len);
+        if ((rc = fhe_plain_prepare(c, plain.data(), (uint32_t)len, (uint64_t *)(d_c + pw * i), s))) return done(rc);
+    }
+    int len = fhe_frac_encode(c->n, c->t, 128.0, int_coeffs, frac_coeffs, plain.data());
+    if (len < 0) return done(len);
+    std::vector<u64> off((size_t)c->k * len);
+    for (u32 i = 0; i < c->k; ++i)
+        for (int j = 0; j < len; ++j) {
+            const u64 qi = c->qb.primes[i], m = plain[j];
+            u64 v = mulmod(c->delta_mod[i], m % qi, qi);
+            if (m >= c->upper_half_threshold) v = addmod(v, c->upper_half_increment[i], qi);
+            off[(size_t)i * len + j] = v;
+        }
+    if ((rc = fhe_dev_alloc(off.size() * sizeof(u64) + 8, (void **)&d_off))) return done(rc);
+    if (hipMemcpy(d_off, off.data(), off.size() * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) return done(fail(FHE_ERR_HIP, "upload failed"));
+    const u64 nrp = count * 2 * c->k;
+    if (nrp > 0x7fffffffULL) return done(fail(FHE_ERR_PARAM, "too many pixels for one launch"));
+    const RnsBase base = c->qb.dev();
+    DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((u64 *)r, (u64 *)g, (u64 *)b, d_c, d_off, (u32)len, base)));
+    if (hipGetLastError() != hipSuccess) return done(fail(FHE_ERR_HIP, "kernel launch failed"));
+    if (hipStreamSynchronize(st) != hipSuccess) return done(fail(FHE_ERR_HIP, "stream sync failed"));
+    return done(FHE_OK);
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic inputs, digests
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_random(u64 *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n,
+                                                     u64 n_res_polys, u64 seed, u64 first) {
+    for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
+        const u64 q = mods[rp % k].q;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 idx = rp * n + i;
+            out[idx] = splitmix64(seed ^ (first + idx)) % q;
+        }
+    }
+}
+extern "C" int fhe_fill_random(const fhe_ctx *c, uint64_t *ct, uint64_t n_polys, uint64_t seed, uint64_t first, fhe_stream s) {
+    if (!c || !ct) return fail(FHE_ERR_PARAM, "null argument");
+    const u64 nrp = n_polys * c->k;
+    if (!nrp) return FHE_OK;
+    dim3 grid((c->n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+    k_fill_random<<<grid, 256, 0, (hipStream_t)s>>>((u64 *)ct, c->qb.d_mod, c->k, c->n, nrp, seed, first);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+__global__ __launch_bounds__(256) void k_digest(const u64 *__restrict__ data, u64 count, u64 index0, u64 *out) {
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (u64)gridDim.x * blockDim.x)
+        acc += splitmix64(data[i] ^ splitmix64(index0 + i));
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" int fhe_digest(const fhe_ctx *, const uint64_t *data, uint64_t count, uint64_t index0, uint64_t *d_out, fhe_stream s) {
+    if (!data || !d_out) return fail(FHE_ERR_PARAM, "null argument");
+    hipStream_t st = (hipStream_t)s;
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(u64), st));
+    if (!count) return FHE_OK;
+    u64 blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_digest<<<(unsigned)blocks, 256, 0, st>>>((const u64 *)data, count, index0, (u64 *)d_out);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ct x ct and relinearisation live in behz.hip
+// ------------------------------------------------------------------------------------------------

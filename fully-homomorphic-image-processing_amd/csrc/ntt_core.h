@@ -1,0 +1,142 @@
+// ntt_core.h -- register-resident negacyclic NTT for one 2^L-point residue polynomial per
+// workgroup (gfx950, wave64).
+//
+// Shape: N/16 threads, 16 coefficients per thread held in VGPRs.  The L butterfly stages are
+// grouped into ceil(L/4) passes of up to four stages; inside a pass every butterfly partner lives
+// in the same thread (radix-16 in registers), between passes the polynomial is transposed through
+// LDS (one 8-byte ds_write / ds_read per coefficient, padded so that neither side bank-conflicts).
+// For L = 12 that is 3 register passes and 2 LDS transposes per direction.
+//
+// Forward: Cooley-Tukey, natural order in -> bit-reversed order out, psi powers merged into the
+// twiddles (Harvey lazy butterflies, values kept in [0, 4q)).  Inverse: Gentleman-Sande, n^-1
+// merged into the last stage.  Twiddle tables hold (w, floor(w 2^64 / q)) pairs.
+//
+// Index algebra.  During pass P the 4 register-index bits stand for coefficient-index bits
+// [LO, LO+4) with LO = max(L - 4P - 4, 0):
+//     j(tid, r) = ((tid >> LO) << (LO + 4)) | (r << LO) | (tid & (2^LO - 1)).
+// Stage sigma pairs indices that differ in bit b = L - 1 - sigma and uses twiddle
+// 2^sigma + (j >> (b + 1)).  Pass 0 therefore reads/writes global memory with consecutive lanes on
+// consecutive coefficients (coalesced), and the last pass holds 16 consecutive slots per thread.
+// NTT-form buffers are stored in "slot order": slot r of thread tid lives at r * (N/16) + tid, so
+// those accesses are coalesced too.  (The order is internal; see include/fhe_hip.h.)
+#pragma once
+#include "modarith.h"
+
+template <int L> struct NttShape {
+    static constexpr int N = 1 << L;
+    static constexpr int TP = N / 16;         // threads per polynomial
+    static constexpr int NP = (L + 3) / 4;    // register passes
+    static constexpr int LDS_WORDS = N + N / 16;
+};
+
+__host__ __device__ constexpr int pass_lo(int L, int p) { return (L - 4 * p - 4) < 0 ? 0 : (L - 4 * p - 4); }
+__host__ __device__ constexpr int pass_stages(int L, int p) { return (L - 4 * p) > 4 ? 4 : (L - 4 * p); }
+__host__ __device__ constexpr int imin(int a, int b) { return a < b ? a : b; }
+
+template <int LO> __device__ __forceinline__ int elem_index(int tid, int r) {
+    return ((tid >> LO) << (LO + 4)) | (r << LO) | (tid & ((1 << LO) - 1));
+}
+template <int LO> __device__ __forceinline__ int lds_pad(int j) { return j + ((j >> (LO + 4)) << LO); }
+
+struct RnsBase {              // device pointers, passed to kernels by value
+    const ulonglong2 *tw;     // [count][n]  psi^bitrev(i) with Shoup companion
+    const ulonglong2 *itw;    // [count][n]  psi^-bitrev(i); entry 0 = n^-1, entry 1 pre-multiplied by n^-1
+    const Modulus *mod;       // [count]
+    u32 count;
+};
+
+template <int L, int P>
+__device__ __forceinline__ void ntt_fwd_pass(u64 (&x)[16], const ulonglong2 *__restrict__ tw, u64 q, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const u64 twoq = 2 * q;
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const u64 X = csub(x[r0], twoq);
+            const u64 T = mul_shoup_lazy(x[r1], w.x, w.y, q);
+            x[r0] = X + T;
+            x[r1] = X - T + twoq;
+        }
+    }
+}
+
+template <int L, int P>
+__device__ __forceinline__ void ntt_inv_pass(u64 (&x)[16], const ulonglong2 *__restrict__ itw, u64 q, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const u64 twoq = 2 * q;
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = S - 1; u >= 0; u--) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = itw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const u64 X = x[r0], Y = x[r1];            // both in [0, 2q)
+            const u64 T = csub(X + Y, twoq);
+            const u64 D = X - Y + twoq;                // [0, 4q)
+            if (sigma == 0) {
+                const ulonglong2 ni = itw[0];
+                x[r0] = mul_shoup_lazy(T, ni.x, ni.y, q);
+            } else {
+                x[r0] = T;
+            }
+            x[r1] = mul_shoup_lazy(D, w.x, w.y, q);    // [0, 2q)
+        }
+    }
+}
+
+template <int LO_FROM, int LO_TO>
+__device__ __forceinline__ void ntt_transpose(u64 (&x)[16], u64 *lds, int tid) {
+    constexpr int PL = imin(LO_FROM, LO_TO);
+    __syncthreads();   // earlier readers of this buffer are done
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[lds_pad<PL>(elem_index<LO_FROM>(tid, r))] = x[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = lds[lds_pad<PL>(elem_index<LO_TO>(tid, r))];
+}
+
+// all forward passes: in = pass-0 register mapping (natural order), out = last-pass mapping
+template <int L, int P = 0>
+__device__ __forceinline__ void ntt_fwd_regs(u64 (&x)[16], const ulonglong2 *__restrict__ tw, u64 q, u64 *lds, int tid) {
+    ntt_fwd_pass<L, P>(x, tw, q, tid);
+    if constexpr (P + 1 < NttShape<L>::NP) {
+        ntt_transpose<pass_lo(L, P), pass_lo(L, P + 1)>(x, lds, tid);
+        ntt_fwd_regs<L, P + 1>(x, tw, q, lds, tid);
+    }
+}
+// all inverse passes: in = last-pass mapping with values in [0, 2q), out = pass-0 mapping, [0, 2q)
+template <int L, int P = NttShape<L>::NP - 1>
+__device__ __forceinline__ void ntt_inv_regs(u64 (&x)[16], const ulonglong2 *__restrict__ itw, u64 q, u64 *lds, int tid) {
+    ntt_inv_pass<L, P>(x, itw, q, tid);
+    if constexpr (P > 0) {
+        ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x, lds, tid);
+        ntt_inv_regs<L, P - 1>(x, itw, q, lds, tid);
+    }
+}
+
+// global <-> register helpers
+template <int L> __device__ __forceinline__ void load_coeff(u64 (&x)[16], const u64 *__restrict__ p, int tid) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = p[elem_index<L - 4>(tid, r)];
+}
+template <int L> __device__ __forceinline__ void store_coeff(const u64 (&x)[16], u64 *__restrict__ p, int tid) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) p[elem_index<L - 4>(tid, r)] = x[r];
+}
+template <int L> __device__ __forceinline__ void load_slots(u64 (&x)[16], const u64 *__restrict__ p, int tid) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = p[r * NttShape<L>::TP + tid];
+}
+template <int L> __device__ __forceinline__ void store_slots(const u64 (&x)[16], u64 *__restrict__ p, int tid) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) p[r * NttShape<L>::TP + tid] = x[r];
+}

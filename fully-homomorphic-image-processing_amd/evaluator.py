@@ -1,0 +1,293 @@
+"""Host-side mirror of the SEAL 2.3 objects the reference's circuits use, over the C ABI.
+
+Names follow seal::{EncryptionParameters, SEALContext, FractionalEncoder, Evaluator} as used at
+homo/server_jpeg.cpp:74-100 and homo/fhe_image.h:196-325.  Ciphertexts are torch int64 tensors on
+the HIP device holding u64 bit patterns, shaped [..., size, k, n] (SEAL-logical order); every
+Evaluator method works on whole batches (leading dimensions) in one launch.  PyTorch is used for
+device memory and streams only -- all arithmetic happens in libfhe_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# Parameter presets
+PRESETS = {
+    "P4096": dict(n=4096, q=[0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001], t=1 << 14),
+    "P8192": dict(n=8192, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),
+    "SEAL23_4096": dict(n=4096, q=[0x7FFFFFFF380001, 0x3FFFFFFF000001], t=1 << 14),
+    "SEAL23_2048": dict(n=2048, q=[0x3FFFFFFF000001], t=1 << 14),
+    "SEAL3_8192": dict(n=8192, q=[0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001, 0xFFFFFEBC001], t=1 << 14),
+}
+YQT = [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+       14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+       49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99]  # homo/fhe_image.h:99
+SEED = 0x5EA12026
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def to_device(arr, device="cuda"):
+    """numpy uint64 -> device int64 tensor with the same bits."""
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    """device int64 tensor -> numpy uint64."""
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+class SEALContext:
+    """EncryptionParameters + SEALContext: poly_modulus_degree n, coeff_modulus q[], plain_modulus t."""
+
+    def __init__(self, n, q, t, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device: this framework has no CPU path")
+        self.n, self.q, self.t, self.k = int(n), [int(x) for x in q], int(t), len(q)
+        self.device = torch.device("cuda", device)
+        arr = (C.c_uint64 * self.k)(*self.q)
+        h = C.c_void_p()
+        _lib.call("fhe_ctx_create", self.n, arr, self.k, self.t, device, C.byref(h))
+        self.h = h
+
+    @classmethod
+    def preset(cls, name, device=0):
+        p = PRESETS[name]
+        return cls(p["n"], p["q"], p["t"], device)
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                _lib.load().fhe_ctx_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def ct_shape(self, *lead, size=2):
+        return tuple(lead) + (size, self.k, self.n)
+
+    def empty(self, *lead, size=2):
+        return torch.empty(self.ct_shape(*lead, size=size), dtype=torch.int64, device=self.device)
+
+    def random_ct(self, *lead, size=2, seed=SEED, first_index=0):
+        """Synthetic ciphertexts: splitmix64(seed ^ linear_index) mod q_i."""
+        out = self.empty(*lead, size=size)
+        n_polys = out.numel() // (self.k * self.n)
+        _lib.call("fhe_fill_random", self.h, _ptr(out), n_polys, seed, first_index, _stream())
+        return out
+
+    def digest(self, t, index0=0):
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.call("fhe_digest", self.h, _ptr(t), t.numel(), index0, _ptr(out), _stream())
+        return int(out.cpu().numpy().view(np.uint64)[0])
+
+
+class FractionalEncoder:
+    """seal::FractionalEncoder(t, poly_modulus, 100, 100, 2) (homo/server_jpeg.cpp:100)."""
+
+    def __init__(self, ctx, int_coeffs=100, frac_coeffs=100):
+        self.ctx, self.int_coeffs, self.frac_coeffs = ctx, int_coeffs, frac_coeffs
+
+    def encode(self, value):
+        out = np.zeros(self.ctx.n, dtype=np.uint64)
+        _lib.call("fhe_frac_encode", self.ctx.n, self.ctx.t, float(value), self.int_coeffs, self.frac_coeffs,
+                  out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def decode(self, plain):
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        return float(_lib.load().fhe_frac_decode(self.ctx.n, self.ctx.t, p.ctypes.data_as(C.c_void_p),
+                                                 self.int_coeffs, self.frac_coeffs))
+
+
+class PreparedPlain:
+    """A Plaintext lifted to the q-base and transformed once (the reference redoes this per call)."""
+
+    def __init__(self, ctx, plain):
+        self.ctx = ctx
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        ln = len(p)
+        while ln > 0 and p[ln - 1] == 0:
+            ln -= 1
+        self.buf = torch.empty(2 * ctx.k * ctx.n, dtype=torch.int64, device=ctx.device)
+        _lib.call("fhe_plain_prepare", ctx.h, p.ctypes.data_as(C.c_void_p), ln, _ptr(self.buf), _stream())
+
+
+class DctPlan:
+    def __init__(self, ctx, quant=YQT, int_coeffs=100, frac_coeffs=100):
+        self.ctx = ctx
+        h = C.c_void_p()
+        qv = None
+        if quant is not None:
+            qv = (C.c_double * 64)(*[float(x) for x in quant])
+        _lib.call("fhe_dct_plan_create", ctx.h, qv, int_coeffs, frac_coeffs, _stream(), C.byref(h))
+        self.h = h
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                _lib.load().fhe_dct_plan_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class Evaluator:
+    """seal::Evaluator over batches.  In-place semantics of SEAL are expressed functionally:
+    every method returns a new tensor unless `out=` is given (which may alias an input)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._scratch = None
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _npolys(self, t):
+        kn = self.ctx.k * self.ctx.n
+        assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() % kn == 0
+        return t.numel() // kn
+
+    def _scratch_buf(self, nbytes):
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.ctx.device)
+        return self._scratch
+
+    def _binary(self, name, a, b, out):
+        sa, sb = a.shape[-3], b.shape[-3]
+        if sa == sb:
+            out = torch.empty_like(a) if out is None else out
+            _lib.call(name, self.ctx.h, _ptr(a), _ptr(b), _ptr(out), self._npolys(a), _stream())
+            return out
+        # unequal sizes: common prefix through the kernel, tail copied (add) or negated (sub of b's tail)
+        lead = a.shape[:-3]
+        s, m = max(sa, sb), min(sa, sb)
+        res = self.ctx.empty(*lead, size=s)
+        pa, pb = a[..., :m, :, :].contiguous(), b[..., :m, :, :].contiguous()
+        pre = torch.empty_like(pa)
+        _lib.call(name, self.ctx.h, _ptr(pa), _ptr(pb), _ptr(pre), self._npolys(pa), _stream())
+        res[..., :m, :, :] = pre
+        if sa > sb:
+            res[..., m:, :, :] = a[..., m:, :, :]
+        else:
+            tail = b[..., m:, :, :].contiguous()
+            if name == "fhe_sub":
+                neg = torch.empty_like(tail)
+                _lib.call("fhe_negate", self.ctx.h, _ptr(tail), _ptr(neg), self._npolys(tail), _stream())
+                tail = neg
+            res[..., m:, :, :] = tail
+        return res
+
+    # -- seal::Evaluator surface -------------------------------------------------------------------
+    def add(self, a, b, out=None):
+        return self._binary("fhe_add", a, b, out)
+
+    def sub(self, a, b, out=None):
+        return self._binary("fhe_sub", a, b, out)
+
+    def negate(self, a, out=None):
+        out = torch.empty_like(a) if out is None else out
+        _lib.call("fhe_negate", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _stream())
+        return out
+
+    def multiply_plain(self, a, plain, out=None):
+        if not isinstance(plain, PreparedPlain):
+            plain = PreparedPlain(self.ctx, plain)
+        out = torch.empty_like(a) if out is None else out
+        _lib.call("fhe_multiply_plain", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _ptr(plain.buf), _stream())
+        return out
+
+    def _plain_addsub(self, a, plain, sign):
+        out = a.clone()
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        ln = len(p)
+        while ln > 0 and p[ln - 1] == 0:
+            ln -= 1
+        size = a.shape[-3]
+        stride = size * self.ctx.k * self.ctx.n
+        count = out.numel() // stride
+        _lib.call("fhe_add_plain", self.ctx.h, _ptr(out), stride, count, p.ctypes.data_as(C.c_void_p), ln, sign, _stream())
+        return out
+
+    def add_plain(self, a, plain):
+        return self._plain_addsub(a, plain, 1)
+
+    def sub_plain(self, a, plain):
+        return self._plain_addsub(a, plain, -1)
+
+    def multiply(self, a, b):
+        sa, sb = a.shape[-3], b.shape[-3]
+        lead = a.shape[:-3]
+        assert b.shape[:-3] == lead
+        count = 1
+        for d in lead:
+            count *= d
+        out = self.ctx.empty(*lead, size=sa + sb - 1)
+        nbytes = _lib.load().fhe_multiply_scratch_bytes(self.ctx.h, sa, sb, count)
+        scr = self._scratch_buf(nbytes)
+        _lib.call("fhe_multiply", self.ctx.h, _ptr(a), sa, _ptr(b), sb, _ptr(out), count, _ptr(scr), nbytes, _stream())
+        return out
+
+    def square(self, a):
+        sa = a.shape[-3]
+        lead = a.shape[:-3]
+        count = 1
+        for d in lead:
+            count *= d
+        out = self.ctx.empty(*lead, size=2 * sa - 1)
+        nbytes = _lib.load().fhe_multiply_scratch_bytes(self.ctx.h, sa, sa, count)
+        scr = self._scratch_buf(nbytes)
+        _lib.call("fhe_square", self.ctx.h, _ptr(a), sa, _ptr(out), count, _ptr(scr), nbytes, _stream())
+        return out
+
+    def relinearize(self, a, evk_ntt, dbc):
+        assert a.shape[-3] == 3
+        work = a.clone()
+        stride = 3 * self.ctx.k * self.ctx.n
+        count = work.numel() // stride
+        nbytes = _lib.load().fhe_relinearize_scratch_bytes(self.ctx.h, dbc, count)
+        scr = self._scratch_buf(nbytes)
+        _lib.call("fhe_relinearize", self.ctx.h, _ptr(work), stride, count, _ptr(evk_ntt), dbc, _ptr(scr), nbytes, _stream())
+        return work[..., :2, :, :].contiguous()
+
+    # -- primitives named by the north star ---------------------------------------------------------
+    def ntt_forward(self, a, out=None):
+        out = torch.empty_like(a) if out is None else out
+        _lib.call("fhe_ntt_forward", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _stream())
+        return out
+
+    def ntt_inverse(self, a, out=None):
+        out = torch.empty_like(a) if out is None else out
+        _lib.call("fhe_ntt_inverse", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _stream())
+        return out
+
+    def dyadic_multiply(self, a, b, out=None):
+        out = torch.empty_like(a) if out is None else out
+        _lib.call("fhe_dyadic_multiply", self.ctx.h, _ptr(a), _ptr(b), _ptr(out), self._npolys(a), _stream())
+        return out
+
+    # -- fused circuits ---------------------------------------------------------------------------
+    def dct8x8_quant(self, plan, blocks, out=None):
+        """encrypted_dct + quantize_fhe on [n_blocks, 64, 2, k, n] (homo/fhe_image.h:196-305)."""
+        assert blocks.shape[-4:] == (64, 2, self.ctx.k, self.ctx.n) and blocks.is_contiguous()
+        out = torch.empty_like(blocks) if out is None else out
+        n_blocks = blocks.numel() // (64 * 2 * self.ctx.k * self.ctx.n)
+        nbytes = _lib.load().fhe_dct8x8_scratch_bytes(self.ctx.h, n_blocks)
+        scr = self._scratch_buf(nbytes)
+        _lib.call("fhe_dct8x8_quant", self.ctx.h, plan.h, _ptr(blocks), _ptr(out), n_blocks, _ptr(scr), nbytes, _stream())
+        return out
+
+    def rgb_to_ycc(self, r, g, b, int_coeffs=100, frac_coeffs=100):
+        """rgb_to_ycc_fhe on [count, 2, k, n] tensors, in place (homo/fhe_image.h:310-325)."""
+        count = r.numel() // (2 * self.ctx.k * self.ctx.n)
+        _lib.call("fhe_rgb_to_ycc", self.ctx.h, _ptr(r), _ptr(g), _ptr(b), count, int_coeffs, frac_coeffs, _stream())
+        return r, g, b

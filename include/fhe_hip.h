@@ -1,0 +1,174 @@
+/*
+ * fhe_hip.h -- C ABI of libfhe_hip.so: BFV ciphertext arithmetic on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the ONE hot path of wfus/Fully-Homomorphic-Image-Processing:
+ * the arithmetic that homo/server_jpeg.cpp, server_resize.cpp and server_decode.cpp reach through
+ * Microsoft SEAL v2.3's C++ class API (seal::Evaluator et al.).  The reference has no FFI of its
+ * own; its seam is `#include "seal/seal.h"` (homo/fhe_image.h:13).  The SEAL-shaped C++ facade in
+ * fully-homomorphic-image-processing_amd/seal/seal.h forwards every Evaluator call to the entry
+ * points below, so homo/fhe_image.h, fhe_resize.h and fhe_decode.h compile unchanged against it.
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types.  `stream` is a hipStream_t passed as void*
+ *    (NULL = the default stream).  Device pointers are ordinary HIP device addresses (hipMalloc,
+ *    torch.empty(device="cuda").data_ptr(), ...).  Calls are asynchronous on `stream`.
+ *  - every function returns FHE_OK (0) or a negative error code; fhe_last_error() gives the text
+ *    (thread-local).  Nothing throws.  There is NO CPU fallback: without a HIP device every
+ *    compute entry point fails with FHE_ERR_HIP.
+ *  - ciphertext layout (SEAL-logical): u64 [ciphertext][poly j][prime i][coeff c], every residue
+ *    fully reduced to [0, q_i).  "n_polys" counts RNS polynomials, i.e. size * number of cts.
+ *  - "NTT form" buffers use a library-internal slot order; they are only meaningful to this
+ *    library (produced by fhe_plain_prepare / fhe_ntt_forward, consumed by the matching calls).
+ */
+#ifndef FHE_HIP_H
+#define FHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHE_OK 0
+#define FHE_ERR_PARAM (-1)  /* invalid argument / unsupported parameter set   */
+#define FHE_ERR_HIP (-2)    /* HIP runtime error (no device, launch failure)  */
+#define FHE_ERR_NOMEM (-3)
+
+#define FHE_MAX_K 8
+
+typedef struct fhe_ctx fhe_ctx;
+typedef struct fhe_dct_plan fhe_dct_plan;
+typedef void *fhe_stream;
+
+const char *fhe_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+uint32_t fhe_abi_version(void);
+
+/* ---- context: replaces seal::EncryptionParameters + seal::SEALContext -------------------------
+ * (homo/server_jpeg.cpp:74-80: set_poly_modulus("1x^n + 1"), set_coeff_modulus(coeff_modulus_128(n)),
+ *  set_plain_modulus(t)).  q_i must be distinct primes < 2^61 with q_i = 1 (mod 2n); n a power of
+ * two in [1024, 16384].  Tables (twiddles, Shoup companions, BEHZ base-conversion constants) are
+ * built on the host and uploaded to `device`. */
+int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int device, fhe_ctx **out);
+int fhe_ctx_destroy(fhe_ctx *ctx);
+uint32_t fhe_ctx_n(const fhe_ctx *ctx);
+uint32_t fhe_ctx_k(const fhe_ctx *ctx);
+uint64_t fhe_ctx_t(const fhe_ctx *ctx);
+uint64_t fhe_ctx_q(const fhe_ctx *ctx, uint32_t i);
+/* SEAL 2.3 `coeff_modulus_128(n)` replacement (homo/server_jpeg.cpp:78).  preset 0 = the
+ * 3x36/37-bit set BASELINE.json names for n=4096 (and the matching sets for other n),
+ * preset 1 = SEAL 2.3.1 defaults.  Returns the number of primes written (<= FHE_MAX_K) or <0. */
+int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out);
+
+/* ---- device memory helpers for hosts without their own allocator (the C++ facade) ------------ */
+int fhe_dev_alloc(size_t bytes, void **dptr);
+int fhe_dev_free(void *dptr);
+int fhe_upload(void *dst_dev, const void *src_host, size_t bytes, fhe_stream stream);
+int fhe_download(void *dst_host, const void *src_dev, size_t bytes, fhe_stream stream);
+int fhe_copy(void *dst_dev, const void *src_dev, size_t bytes, fhe_stream stream);
+int fhe_stream_sync(fhe_stream stream);
+
+/* ---- seal::FractionalEncoder(t, poly_modulus, int_coeffs, frac_coeffs, base=2) ------------------
+ * (ctor homo/server_jpeg.cpp:100; encode() call sites homo/fhe_image.h:221-236,259,301,317-319).
+ * Host-side, no device work.  plain_out must hold n coefficients; returns the significant
+ * coefficient count (0 for the zero plaintext) or <0. */
+int fhe_frac_encode(uint32_t n, uint64_t t, double value, int int_coeffs, int frac_coeffs,
+                    uint64_t *plain_out);
+double fhe_frac_decode(uint32_t n, uint64_t t, const uint64_t *plain, int int_coeffs, int frac_coeffs);
+
+/* ---- seal::Evaluator::add / sub / negate (homo/fhe_image.h:207-220, fhe_resize.h:151-169,
+ * fhe_decode.h:219).  Element-wise over n_polys RNS polynomials; out may alias a or b.
+ * Unequal ciphertext sizes are handled by the caller (facade) by running the common prefix
+ * through add/sub and the tail through copy/negate, as SEAL does. */
+int fhe_add(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys,
+            fhe_stream stream);
+int fhe_sub(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys,
+            fhe_stream stream);
+int fhe_negate(const fhe_ctx *ctx, const uint64_t *a, uint64_t *out, uint64_t n_polys, fhe_stream stream);
+
+/* ---- plaintext operands ---------------------------------------------------------------------------
+ * fhe_plain_prepare: centred lift of a seal::Plaintext (coefficients in [0,t), host memory) to the
+ * q-base followed by a forward NTT; writes 2*k*n u64 to d_plain_ntt (value + Shoup companion per
+ * slot).  Cache the result: the reference re-encodes and re-transforms the same 13 constants on
+ * every call (homo/fhe_image.h:221-236). */
+size_t fhe_plain_ntt_words(const fhe_ctx *ctx);
+int fhe_plain_prepare(const fhe_ctx *ctx, const uint64_t *plain_host, uint32_t plain_len,
+                      uint64_t *d_plain_ntt, fhe_stream stream);
+/* product of two prepared plaintexts as ring elements (used to fold encode(0.125)*encode(1/q)) */
+int fhe_plain_ntt_mul(const fhe_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out,
+                      fhe_stream stream);
+
+/* seal::Evaluator::multiply_plain (homo/fhe_image.h:221 etc.): every polynomial of the n_polys
+ * inputs is multiplied in R_q by the prepared plaintext (fused NTT -> dyadic -> inverse NTT).
+ * n_polys must be a multiple of k (whole RNS polynomials).  out may alias in. */
+int fhe_multiply_plain(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                       const uint64_t *d_plain_ntt, fhe_stream stream);
+/* seal::Evaluator::add_plain / sub_plain (homo/fhe_image.h:317 sub_plain(128.0); fhe_resize.h:196;
+ * fhe_decode.h:57,113,218,220,229): c_0 += sign * Delta * m' for `count` ciphertexts whose first
+ * polynomial starts every ct_stride_words u64. sign = +1 / -1. */
+int fhe_add_plain(const fhe_ctx *ctx, uint64_t *ct, uint64_t ct_stride_words, uint64_t count,
+                  const uint64_t *plain_host, uint32_t plain_len, int sign, fhe_stream stream);
+
+/* ---- negacyclic NTT over the q-base (north_star primitive; SEAL-internal in the reference) -----
+ * in: [n_polys][k][n] coefficient form; out: NTT form (internal slot order), values in [0,q_i). */
+int fhe_ntt_forward(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                    fhe_stream stream);
+int fhe_ntt_inverse(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                    fhe_stream stream);
+/* coefficient-wise (dyadic) product of two NTT-form operands with Barrett reduction */
+int fhe_dyadic_multiply(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out,
+                        uint64_t n_polys, fhe_stream stream);
+
+/* ---- seal::Evaluator::multiply / square (homo/fhe_resize.h:174-179,197-198; fhe_decode.h:67-97,
+ * 235,239): full-RNS BEHZ product of `count` pairs of ciphertexts of sizes size_a, size_b
+ * (each operand contiguous, [count][size][k][n]); out has size_a+size_b-1 polys per pair.
+ * scratch: device memory of at least fhe_multiply_scratch_bytes(). */
+size_t fhe_multiply_scratch_bytes(const fhe_ctx *ctx, uint32_t size_a, uint32_t size_b, uint64_t count);
+int fhe_multiply(const fhe_ctx *ctx, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                 uint32_t size_b, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes,
+                 fhe_stream stream);
+int fhe_square(const fhe_ctx *ctx, const uint64_t *a, uint32_t size_a, uint64_t *out, uint64_t count,
+               void *scratch, size_t scratch_bytes, fhe_stream stream);
+
+/* ---- seal::Evaluator::relinearize (north_star API surface; the reference never calls it, only
+ * tests/parameters.cpp:112 touches evaluation keys).  Key-switch inner product for `count`
+ * size-3 ciphertexts -> size 2, in place on the first two polys.  evk (device):
+ * [k][n_digits][2][k][n] in NTT form (internal order) as produced by fhe_evk_to_ntt. */
+uint32_t fhe_evk_digits(const fhe_ctx *ctx, uint32_t dbc);
+int fhe_relinearize(const fhe_ctx *ctx, uint64_t *ct3, uint64_t ct_stride_words, uint64_t count,
+                    const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch, size_t scratch_bytes,
+                    fhe_stream stream);
+size_t fhe_relinearize_scratch_bytes(const fhe_ctx *ctx, uint32_t dbc, uint64_t count);
+
+/* ---- fused block circuit: encrypted_dct (homo/fhe_image.h:196-288) followed by quantize_fhe
+ * (homo/fhe_image.h:294-305) on n_blocks independent 8x8 blocks.  in/out: [n_blocks][64][2][k][n].
+ * The 832 Evaluator calls per block are exact operations in R_q, so the kernels transform each
+ * input polynomial once, evaluate the whole linear circuit per NTT slot, and transform back:
+ * the ciphertexts are bit-identical to the op-at-a-time evaluation.
+ * quant64 == NULL builds a plan for encrypted_dct alone. */
+int fhe_dct_plan_create(const fhe_ctx *ctx, const double *quant64, int int_coeffs, int frac_coeffs,
+                        fhe_stream stream, fhe_dct_plan **out);
+int fhe_dct_plan_destroy(fhe_dct_plan *plan);
+size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *ctx, uint64_t n_blocks);
+int fhe_dct8x8_quant(const fhe_ctx *ctx, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out,
+                     uint64_t n_blocks, void *scratch, size_t scratch_bytes, fhe_stream stream);
+
+/* rgb_to_ycc_fhe (homo/fhe_image.h:310-325) on `count` pixels; r,g,b: [count][2][k][n], in place. */
+int fhe_rgb_to_ycc(const fhe_ctx *ctx, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count,
+                   int int_coeffs, int frac_coeffs, fhe_stream stream);
+
+/* ---- synthetic inputs and digests (bench / parity harness) --------------------------------------
+ * fill: value = splitmix64(seed ^ (first_linear_index + linear index)) mod q_i */
+int fhe_fill_random(const fhe_ctx *ctx, uint64_t *ct, uint64_t n_polys, uint64_t seed,
+                    uint64_t first_linear_index, fhe_stream stream);
+/* order-independent 64-bit digest: sum over elements of splitmix64(value ^ splitmix64(index0+i))
+ * mod 2^64, written to *d_out (device u64). */
+int fhe_digest(const fhe_ctx *ctx, const uint64_t *data, uint64_t count, uint64_t index0,
+               uint64_t *d_out, fhe_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

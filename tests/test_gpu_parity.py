@@ -1,0 +1,246 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle, bit for bit.
+
+All tests call libfhe_hip.so through the C ABI (ctypes) and compare with oracle/ on the same
+seeded inputs.  Integer work => the bar is exact equality.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(n=1024, q=[0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001], t=1 << 14)
+
+
+def _pair(fhe, om, name):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    p = SMALL if name == "SMALL" else om.PRESETS[name]
+    return fhe.SEALContext(p["n"], p["q"], p["t"]), om.Oracle(p["n"], p["q"], p["t"])
+
+
+@pytest.fixture(scope="module", params=["SMALL", "P4096", "P8192"])
+def pair(request, fhe, oracle_mod):
+    return _pair(fhe, oracle_mod, request.param)
+
+
+def test_fill_random_matches_oracle(pair, fhe):
+    ctx, orc = pair
+    g = fhe.to_host(ctx.random_ct(3, seed=fhe.SEED, first_index=17))
+    o = orc.random_ct(3, seed=fhe.SEED, first_index=17)
+    assert np.array_equal(g, o)
+
+
+def test_add_sub_negate(pair, fhe):
+    ctx, orc = pair
+    ev = fhe.Evaluator(ctx)
+    a, b = ctx.random_ct(4, seed=1), ctx.random_ct(4, seed=2)
+    ha, hb = fhe.to_host(a), fhe.to_host(b)
+    for i in range(4):
+        assert np.array_equal(fhe.to_host(ev.add(a, b))[i], orc.add(ha[i], hb[i]))
+        assert np.array_equal(fhe.to_host(ev.sub(a, b))[i], orc.sub(ha[i], hb[i]))
+        assert np.array_equal(fhe.to_host(ev.negate(a))[i], orc.negate(ha[i]))
+
+
+def test_add_sub_edge_values(pair, fhe):
+    """0, q-1 and equal operands: the modular wrap cases."""
+    ctx, orc = pair
+    ev = fhe.Evaluator(ctx)
+    a = np.zeros((2, ctx.k, ctx.n), dtype=np.uint64)
+    b = np.zeros_like(a)
+    for i, q in enumerate(ctx.q):
+        a[0, i, :] = q - 1
+        b[0, i, ::2] = q - 1
+        b[1, i, 1::2] = 1
+    da, db = fhe.to_device(a), fhe.to_device(b)
+    assert np.array_equal(fhe.to_host(ev.add(da, db)), orc.add(a, b))
+    assert np.array_equal(fhe.to_host(ev.sub(da, db)), orc.sub(a, b))
+    assert np.array_equal(fhe.to_host(ev.sub(db, da)), orc.sub(b, a))
+    assert np.array_equal(fhe.to_host(ev.negate(db)), orc.negate(b))
+
+
+def test_add_unequal_sizes(pair, fhe):
+    ctx, orc = pair
+    ev = fhe.Evaluator(ctx)
+    a, b = ctx.random_ct(size=2, seed=3), ctx.random_ct(size=4, seed=4)
+    ha, hb = fhe.to_host(a), fhe.to_host(b)
+    assert np.array_equal(fhe.to_host(ev.add(a, b)), orc.add(ha, hb))
+    assert np.array_equal(fhe.to_host(ev.sub(a, b)), orc.sub(ha, hb))
+    assert np.array_equal(fhe.to_host(ev.sub(b, a)), orc.sub(hb, ha))
+
+
+def test_ntt_roundtrip_and_product(pair, fhe):
+    """inverse(forward(x)) == x, and forward/dyadic/inverse == the oracle's ring product."""
+    ctx, orc = pair
+    ev = fhe.Evaluator(ctx)
+    a, b = ctx.random_ct(2, seed=5), ctx.random_ct(2, seed=6)
+    fa, fb = ev.ntt_forward(a), ev.ntt_forward(b)
+    assert np.array_equal(fhe.to_host(ev.ntt_inverse(fa)), fhe.to_host(a))
+    prod = fhe.to_host(ev.ntt_inverse(ev.dyadic_multiply(fa, fb)))
+    ha, hb = fhe.to_host(a), fhe.to_host(b)
+    for c in range(2):
+        for j in range(2):
+            for i, q in enumerate(ctx.q):
+                x, y = orc.ntt_fwd(ha[c, j, i], i), orc.ntt_fwd(hb[c, j, i], i)
+                ref = orc.ntt_inv(np.array([(int(u) * int(v)) % q for u, v in zip(x, y)], dtype=np.uint64), i)
+                assert np.array_equal(prod[c, j, i], ref)
+    # the forward transform is a permutation of the oracle's (slot order is internal)
+    h = fhe.to_host(fa)
+    assert np.array_equal(np.sort(h[0, 0, 0]), np.sort(orc.ntt_fwd(ha[0, 0, 0], 0)))
+
+
+CONSTS = [0.541196100, -1.847759065, 0.125, 3.0, 128.0, 1 / 16.0, -0.168736, 1.0, -1.0, 0.0, 1 / 99.0, -4.71238898038469]
+
+
+def test_encoder_matches_oracle(pair, fhe):
+    ctx, orc = pair
+    enc = fhe.FractionalEncoder(ctx)
+    for v in CONSTS + [255.0, -255.75, 1e-9, 12345.678]:
+        assert np.array_equal(enc.encode(v), orc.encode(v)), v
+        assert enc.decode(enc.encode(v)) == orc.decode(orc.encode(v))
+
+
+def test_multiply_plain(pair, fhe):
+    ctx, orc = pair
+    ev, enc = fhe.Evaluator(ctx), fhe.FractionalEncoder(ctx)
+    a = ctx.random_ct(2, seed=7)
+    ha = fhe.to_host(a)
+    for v in CONSTS:
+        got = fhe.to_host(ev.multiply_plain(a, enc.encode(v)))
+        for i in range(2):
+            assert np.array_equal(got[i], orc.multiply_plain(ha[i], orc.encode(v))), v
+
+
+def test_multiply_plain_dense_plaintext(pair, fhe):
+    """a plaintext with every coefficient set, including upper-half (negative) values"""
+    ctx, orc = pair
+    ev = fhe.Evaluator(ctx)
+    rng = np.random.default_rng(5)
+    plain = rng.integers(0, ctx.t, size=ctx.n, dtype=np.uint64)
+    plain[0], plain[1], plain[2] = ctx.t - 1, (ctx.t + 1) // 2, (ctx.t + 1) // 2 - 1
+    a = ctx.random_ct(size=3, seed=8)
+    assert np.array_equal(fhe.to_host(ev.multiply_plain(a, plain)), orc.multiply_plain(fhe.to_host(a), plain))
+
+
+def test_add_sub_plain(pair, fhe):
+    ctx, orc = pair
+    ev, enc = fhe.Evaluator(ctx), fhe.FractionalEncoder(ctx)
+    a = ctx.random_ct(3, seed=9)
+    ha = fhe.to_host(a)
+    for v in [128.0, -0.5, 1.0, -4.71238898038469, 3.0]:
+        p = enc.encode(v)
+        ga, gs = fhe.to_host(ev.add_plain(a, p)), fhe.to_host(ev.sub_plain(a, p))
+        for i in range(3):
+            assert np.array_equal(ga[i], orc.add_plain(ha[i], p)), v
+            assert np.array_equal(gs[i], orc.sub_plain(ha[i], p)), v
+
+
+@pytest.mark.parametrize("preset,n_blocks", [("SMALL", 3), ("P4096", 2)])
+def test_dct_quant_fused_vs_op_at_a_time(fhe, oracle_mod, preset, n_blocks):
+    """fused block circuit == the reference's 832 Evaluator calls, bit for bit"""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    blocks = ctx.random_ct(n_blocks, 64, seed=fhe.SEED)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    got = fhe.to_host(ev.dct8x8_quant(plan, blocks))
+    hb = fhe.to_host(blocks)
+    for b in range(n_blocks):
+        assert np.array_equal(got[b], orc.dct_quant(hb[b], fhe.YQT)), b
+
+
+def test_dct_without_quant(fhe, oracle_mod):
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    blocks = ctx.random_ct(1, 64, seed=77)
+    got = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, None), blocks))
+    assert np.array_equal(got[0], orc.encrypted_dct(fhe.to_host(blocks)[0]))
+
+
+def test_dct_via_evaluator_calls_matches_fused(fhe, oracle_mod):
+    """drive the GPU one Evaluator call at a time (the reference's shape) and compare with the fused kernel"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev, enc = fhe.Evaluator(ctx), fhe.FractionalEncoder(ctx)
+    blocks = ctx.random_ct(2, 64, seed=123)
+    cache = {}
+
+    def P(v):
+        if v not in cache:
+            cache[v] = fhe.PreparedPlain(ctx, enc.encode(v))
+        return cache[v]
+
+    def line(d, scale):
+        A, S, M = ev.add, ev.sub, ev.multiply_plain
+        t0, t7, t1, t6 = A(d[0], d[7]), S(d[0], d[7]), A(d[1], d[6]), S(d[1], d[6])
+        t2, t5, t3, t4 = A(d[2], d[5]), S(d[2], d[5]), A(d[3], d[4]), S(d[3], d[4])
+        t10, t13, t11, t12 = A(t0, t3), S(t0, t3), A(t1, t2), S(t1, t2)
+        o = [None] * 8
+        o[0], o[4] = A(t10, t11), S(t10, t11)
+        z1 = M(A(t12, t13), P(0.541196100))
+        o[2], o[6] = A(z1, M(t13, P(0.765366865))), A(z1, M(t12, P(-1.847759065)))
+        z1, z2, z3, z4 = A(t4, t7), A(t5, t6), A(t4, t6), A(t5, t7)
+        z5 = M(A(z3, z4), P(1.175875602))
+        t4, t5, t6, t7 = M(t4, P(0.298631336)), M(t5, P(2.053119869)), M(t6, P(3.072711026)), M(t7, P(1.501321110))
+        z1, z2 = M(z1, P(-0.899976223)), M(z2, P(-2.562915447))
+        z3, z4 = A(M(z3, P(-1.961570560)), z5), A(M(z4, P(-0.390180644)), z5)
+        o[7], o[5], o[3], o[1] = A(A(t4, z1), z3), A(A(t5, z2), z4), A(A(t6, z2), z3), A(A(t7, z1), z4)
+        return [M(x, P(0.125)) for x in o] if scale else o
+
+    data = [blocks[:, i].contiguous() for i in range(64)]      # each [n_blocks, 2, k, n]
+    for r in range(8):
+        data[8 * r:8 * r + 8] = line(data[8 * r:8 * r + 8], False)
+    for c in range(8):
+        col = line([data[c + 8 * i] for i in range(8)], True)
+        for i in range(8):
+            data[c + 8 * i] = col[i]
+    data = [ev.multiply_plain(d, P(1 / qv)) for d, qv in zip(data, fhe.YQT)]
+    import torch
+    stepwise = fhe.to_host(torch.stack(data, dim=1))
+    fused = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
+    assert np.array_equal(stepwise, fused)
+    assert np.array_equal(fused[1], orc.dct_quant(fhe.to_host(blocks)[1], fhe.YQT))
+
+
+def test_rgb_to_ycc(fhe, oracle_mod):
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    r, g, b = ctx.random_ct(3, seed=31), ctx.random_ct(3, seed=32), ctx.random_ct(3, seed=33)
+    hr, hg, hb = fhe.to_host(r).copy(), fhe.to_host(g).copy(), fhe.to_host(b).copy()
+    ev.rgb_to_ycc(r, g, b)
+    for i in range(3):
+        y, u, v = orc.rgb_to_ycc(hr[i], hg[i], hb[i])
+        assert np.array_equal(fhe.to_host(r)[i], y)
+        assert np.array_equal(fhe.to_host(g)[i], u)
+        assert np.array_equal(fhe.to_host(b)[i], v)
+
+
+def test_dct_known_answer_through_decrypt(fhe, oracle_mod):
+    """decrypt(GPU circuit(encrypt(pixels))) == the plaintext DCT of homo/fhe_image.h:400-484 / quant"""
+    from oracle import bigint_model as bm
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    ev = fhe.Evaluator(ctx)
+    sk, pk = orc.keygen(42)
+    vals = [float((37 * x + 101 * y + 13) % 256) - 128.0 for y in range(8) for x in range(8)]
+    blk = np.stack([orc.encrypt(pk, orc.encode(v), seed=1000 + i) for i, v in enumerate(vals)])[None]
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))[0]
+    expect = bm.plain_dct(vals)
+    for i in range(64):
+        plain, budget = orc.decrypt(sk, out[i])
+        assert budget > 0
+        assert abs(orc.decode(plain) - expect[i] / fhe.YQT[i]) < 1e-6   # tolerance: decode is exact up to double rounding
+
+
+def test_digest_is_order_independent_and_matches_numpy(fhe, oracle_mod):
+    ctx, _ = _pair(fhe, oracle_mod, "SMALL")
+    a = ctx.random_ct(2, seed=55)
+    h = fhe.to_host(a).ravel()
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    ref = 0
+    for i, v in enumerate(h[:5000]):
+        ref = (ref + sm(int(v) ^ sm(i))) & M
+    assert ctx.digest(a.view(-1)[:5000].contiguous()) == ref
