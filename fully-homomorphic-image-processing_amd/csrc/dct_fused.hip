@@ -1,0 +1,300 @@
+// dct_fused.hip -- the headline kernels: encrypted_dct + quantize_fhe (homo/fhe_image.h:196-305)
+// as two fused launches per wave of blocks, with exact FP64-FMA modular arithmetic.
+//
+// Why FP64.  gfx950 has no 64-bit integer multiplier; a Shoup modular product costs ~10 quarter/half
+// rate 32-bit multiplies (measured 4.6 lane-products/clk/CU, profiles/r01_ubench_*).  For primes
+// below 2^48 the same residue can be computed EXACTLY with five double-precision operations
+//     h = y*w;  l = fma(y,w,-h);  q = rint(h/p);  r = fma(-q,p,h) + l          (|r| <= p/2 + eps)
+// (h+l is the exact 106-bit product, q p is exact, so r is the exact centred remainder), measured
+// at 10.1 lane-products/clk/CU.  Values stay integers of magnitude < 2^53 throughout, additions
+// need no reduction at all, and the final residues are bit-identical to the u64 path.  This is
+// integer modular arithmetic carried by the FP64 FMA pipe, not floating-point approximation.
+//
+// Dataflow per (block, polynomial j, prime i):
+//   kernel A (rows):    for each row: x_m = d_m +- d_(7-m) on coefficients, forward NTT of the
+//                       four sums (even half) or differences (odd half), the even/odd part of the
+//                       LL&M row pass per NTT slot, store the four row outputs (NTT form, FP64)
+//   kernel B (columns): same for columns on the NTT-form intermediates, per-output scale
+//                       encode(0.125)*encode(1/quant) folded into one product, inverse NTT, store.
+// Each workgroup (256 threads at n=4096) carries 4 polynomials x 16 coefficients per thread in
+// registers and shares every twiddle across the four; the even and odd workgroup of a line read the
+// same eight inputs and are placed on the same XCD (blockIdx = 16g+u and 16g+8+u) so the second
+// read is an L2 hit.  All 832 Evaluator calls of the reference are exact ring operations, so this
+// evaluation order yields bit-identical ciphertexts.
+#include "internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ double mm(double y, double w, double p, double pinv) {
+    const double h = y * w;
+    const double l = __builtin_fma(y, w, -h);
+    const double q = __builtin_rint(h * pinv);
+    return __builtin_fma(-q, p, h) + l;
+}
+__device__ __forceinline__ double red(double x, double p, double pinv) {
+    return __builtin_fma(-__builtin_rint(x * pinv), p, x);
+}
+
+template <int L, int P, int M>
+__device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double *__restrict__ tw, double p, double pinv, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const double w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double T = mm(x[m][r1], w, p, pinv);
+                const double X = x[m][r0];
+                x[m][r0] = X + T;
+                x[m][r1] = X - T;
+            }
+        }
+    }
+}
+
+template <int L, int P, int M>
+__device__ __forceinline__ void inv_pass(double (&x)[M][16], const double *__restrict__ itw, double p, double pinv, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = S - 1; u >= 0; u--) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const double w = itw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double X = x[m][r0], Y = x[m][r1];
+                const double Sm = X + Y, D = X - Y;
+                x[m][r0] = (sigma == 0) ? mm(Sm, itw[0], p, pinv) : Sm;
+                x[m][r1] = mm(D, w, p, pinv);
+            }
+        }
+    }
+}
+
+// M polynomials through two alternating LDS buffers: one barrier per polynomial
+template <int L, int LO_FROM, int LO_TO, int M>
+__device__ __forceinline__ void transpose(double (&x)[M][16], double *lds, int tid, int &phase) {
+    constexpr int PL = imin(LO_FROM, LO_TO);
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        double *buf = lds + (phase & 1) * NttShape<L>::LDS_WORDS;
+        phase++;
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf[lds_pad<PL>(elem_index<LO_FROM>(tid, r))] = x[m][r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[m][r] = buf[lds_pad<PL>(elem_index<LO_TO>(tid, r))];
+    }
+}
+
+template <int L, int M, int P = 0>
+__device__ __forceinline__ void ntt_fwd(double (&x)[M][16], const double *__restrict__ tw, double p, double pinv, double *lds, int tid, int &phase) {
+    fwd_pass<L, P, M>(x, tw, p, pinv, tid);
+    if constexpr (P + 1 < NttShape<L>::NP) {
+        transpose<L, pass_lo(L, P), pass_lo(L, P + 1), M>(x, lds, tid, phase);
+        ntt_fwd<L, M, P + 1>(x, tw, p, pinv, lds, tid, phase);
+    }
+}
+template <int L, int M, bool BIG, int P = NttShape<L>::NP - 1>
+__device__ __forceinline__ void ntt_inv(double (&x)[M][16], const double *__restrict__ itw, double p, double pinv, double *lds, int tid, int &phase) {
+    inv_pass<L, P, M>(x, itw, p, pinv, tid);
+    if constexpr (P > 0) {
+        if constexpr (BIG) {
+#pragma unroll
+            for (int m = 0; m < M; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) x[m][r] = red(x[m][r], p, pinv);
+        }
+        transpose<L, pass_lo(L, P), pass_lo(L, P - 1), M>(x, lds, tid, phase);
+        ntt_inv<L, M, BIG, P - 1>(x, itw, p, pinv, lds, tid, phase);
+    }
+}
+
+// Even / odd half of one LL&M line (homo/fhe_image.h:215-242) on a single NTT slot.
+// In:  even: x[m] = d_m + d_(7-m) (tmp0..tmp3);  odd: x[m] = d_m - d_(7-m) (tmp7,tmp6,tmp5,tmp4).
+// Out: x[m] = line output 2m + half.   C(cid) = constant cid at this slot.
+template <typename CF>
+__device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, double &x3, int half, double p, double pinv, CF C) {
+    if (half == 0) {
+        const double tmp10 = x0 + x3, tmp13 = x0 - x3, tmp11 = x1 + x2, tmp12 = x1 - x2;
+        const double z1 = mm(tmp12 + tmp13, C(0), p, pinv);
+        x0 = tmp10 + tmp11;                        // out 0
+        x2 = tmp10 - tmp11;                        // out 4
+        x1 = z1 + mm(tmp13, C(1), p, pinv);        // out 2
+        x3 = z1 + mm(tmp12, C(2), p, pinv);        // out 6
+    } else {
+        const double tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
+        double z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+        const double z5 = mm(z3 + z4, C(3), p, pinv);
+        const double t4 = mm(tmp4, C(4), p, pinv), t5 = mm(tmp5, C(5), p, pinv);
+        const double t6 = mm(tmp6, C(6), p, pinv), t7 = mm(tmp7, C(7), p, pinv);
+        z1 = mm(z1, C(8), p, pinv);
+        z2 = mm(z2, C(9), p, pinv);
+        z3 = mm(z3, C(10), p, pinv) + z5;
+        z4 = mm(z4, C(11), p, pinv) + z5;
+        x0 = t7 + z1 + z4;                         // out 1
+        x1 = t6 + z2 + z3;                         // out 3
+        x2 = t5 + z2 + z4;                         // out 5
+        x3 = t4 + z1 + z3;                         // out 7
+    }
+}
+
+struct Work { u32 blk, line, poly, prime, half; };
+// blockIdx -> work item; the two halves of an item sit 8 apart so they land on the same XCD
+__device__ __forceinline__ Work decode(u32 idx, u32 k) {
+    const u32 w = ((idx >> 4) << 3) | (idx & 7);
+    Work o;
+    o.half = (idx >> 3) & 1;
+    o.prime = w % k;
+    u32 t = w / k;
+    o.poly = t & 1;
+    t >>= 1;
+    o.line = t & 7;
+    o.blk = t >> 3;
+    return o;
+}
+
+template <int L, bool BIG>
+__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
+                                                               const double *__restrict__ consts, const double *__restrict__ tw_all,
+                                                               const Modulus *__restrict__ mods, u32 k) {
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const Work wk = decode(blockIdx.x, k);
+    const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
+    const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
+    const size_t base = ((size_t)wk.blk * 64 + 8 * wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
+    double x[4][16];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const u64 *a = in + base + (size_t)m * ct_words, *b = in + base + (size_t)(7 - m) * ct_words;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = elem_index<L - 4>(tid, r);
+            const double A = (double)a[j], B = (double)b[j];
+            x[m][r] = wk.half ? A - B : A + B;
+        }
+    }
+    int phase = 0;
+    ntt_fwd<L, 4>(x, tw_all + (size_t)wk.prime * N, p, pinv, lds, tid, phase);
+    const double *cp = consts + (size_t)wk.prime * N + tid;
+    const size_t cstride = (size_t)k * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
+        line_half(x[0][r], x[1][r], x[2][r], x[3][r], wk.half, p, pinv, C);
+        if (BIG) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) x[m][r] = red(x[m][r], p, pinv);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        double *o = mid + base + (size_t)(2 * m + wk.half) * ct_words + tid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r * TP] = x[m][r];
+    }
+}
+
+template <int L, bool BIG>
+__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
+                                                               const double *__restrict__ consts, const double *__restrict__ itw_all,
+                                                               const Modulus *__restrict__ mods, u32 k) {
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const Work wk = decode(blockIdx.x, k);   // line = column index
+    const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
+    const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
+    const size_t base = ((size_t)wk.blk * 64 + wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
+    const size_t row_stride = 8 * ct_words;
+    double x[4][16];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const double *a = mid + base + (size_t)m * row_stride + tid, *b = mid + base + (size_t)(7 - m) * row_stride + tid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double A = a[r * TP], B = b[r * TP];
+            x[m][r] = wk.half ? A - B : A + B;
+        }
+    }
+    const double *cp = consts + (size_t)wk.prime * N + tid;
+    const size_t cstride = (size_t)k * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
+        line_half(x[0][r], x[1][r], x[2][r], x[3][r], wk.half, p, pinv, C);
+#pragma unroll
+        for (int m = 0; m < 4; m++)   // output (row 2m+half, column line): scale id 12 + 8*row + col
+            x[m][r] = mm(x[m][r], C(12 + 8 * (2 * m + (int)wk.half) + (int)wk.line), p, pinv);
+    }
+    int phase = 0;
+    ntt_inv<L, 4, BIG>(x, itw_all + (size_t)wk.prime * N, p, pinv, lds, tid, phase);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        u64 *o = out + base + (size_t)(2 * m + wk.half) * row_stride;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            double v = x[m][r];
+            v = v < 0.0 ? v + p : v;
+            o[elem_index<L - 4>(tid, r)] = (u64)v;
+        }
+    }
+}
+
+__global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n, u32 total) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 q = mods[(i / n) % k].q;
+    const u64 w = in[i].x;
+    out[i] = w > q / 2 ? -(double)(q - w) : (double)w;
+}
+
+}  // namespace
+
+bool fhe_dct_f64_supported(const fhe_ctx *c) {
+    return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && c->logn >= 10 && c->logn <= 13;
+}
+
+int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
+    const u32 total = DCT_NCONST * c->k * c->n;
+    HIP_TRY(hipMalloc(&plan->d_consts_f64, sizeof(double) * total));
+    k_consts_to_f64<<<(total + 255) / 256, 256, 0, st>>>(plan->d_consts, plan->d_consts_f64, c->qb.d_mod, c->k, c->n, total);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st) {
+    const u64 items = n_blocks * 8 * 2 * c->k;   // (block, line, poly, prime), multiple of 8
+    const u64 grid = items * 2;
+    if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
+    const bool big = c->max_prime_bits > 40;
+#define LAUNCH(LL, BB)                                                                                                        \
+    do {                                                                                                                      \
+        k_dct_rows<LL, BB><<<(unsigned)grid, NttShape<LL>::TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);  \
+        k_dct_cols<LL, BB><<<(unsigned)grid, NttShape<LL>::TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k); \
+    } while (0)
+    switch (c->logn) {
+        case 10: if (big) LAUNCH(10, true); else LAUNCH(10, false); break;
+        case 11: if (big) LAUNCH(11, true); else LAUNCH(11, false); break;
+        case 12: if (big) LAUNCH(12, true); else LAUNCH(12, false); break;
+        case 13: if (big) LAUNCH(13, true); else LAUNCH(13, false); break;
+        default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in [1024, 8192]");
+    }
+#undef LAUNCH
+    KERNEL_CHECK();
+    return FHE_OK;
+}

@@ -1,26 +1,24 @@
 // fhe_hip.hip -- libfhe_hip.so: HIP kernels (gfx950) + the C ABI of include/fhe_hip.h.
 //
 // Product code.  Never includes, links or calls anything under oracle/.
-#include "../../include/fhe_hip.h"
-
-#include <hip/hip_runtime.h>
+#include "internal.h"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "host_math.h"
-#include "modarith.h"
-#include "ntt_core.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int fhe_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -29,16 +27,6 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
-    } while (0)
-#define KERNEL_CHECK()                                                                            \
-    do {                                                                                          \
-        hipError_t e_ = hipGetLastError();                                                        \
-        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e_)); \
-    } while (0)
 
 extern "C" const char *fhe_last_error(void) { return g_err.c_str(); }
 extern "C" uint32_t fhe_abi_version(void) { return 1; }
@@ -46,27 +34,7 @@ extern "C" uint32_t fhe_abi_version(void) { return 1; }
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-struct BaseTables {
-    std::vector<u64> primes;
-    ulonglong2 *d_tw = nullptr, *d_itw = nullptr;
-    Modulus *d_mod = nullptr;
-    std::vector<Modulus> h_mod;
-    RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size()}; }
-};
-
-struct fhe_ctx {
-    u32 n = 0, logn = 0, k = 0;
-    u64 t = 0;
-    int device = 0;
-    BaseTables qb;     // q-base
-    // plaintext lifting (SEAL 2.3 multiply_plain / preencrypt semantics)
-    u64 upper_half_threshold = 0;
-    u64 plain_upper_half_increment[FHE_MAX_K] = {0};   // (q - t) mod q_i
-    u64 delta_mod[FHE_MAX_K] = {0};                    // floor(q/t) mod q_i
-    u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
-};
-
-static int build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn) {
+int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64) {
     using namespace hostmath;
     const size_t cnt = primes.size();
     B.primes = primes;
@@ -104,12 +72,31 @@ static int build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 
     HIP_TRY(hipMemcpy(B.d_tw, tw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(B.d_itw, itw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(B.d_mod, B.h_mod.data(), sizeof(Modulus) * cnt, hipMemcpyHostToDevice));
+    if (want_f64) {
+        // the same twiddles as centred doubles for the exact-FP64 kernels (dct_fused.hip)
+        std::vector<double> twd(cnt * n), itwd(cnt * n);
+        for (size_t i = 0; i < cnt; ++i) {
+            const u64 q = primes[i];
+            auto centred = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
+            for (u32 j = 0; j < n; ++j) {
+                twd[i * n + j] = centred(tw[i * n + j].x);
+                itwd[i * n + j] = centred(itw[i * n + j].x);
+            }
+        }
+        HIP_TRY(hipMalloc(&B.d_tw_f64, sizeof(double) * cnt * n));
+        HIP_TRY(hipMalloc(&B.d_itw_f64, sizeof(double) * cnt * n));
+        HIP_TRY(hipMemcpy(B.d_tw_f64, twd.data(), sizeof(double) * cnt * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(B.d_itw_f64, itwd.data(), sizeof(double) * cnt * n, hipMemcpyHostToDevice));
+    }
     return FHE_OK;
 }
-static void free_base(BaseTables &B) {
+void fhe_free_base(BaseTables &B) {
     if (B.d_tw) (void)hipFree(B.d_tw);
     if (B.d_itw) (void)hipFree(B.d_itw);
     if (B.d_mod) (void)hipFree(B.d_mod);
+    if (B.d_tw_f64) (void)hipFree(B.d_tw_f64);
+    if (B.d_itw_f64) (void)hipFree(B.d_itw_f64);
+    B.d_tw_f64 = B.d_itw_f64 = nullptr;
     B.d_tw = B.d_itw = nullptr;
     B.d_mod = nullptr;
 }
@@ -167,7 +154,8 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
     c->t = t;
     c->device = device;
     while ((1u << c->logn) < n) ++c->logn;
-    int rc = build_base(c->qb, primes, n, c->logn);
+    for (u32 i = 0; i < k; ++i) c->max_prime_bits = std::max(c->max_prime_bits, bit_length(primes[i]));
+    int rc = fhe_build_base(c->qb, primes, n, c->logn, c->max_prime_bits <= 47);
     if (rc) { delete c; return rc; }
     // plaintext lifting constants
     BigUInt Q(1);
@@ -186,7 +174,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
 
 extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     if (!c) return FHE_OK;
-    free_base(c->qb);
+    fhe_free_base(c->qb);
     delete c;
     return FHE_OK;
 }
@@ -419,17 +407,7 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_mulplain(const u64 *__restr
     store_coeff<L>(x, out + rp * N, tid);
 }
 
-#define DISPATCH_L(logn, ...)                                                    \
-    switch (logn) {                                                              \
-        case 10: { constexpr int L = 10; __VA_ARGS__; } break;                          \
-        case 11: { constexpr int L = 11; __VA_ARGS__; } break;                          \
-        case 12: { constexpr int L = 12; __VA_ARGS__; } break;                          \
-        case 13: { constexpr int L = 13; __VA_ARGS__; } break;                          \
-        case 14: { constexpr int L = 14; __VA_ARGS__; } break;                          \
-        default: return fail(FHE_ERR_PARAM, "unsupported log2(n)=%u", logn);     \
-    }
-
-static int ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st) {
+int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st) {
     if (n_res_polys == 0) return FHE_OK;
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const RnsBase base = B.dev();
@@ -443,11 +421,11 @@ static int ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const
 
 extern "C" int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
-    return ntt_launch(false, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
+    return fhe_ntt_launch(false, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 extern "C" int fhe_ntt_inverse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
-    return ntt_launch(true, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
+    return fhe_ntt_launch(true, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 
 extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys,
@@ -503,7 +481,7 @@ extern "C" int fhe_plain_prepare(const fhe_ctx *c, const uint64_t *plain, uint32
     HIP_TRY(hipMallocAsync((void **)&tmp, 2 * words * sizeof(u64), st));
     HIP_TRY(hipMemcpyAsync(tmp, lifted.data(), words * sizeof(u64), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    rc = ntt_launch(false, c, c->qb, tmp, tmp + words, c->k, st);
+    rc = fhe_ntt_launch(false, c, c->qb, tmp, tmp + words, c->k, st);
     if (rc) return rc;
     k_make_shoup<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(tmp + words, (ulonglong2 *)d_out, c->qb.d_mod, c->n, (u32)words);
     KERNEL_CHECK();
@@ -555,14 +533,6 @@ extern "C" int fhe_dyadic_multiply(const fhe_ctx *c, const uint64_t *a, const ui
 //   cid 12..75 : per-output scale = encode(0.125) [* encode(1/quant[i])], i = row-major output index
 static const double kDctConst[12] = {0.541196100, 0.765366865, -1.847759065, 1.175875602, 0.298631336, 2.053119869,
                                      3.072711026, 1.501321110, -0.899976223, -2.562915447, -1.961570560, -0.390180644};
-#define DCT_NCONST 76
-
-struct fhe_dct_plan {
-    ulonglong2 *d_consts = nullptr;   // [DCT_NCONST][k][n]
-    u32 k = 0, n = 0;
-    bool has_quant = false;
-};
-
 // One 1-D LL&M pass on eight fully reduced residues (same dataflow as homo/fhe_image.h:207-242).
 // C(cid) yields the Shoup pair of constant cid at this thread's slot.
 template <typename CF>
@@ -642,7 +612,7 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
     auto cleanup = [&](int code) {
         if (d_eighth) (void)hipFree(d_eighth);
         if (d_tmp) (void)hipFree(d_tmp);
-        if (code) { (void)hipFree(p->d_consts); delete p; }
+        if (code) { (void)hipFree(p->d_consts); if (p->d_consts_f64) (void)hipFree(p->d_consts_f64); delete p; }
         return code;
     };
     auto prep = [&](double v, ulonglong2 *dst) -> int {
@@ -666,6 +636,7 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
                 return cleanup(rc);
         }
     }
+    if (fhe_dct_f64_supported(c) && (rc = fhe_dct_f64_make_consts(c, p, (hipStream_t)s))) return cleanup(rc);
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return cleanup(fail(FHE_ERR_HIP, "stream sync failed"));
     *out = p;
     return cleanup(FHE_OK);
@@ -673,29 +644,53 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
 extern "C" int fhe_dct_plan_destroy(fhe_dct_plan *p) {
     if (!p) return FHE_OK;
     if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_consts_f64) (void)hipFree(p->d_consts_f64);
     delete p;
     return FHE_OK;
 }
-extern "C" size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *, uint64_t) { return 0; }
+// The fused path keeps one row-transformed copy of a wave of blocks between its two kernels.
+// Waves are capped so the intermediate (12 MiB per block at n=4096, k=3) can be reused while it
+// is still resident in the 256 MiB Infinity Cache.
+static u64 dct_wave_blocks() {
+    if (const char *e = getenv("FHE_DCT_WAVE_BLOCKS")) { u64 v = strtoull(e, nullptr, 10); if (v) return v; }
+    return 64;
+}
+extern "C" size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *c, uint64_t n_blocks) {
+    if (!c || !fhe_dct_f64_supported(c)) return 0;
+    const u64 wave = dct_wave_blocks() < n_blocks ? dct_wave_blocks() : n_blocks;
+    return (size_t)wave * 64 * 2 * c->k * c->n * sizeof(double);
+}
 
 extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out, uint64_t n_blocks,
-                                void *, size_t, fhe_stream s) {
+                                void *scratch, size_t scratch_bytes, fhe_stream s) {
     if (!c || !plan || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
     if (plan->k != c->k || plan->n != c->n) return fail(FHE_ERR_PARAM, "plan was built for another context");
     if (n_blocks == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)s;
-    // launches are chunked so that grid dimensions stay in range
+    if (plan->d_consts_f64 && fhe_dct_f64_supported(c) && !getenv("FHE_DCT_FORCE_U64")) {
+        const size_t per_block = (size_t)64 * 2 * c->k * c->n;
+        const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(double)) : 0;
+        if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
+        const u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
+        for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
+            const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
+            int rc = fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st);
+            if (rc) return rc;
+        }
+        return FHE_OK;
+    }
+    // general path (any prime below 2^61): three launches per chunk, u64 Shoup arithmetic
     const u64 polys_per_block = 64 * 2;   // RNS polynomials (of k residues) per block
     const u64 max_blocks = 4096;
     for (u64 b0 = 0; b0 < n_blocks; b0 += max_blocks) {
         const u64 nb = (n_blocks - b0) < max_blocks ? (n_blocks - b0) : max_blocks;
         const size_t off = (size_t)b0 * polys_per_block * c->k * c->n;
-        int rc = ntt_launch(false, c, c->qb, (const u64 *)in + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
+        int rc = fhe_ntt_launch(false, c, c->qb, (const u64 *)in + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
         if (rc) return rc;
         dim3 grid(c->n / 256, (unsigned)(nb * 2 * c->k));
         k_dct_slots<<<grid, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_mod, c->k, c->n);
         KERNEL_CHECK();
-        rc = ntt_launch(true, c, c->qb, (const u64 *)out + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
+        rc = fhe_ntt_launch(true, c, c->qb, (const u64 *)out + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
         if (rc) return rc;
     }
     return FHE_OK;

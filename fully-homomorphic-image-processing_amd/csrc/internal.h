@@ -1,0 +1,75 @@
+// internal.h -- shared declarations of the library's translation units (not part of the ABI).
+#pragma once
+#include "../../include/fhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "modarith.h"
+#include "ntt_core.h"
+
+int fhe_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail fhe_fail
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+#define KERNEL_CHECK()                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(FHE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+struct BaseTables {
+    std::vector<u64> primes;
+    ulonglong2 *d_tw = nullptr, *d_itw = nullptr;
+    Modulus *d_mod = nullptr;
+    std::vector<Modulus> h_mod;
+    // exact-FP64 companion tables (only when every prime is below 2^48): centred twiddles as doubles
+    double *d_tw_f64 = nullptr, *d_itw_f64 = nullptr;   // [count][n]
+    RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size()}; }
+};
+
+struct fhe_ctx {
+    u32 n = 0, logn = 0, k = 0;
+    u64 t = 0;
+    int device = 0;
+    int max_prime_bits = 0;
+    BaseTables qb;     // q-base
+    // plaintext lifting (SEAL 2.3 multiply_plain / preencrypt semantics)
+    u64 upper_half_threshold = 0;
+    u64 plain_upper_half_increment[FHE_MAX_K] = {0};   // (q - t) mod q_i
+    u64 delta_mod[FHE_MAX_K] = {0};                    // floor(q/t) mod q_i
+    u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
+    struct BehzTables *behz = nullptr;                 // ct x ct tables (behz.hip)
+};
+
+#define DCT_NCONST 76
+struct fhe_dct_plan {
+    ulonglong2 *d_consts = nullptr;   // [DCT_NCONST][k][n] Shoup pairs, slot order
+    double *d_consts_f64 = nullptr;   // [DCT_NCONST][k][n] centred doubles (FP64 path), or null
+    u32 k = 0, n = 0;
+    bool has_quant = false;
+};
+
+#define DISPATCH_L(logn, ...)                                                    \
+    switch (logn) {                                                              \
+        case 10: { constexpr int L = 10; __VA_ARGS__; } break;                   \
+        case 11: { constexpr int L = 11; __VA_ARGS__; } break;                   \
+        case 12: { constexpr int L = 12; __VA_ARGS__; } break;                   \
+        case 13: { constexpr int L = 13; __VA_ARGS__; } break;                   \
+        case 14: { constexpr int L = 14; __VA_ARGS__; } break;                   \
+        default: return fail(FHE_ERR_PARAM, "unsupported log2(n)=%u", logn);     \
+    }
+
+// cross-TU internals
+int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
+int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
+void fhe_free_base(BaseTables &B);
+// fused FP64 DCT path (dct_fused.hip)
+bool fhe_dct_f64_supported(const fhe_ctx *c);
+int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st);
+int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);

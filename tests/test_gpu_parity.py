@@ -244,3 +244,31 @@ def test_digest_is_order_independent_and_matches_numpy(fhe, oracle_mod):
     for i, v in enumerate(h[:5000]):
         ref = (ref + sm(int(v) ^ sm(i))) & M
     assert ctx.digest(a.view(-1)[:5000].contiguous()) == ref
+
+
+@pytest.mark.parametrize("preset,n_blocks", [("P4096", 3), ("SEAL3_8192", 1), ("SEAL23_4096", 1)])
+def test_dct_fp64_path_equals_u64_path(fhe, oracle_mod, preset, n_blocks, monkeypatch):
+    """The exact-FP64 fused kernels and the general u64 Shoup kernels produce identical bytes
+    (SEAL23_4096 has 55-bit primes and always takes the u64 path)."""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    blocks = ctx.random_ct(n_blocks, 64, seed=99)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    fused = fhe.to_host(ev.dct8x8_quant(plan, blocks))
+    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
+    general = fhe.to_host(ev.dct8x8_quant(plan, blocks))
+    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    assert np.array_equal(fused, general)
+    assert np.array_equal(fused[0], orc.dct_quant(fhe.to_host(blocks)[0], fhe.YQT))
+
+
+def test_dct_extreme_residues(fhe, oracle_mod):
+    """all-(q-1) and all-zero inputs: largest magnitudes through the lazy FP64 pipeline"""
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    ev = fhe.Evaluator(ctx)
+    blk = np.zeros((1, 64, 2, ctx.k, ctx.n), dtype=np.uint64)
+    for i, q in enumerate(ctx.q):
+        blk[0, :, :, i, :] = q - 1
+    blk[0, 5] = 0
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))
+    assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
