@@ -37,47 +37,68 @@ __device__ __forceinline__ double red(double x, double p, double pinv) {
     return __builtin_fma(-__builtin_rint(x * pinv), p, x);
 }
 
-template <int L, int P, int M>
-__device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double *__restrict__ tw, double p, double pinv, int tid) {
-    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
-    const int th = (P == 0) ? 0 : (tid >> LO);
+// exact integer <-> double moves: for 0 <= v < 2^52, bits(2^52 + v) = 0x4330000000000000 | v
+__device__ __forceinline__ double u52_to_f64(u64 v) { return __longlong_as_double((long long)(v | 0x4330000000000000ULL)) - 4503599627370496.0; }
+__device__ __forceinline__ u64 f64_to_u52(double v) { return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL; }
+
+// twiddles of one register pass, fetched ahead of use (before the preceding LDS barrier) so that
+// their L2 latency is hidden behind the previous pass: 2^(3-rb) values per stage, at most 15.
+template <int L, int P> struct PassTw {
+    static constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    static constexpr int rb(int u) { return (L - 1 - (4 * P + u)) - LO; }
+    static constexpr int count(int u) { return 1 << (3 - rb(u)); }
+    static constexpr int offset(int u) { int o = 0; for (int v = 0; v < u; v++) o += count(v); return o; }
+};
+template <int L, int P>
+__device__ __forceinline__ void load_tw(double (&w)[15], const double *__restrict__ tw, int tid) {
+    using T = PassTw<L, P>;
+    const int th = (P == 0) ? 0 : (tid >> T::LO);
 #pragma unroll
-    for (int u = 0; u < S; u++) {
-        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+    for (int u = 0; u < T::S; u++) {
+#pragma unroll
+        for (int i = 0; i < T::count(u); i++) w[T::offset(u) + i] = tw[(1 << (4 * P + u)) + ((th << (3 - T::rb(u))) | i)];
+    }
+}
+
+template <int L, int P, int M>
+__device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double (&w)[15], double p, double pinv) {
+    using T = PassTw<L, P>;
+#pragma unroll
+    for (int u = 0; u < T::S; u++) {
+        const int rb = T::rb(u);
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0++) {
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
-            const double w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double T = mm(x[m][r1], w, p, pinv);
+                const double Tm = mm(x[m][r1], wv, p, pinv);
                 const double X = x[m][r0];
-                x[m][r0] = X + T;
-                x[m][r1] = X - T;
+                x[m][r0] = X + Tm;
+                x[m][r1] = X - Tm;
             }
         }
     }
 }
 
 template <int L, int P, int M>
-__device__ __forceinline__ void inv_pass(double (&x)[M][16], const double *__restrict__ itw, double p, double pinv, int tid) {
-    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
-    const int th = (P == 0) ? 0 : (tid >> LO);
+__device__ __forceinline__ void inv_pass(double (&x)[M][16], const double (&w)[15], double ninv, double p, double pinv) {
+    using T = PassTw<L, P>;
 #pragma unroll
-    for (int u = S - 1; u >= 0; u--) {
-        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+    for (int u = T::S - 1; u >= 0; u--) {
+        const int sigma = 4 * P + u, rb = T::rb(u);
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0++) {
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
-            const double w = itw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const double X = x[m][r0], Y = x[m][r1];
                 const double Sm = X + Y, D = X - Y;
-                x[m][r0] = (sigma == 0) ? mm(Sm, itw[0], p, pinv) : Sm;
-                x[m][r1] = mm(D, w, p, pinv);
+                x[m][r0] = (sigma == 0) ? mm(Sm, ninv, p, pinv) : Sm;
+                x[m][r1] = mm(D, wv, p, pinv);
             }
         }
     }
@@ -99,18 +120,29 @@ __device__ __forceinline__ void transpose(double (&x)[M][16], double *lds, int t
     }
 }
 
-template <int L, int M, int P = 0>
-__device__ __forceinline__ void ntt_fwd(double (&x)[M][16], const double *__restrict__ tw, double p, double pinv, double *lds, int tid, int &phase) {
-    fwd_pass<L, P, M>(x, tw, p, pinv, tid);
+// forward transform; `w` holds the pass-0 twiddles on entry.  `pre()` is invoked once, right
+// before the last transpose, so that the caller can start fetching what it needs after the NTT.
+template <int L, int M, typename PRE, int P = 0>
+__device__ __forceinline__ void ntt_fwd(double (&x)[M][16], double (&w)[15], const double *__restrict__ tw, double p, double pinv,
+                                        double *lds, int tid, int &phase, PRE pre) {
     if constexpr (P + 1 < NttShape<L>::NP) {
+        double wn[15];
+        load_tw<L, P + 1>(wn, tw, tid);          // in flight during this pass and the transpose
+        fwd_pass<L, P, M>(x, w, p, pinv);
+        if constexpr (P + 2 == NttShape<L>::NP) pre();
         transpose<L, pass_lo(L, P), pass_lo(L, P + 1), M>(x, lds, tid, phase);
-        ntt_fwd<L, M, P + 1>(x, tw, p, pinv, lds, tid, phase);
+        ntt_fwd<L, M, PRE, P + 1>(x, wn, tw, p, pinv, lds, tid, phase, pre);
+    } else {
+        fwd_pass<L, P, M>(x, w, p, pinv);
     }
 }
 template <int L, int M, bool BIG, int P = NttShape<L>::NP - 1>
-__device__ __forceinline__ void ntt_inv(double (&x)[M][16], const double *__restrict__ itw, double p, double pinv, double *lds, int tid, int &phase) {
-    inv_pass<L, P, M>(x, itw, p, pinv, tid);
+__device__ __forceinline__ void ntt_inv(double (&x)[M][16], double (&w)[15], const double *__restrict__ itw, double p, double pinv,
+                                        double *lds, int tid, int &phase) {
     if constexpr (P > 0) {
+        double wn[15];
+        load_tw<L, P - 1>(wn, itw, tid);
+        inv_pass<L, P, M>(x, w, 0.0, p, pinv);
         if constexpr (BIG) {
 #pragma unroll
             for (int m = 0; m < M; m++)
@@ -118,38 +150,41 @@ __device__ __forceinline__ void ntt_inv(double (&x)[M][16], const double *__rest
                 for (int r = 0; r < 16; r++) x[m][r] = red(x[m][r], p, pinv);
         }
         transpose<L, pass_lo(L, P), pass_lo(L, P - 1), M>(x, lds, tid, phase);
-        ntt_inv<L, M, BIG, P - 1>(x, itw, p, pinv, lds, tid, phase);
+        ntt_inv<L, M, BIG, P - 1>(x, wn, itw, p, pinv, lds, tid, phase);
+    } else {
+        inv_pass<L, P, M>(x, w, itw[0], p, pinv);
     }
 }
 
 // Even / odd half of one LL&M line (homo/fhe_image.h:215-242) on a single NTT slot.
 // In:  even: x[m] = d_m + d_(7-m) (tmp0..tmp3);  odd: x[m] = d_m - d_(7-m) (tmp7,tmp6,tmp5,tmp4).
-// Out: x[m] = line output 2m + half.   C(cid) = constant cid at this slot.
-template <typename CF>
-__device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, double &x3, int half, double p, double pinv, CF C) {
-    if (half == 0) {
+// Out: x[m] = line output 2m + HALF.  c[] = constants 0..2 (even) or 3..11 (odd) at this slot.
+template <int HALF>
+__device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, double &x3, const double (&c)[9], double p, double pinv) {
+    if constexpr (HALF == 0) {
         const double tmp10 = x0 + x3, tmp13 = x0 - x3, tmp11 = x1 + x2, tmp12 = x1 - x2;
-        const double z1 = mm(tmp12 + tmp13, C(0), p, pinv);
+        const double z1 = mm(tmp12 + tmp13, c[0], p, pinv);
         x0 = tmp10 + tmp11;                        // out 0
         x2 = tmp10 - tmp11;                        // out 4
-        x1 = z1 + mm(tmp13, C(1), p, pinv);        // out 2
-        x3 = z1 + mm(tmp12, C(2), p, pinv);        // out 6
+        x1 = z1 + mm(tmp13, c[1], p, pinv);        // out 2
+        x3 = z1 + mm(tmp12, c[2], p, pinv);        // out 6
     } else {
         const double tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
         double z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
-        const double z5 = mm(z3 + z4, C(3), p, pinv);
-        const double t4 = mm(tmp4, C(4), p, pinv), t5 = mm(tmp5, C(5), p, pinv);
-        const double t6 = mm(tmp6, C(6), p, pinv), t7 = mm(tmp7, C(7), p, pinv);
-        z1 = mm(z1, C(8), p, pinv);
-        z2 = mm(z2, C(9), p, pinv);
-        z3 = mm(z3, C(10), p, pinv) + z5;
-        z4 = mm(z4, C(11), p, pinv) + z5;
+        const double z5 = mm(z3 + z4, c[0], p, pinv);
+        const double t4 = mm(tmp4, c[1], p, pinv), t5 = mm(tmp5, c[2], p, pinv);
+        const double t6 = mm(tmp6, c[3], p, pinv), t7 = mm(tmp7, c[4], p, pinv);
+        z1 = mm(z1, c[5], p, pinv);
+        z2 = mm(z2, c[6], p, pinv);
+        z3 = mm(z3, c[7], p, pinv) + z5;
+        z4 = mm(z4, c[8], p, pinv) + z5;
         x0 = t7 + z1 + z4;                         // out 1
         x1 = t6 + z2 + z3;                         // out 3
         x2 = t5 + z2 + z4;                         // out 5
         x3 = t4 + z1 + z3;                         // out 7
     }
 }
+template <int HALF> struct HalfC { static constexpr int NC = HALF ? 9 : 3, FIRST = HALF ? 3 : 0; };
 
 struct Work { u32 blk, line, poly, prime, half; };
 // blockIdx -> work item; the two halves of an item sit 8 apart so they land on the same XCD
@@ -166,36 +201,63 @@ __device__ __forceinline__ Work decode(u32 idx, u32 k) {
     return o;
 }
 
-template <int L, bool BIG>
-__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
-                                                               const double *__restrict__ consts, const double *__restrict__ tw_all,
-                                                               const Modulus *__restrict__ mods, u32 k) {
-    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
-    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+template <int L, bool BIG, int HALF>
+__device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__restrict__ mid, const double *__restrict__ consts,
+                                          const double *__restrict__ tw, const Work &wk, double p, double pinv, u32 k, double *lds) {
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
     const int tid = threadIdx.x;
-    const Work wk = decode(blockIdx.x, k);
-    const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + 8 * wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
+    double w0[15];
+    load_tw<L, 0>(w0, tw, tid);
     double x[4][16];
+    // d_m +- d_(7-m) in integers (inputs are < 2^47), then one exact move to double.  Two line
+    // pairs (64 loads per thread) are kept in flight; the compiler fences stop it from hoisting all
+    // 128 loads to the top, which would not fit the register file.
+    constexpr u64 OFF = 1ULL << 48;
+    u64 ra[2][16], rb[2][16];
+    auto issue = [&](int m) {
+        const u64 *a = in + base + (size_t)m * ct_words + tid, *b = in + base + (size_t)(7 - m) * ct_words + tid;
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const u64 *a = in + base + (size_t)m * ct_words, *b = in + base + (size_t)(7 - m) * ct_words;
+        for (int r = 0; r < 16; r++) {       // pass-0 mapping: coefficient r*TP + tid
+            ra[m & 1][r] = a[r * TP];
+            rb[m & 1][r] = b[r * TP];
+        }
+    };
+    auto combine = [&](int m) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int j = elem_index<L - 4>(tid, r);
-            const double A = (double)a[j], B = (double)b[j];
-            x[m][r] = wk.half ? A - B : A + B;
+            const u64 A = ra[m & 1][r], B = rb[m & 1][r];
+            x[m][r] = HALF ? u52_to_f64(A + OFF - B) - (double)OFF : u52_to_f64(A + B);
         }
-    }
-    int phase = 0;
-    ntt_fwd<L, 4>(x, tw_all + (size_t)wk.prime * N, p, pinv, lds, tid, phase);
-    const double *cp = consts + (size_t)wk.prime * N + tid;
+    };
+    issue(0);
+    issue(1);
+    asm volatile("" ::: "memory");
+    combine(0);
+    issue(2);
+    asm volatile("" ::: "memory");
+    combine(1);
+    issue(3);
+    asm volatile("" ::: "memory");
+    combine(2);
+    combine(3);
+    const double *cp = consts + (size_t)FIRST * k * N + (size_t)wk.prime * N + tid;
     const size_t cstride = (size_t)k * N;
+    double cn[9];
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
+    };
+    int phase = 0;
+    ntt_fwd<L, 4>(x, w0, tw, p, pinv, lds, tid, phase, [&] { fetch(0); });
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
-        line_half(x[0][r], x[1][r], x[2][r], x[3][r], wk.half, p, pinv, C);
+        double c[9];
+#pragma unroll
+        for (int i = 0; i < NC; i++) c[i] = cn[i];
+        if (r + 1 < 16) fetch(r + 1);
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         if (BIG) {
 #pragma unroll
             for (int m = 0; m < 4; m++) x[m][r] = red(x[m][r], p, pinv);
@@ -203,24 +265,47 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_rows(const u64 *__re
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        double *o = mid + base + (size_t)(2 * m + wk.half) * ct_words + tid;
+        double *o = mid + base + (size_t)(2 * m + HALF) * ct_words + tid;
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r * TP] = x[m][r];
     }
 }
 
 template <int L, bool BIG>
-__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
-                                                               const double *__restrict__ consts, const double *__restrict__ itw_all,
-                                                               const Modulus *__restrict__ mods, u32 k) {
-    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
+                                                                  const double *__restrict__ consts, const double *__restrict__ tw_all,
+                                                                  const Modulus *__restrict__ mods, u32 k) {
     __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
-    const int tid = threadIdx.x;
-    const Work wk = decode(blockIdx.x, k);   // line = column index
+    const Work wk = decode(blockIdx.x, k);
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
+    const double *tw = tw_all + (size_t)wk.prime * NttShape<L>::N;
+    if (wk.half) rows_body<L, BIG, 1>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    else rows_body<L, BIG, 0>(in, mid, consts, tw, wk, p, pinv, k, lds);
+}
+
+template <int L, bool BIG, int HALF>
+__device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *__restrict__ out, const double *__restrict__ consts,
+                                          const double *__restrict__ itw, const Work &wk, double p, double pinv, u32 k, double *lds) {
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
+    constexpr int LASTP = NttShape<L>::NP - 1;
+    const int tid = threadIdx.x;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
     const size_t row_stride = 8 * ct_words;
+    const size_t cstride = (size_t)k * N;
+    const double *cp = consts + (size_t)FIRST * cstride + (size_t)wk.prime * N + tid;
+    // per-output scale: row 2m+HALF, column wk.line -> constant 12 + 8*row + col
+    const double *sp = consts + (size_t)(12 + 8 * HALF + wk.line) * cstride + (size_t)wk.prime * N + tid;
+    double cn[9], sn[4];
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
+#pragma unroll
+        for (int m = 0; m < 4; m++) sn[m] = sp[(size_t)(16 * m) * cstride + r * TP];
+    };
+    fetch(0);
+    double wl[15];
+    load_tw<L, LASTP>(wl, itw, tid);
     double x[4][16];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -228,31 +313,45 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_cols(const double *_
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const double A = a[r * TP], B = b[r * TP];
-            x[m][r] = wk.half ? A - B : A + B;
+            x[m][r] = HALF ? A - B : A + B;
         }
     }
-    const double *cp = consts + (size_t)wk.prime * N + tid;
-    const size_t cstride = (size_t)k * N;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
-        line_half(x[0][r], x[1][r], x[2][r], x[3][r], wk.half, p, pinv, C);
+        double c[9], sc[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++)   // output (row 2m+half, column line): scale id 12 + 8*row + col
-            x[m][r] = mm(x[m][r], C(12 + 8 * (2 * m + (int)wk.half) + (int)wk.line), p, pinv);
+        for (int i = 0; i < NC; i++) c[i] = cn[i];
+#pragma unroll
+        for (int m = 0; m < 4; m++) sc[m] = sn[m];
+        if (r + 1 < 16) fetch(r + 1);
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m][r] = mm(x[m][r], sc[m], p, pinv);
     }
     int phase = 0;
-    ntt_inv<L, 4, BIG>(x, itw_all + (size_t)wk.prime * N, p, pinv, lds, tid, phase);
+    ntt_inv<L, 4, BIG>(x, wl, itw, p, pinv, lds, tid, phase);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        u64 *o = out + base + (size_t)(2 * m + wk.half) * row_stride;
+        u64 *o = out + base + (size_t)(2 * m + HALF) * row_stride + tid;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             double v = x[m][r];
             v = v < 0.0 ? v + p : v;
-            o[elem_index<L - 4>(tid, r)] = (u64)v;
+            o[r * TP] = f64_to_u52(v);
         }
     }
+}
+
+template <int L, bool BIG>
+__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
+                                                                  const double *__restrict__ consts, const double *__restrict__ itw_all,
+                                                                  const Modulus *__restrict__ mods, u32 k) {
+    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+    const Work wk = decode(blockIdx.x, k);   // line = column index
+    const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
+    const double *itw = itw_all + (size_t)wk.prime * NttShape<L>::N;
+    if (wk.half) cols_body<L, BIG, 1>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    else cols_body<L, BIG, 0>(mid, out, consts, itw, wk, p, pinv, k, lds);
 }
 
 __global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n, u32 total) {
@@ -266,7 +365,7 @@ __global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__res
 }  // namespace
 
 bool fhe_dct_f64_supported(const fhe_ctx *c) {
-    return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && c->logn >= 10 && c->logn <= 13;
+    return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && (c->logn == 10 || c->logn == 12 || c->logn == 13);
 }
 
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
@@ -289,7 +388,6 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     } while (0)
     switch (c->logn) {
         case 10: if (big) LAUNCH(10, true); else LAUNCH(10, false); break;
-        case 11: if (big) LAUNCH(11, true); else LAUNCH(11, false); break;
         case 12: if (big) LAUNCH(12, true); else LAUNCH(12, false); break;
         case 13: if (big) LAUNCH(13, true); else LAUNCH(13, false); break;
         default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in [1024, 8192]");
