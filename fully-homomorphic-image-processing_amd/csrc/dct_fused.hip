@@ -36,6 +36,24 @@ __device__ __forceinline__ double mm(double y, double w, double p, double pinv) 
 __device__ __forceinline__ double red(double x, double p, double pinv) {
     return __builtin_fma(-__builtin_rint(x * pinv), p, x);
 }
+// K independent products written stage by stage: with only two waves per SIMD the FP64 pipe needs
+// instruction-level parallelism, and hipcc otherwise emits each five-op chain back to back.
+template <int K>
+__device__ __forceinline__ void mmv(double (&y)[K], const double (&w)[K], double p, double pinv) {
+    double h[K], l[K], q[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) h[i] = y[i] * w[i];
+#pragma unroll
+    for (int i = 0; i < K; i++) q[i] = h[i] * pinv;
+#pragma unroll
+    for (int i = 0; i < K; i++) l[i] = __builtin_fma(y[i], w[i], -h[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) q[i] = __builtin_rint(q[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) h[i] = __builtin_fma(-q[i], p, h[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) y[i] = h[i] + l[i];
+}
 
 // exact integer <-> double moves: for 0 <= v < 2^52, bits(2^52 + v) = 0x4330000000000000 | v
 __device__ __forceinline__ double u52_to_f64(u64 v) { return __longlong_as_double((long long)(v | 0x4330000000000000ULL)) - 4503599627370496.0; }
@@ -71,12 +89,15 @@ __device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double (&w)[1
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
             const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
+            double t[M], wm[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) { t[m] = x[m][r1]; wm[m] = wv; }
+            mmv<M>(t, wm, p, pinv);
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double Tm = mm(x[m][r1], wv, p, pinv);
                 const double X = x[m][r0];
-                x[m][r0] = X + Tm;
-                x[m][r1] = X - Tm;
+                x[m][r0] = X + t[m];
+                x[m][r1] = X - t[m];
             }
         }
     }
@@ -93,12 +114,28 @@ __device__ __forceinline__ void inv_pass(double (&x)[M][16], const double (&w)[1
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
             const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
+            if (sigma == 0) {
+                double t[2 * M], wm[2 * M];
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const double X = x[m][r0], Y = x[m][r1];
-                const double Sm = X + Y, D = X - Y;
-                x[m][r0] = (sigma == 0) ? mm(Sm, ninv, p, pinv) : Sm;
-                x[m][r1] = mm(D, wv, p, pinv);
+                for (int m = 0; m < M; m++) {
+                    const double X = x[m][r0], Y = x[m][r1];
+                    t[m] = X + Y; wm[m] = ninv;
+                    t[M + m] = X - Y; wm[M + m] = wv;
+                }
+                mmv<2 * M>(t, wm, p, pinv);
+#pragma unroll
+                for (int m = 0; m < M; m++) { x[m][r0] = t[m]; x[m][r1] = t[M + m]; }
+            } else {
+                double t[M], wm[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const double X = x[m][r0], Y = x[m][r1];
+                    x[m][r0] = X + Y;
+                    t[m] = X - Y; wm[m] = wv;
+                }
+                mmv<M>(t, wm, p, pinv);
+#pragma unroll
+                for (int m = 0; m < M; m++) x[m][r1] = t[m];
             }
         }
     }
@@ -163,25 +200,24 @@ template <int HALF>
 __device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, double &x3, const double (&c)[9], double p, double pinv) {
     if constexpr (HALF == 0) {
         const double tmp10 = x0 + x3, tmp13 = x0 - x3, tmp11 = x1 + x2, tmp12 = x1 - x2;
-        const double z1 = mm(tmp12 + tmp13, c[0], p, pinv);
-        x0 = tmp10 + tmp11;                        // out 0
-        x2 = tmp10 - tmp11;                        // out 4
-        x1 = z1 + mm(tmp13, c[1], p, pinv);        // out 2
-        x3 = z1 + mm(tmp12, c[2], p, pinv);        // out 6
+        double y[3] = {tmp12 + tmp13, tmp13, tmp12};
+        const double w[3] = {c[0], c[1], c[2]};
+        mmv<3>(y, w, p, pinv);
+        x0 = tmp10 + tmp11;        // out 0
+        x2 = tmp10 - tmp11;        // out 4
+        x1 = y[0] + y[1];          // out 2
+        x3 = y[0] + y[2];          // out 6
     } else {
         const double tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
-        double z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
-        const double z5 = mm(z3 + z4, c[0], p, pinv);
-        const double t4 = mm(tmp4, c[1], p, pinv), t5 = mm(tmp5, c[2], p, pinv);
-        const double t6 = mm(tmp6, c[3], p, pinv), t7 = mm(tmp7, c[4], p, pinv);
-        z1 = mm(z1, c[5], p, pinv);
-        z2 = mm(z2, c[6], p, pinv);
-        z3 = mm(z3, c[7], p, pinv) + z5;
-        z4 = mm(z4, c[8], p, pinv) + z5;
-        x0 = t7 + z1 + z4;                         // out 1
-        x1 = t6 + z2 + z3;                         // out 3
-        x2 = t5 + z2 + z4;                         // out 5
-        x3 = t4 + z1 + z3;                         // out 7
+        const double z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+        double y[9] = {z3 + z4, tmp4, tmp5, tmp6, tmp7, z1, z2, z3, z4};
+        const double w[9] = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
+        mmv<9>(y, w, p, pinv);
+        const double z3b = y[7] + y[0], z4b = y[8] + y[0];
+        x0 = y[4] + y[5] + z4b;    // out 1 = tmp7' + z1' + z4
+        x1 = y[3] + y[6] + z3b;    // out 3 = tmp6' + z2' + z3
+        x2 = y[2] + y[6] + z4b;    // out 5 = tmp5' + z2' + z4
+        x3 = y[1] + y[5] + z3b;    // out 7 = tmp4' + z1' + z3
     }
 }
 template <int HALF> struct HalfC { static constexpr int NC = HALF ? 9 : 3, FIRST = HALF ? 3 : 0; };
@@ -325,8 +361,10 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
         for (int m = 0; m < 4; m++) sc[m] = sn[m];
         if (r + 1 < 16) fetch(r + 1);
         line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+        double y[4] = {x[0][r], x[1][r], x[2][r], x[3][r]};
+        mmv<4>(y, sc, p, pinv);
 #pragma unroll
-        for (int m = 0; m < 4; m++) x[m][r] = mm(x[m][r], sc[m], p, pinv);
+        for (int m = 0; m < 4; m++) x[m][r] = y[m];
     }
     int phase = 0;
     ntt_inv<L, 4, BIG>(x, wl, itw, p, pinv, lds, tid, phase);
