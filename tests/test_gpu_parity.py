@@ -272,3 +272,42 @@ def test_dct_extreme_residues(fhe, oracle_mod):
     blk[0, 5] = 0
     out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))
     assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
+
+
+def test_fused_dct_matches_bigint_model_golden_n4096(fhe):
+    """the HIP fused path against the big-integer model's committed SHA-256 (no oracle in between)"""
+    import hashlib
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dct_quant_n4096_digest.npz"))
+    ctx = fhe.SEALContext(int(d["n"]), d["q"].tolist(), int(d["t"]))
+    ev = fhe.Evaluator(ctx)
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, d["quant"].tolist()), ctx.random_ct(1, 64, seed=fhe.SEED)))[0]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(d["sha256_dct_quant"])
+    assert np.array_equal(out[d["sample_index"]][:, :, :, :16], d["dct_quant_sample"])
+
+
+def test_full_size_properties_1024_blocks(fhe, oracle_mod):
+    """BASELINE.json configs[1] at full size (1024 blocks): size-independent checks.
+    (a) linearity: circuit(a + b) == circuit(a) + circuit(b) over all blocks (digest equality);
+    (b) every rank-style shard regenerates the same bytes: digest of two halves == digest of the whole;
+    (c) sampled blocks bit-equal to the oracle."""
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    ev = fhe.Evaluator(ctx)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    B = 1024
+    a = ctx.random_ct(B, 64, seed=fhe.SEED)
+    ca = ev.dct8x8_quant(plan, a)
+    wpb = 64 * 2 * ctx.k * ctx.n
+    whole = ctx.digest(ca.view(-1))
+    halves = (ctx.digest(ca[:512].reshape(-1), 0) + ctx.digest(ca[512:].reshape(-1), 512 * wpb)) & ((1 << 64) - 1)
+    assert whole == halves
+    for b in (0, 777):
+        assert np.array_equal(fhe.to_host(ca[b]), orc.dct_quant(fhe.to_host(a[b]), fhe.YQT))
+    # linearity on a 256-block slice (memory: three more 3 GiB tensors)
+    bsl = ctx.random_ct(256, 64, seed=12345)
+    s = ev.add(a[:256].contiguous(), bsl)
+    lhs = ev.dct8x8_quant(plan, s)
+    rhs = ev.add(ca[:256].contiguous(), ev.dct8x8_quant(plan, bsl))
+    assert ctx.digest(lhs.view(-1)) == ctx.digest(rhs.view(-1))
+    import torch
+    assert torch.equal(lhs, rhs)
