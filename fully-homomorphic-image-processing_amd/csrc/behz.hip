@@ -1,8 +1,349 @@
-// behz.hip -- ct x ct (BEHZ) and relinearisation entry points.  (placeholder: implemented next)
-#include "../../include/fhe_hip.h"
-extern "C" size_t fhe_multiply_scratch_bytes(const fhe_ctx *, uint32_t, uint32_t, uint64_t) { return 0; }
-extern "C" int fhe_multiply(const fhe_ctx *, const uint64_t *, uint32_t, const uint64_t *, uint32_t, uint64_t *, uint64_t, void *, size_t, fhe_stream) { return FHE_ERR_PARAM; }
-extern "C" int fhe_square(const fhe_ctx *, const uint64_t *, uint32_t, uint64_t *, uint64_t, void *, size_t, fhe_stream) { return FHE_ERR_PARAM; }
-extern "C" uint32_t fhe_evk_digits(const fhe_ctx *, uint32_t) { return 0; }
-extern "C" int fhe_relinearize(const fhe_ctx *, uint64_t *, uint64_t, uint64_t, const uint64_t *, uint32_t, void *, size_t, fhe_stream) { return FHE_ERR_PARAM; }
-extern "C" size_t fhe_relinearize_scratch_bytes(const fhe_ctx *, uint32_t, uint64_t) { return 0; }
+// behz.hip -- seal::Evaluator::multiply / square (full-RNS BEHZ) and relinearize on gfx950.
+//
+// Algorithm: Bajard, Eynard, Hasan, Zucca, "A Full RNS Variant of FV like Somewhat Homomorphic
+// Encryption Schemes" (SAC 2016) with the conventions of SEAL 2.3:
+//   0. FastBConv of m~*c from q to Bsk u {m~}, m~ = 2^32
+//   1. small Montgomery reduction: r = -x q^-1 mod m~ (centred), c' = (x + q r)/m~ in Bsk
+//   2. NTT in q and Bsk, tensor product sum_{a+b=o} c'1_a c'2_b, inverse NTT, times t
+//   3. fast floor: (t D - FastBConv([t D]_q -> Bsk)) q^-1 in Bsk
+//   4. Shenoy-Kumaresan conversion Bsk -> q with m_sk
+// The result is a function of (inputs, q, t, m~) only; the auxiliary primes (k 61-bit NTT primes
+// + m_sk, the first primes = 1 mod 2^17 below 2^61) just have to be large enough.
+// Reference call sites: homo/fhe_resize.h:174-179,197-198; homo/fhe_decode.h:67-97,235,239.
+#include "internal.h"
+
+#include <cstring>
+
+#include "host_math.h"
+
+#define BK FHE_MAX_K
+
+struct BehzDev {   // passed to kernels by value
+    u32 k;         // |q-base|; Bsk has k+1 primes, index k = m_sk
+    Modulus q[BK], b[BK + 1];
+    u64 r64q[BK], r64b[BK + 1];            // floor(2^64 / modulus) for single-word reductions
+    u64 mt_inv_punct[BK], mt_inv_punct_s[BK];      // m~ * (q/q_i)^-1 mod q_i  (+ Shoup)
+    u64 inv_punct[BK], inv_punct_s[BK];            // (q/q_i)^-1 mod q_i
+    u64 punct_q_mod_b[BK][BK + 1];         // (q/q_i) mod b_j
+    u64 punct_q_mod_mt[BK];                // (q/q_i) mod 2^32
+    u64 neg_inv_q_mod_mt;                  // -q^-1 mod 2^32
+    u64 q_mod_b[BK + 1], inv_mt_mod_b[BK + 1], inv_q_mod_b[BK + 1];
+    u64 t_mod_q[BK], t_mod_b[BK + 1];
+    u64 inv_punct_B[BK];                   // (B/b_j)^-1 mod b_j
+    u64 punct_B_mod_q[BK][BK];             // (B/b_j) mod q_i
+    u64 punct_B_mod_msk[BK];
+    u64 inv_B_mod_msk;
+    u64 B_mod_q[BK];
+};
+
+struct BehzTables {
+    BaseTables aux;     // NTT tables of Bsk (k+1 primes)
+    BehzDev dev;
+};
+
+namespace {
+
+__device__ __forceinline__ u64 reduce64(u64 x, u64 q, u64 r64) {   // x mod q for any x < 2^64
+    u64 r = x - __umul64hi(x, r64) * q;
+    r = csub(r, 2 * q);
+    return csub(r, q);
+}
+
+// steps 0+1 for every coefficient of every input polynomial: in [polys][k][n] -> out [polys][k+1][n]
+__global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in, u64 *__restrict__ out, BehzDev T, u32 n, u64 n_polys) {
+    const u32 k = T.k;
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+            u64 y[BK];
+            u64 xm = 0;
+            for (u32 i = 0; i < k; i++) {
+                y[i] = mul_shoup(in[(p * k + i) * n + c], T.mt_inv_punct[i], T.mt_inv_punct_s[i], T.q[i].q);
+                xm += (y[i] & 0xffffffffULL) * T.punct_q_mod_mt[i];
+            }
+            const u64 r = ((xm & 0xffffffffULL) * T.neg_inv_q_mod_mt) & 0xffffffffULL;
+            for (u32 j = 0; j <= k; j++) {
+                const Modulus &m = T.b[j];
+                u64 acc = 0;
+                for (u32 i = 0; i < k; i++) acc = addmod(acc, mul_barrett(y[i], T.punct_q_mod_b[i][j], m), m.q);   // y_i < q_i < b_j
+                const u64 rb = r >= 0x80000000ULL ? r + m.q - 0x100000000ULL : r;       // centred remainder
+                acc = addmod(acc, mul_barrett(T.q_mod_b[j], rb, m), m.q);
+                out[(p * (k + 1) + j) * n + c] = mul_barrett(acc, T.inv_mt_mod_b[j], m);
+            }
+        }
+    }
+}
+
+// tensor product in NTT form over one base: A [count][sa][nb][n], Bm [count][sb][nb][n] -> D [count][sa+sb-1][nb][n]
+__global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
+                                                     const Modulus *__restrict__ mods, u32 nb, u32 n, u32 sa, u32 sb, u64 count) {
+    const u32 so = sa + sb - 1;
+    for (u64 cp = blockIdx.y; cp < count * nb; cp += gridDim.y) {
+        const u64 c = cp / nb;
+        const u32 j = (u32)(cp % nb);
+        const Modulus m = mods[j];
+        for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+            for (u32 o = 0; o < so; o++) {
+                u64 acc = 0;
+                const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
+                for (u32 ja = lo; ja <= hi; ja++) {
+                    const u64 x = A[((c * sa + ja) * nb + j) * n + s], y = Bm[((c * sb + (o - ja)) * nb + j) * n + s];
+                    acc = addmod(acc, mul_barrett(x, y, m), m.q);
+                }
+                D[((c * so + o) * nb + j) * n + s] = acc;
+            }
+        }
+    }
+}
+
+// steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
+__global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
+                                                         BehzDev T, u32 n, u64 n_polys) {
+    const u32 k = T.k;
+    const Modulus &msk = T.b[k];
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+            u64 y[BK], f[BK + 1], z[BK];
+            for (u32 i = 0; i < k; i++) {
+                const u64 td = mul_barrett(Dq[(p * k + i) * n + c], T.t_mod_q[i], T.q[i]);
+                y[i] = mul_shoup(td, T.inv_punct[i], T.inv_punct_s[i], T.q[i].q);
+            }
+            for (u32 j = 0; j <= k; j++) {     // fast floor
+                const Modulus &m = T.b[j];
+                u64 conv = 0;
+                for (u32 i = 0; i < k; i++) conv = addmod(conv, mul_barrett(y[i], T.punct_q_mod_b[i][j], m), m.q);
+                const u64 td = mul_barrett(Db[(p * (k + 1) + j) * n + c], T.t_mod_b[j], m);
+                f[j] = mul_barrett(submod(td, conv, m.q), T.inv_q_mod_b[j], m);
+            }
+            u64 conv_sk = 0;
+            for (u32 j = 0; j < k; j++) {
+                z[j] = mul_barrett(f[j], T.inv_punct_B[j], T.b[j]);
+                conv_sk = addmod(conv_sk, mul_barrett(reduce64(z[j], msk.q, T.r64b[k]), T.punct_B_mod_msk[j], msk), msk.q);
+            }
+            const u64 alpha = mul_barrett(submod(conv_sk, f[k], msk.q), T.inv_B_mod_msk, msk);
+            const bool neg = alpha > (msk.q >> 1);
+            for (u32 i = 0; i < k; i++) {
+                const Modulus &m = T.q[i];
+                u64 conv = 0;
+                for (u32 j = 0; j < k; j++) conv = addmod(conv, mul_barrett(reduce64(z[j], m.q, T.r64q[i]), T.punct_B_mod_q[j][i], m), m.q);
+                const u64 a = reduce64(neg ? msk.q - alpha : alpha, m.q, T.r64q[i]);
+                const u64 corr = mul_barrett(a, T.B_mod_q[i], m);
+                out[(p * k + i) * n + c] = neg ? addmod(conv, corr, m.q) : submod(conv, corr, m.q);
+            }
+        }
+    }
+}
+
+// relinearisation ------------------------------------------------------------------------------
+// digits: for ciphertext c, source prime i, digit d, target prime ii: ((c2_i >> (dbc d)) & mask) mod q_ii
+__global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, BehzDev T,
+                                                      u32 n, u32 nd, u32 dbc, u64 count) {
+    const u32 k = T.k;
+    const u64 mask = dbc >= 64 ? ~0ULL : ((1ULL << dbc) - 1);
+    const u64 units = count * k * nd;
+    for (u64 u = blockIdx.y; u < units; u += gridDim.y) {
+        const u32 d = (u32)(u % nd);
+        const u32 i = (u32)((u / nd) % k);
+        const u64 c = u / ((u64)nd * k);
+        const u64 *c2 = ct + c * stride + ((u64)2 * k + i) * n;
+        for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+            const u64 v = (c2[s] >> (dbc * d)) & mask;
+            for (u32 ii = 0; ii < k; ii++) dig[(u * k + ii) * n + s] = reduce64(v, T.q[ii].q, T.r64q[ii]);
+        }
+    }
+}
+// acc[c][pp][ii][s] = sum_{i,d} dig[c][i][d][ii][s] * evk[i][d][pp][ii][s]
+__global__ __launch_bounds__(256) void k_relin_accum(const u64 *__restrict__ dig, const u64 *__restrict__ evk, u64 *__restrict__ acc,
+                                                     BehzDev T, u32 n, u32 nd, u64 count) {
+    const u32 k = T.k;
+    for (u64 u = blockIdx.y; u < count * k; u += gridDim.y) {
+        const u32 ii = (u32)(u % k);
+        const u64 c = u / k;
+        const Modulus m = T.q[ii];
+        for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+            u64 a0 = 0, a1 = 0;
+            for (u32 i = 0; i < k; i++)
+                for (u32 d = 0; d < nd; d++) {
+                    const u64 x = dig[(((c * k + i) * nd + d) * k + ii) * n + s];
+                    const u64 *e = evk + ((((u64)i * nd + d) * 2) * k + ii) * n + s;
+                    a0 = addmod(a0, mul_barrett(x, e[0], m), m.q);
+                    a1 = addmod(a1, mul_barrett(x, e[(u64)k * n], m), m.q);
+                }
+            acc[((c * 2 + 0) * k + ii) * n + s] = a0;
+            acc[((c * 2 + 1) * k + ii) * n + s] = a1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, BehzDev T, u32 n, u64 count) {
+    const u32 k = T.k;
+    for (u64 u = blockIdx.y; u < count * 2 * k; u += gridDim.y) {
+        const u32 ii = (u32)(u % k);
+        const u32 pp = (u32)((u / k) & 1);
+        const u64 c = u / (2 * k);
+        u64 *dst = ct + c * stride + ((u64)pp * k + ii) * n;
+        for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+            dst[s] = addmod(dst[s], acc[u * n + s], T.q[ii].q);
+    }
+}
+
+inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(rows < 32768 ? (rows ? rows : 1) : 32768)); }
+
+}  // namespace
+
+static int behz_build(fhe_ctx *c) {
+    using namespace hostmath;
+    if (c->behz) return FHE_OK;
+    const u32 k = c->k, n = c->n;
+    BehzTables *T = new BehzTables();
+    BehzDev &D = T->dev;
+    memset(&D, 0, sizeof(D));
+    D.k = k;
+    const std::vector<u64> &q = c->qb.primes;
+    // auxiliary primes: 61-bit, = 1 (mod 2^17), descending; first one is m_sk, the next k form B
+    std::vector<u64> found;
+    for (u64 cand = (1ULL << 61) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
+        if (!is_prime(cand)) continue;
+        bool clash = false;
+        for (u64 qi : q) clash |= (qi == cand);
+        if (!clash) found.push_back(cand);
+    }
+    std::vector<u64> bsk(k + 1);
+    for (u32 j = 0; j < k; ++j) bsk[j] = found[j + 1];
+    bsk[k] = found[0];
+    int rc = fhe_build_base(T->aux, bsk, n, c->logn, false);
+    if (rc) { delete T; return rc; }
+    const u64 mt = 1ULL << 32;
+    for (u32 i = 0; i < k; ++i) {
+        D.q[i] = c->qb.h_mod[i];
+        D.r64q[i] = (u64)((((u128)1) << 64) / q[i]);
+        const u64 ip = invmod(prod_mod(q.data(), (int)k, (int)i, q[i]), q[i]);
+        D.inv_punct[i] = ip;
+        D.inv_punct_s[i] = shoup(ip, q[i]);
+        D.mt_inv_punct[i] = mulmod(mt % q[i], ip, q[i]);
+        D.mt_inv_punct_s[i] = shoup(D.mt_inv_punct[i], q[i]);
+        for (u32 j = 0; j <= k; ++j) D.punct_q_mod_b[i][j] = prod_mod(q.data(), (int)k, (int)i, bsk[j]);
+        D.punct_q_mod_mt[i] = prod_mod(q.data(), (int)k, (int)i, mt);
+        D.t_mod_q[i] = c->t % q[i];
+        D.B_mod_q[i] = prod_mod(bsk.data(), (int)k, -1, q[i]);
+    }
+    {
+        const u64 qm = prod_mod(q.data(), (int)k, -1, mt);   // odd
+        u64 x = qm;
+        for (int it = 0; it < 6; ++it) x = (x * (2 - qm * x)) & (mt - 1);
+        D.neg_inv_q_mod_mt = (mt - x) & (mt - 1);
+    }
+    for (u32 j = 0; j <= k; ++j) {
+        D.b[j] = T->aux.h_mod[j];
+        D.r64b[j] = (u64)((((u128)1) << 64) / bsk[j]);
+        D.q_mod_b[j] = prod_mod(q.data(), (int)k, -1, bsk[j]);
+        D.inv_q_mod_b[j] = invmod(D.q_mod_b[j], bsk[j]);
+        D.inv_mt_mod_b[j] = invmod(mt % bsk[j], bsk[j]);
+        D.t_mod_b[j] = c->t % bsk[j];
+    }
+    for (u32 j = 0; j < k; ++j) {
+        D.inv_punct_B[j] = invmod(prod_mod(bsk.data(), (int)k, (int)j, bsk[j]), bsk[j]);
+        for (u32 i = 0; i < k; ++i) D.punct_B_mod_q[j][i] = prod_mod(bsk.data(), (int)k, (int)j, q[i]);
+        D.punct_B_mod_msk[j] = prod_mod(bsk.data(), (int)k, (int)j, bsk[k]);
+    }
+    D.inv_B_mod_msk = invmod(prod_mod(bsk.data(), (int)k, -1, bsk[k]), bsk[k]);
+    c->behz = T;
+    return FHE_OK;
+}
+
+void fhe_behz_free(fhe_ctx *c) {
+    if (c && c->behz) {
+        fhe_free_base(c->behz->aux);
+        delete c->behz;
+        c->behz = nullptr;
+    }
+}
+
+static size_t mul_words(const fhe_ctx *c, u32 sa, u32 sb, u64 count, bool square) {
+    const size_t kn = (size_t)c->k * c->n, bn = (size_t)(c->k + 1) * c->n;
+    const size_t so = sa + sb - 1;
+    size_t w = count * sa * (kn + bn) + count * so * (kn + bn);
+    if (!square) w += count * sb * (kn + bn);
+    return w;
+}
+extern "C" size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint32_t sb, uint64_t count) {
+    if (!c || !sa || !sb) return 0;
+    return mul_words(c, sa, sb, count, false) * sizeof(u64);
+}
+
+static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, u32 sb, u64 *out, u64 count, void *scratch,
+                         size_t scratch_bytes, hipStream_t st) {
+    if (!cc || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (sa < 1 || sb < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
+    if (!count) return FHE_OK;
+    fhe_ctx *c = const_cast<fhe_ctx *>(cc);   // lazily built tables; contexts are not shared across threads during creation
+    int rc = behz_build(c);
+    if (rc) return rc;
+    const bool square = (a == b && sa == sb);
+    if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
+        return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
+    const BehzDev &T = c->behz->dev;
+    const u32 k = c->k, n = c->n, so = sa + sb - 1;
+    const size_t kn = (size_t)k * n, bn = (size_t)(k + 1) * n;
+    u64 *Aq = (u64 *)scratch, *Ab = Aq + count * sa * kn;
+    u64 *p = Ab + count * sa * bn;
+    u64 *Bq = Aq, *Bb = Ab;
+    if (!square) { Bq = p; Bb = Bq + count * sb * kn; p = Bb + count * sb * bn; }
+    u64 *Dq = p, *Db = Dq + count * so * kn;
+    auto prep = [&](const u64 *src, u32 s, u64 *xq, u64 *xb) -> int {
+        k_behz_to_bsk<<<grid2(n, count * s), 256, 0, st>>>(src, xb, T, n, count * s);
+        int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
+        if (r) return r;
+        return fhe_ntt_launch(false, c, c->qb, src, xq, count * s * k, st);
+    };
+    if ((rc = prep(a, sa, Aq, Ab))) return rc;
+    if (!square && (rc = prep(b, sb, Bq, Bb))) return rc;
+    k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, k, n, sa, sb, count);
+    k_behz_tensor<<<grid2(n, count * (k + 1)), 256, 0, st>>>(Ab, Bb, Db, c->behz->aux.d_mod, k + 1, n, sa, sb, count);
+    if ((rc = fhe_ntt_launch(true, c, c->qb, Dq, Dq, count * so * k, st))) return rc;
+    if ((rc = fhe_ntt_launch(true, c, c->behz->aux, Db, Db, count * so * (k + 1), st))) return rc;
+    k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, T, n, count * so);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+extern "C" int fhe_multiply(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out,
+                            uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    return behz_multiply(c, (const u64 *)a, sa, (const u64 *)b, sb, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
+}
+// SEAL special-cases size 2 as (c0^2, 2 c0 c1, c1^2); that is the same ring tensor the generic
+// product forms, so square shares the multiply path (transforming the operand once).
+extern "C" int fhe_square(const fhe_ctx *c, const uint64_t *a, uint32_t sa, uint64_t *out, uint64_t count, void *scratch,
+                          size_t scratch_bytes, fhe_stream s) {
+    return behz_multiply(c, (const u64 *)a, sa, (const u64 *)a, sa, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
+}
+
+extern "C" uint32_t fhe_evk_digits(const fhe_ctx *c, uint32_t dbc) {
+    if (!c || !dbc) return 0;
+    return (uint32_t)((c->max_prime_bits + dbc - 1) / dbc);
+}
+extern "C" size_t fhe_relinearize_scratch_bytes(const fhe_ctx *c, uint32_t dbc, uint64_t count) {
+    if (!c || !dbc) return 0;
+    const size_t kn = (size_t)c->k * c->n;
+    return (count * c->k * fhe_evk_digits(c, dbc) * kn + count * 2 * kn) * sizeof(u64);
+}
+extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride, uint64_t count, const uint64_t *evk, uint32_t dbc,
+                               void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!cc || !ct3 || !evk) return fail(FHE_ERR_PARAM, "null argument");
+    if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
+    if (!count) return FHE_OK;
+    fhe_ctx *c = const_cast<fhe_ctx *>(cc);
+    int rc = behz_build(c);
+    if (rc) return rc;
+    if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
+    if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
+    hipStream_t st = (hipStream_t)s;
+    const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
+    const BehzDev &T = c->behz->dev;
+    u64 *dig = (u64 *)scratch, *acc = dig + count * k * nd * k * n;
+    k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count);
+    if ((rc = fhe_ntt_launch(false, c, c->qb, dig, dig, count * k * nd * k, st))) return rc;
+    k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);
+    if ((rc = fhe_ntt_launch(true, c, c->qb, acc, acc, count * 2 * k, st))) return rc;
+    k_relin_add<<<grid2(n, count * 2 * k), 256, 0, st>>>((u64 *)ct3, stride, acc, T, n, count);
+    KERNEL_CHECK();
+    return FHE_OK;
+}

@@ -174,6 +174,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
 
 extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     if (!c) return FHE_OK;
+    fhe_behz_free(c);
     fhe_free_base(c->qb);
     delete c;
     return FHE_OK;

@@ -69,6 +69,7 @@ struct fhe_dct_plan {
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
 int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
 void fhe_free_base(BaseTables &B);
+void fhe_behz_free(fhe_ctx *c);
 // fused FP64 DCT path (dct_fused.hip)
 bool fhe_dct_f64_supported(const fhe_ctx *c);
 int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st);

@@ -311,3 +311,79 @@ def test_full_size_properties_1024_blocks(fhe, oracle_mod):
     assert ctx.digest(lhs.view(-1)) == ctx.digest(rhs.view(-1))
     import torch
     assert torch.equal(lhs, rhs)
+
+
+# ---------------------------------------------------------------------------------------------
+# ct x ct (BEHZ) and relinearisation
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192", "SEAL23_4096"])
+def test_multiply_square_all_shapes(fhe, oracle_mod, preset):
+    """the multiply shapes the reference's circuits exercise: 2x2, square(2),
+    2x3, 4x3, 4x2, square(3), batched over two pairs"""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    a2, b2 = ctx.random_ct(2, size=2, seed=201), ctx.random_ct(2, size=2, seed=202)
+    h = fhe.to_host
+    ab = ev.multiply(a2, b2)
+    for i in range(2):
+        assert np.array_equal(h(ab)[i], orc.multiply(h(a2)[i], h(b2)[i]))
+    sq = ev.square(a2)
+    for i in range(2):
+        assert np.array_equal(h(sq)[i], orc.square(h(a2)[i]))
+    a4 = ctx.random_ct(2, size=4, seed=203)
+    m23, m43, m42 = ev.multiply(a2, ab), ev.multiply(a4, ab), ev.multiply(a4, b2)
+    sq3 = ev.square(ab)
+    for i in range(2):
+        assert np.array_equal(h(m23)[i], orc.multiply(h(a2)[i], h(ab)[i]))
+        assert np.array_equal(h(m43)[i], orc.multiply(h(a4)[i], h(ab)[i]))
+        assert np.array_equal(h(m42)[i], orc.multiply(h(a4)[i], h(b2)[i]))
+        assert np.array_equal(h(sq3)[i], orc.square(h(ab)[i]))
+    assert m43.shape[-3] == 6 and sq3.shape[-3] == 5
+
+
+def test_multiply_large_sizes_decode_shapes(fhe, oracle_mod):
+    """(11 x 11) -> 21 and (21 x 2) -> 22: the term/amplitude products of approximated_step"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    a, b, c = ctx.random_ct(1, size=11, seed=301), ctx.random_ct(1, size=11, seed=302), ctx.random_ct(1, size=2, seed=303)
+    t = ev.multiply(a, b)
+    assert t.shape[-3] == 21
+    assert np.array_equal(fhe.to_host(t)[0], orc.multiply(fhe.to_host(a)[0], fhe.to_host(b)[0]))
+    u = ev.multiply(t, c)
+    assert u.shape[-3] == 22
+    assert np.array_equal(fhe.to_host(u)[0], orc.multiply(fhe.to_host(t)[0], fhe.to_host(c)[0]))
+
+
+def test_multiply_edge_inputs(fhe, oracle_mod):
+    """zero, q-1 everywhere: extremes of the base conversions"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    a = np.zeros((1, 2, ctx.k, ctx.n), dtype=np.uint64)
+    for i, q in enumerate(ctx.q):
+        a[0, :, i, :] = q - 1
+    z = np.zeros_like(a)
+    da, dz = fhe.to_device(a), fhe.to_device(z)
+    assert np.array_equal(fhe.to_host(ev.multiply(da, da))[0], orc.multiply(a[0], a[0]))
+    assert np.array_equal(fhe.to_host(ev.multiply(da, dz))[0], orc.multiply(a[0], z[0]))
+    assert np.array_equal(fhe.to_host(ev.square(da))[0], orc.square(a[0]))
+
+
+@pytest.mark.parametrize("dbc", [16, 30])
+def test_relinearize(fhe, oracle_mod, dbc):
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    sk, pk = orc.keygen(77)
+    evk = orc.evk_gen(sk, dbc=dbc)                       # oracle NTT form [k][nd][2][k][n]
+    coeff = np.zeros_like(evk)
+    for idx in np.ndindex(evk.shape[:3]):
+        for i in range(ctx.k):
+            coeff[idx + (i,)] = orc.ntt_inv(evk[idx + (i,)], i)
+    evk_dev = ev.ntt_forward(fhe.to_device(coeff))       # library slot order
+    c1 = orc.encrypt(pk, orc.encode(3.5), seed=1)
+    c2 = orc.encrypt(pk, orc.encode(-2.25), seed=2)
+    prod = np.stack([orc.multiply(c1, c2), orc.square(c1)])
+    got = fhe.to_host(ev.relinearize(fhe.to_device(prod), evk_dev, dbc))
+    for i in range(2):
+        assert np.array_equal(got[i], orc.relinearize(prod[i], evk, dbc=dbc))
+    assert orc.decode(orc.decrypt(sk, got[0])[0]) == 3.5 * -2.25
+    assert orc.decode(orc.decrypt(sk, got[1])[0]) == 3.5 * 3.5
