@@ -1,0 +1,184 @@
+"""The reference's homomorphic circuits, re-expressed over the batched Evaluator.
+
+Each function follows the Evaluator call sequence of the cited reference lines, but on whole
+batches: the leading dimension of every ciphertext tensor ([B, size, k, n]) runs over independent
+pixels / output positions, which the reference visits in serial loops
+(homo/server_jpeg.cpp:113, homo/fhe_resize.h:350,381, homo/server_decode.cpp:120-137).
+
+Server-side fresh encryptions inside the reference's circuits (the fractional offsets in
+SampleLinear/SampleBicubic, homo/fhe_resize.h:230-266, and the Enc(0) accumulators of
+homomorphic_sin/cos, homo/fhe_decode.h:54,134) are randomised; here they are explicit inputs so that
+results are reproducible.
+"""
+import math
+
+import torch
+
+from .evaluator import FractionalEncoder, PreparedPlain
+
+
+class PlainCache:
+    """encode + lift + NTT each distinct constant once (the reference redoes it on every call)."""
+
+    def __init__(self, ctx, encoder=None):
+        self.ctx = ctx
+        self.enc = encoder or FractionalEncoder(ctx)
+        self._prepared = {}
+        self._plain = {}
+
+    def plain(self, v):
+        v = float(v)
+        if v not in self._plain:
+            self._plain[v] = self.enc.encode(v)
+        return self._plain[v]
+
+    def prepared(self, v):
+        v = float(v)
+        if v not in self._prepared:
+            self._prepared[v] = PreparedPlain(self.ctx, self.plain(v))
+        return self._prepared[v]
+
+
+# ------------------------------------------------------------------------------------------------
+# JPEG path, op-at-a-time (the fused kernel is Evaluator.dct8x8_quant)
+# ------------------------------------------------------------------------------------------------
+def rgb_to_ycc(ev, pc, r, g, b):
+    """homo/fhe_image.h:310-325 as separate Evaluator calls (fused form: Evaluator.rgb_to_ycc)."""
+    M, P = ev.multiply_plain, pc.prepared
+    y = ev.sub_plain(ev.add(ev.add(M(r, P(0.299)), M(g, P(0.587))), M(b, P(0.114))), pc.plain(128.0))
+    u = ev.add(ev.sub(M(r, P(-0.168736)), M(g, P(0.331264))), M(b, P(0.5)))
+    v = ev.sub(ev.sub(M(r, P(0.5)), M(g, P(0.418688))), M(b, P(0.081312)))
+    return y, u, v
+
+
+# ------------------------------------------------------------------------------------------------
+# resize path
+# ------------------------------------------------------------------------------------------------
+def cubic(ev, pc, A, B, C, D, t):
+    """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189.  Note t3 = t*t exactly as the reference
+    computes it (:175), and t2/t3 are recomputed per call as there."""
+    M, P = ev.multiply_plain, pc.prepared
+    a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
+    b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
+    c = ev.sub(C, A)
+    t2 = ev.square(t)
+    t3 = ev.multiply(t, t)
+    a = ev.multiply(a, t3)
+    b = ev.multiply(b, t2)
+    c = ev.multiply(c, t)
+    a = ev.add(ev.add(a, b), c)
+    a = M(a, P(0.5))
+    return ev.add(a, B)
+
+
+def linear(ev, pc, A, B, t):
+    """Linear(result, A,B,t): homo/fhe_resize.h:191-204: (1 - t) A + t B."""
+    omt = ev.add_plain(ev.negate(t), pc.plain(1.0))
+    return ev.add(ev.multiply(omt, A), ev.multiply(B, t))
+
+
+def _clamp(v, lo, hi):
+    return lo if v < lo else hi if v > hi else v
+
+
+def resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic=True):
+    """The index arithmetic of ResizeImage / SampleBicubic / SampleLinear / GetPixelClamped
+    (homo/fhe_resize.h:350-351, 381-382, 260-290, 215-220), in float32 like the reference.
+    Returns per output pixel: the clamped source pixel indices (16 for bicubic, row-major 4x4;
+    4 for bilinear) and the fractional offsets (xfract, yfract)."""
+    import numpy as np
+    f32 = np.float32
+    taps, fx, fy = [], [], []
+    for y in range(dst_h):
+        v = f32(f32(y) / f32(dst_h - 1) * f32(src_h)) - f32(0.5)
+        for x in range(dst_w):
+            u = f32(f32(x) / f32(dst_w - 1) * f32(src_w)) - f32(0.5)
+            xi, yi = int(u), int(v)
+            fx.append(float(u - f32(math.floor(u))))
+            fy.append(float(v - f32(math.floor(v))))
+            offs = [(-1, -1), (0, -1), (1, -1), (2, -1), (-1, 0), (0, 0), (1, 0), (2, 0),
+                    (-1, 1), (0, 1), (1, 1), (2, 1), (-1, 2), (0, 2), (1, 2), (2, 2)] if bicubic else \
+                   [(0, 0), (1, 0), (0, 1), (1, 1)]
+            taps.append([_clamp(yi + dy, 0, src_h - 1) * src_w + _clamp(xi + dx, 0, src_w - 1) for dx, dy in offs])
+    return taps, fx, fy
+
+
+def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
+    """SampleBicubic for a batch of output pixels and one colour channel (homo/fhe_resize.h:254-305).
+    pixels: [src_pixels, 2, k, n]; taps: [B][16] source indices; xfract/yfract: [B, 2, k, n]
+    ciphertexts of the fractional offsets.  Returns [B, 6, k, n]."""
+    idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 16]
+    p = [pixels[idx[:, i]].contiguous() for i in range(16)]
+    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract) for r in range(4)]
+    return cubic(ev, pc, cols[0], cols[1], cols[2], cols[3], yfract)
+
+
+def sample_linear(ev, pc, pixels, taps, xfract, yfract):
+    """SampleLinear for one channel (homo/fhe_resize.h:222-252).  Returns [B, 4, k, n]."""
+    idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 4]
+    p00, p10, p01, p11 = (pixels[idx[:, i]].contiguous() for i in range(4))
+    col0 = linear(ev, pc, p00, p10, xfract)
+    col1 = linear(ev, pc, p01, p11, xfract)
+    return linear(ev, pc, col0, col1, yfract)
+
+
+# ------------------------------------------------------------------------------------------------
+# decode path
+# ------------------------------------------------------------------------------------------------
+def _taylor(ev, pc, x, zero, coeffs, constant):
+    """shared body of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:56-119 / :136-199):
+    even Taylor polynomial of degree 10 in (x - 3 pi / 2); only the five coefficients differ."""
+    M, P = ev.multiply_plain, pc.prepared
+    sx = ev.add_plain(x, pc.plain(-3 * math.pi / 2.0))
+    p2 = M(ev.square(sx), P(coeffs[0]))
+    p4 = M(ev.square(ev.square(sx)), P(coeffs[1]))
+    p6 = ev.square(ev.square(sx))
+    p6 = M(ev.multiply(ev.multiply(p6, sx), sx), P(coeffs[2]))
+    p8 = M(ev.square(ev.square(ev.square(sx))), P(coeffs[3]))
+    p10 = ev.square(ev.square(ev.square(sx)))
+    p10 = M(ev.multiply(ev.multiply(p10, sx), sx), P(coeffs[4]))
+    res = ev.add_plain(zero, pc.plain(constant))
+    for term in (p2, p4, p6, p8, p10):
+        res = ev.add(res, term)
+    return res
+
+
+def homomorphic_sin(ev, pc, x, zero):
+    """homo/fhe_decode.h:48-120; `zero` plays the role of encrypt(encode(0.0)) (:54)."""
+    return _taylor(ev, pc, x, zero, (0.5, -1.0 / 24.0, 1.0 / 720.0, -1.0 / 40320.0, 1.0 / 3628800.0), -1.0)
+
+
+def homomorphic_cos(ev, pc, x, zero):
+    """homo/fhe_decode.h:128-200 (the reference shifts by -3pi/2 here too, :137, and falls off the end
+    without a return statement, :200; the value it leaves in `res` is what is returned here)."""
+    return _taylor(ev, pc, x, zero, (-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0), 1.0)
+
+
+def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros):
+    """The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run.
+    amplitude/index/count: [1, 2, k, n].  zeros: callable (i, j, which) -> [1, 2, k, n] encryption of
+    zero for position i, harmonic j, which in {"sin", "cos"}.  Returns a list of width*height
+    ciphertexts [1, 22, k, n].
+
+    Faithful to the reference's quirk: `offset` is advanced by add_plain(offset, encode(i)) INSIDE
+    the harmonic loop (:229), after cos_arg was copied from it."""
+    M, P = ev.multiply_plain, pc.prepared
+    b = M(count, P(0.5))
+    offset = ev.negate(ev.add_plain(ev.add(index, b), pc.plain(-0.5)))
+    b = ev.add_plain(b, pc.plain(delta - 0.5))
+    run = []
+    for i in range(width * height):
+        c = M(b, P(1.0 / float(order)))
+        for j in range(1, degree + 1):
+            import numpy as np
+            arg_factor = float(np.float32(j)) * math.pi / float(order)
+            sin_arg = M(b, P(arg_factor))
+            cos_arg = offset
+            offset = ev.add_plain(offset, pc.plain(float(i)))
+            cos_arg = M(cos_arg, P(arg_factor))
+            s = homomorphic_sin(ev, pc, sin_arg, zeros(i, j, "sin"))
+            co = homomorphic_cos(ev, pc, cos_arg, zeros(i, j, "cos"))
+            term = M(ev.multiply(s, co), P(2.0 / (math.pi * float(np.float32(j)))))
+            c = ev.add(c, term)
+        run.append(ev.multiply(c, amplitude))
+    return run

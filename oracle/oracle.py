@@ -300,3 +300,63 @@ class Oracle:
 def digest(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return int(lib().fo_digest(_p(a), a.size))
+
+
+# ---------------------------------------------------------------------------------------------
+# decode circuits (homo/fhe_decode.h), composed from the C oracle's single operations.
+# Written as explicit operation lists, independently of the product's circuits.py.
+# ---------------------------------------------------------------------------------------------
+import math as _math
+
+
+def _taylor_terms(sign):
+    # (number of squarings, number of extra multiplies by shifted_x, coefficient)
+    # homo/fhe_decode.h:66-98 (sin) / :146-178 (cos); sin coefficients are -1 * cos coefficients
+    return [(1, 0, sign * 0.5), (2, 0, sign * -1.0 / 24.0), (2, 2, sign * 1.0 / 720.0),
+            (3, 0, sign * -1.0 / 40320.0), (3, 2, sign * 1.0 / 3628800.0)]
+
+
+def _oracle_taylor(orc, x, zero, sign, constant):
+    shifted = orc.add_plain(x, orc.encode(-3 * _math.pi / 2.0))      # :57 / :137
+    res = orc.add_plain(zero, orc.encode(constant))                   # :113 / :193
+    for squarings, mults, coeff in _taylor_terms(sign):
+        p = shifted
+        for _ in range(squarings):
+            p = orc.square(p)
+        for _ in range(mults):
+            p = orc.multiply(p, shifted)
+        res = orc.add(res, orc.multiply_plain(p, orc.encode(coeff)))  # :114-118
+    return res
+
+
+def oracle_homomorphic_sin(orc, x, zero):
+    return _oracle_taylor(orc, x, zero, +1.0, -1.0)
+
+
+def oracle_homomorphic_cos(orc, x, zero):
+    return _oracle_taylor(orc, x, zero, -1.0, 1.0)
+
+
+def oracle_approximated_step(orc, amplitude, index, count, order, degree, delta, width, height, zeros):
+    """homo/fhe_decode.h:202-242 (homomorphic overload), including the offset mutation at :229."""
+    b = orc.multiply_plain(count, orc.encode(0.5))                    # :214-215
+    offset = orc.add(index, b)                                        # :216-217
+    offset = orc.add_plain(offset, orc.encode(-0.5))                  # :218
+    offset = orc.negate(offset)                                       # :219
+    b = orc.add_plain(b, orc.encode(delta - 0.5))                     # :220
+    run = []
+    for i in range(width * height):
+        c = orc.multiply_plain(b, orc.encode(1.0 / float(order)))     # :222-223
+        for j in range(1, degree + 1):
+            arg_factor = float(np.float32(j)) * _math.pi / float(order)   # :225
+            sin_arg = orc.multiply_plain(b, orc.encode(arg_factor))   # :226-227
+            cos_arg = offset.copy()                                   # :228
+            offset = orc.add_plain(offset, orc.encode(float(i)))      # :229
+            cos_arg = orc.multiply_plain(cos_arg, orc.encode(arg_factor))   # :230
+            s = oracle_homomorphic_sin(orc, sin_arg, zeros(i, j, "sin"))
+            co = oracle_homomorphic_cos(orc, cos_arg, zeros(i, j, "cos"))
+            term = orc.multiply(s, co)                                # :234-235
+            term = orc.multiply_plain(term, orc.encode(2.0 / (_math.pi * float(np.float32(j)))))   # :236
+            c = orc.add(c, term)                                      # :237
+        run.append(orc.multiply(c, amplitude))                       # :239-240
+    return run

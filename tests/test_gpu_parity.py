@@ -387,3 +387,100 @@ def test_relinearize(fhe, oracle_mod, dbc):
         assert np.array_equal(got[i], orc.relinearize(prod[i], evk, dbc=dbc))
     assert orc.decode(orc.decrypt(sk, got[0])[0]) == 3.5 * -2.25
     assert orc.decode(orc.decrypt(sk, got[1])[0]) == 3.5 * 3.5
+
+
+# ---------------------------------------------------------------------------------------------
+# resize and decode circuits (BASELINE.json configs[2], configs[3] shapes at test sizes)
+# ---------------------------------------------------------------------------------------------
+def test_cubic_linear_vs_oracle(fhe, oracle_mod):
+    """Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 -> 4, batched"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    pc = fhe.circuits.PlainCache(ctx)
+    h = fhe.to_host
+    A, B, C, D = (ctx.random_ct(2, size=2, seed=400 + i) for i in range(4))
+    t = ctx.random_ct(2, size=2, seed=410)
+    r1 = fhe.circuits.cubic(ev, pc, A, B, C, D, t)
+    assert r1.shape[-3] == 4
+    for i in range(2):
+        assert np.array_equal(h(r1)[i], orc.cubic(h(A)[i], h(B)[i], h(C)[i], h(D)[i], h(t)[i]))
+    A4, B4, C4, D4 = (ctx.random_ct(2, size=4, seed=420 + i) for i in range(4))
+    r2 = fhe.circuits.cubic(ev, pc, A4, B4, C4, D4, t)
+    assert r2.shape[-3] == 6
+    for i in range(2):
+        assert np.array_equal(h(r2)[i], orc.cubic(h(A4)[i], h(B4)[i], h(C4)[i], h(D4)[i], h(t)[i]))
+    l1 = fhe.circuits.linear(ev, pc, A, B, t)
+    l2 = fhe.circuits.linear(ev, pc, l1, l1, t)
+    assert l1.shape[-3] == 3 and l2.shape[-3] == 4
+    for i in range(2):
+        o1 = orc.linear(h(A)[i], h(B)[i], h(t)[i])
+        assert np.array_equal(h(l1)[i], o1)
+        assert np.array_equal(h(l2)[i], orc.linear(o1, o1, h(t)[i]))
+
+
+def test_bicubic_resize_8x8_to_4x4(fhe, oracle_mod):
+    """ResizeImage/SampleBicubic (homo/fhe_resize.h:254-392) on a small image, one channel:
+    the product's batched sampler against per-pixel oracle Cubic calls, plus a decrypt known answer"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    pc = fhe.circuits.PlainCache(ctx)
+    sk, pk = orc.keygen(21)
+    W = H = 8
+    w = h_ = 4
+    vals = [float((29 * x + 53 * y) % 256) for y in range(H) for x in range(W)]
+    pix = np.stack([orc.encrypt(pk, orc.encode(v), seed=500 + i) for i, v in enumerate(vals)])
+    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=True)
+    xf = np.stack([orc.encrypt(pk, orc.encode(f), seed=600 + i) for i, f in enumerate(fx)])
+    yf = np.stack([orc.encrypt(pk, orc.encode(f), seed=700 + i) for i, f in enumerate(fy)])
+    out = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, fhe.to_device(pix), taps, fhe.to_device(xf), fhe.to_device(yf)))
+    assert out.shape == (w * h_, 6, ctx.k, ctx.n)
+
+    def plain_cubic(A, B, C, D, t):     # closed form of homo/fhe_resize.h:149-185 with t3 = t*t
+        a, b, c = -A + 3 * B - 3 * C + D, 2 * A - 5 * B + 4 * C - D, C - A
+        return 0.5 * (a * t * t + b * t * t + c * t) + B
+
+    for o in (0, 5, 15):
+        p = [pix[i] for i in taps[o]]
+        cols = [orc.cubic(p[4 * r], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xf[o]) for r in range(4)]
+        ref = orc.cubic(cols[0], cols[1], cols[2], cols[3], yf[o])
+        assert np.array_equal(out[o], ref)
+        v = [vals[i] for i in taps[o]]
+        pc_cols = [plain_cubic(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3], fx[o]) for r in range(4)]
+        expect = plain_cubic(pc_cols[0], pc_cols[1], pc_cols[2], pc_cols[3], fy[o])
+        plain, budget = orc.decrypt(sk, out[o])
+        assert budget > 0 and abs(orc.decode(plain) - expect) < 1e-6
+
+
+def test_homomorphic_sin_cos_vs_oracle(fhe, oracle_mod):
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    pc = fhe.circuits.PlainCache(ctx)
+    x, z = ctx.random_ct(2, size=2, seed=800), ctx.random_ct(2, size=2, seed=801)
+    s = fhe.circuits.homomorphic_sin(ev, pc, x, z)
+    c = fhe.circuits.homomorphic_cos(ev, pc, x, z)
+    assert s.shape[-3] == 11 and c.shape[-3] == 11
+    for i in range(2):
+        assert np.array_equal(fhe.to_host(s)[i], oracle_mod.oracle_homomorphic_sin(orc, fhe.to_host(x)[i], fhe.to_host(z)[i]))
+        assert np.array_equal(fhe.to_host(c)[i], oracle_mod.oracle_homomorphic_cos(orc, fhe.to_host(x)[i], fhe.to_host(z)[i]))
+
+
+def test_approximated_step_vs_oracle(fhe, oracle_mod):
+    """the deepest circuit (sizes up to 22) at a reduced harmonic count: W*H = 2, degree 2"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    pc = fhe.circuits.PlainCache(ctx)
+    amp, idx, cnt = (ctx.random_ct(1, size=2, seed=900 + i) for i in range(3))
+    zbank = {}
+
+    def zeros_dev(i, j, which):
+        return ctx.random_ct(1, size=2, seed=1000 + 100 * i + 10 * j + (which == "cos"))
+
+    def zeros_host(i, j, which):
+        return fhe.to_host(zeros_dev(i, j, which))[0]
+
+    run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=2, delta=0.5, width=2, height=1, zeros=zeros_dev)
+    ref = oracle_mod.oracle_approximated_step(orc, fhe.to_host(amp)[0], fhe.to_host(idx)[0], fhe.to_host(cnt)[0], 64, 2, 0.5, 2, 1, zeros_host)
+    assert len(run) == 2
+    for g, r in zip(run, ref):
+        assert g.shape[-3] == 22
+        assert np.array_equal(fhe.to_host(g)[0], r)
