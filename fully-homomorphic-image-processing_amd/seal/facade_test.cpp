@@ -1,0 +1,106 @@
+// facade_test.cpp -- exercises the SEAL-shaped facade (seal/seal.h) end to end on the GPU:
+// keygen, encrypt, every Evaluator operation, relinearize, save/load, decrypt, and the fused
+// DCT+quant helper against the plaintext dct() model restated from homo/fhe_image.h:400-484.
+// Exit code 0 = all checks passed.  Built by seal/Makefile; run by tests/test_gpu_facade.py.
+#include <cstdio>
+#include <sstream>
+
+#include "seal/seal.h"
+
+using namespace seal;
+
+static int failures = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+static void plain_line(double *v, int stride, bool scale) {
+    double d[8];
+    for (int i = 0; i < 8; i++) d[i] = v[i * stride];
+    double tmp0 = d[0] + d[7], tmp7 = d[0] - d[7], tmp1 = d[1] + d[6], tmp6 = d[1] - d[6];
+    double tmp2 = d[2] + d[5], tmp5 = d[2] - d[5], tmp3 = d[3] + d[4], tmp4 = d[3] - d[4];
+    double tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    double o[8];
+    o[0] = tmp10 + tmp11;
+    o[4] = tmp10 - tmp11;
+    double z1 = (tmp12 + tmp13) * 0.541196100;
+    o[2] = z1 + tmp13 * 0.765366865;
+    o[6] = z1 + tmp12 * -1.847759065;
+    z1 = tmp4 + tmp7;
+    double z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7, z5 = (z3 + z4) * 1.175875602;
+    tmp4 *= 0.298631336; tmp5 *= 2.053119869; tmp6 *= 3.072711026; tmp7 *= 1.501321110;
+    z1 *= -0.899976223; z2 *= -2.562915447; z3 *= -1.961570560; z4 *= -0.390180644;
+    z3 += z5; z4 += z5;
+    o[7] = tmp4 + z1 + z3; o[5] = tmp5 + z2 + z4; o[3] = tmp6 + z2 + z3; o[1] = tmp7 + z1 + z4;
+    for (int i = 0; i < 8; i++) v[i * stride] = scale ? o[i] / 8.0 : o[i];
+}
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? std::atoi(argv[1]) : 4096;
+    EncryptionParameters params;
+    char poly_mod[32];
+    std::snprintf(poly_mod, sizeof poly_mod, "1x^%i + 1", n);
+    params.set_poly_modulus(poly_mod);
+    params.set_coeff_modulus(coeff_modulus_128(n));
+    params.set_plain_modulus(1 << 14);
+    SEALContext context(params);
+    std::printf("poly_modulus %s, coeff_modulus %d bits, plain_modulus %llu\n", context.poly_modulus().to_string().c_str(),
+                context.total_coeff_modulus().significant_bit_count(), (unsigned long long)context.plain_modulus().value());
+    KeyGenerator keygen(context);
+    PublicKey pk = keygen.public_key();
+    SecretKey sk = keygen.secret_key();
+    Encryptor encryptor(context, pk);
+    Decryptor decryptor(context, sk);
+    Evaluator evaluator(context);
+    FractionalEncoder encoder(context.plain_modulus(), context.poly_modulus(), 100, 100, 2);
+    auto dec = [&](const Ciphertext &c) { Plaintext p; decryptor.decrypt(c, p); return encoder.decode(p); };
+
+    Ciphertext a, b;
+    encryptor.encrypt(encoder.encode(37.25), a);
+    encryptor.encrypt(encoder.encode(-2.5), b);
+    CHECK(a.size() == 2, "fresh ciphertext size");
+    CHECK(dec(a) == 37.25 && dec(b) == -2.5, "encrypt/decrypt round trip: %g %g", dec(a), dec(b));
+    CHECK(decryptor.invariant_noise_budget(a) > 50, "fresh noise budget %d", decryptor.invariant_noise_budget(a));
+
+    { Ciphertext c(a); evaluator.add(c, b); CHECK(dec(c) == 34.75, "add -> %g", dec(c)); }
+    { Ciphertext c(a); evaluator.sub(c, b); CHECK(dec(c) == 39.75, "sub -> %g", dec(c)); }
+    { Ciphertext c(a); evaluator.negate(c); CHECK(dec(c) == -37.25, "negate -> %g", dec(c)); }
+    { Ciphertext c(a); evaluator.add_plain(c, encoder.encode(0.75)); CHECK(dec(c) == 38.0, "add_plain -> %g", dec(c)); }
+    { Ciphertext c(a); evaluator.sub_plain(c, encoder.encode(128.0)); CHECK(dec(c) == 37.25 - 128.0, "sub_plain -> %g", dec(c)); }
+    { Ciphertext c(a); evaluator.multiply_plain(c, encoder.encode(0.541196100)); CHECK(std::fabs(dec(c) - 37.25 * 0.541196100) < 1e-9, "multiply_plain -> %.12g", dec(c)); }
+    { Ciphertext c(a); evaluator.multiply(c, b); CHECK(c.size() == 3 && dec(c) == 37.25 * -2.5, "multiply -> size %d value %g", c.size(), dec(c));
+      Ciphertext d(c); evaluator.add(d, a); CHECK(d.size() == 3 && dec(d) == 37.25 * -2.5 + 37.25, "add 3+2 -> %g", dec(d));
+      Ciphertext e(a); evaluator.sub(e, c); CHECK(e.size() == 3 && dec(e) == 37.25 - 37.25 * -2.5, "sub 2-3 -> %g", dec(e));
+      EvaluationKeys evk; keygen.generate_evaluation_keys(30, evk);
+      evaluator.relinearize(c, evk); CHECK(c.size() == 2 && dec(c) == 37.25 * -2.5, "relinearize -> size %d value %g", c.size(), dec(c));
+      CHECK(decryptor.invariant_noise_budget(c) > 0, "budget after relinearize"); }
+    { Ciphertext c(b); evaluator.square(c); CHECK(c.size() == 3 && dec(c) == 6.25, "square -> %g", dec(c));
+      Ciphertext d(b); evaluator.multiply(d, b); CHECK(dec(d) == 6.25, "multiply(x,x) -> %g", dec(d)); }
+    { std::stringstream ss; a.save(ss); b.save(ss); Ciphertext c, d; c.load(ss); d.load(ss);
+      CHECK(dec(c) == 37.25 && dec(d) == -2.5, "save/load stream of two ciphertexts");
+      std::stringstream ks; pk.save(ks); sk.save(ks); PublicKey pk2; SecretKey sk2; pk2.load(ks); sk2.load(ks);
+      Encryptor e2(context, pk2); Decryptor d2(context, sk2); Ciphertext x; e2.encrypt(encoder.encode(5.0), x); Plaintext p; d2.decrypt(x, p);
+      CHECK(encoder.decode(p) == 5.0, "key save/load"); }
+    { bool threw = false; try { Ciphertext empty; evaluator.negate(empty); } catch (const std::invalid_argument &) { threw = true; } CHECK(threw, "empty ciphertext must throw"); }
+
+    // fused block circuit on one encrypted 8x8 block
+    const std::vector<double> yqt = {16,11,10,16,24,40,51,61,12,12,14,19,26,58,60,55,14,13,16,24,40,57,69,56,14,17,22,29,51,87,80,62,
+                                     18,22,37,56,68,109,103,77,24,35,55,64,81,104,113,92,49,64,78,87,103,121,120,101,72,92,95,98,112,100,103,99};
+    std::vector<Ciphertext> block(64);
+    double plain[64];
+    for (int i = 0; i < 64; i++) {
+        plain[i] = (double)((37 * (i % 8) + 101 * (i / 8) + 13) % 256) - 128.0;
+        encryptor.encrypt(encoder.encode(plain[i]), block[i]);
+    }
+    hip::dct8x8_quant(context, block, &yqt);
+    for (int r = 0; r < 8; r++) plain_line(plain + 8 * r, 1, false);
+    for (int c = 0; c < 8; c++) plain_line(plain + c, 8, true);
+    double worst = 0;
+    int min_budget = 1 << 30;
+    for (int i = 0; i < 64; i++) {
+        worst = std::max(worst, std::fabs(dec(block[i]) - plain[i] / yqt[i]));
+        min_budget = std::min(min_budget, decryptor.invariant_noise_budget(block[i]));
+    }
+    CHECK(worst < 1e-6 && min_budget > 0, "fused DCT+quant known answer: max err %g, min budget %d", worst, min_budget);
+    std::printf("fused DCT+quant: max |err| %.3g, min noise budget %d bits\n", worst, min_budget);
+    std::printf(failures ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK\n", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,656 @@
+// seal/seal.h -- SEAL-2.3-shaped C++ facade over the C ABI of libfhe_hip.so (include/fhe_hip.h).
+//
+// Purpose: let the reference's circuit headers compile UNCHANGED against the MI355X library:
+//     homo/fhe_image.h:13, homo/fhe_resize.h:11, homo/fhe_decode.h:11   -> #include "seal/seal.h"
+// The surface is exactly what those headers and the six mains use:
+// EncryptionParameters, SEALContext, SmallModulus, BigPoly, BigUInt, Plaintext, Ciphertext,
+// PublicKey, SecretKey, EvaluationKeys, KeyGenerator, Encryptor, Decryptor, Evaluator,
+// FractionalEncoder, coeff_modulus_128.  Semantics follow SEAL 2.3: value-type ciphertexts with deep
+// copies, in-place Evaluator operations on the first argument, std::invalid_argument on misuse.
+//
+// Ciphertexts live in HBM; every Evaluator call is one or a few asynchronous kernel launches on the
+// default stream, and the host synchronises only in save()/decrypt().  This is the drop-in,
+// one-ciphertext-at-a-time mode; the throughput path is the batched/fused C ABI (fhe_dct8x8_quant
+// etc.), which the facade exposes through seal::hip::* helpers at the bottom of this file.
+//
+// The reference headers rely on `using namespace std` leaking out of SEAL's headers
+// (homo/fhe_image.h:286 `chrono::duration<double, milli>`), hence the
+// using-directive inside namespace seal below.
+#ifndef FHE_HIP_SEAL_FACADE_H
+#define FHE_HIP_SEAL_FACADE_H
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fhe_hip.h"
+
+namespace seal {
+using namespace std;   // see header comment
+
+namespace detail {
+typedef unsigned __int128 u128;
+inline void check(int rc, const char *what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + fhe_last_error());
+}
+inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)(((u128)a * b) % m); }
+inline uint64_t powmod(uint64_t a, uint64_t e, uint64_t m) {
+    uint64_t r = 1 % m;
+    for (a %= m; e; e >>= 1) { if (e & 1) r = mulmod(r, a, m); a = mulmod(a, a, m); }
+    return r;
+}
+// little-endian multi-word unsigned integer: enough for CRT composition and t*x/q rounding
+struct Big {
+    std::vector<uint64_t> w;
+    explicit Big(uint64_t v = 0, size_t words = 12) : w(words, 0) { w[0] = v; }
+    void mul_small(uint64_t s) { u128 c = 0; for (auto &x : w) { c += (u128)x * s; x = (uint64_t)c; c >>= 64; } }
+    void add(const Big &o) { u128 c = 0; for (size_t i = 0; i < w.size(); ++i) { c += (u128)w[i] + o.w[i]; w[i] = (uint64_t)c; c >>= 64; } }
+    void sub(const Big &o) { uint64_t br = 0; for (size_t i = 0; i < w.size(); ++i) { u128 d = (u128)w[i] - o.w[i] - br; w[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+    int cmp(const Big &o) const { for (size_t i = w.size(); i-- > 0;) if (w[i] != o.w[i]) return w[i] > o.w[i] ? 1 : -1; return 0; }
+    uint64_t mod_small(uint64_t m) const { u128 r = 0; for (size_t i = w.size(); i-- > 0;) r = ((r << 64) | w[i]) % m; return (uint64_t)r; }
+    int bits() const { for (size_t i = w.size(); i-- > 0;) if (w[i]) return (int)(64 * i) + 64 - __builtin_clzll(w[i]); return 0; }
+    void shr1() { for (size_t i = 0; i < w.size(); ++i) w[i] = (w[i] >> 1) | (i + 1 < w.size() ? w[i + 1] << 63 : 0); }
+};
+// device buffer with value semantics
+class DevBuf {
+public:
+    DevBuf() : p_(nullptr), words_(0) {}
+    explicit DevBuf(size_t words) : p_(nullptr), words_(0) { resize(words); }
+    DevBuf(const DevBuf &o) : p_(nullptr), words_(0) { *this = o; }
+    DevBuf(DevBuf &&o) noexcept : p_(o.p_), words_(o.words_) { o.p_ = nullptr; o.words_ = 0; }
+    DevBuf &operator=(const DevBuf &o) {
+        if (this == &o) return *this;
+        resize(o.words_);
+        if (words_) check(fhe_copy(p_, o.p_, words_ * 8, nullptr), "device copy");
+        return *this;
+    }
+    DevBuf &operator=(DevBuf &&o) noexcept { std::swap(p_, o.p_); std::swap(words_, o.words_); return *this; }
+    ~DevBuf() { if (p_) fhe_dev_free(p_); }
+    void resize(size_t words) {
+        if (words == words_) return;
+        if (p_) { fhe_dev_free(p_); p_ = nullptr; }
+        words_ = words;
+        if (words) { void *q = nullptr; check(fhe_dev_alloc(words * 8, &q), "device alloc"); p_ = (uint64_t *)q; }
+    }
+    uint64_t *ptr() { return p_; }
+    const uint64_t *ptr() const { return p_; }
+    size_t words() const { return words_; }
+    void upload(const uint64_t *src, size_t words, size_t at = 0) {
+        check(fhe_upload(p_ + at, src, words * 8, nullptr), "upload");
+        check(fhe_stream_sync(nullptr), "sync");
+    }
+    void download(uint64_t *dst, size_t words, size_t at = 0) const { check(fhe_download(dst, p_ + at, words * 8, nullptr), "download"); }
+private:
+    uint64_t *p_;
+    size_t words_;
+};
+}  // namespace detail
+
+// ---- small value types -----------------------------------------------------------------------
+class SmallModulus {
+public:
+    SmallModulus(uint64_t v = 0) : v_(v) {}
+    uint64_t value() const { return v_; }
+    int bit_count() const { return v_ ? 64 - __builtin_clzll(v_) : 0; }
+private:
+    uint64_t v_;
+};
+
+class BigPoly {   // only ever holds the polynomial modulus "1x^N + 1"
+public:
+    BigPoly() : n_(0) {}
+    explicit BigPoly(const std::string &s) { parse(s); }
+    std::string to_string() const { std::ostringstream o; o << "1x^" << n_ << " + 1"; return o.str(); }
+    int coeff_count() const { return n_ + 1; }
+    int significant_coeff_count() const { return n_ + 1; }
+    int degree() const { return n_; }
+private:
+    void parse(const std::string &s) {
+        size_t c = s.find('^');
+        if (c == std::string::npos) throw std::invalid_argument("poly_modulus must look like \"1x^N + 1\"");
+        n_ = std::atoi(s.c_str() + c + 1);
+        if (n_ <= 0 || (n_ & (n_ - 1))) throw std::invalid_argument("poly_modulus degree must be a power of two");
+    }
+    int n_;
+};
+
+class BigUInt {
+public:
+    BigUInt() : bits_(0) {}
+    explicit BigUInt(int bits) : bits_(bits) {}
+    int significant_bit_count() const { return bits_; }
+private:
+    int bits_;
+};
+
+// SEAL's coeff_modulus_128(n) (homo/server_jpeg.cpp:78).  Default: the 36/37-bit sets BASELINE.json
+// names ("n=4096, 3 coeff moduli"); export FHE_SEAL23_MODULI=1 for the SEAL 2.3.1 tables.
+inline std::vector<SmallModulus> coeff_modulus_128(int poly_modulus_degree) {
+    uint64_t q[FHE_MAX_K];
+    const char *e = std::getenv("FHE_SEAL23_MODULI");
+    int cnt = fhe_default_coeff_modulus((uint32_t)poly_modulus_degree, (e && *e == '1') ? 1 : 0, q);
+    if (cnt < 0) throw std::invalid_argument(fhe_last_error());
+    return std::vector<SmallModulus>(q, q + cnt);
+}
+
+class EncryptionParameters {
+public:
+    EncryptionParameters() : n_(0), t_(0) {}
+    void set_poly_modulus(const std::string &s) { poly_ = BigPoly(s); n_ = poly_.degree(); }
+    void set_poly_modulus(const BigPoly &p) { poly_ = p; n_ = p.degree(); }
+    void set_coeff_modulus(const std::vector<SmallModulus> &q) { q_ = q; }
+    void set_plain_modulus(const SmallModulus &t) { t_ = t.value(); }
+    void set_plain_modulus(uint64_t t) { t_ = t; }
+    const BigPoly &poly_modulus() const { return poly_; }
+    const std::vector<SmallModulus> &coeff_modulus() const { return q_; }
+    SmallModulus plain_modulus() const { return SmallModulus(t_); }
+private:
+    friend class SEALContext;
+    BigPoly poly_;
+    int n_;
+    std::vector<SmallModulus> q_;
+    uint64_t t_;
+};
+
+namespace detail {
+struct CtxState {
+    fhe_ctx *h;
+    uint32_t n, k;
+    uint64_t t;
+    std::vector<uint64_t> q;
+    Big Q, Qhalf;
+    std::vector<Big> punct;            // Q / q_i
+    std::vector<uint64_t> inv_punct;   // (Q/q_i)^-1 mod q_i
+    CtxState() : h(nullptr), n(0), k(0), t(0) {}
+    ~CtxState() { if (h) fhe_ctx_destroy(h); }
+    size_t poly_words() const { return (size_t)k * n; }
+};
+}  // namespace detail
+
+class SEALContext {
+public:
+    SEALContext(const EncryptionParameters &p) : st_(std::make_shared<detail::CtxState>()), poly_(p.poly_), plain_(p.t_) {
+        if (p.n_ <= 0 || p.q_.empty() || p.t_ == 0) throw std::invalid_argument("encryption parameters are not set");
+        detail::CtxState &s = *st_;
+        s.n = (uint32_t)p.n_;
+        s.k = (uint32_t)p.q_.size();
+        s.t = p.t_;
+        for (const auto &m : p.q_) s.q.push_back(m.value());
+        int dev = 0;
+        if (const char *e = std::getenv("FHE_DEVICE")) dev = std::atoi(e);
+        detail::check(fhe_ctx_create(s.n, s.q.data(), s.k, s.t, dev, &s.h), "SEALContext");
+        s.Q = detail::Big(1);
+        for (uint64_t qi : s.q) s.Q.mul_small(qi);
+        s.Qhalf = s.Q;
+        s.Qhalf.shr1();
+        for (uint32_t i = 0; i < s.k; ++i) {
+            detail::Big pi(1);
+            for (uint32_t j = 0; j < s.k; ++j) if (j != i) pi.mul_small(s.q[j]);
+            s.inv_punct.push_back(detail::powmod(pi.mod_small(s.q[i]), s.q[i] - 2, s.q[i]));
+            s.punct.push_back(pi);
+        }
+        total_ = BigUInt(s.Q.bits());
+    }
+    const SmallModulus &plain_modulus() const { return plain_; }
+    const BigPoly &poly_modulus() const { return poly_; }
+    const BigUInt &total_coeff_modulus() const { return total_; }
+    double noise_standard_deviation() const { return 3.19; }
+    const std::shared_ptr<detail::CtxState> &state() const { return st_; }
+private:
+    std::shared_ptr<detail::CtxState> st_;
+    BigPoly poly_;
+    SmallModulus plain_;
+    BigUInt total_;
+};
+
+class Plaintext {
+public:
+    Plaintext() {}
+    explicit Plaintext(std::vector<uint64_t> c) : c_(std::move(c)) {}
+    int coeff_count() const { return (int)c_.size(); }
+    int significant_coeff_count() const { int n = (int)c_.size(); while (n > 0 && c_[n - 1] == 0) --n; return n; }
+    uint64_t operator[](int i) const { return c_[i]; }
+    const std::vector<uint64_t> &data() const { return c_; }
+    std::vector<uint64_t> &data() { return c_; }
+    std::string to_string() const {   // SEAL style: "7FFx^3 + 1x^1 + 2"
+        std::ostringstream o;
+        bool first = true;
+        for (int i = (int)c_.size() - 1; i >= 0; --i) {
+            if (!c_[i]) continue;
+            if (!first) o << " + ";
+            o << std::hex << std::uppercase << c_[i] << std::dec;
+            if (i) o << "x^" << i;
+            first = false;
+        }
+        if (first) o << "0";
+        return o.str();
+    }
+private:
+    std::vector<uint64_t> c_;
+};
+
+// Wire format of save()/load() for ciphertexts and keys (self-consistent; SEAL 2.3's own format is
+// not pinned by anything in the reference -- SURVEY.md App. A.6): magic "FHEHIP1\0", u32 polys,
+// u32 k, u32 n, u32 reserved, then polys*k*n little-endian u64.
+namespace detail {
+inline void save_words(std::ostream &os, const DevBuf &buf, uint32_t polys, uint32_t k, uint32_t n) {
+    const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
+    uint32_t hdr[4] = {polys, k, n, 0};
+    os.write(magic, 8);
+    os.write((const char *)hdr, sizeof hdr);
+    std::vector<uint64_t> h(buf.words());
+    if (!h.empty()) buf.download(h.data(), h.size());
+    os.write((const char *)h.data(), (std::streamsize)(h.size() * 8));
+}
+inline void load_words(std::istream &is, DevBuf &buf, uint32_t &polys, uint32_t &k, uint32_t &n) {
+    char magic[8];
+    uint32_t hdr[4];
+    is.read(magic, 8);
+    is.read((char *)hdr, sizeof hdr);
+    if (!is || std::memcmp(magic, "FHEHIP1", 7) != 0) throw std::invalid_argument("stream does not hold a ciphertext/key");
+    polys = hdr[0]; k = hdr[1]; n = hdr[2];
+    std::vector<uint64_t> h((size_t)polys * k * n);
+    is.read((char *)h.data(), (std::streamsize)(h.size() * 8));
+    if (!is) throw std::invalid_argument("truncated ciphertext/key stream");
+    buf.resize(h.size());
+    if (!h.empty()) buf.upload(h.data(), h.size());
+}
+}  // namespace detail
+
+class Ciphertext {
+public:
+    Ciphertext() : size_(0), k_(0), n_(0) {}
+    int size() const { return (int)size_; }
+    void save(std::ostream &os) const { detail::save_words(os, buf_, size_, k_, n_); }
+    void load(std::istream &is) { detail::load_words(is, buf_, size_, k_, n_); }
+    // facade internals
+    void shape(uint32_t size, uint32_t k, uint32_t n) { size_ = size; k_ = k; n_ = n; buf_.resize((size_t)size * k * n); }
+    uint64_t *ptr() { return buf_.ptr(); }
+    const uint64_t *ptr() const { return buf_.ptr(); }
+    uint32_t k() const { return k_; }
+    uint32_t n() const { return n_; }
+    detail::DevBuf &buffer() { return buf_; }
+    const detail::DevBuf &buffer() const { return buf_; }
+private:
+    detail::DevBuf buf_;
+    uint32_t size_, k_, n_;
+};
+
+class PublicKey {
+public:
+    void save(std::ostream &os) const { detail::save_words(os, buf, 2, k, n); }
+    void load(std::istream &is) { uint32_t polys; detail::load_words(is, buf, polys, k, n); }
+    detail::DevBuf buf;   // [2][k][n] coefficient form
+    uint32_t k = 0, n = 0;
+};
+class SecretKey {
+public:
+    void save(std::ostream &os) const { detail::save_words(os, buf, 1, k, n); }
+    void load(std::istream &is) { uint32_t polys; detail::load_words(is, buf, polys, k, n); }
+    detail::DevBuf buf;   // [k][n] coefficient form
+    uint32_t k = 0, n = 0;
+};
+class EvaluationKeys {
+public:
+    int decomposition_bit_count() const { return (int)dbc; }
+    detail::DevBuf buf;   // [k][digits][2][k][n], NTT form (library slot order)
+    uint32_t dbc = 0, digits = 0;
+};
+
+namespace detail {
+// samplers (host): ternary, clipped normal sigma 3.19 (|e| <= 6 sigma), uniform
+class Sampler {
+public:
+    explicit Sampler(const CtxState &s) : s_(s) {
+        uint64_t seed = std::random_device{}();
+        if (const char *e = std::getenv("FHE_SEED")) seed = std::strtoull(e, nullptr, 0);
+        static uint64_t counter = 0;
+        rng_.seed(seed + 0x9E3779B97F4A7C15ULL * (++counter));
+    }
+    std::vector<uint64_t> ternary() {
+        std::vector<uint64_t> v(s_.poly_words());
+        for (uint32_t c = 0; c < s_.n; ++c) {
+            uint64_t r = rng_() % 3;
+            for (uint32_t i = 0; i < s_.k; ++i) v[(size_t)i * s_.n + c] = r == 2 ? s_.q[i] - 1 : r;
+        }
+        return v;
+    }
+    std::vector<uint64_t> noise() {
+        std::normal_distribution<double> d(0.0, 3.19);
+        std::vector<uint64_t> v(s_.poly_words());
+        for (uint32_t c = 0; c < s_.n; ++c) {
+            double g;
+            do g = d(rng_); while (std::fabs(g) > 19.14);
+            long long e = std::llround(g);
+            for (uint32_t i = 0; i < s_.k; ++i) v[(size_t)i * s_.n + c] = e < 0 ? s_.q[i] - (uint64_t)(-e) : (uint64_t)e;
+        }
+        return v;
+    }
+    std::vector<uint64_t> uniform() {
+        std::vector<uint64_t> v(s_.poly_words());
+        for (uint32_t i = 0; i < s_.k; ++i)
+            for (uint32_t c = 0; c < s_.n; ++c) v[(size_t)i * s_.n + c] = rng_() % s_.q[i];
+        return v;
+    }
+private:
+    const CtxState &s_;
+    std::mt19937_64 rng_;
+};
+// out = a * b in R_q, all [polys][k][n] coefficient form on device (polys of a; b is one polynomial)
+inline void ring_mul(const CtxState &s, const DevBuf &a, size_t a_polys, const DevBuf &b_ntt, DevBuf &out) {
+    out.resize(a_polys * s.poly_words());
+    check(fhe_ntt_forward(s.h, a.ptr(), out.ptr(), a_polys, nullptr), "ntt");
+    for (size_t p = 0; p < a_polys; ++p)
+        check(fhe_dyadic_multiply(s.h, out.ptr() + p * s.poly_words(), b_ntt.ptr(), out.ptr() + p * s.poly_words(), 1, nullptr), "dyadic");
+    check(fhe_ntt_inverse(s.h, out.ptr(), out.ptr(), a_polys, nullptr), "intt");
+}
+}  // namespace detail
+
+class KeyGenerator {
+public:
+    explicit KeyGenerator(const SEALContext &ctx) : st_(ctx.state()) {
+        const detail::CtxState &s = *st_;
+        detail::Sampler smp(s);
+        const size_t pw = s.poly_words();
+        sk_.k = pk_.k = s.k;
+        sk_.n = pk_.n = s.n;
+        std::vector<uint64_t> sk = smp.ternary(), a = smp.uniform(), e = smp.noise();
+        sk_.buf.resize(pw);
+        sk_.buf.upload(sk.data(), pw);
+        sk_ntt_.resize(pw);
+        detail::check(fhe_ntt_forward(s.h, sk_.buf.ptr(), sk_ntt_.ptr(), 1, nullptr), "ntt");
+        detail::DevBuf da(pw), de(pw), as;
+        da.upload(a.data(), pw);
+        de.upload(e.data(), pw);
+        detail::ring_mul(s, da, 1, sk_ntt_, as);
+        pk_.buf.resize(2 * pw);
+        detail::check(fhe_add(s.h, as.ptr(), de.ptr(), as.ptr(), 1, nullptr), "add");
+        detail::check(fhe_negate(s.h, as.ptr(), pk_.buf.ptr(), 1, nullptr), "negate");     // -(a s + e)
+        detail::check(fhe_copy(pk_.buf.ptr() + pw, da.ptr(), pw * 8, nullptr), "copy");      // a
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+    const PublicKey &public_key() const { return pk_; }
+    const SecretKey &secret_key() const { return sk_; }
+    // evaluation keys for s^2 (SEAL 2.3 generate_evaluation_keys(dbc, keys))
+    void generate_evaluation_keys(int decomposition_bit_count, EvaluationKeys &evk) {
+        const detail::CtxState &s = *st_;
+        if (decomposition_bit_count < 1 || decomposition_bit_count > 60) throw std::invalid_argument("decomposition_bit_count");
+        detail::Sampler smp(s);
+        const size_t pw = s.poly_words();
+        const uint32_t nd = fhe_evk_digits(s.h, (uint32_t)decomposition_bit_count);
+        evk.dbc = (uint32_t)decomposition_bit_count;
+        evk.digits = nd;
+        evk.buf.resize((size_t)s.k * nd * 2 * pw);
+        detail::DevBuf s2;
+        detail::ring_mul(s, sk_.buf, 1, sk_ntt_, s2);
+        std::vector<uint64_t> hs2(pw);
+        s2.download(hs2.data(), pw);
+        for (uint32_t i = 0; i < s.k; ++i)
+            for (uint32_t d = 0; d < nd; ++d) {
+                std::vector<uint64_t> a = smp.uniform(), e = smp.noise();
+                detail::DevBuf da(pw), de(pw), as;
+                da.upload(a.data(), pw);
+                de.upload(e.data(), pw);
+                detail::ring_mul(s, da, 1, sk_ntt_, as);
+                detail::check(fhe_add(s.h, as.ptr(), de.ptr(), as.ptr(), 1, nullptr), "add");
+                detail::check(fhe_negate(s.h, as.ptr(), as.ptr(), 1, nullptr), "negate");
+                std::vector<uint64_t> k0(pw);
+                as.download(k0.data(), pw);
+                const uint64_t qi = s.q[i], wd = detail::powmod(2, (uint64_t)decomposition_bit_count * d, qi);
+                for (uint32_t c = 0; c < s.n; ++c) {        // + w^d s^2 in RNS component i only
+                    uint64_t &x = k0[(size_t)i * s.n + c];
+                    x = (uint64_t)(((detail::u128)x + detail::mulmod(hs2[(size_t)i * s.n + c], wd, qi)) % qi);
+                }
+                uint64_t *dst = evk.buf.ptr() + (((size_t)i * nd + d) * 2) * pw;
+                detail::check(fhe_upload(dst, k0.data(), pw * 8, nullptr), "upload");
+                detail::check(fhe_upload(dst + pw, a.data(), pw * 8, nullptr), "upload");
+                detail::check(fhe_stream_sync(nullptr), "sync");
+            }
+        detail::check(fhe_ntt_forward(s.h, evk.buf.ptr(), evk.buf.ptr(), (uint64_t)s.k * nd * 2, nullptr), "ntt");
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+private:
+    std::shared_ptr<detail::CtxState> st_;
+    PublicKey pk_;
+    SecretKey sk_;
+    detail::DevBuf sk_ntt_;
+};
+
+class Encryptor {
+public:
+    Encryptor(const SEALContext &ctx, const PublicKey &pk) : st_(ctx.state()) {
+        const detail::CtxState &s = *st_;
+        if (pk.buf.words() != 2 * s.poly_words()) throw std::invalid_argument("public key does not match the context");
+        pk_ntt_.resize(2 * s.poly_words());
+        detail::check(fhe_ntt_forward(s.h, pk.buf.ptr(), pk_ntt_.ptr(), 2, nullptr), "ntt");
+    }
+    // Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2)   
+    void encrypt(const Plaintext &plain, Ciphertext &out) {
+        const detail::CtxState &s = *st_;
+        const size_t pw = s.poly_words();
+        detail::Sampler smp(s);
+        std::vector<uint64_t> u = smp.ternary(), e = smp.noise(), e2 = smp.noise();
+        e.insert(e.end(), e2.begin(), e2.end());
+        detail::DevBuf du(pw), de(2 * pw), un(pw);
+        du.upload(u.data(), pw);
+        de.upload(e.data(), 2 * pw);
+        out.shape(2, s.k, s.n);
+        detail::check(fhe_ntt_forward(s.h, du.ptr(), un.ptr(), 1, nullptr), "ntt");
+        for (int j = 0; j < 2; ++j)
+            detail::check(fhe_dyadic_multiply(s.h, pk_ntt_.ptr() + j * pw, un.ptr(), out.ptr() + j * pw, 1, nullptr), "dyadic");
+        detail::check(fhe_ntt_inverse(s.h, out.ptr(), out.ptr(), 2, nullptr), "intt");
+        detail::check(fhe_add(s.h, out.ptr(), de.ptr(), out.ptr(), 2, nullptr), "add");
+        const int len = plain.significant_coeff_count();
+        if (len) detail::check(fhe_add_plain(s.h, out.ptr(), 2 * pw, 1, plain.data().data(), (uint32_t)len, +1, nullptr), "add_plain");
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+private:
+    std::shared_ptr<detail::CtxState> st_;
+    detail::DevBuf pk_ntt_;
+};
+
+class Decryptor {
+public:
+    Decryptor(const SEALContext &ctx, const SecretKey &sk) : st_(ctx.state()) {
+        const detail::CtxState &s = *st_;
+        if (sk.buf.words() != s.poly_words()) throw std::invalid_argument("secret key does not match the context");
+        sk_ntt_.resize(s.poly_words());
+        detail::check(fhe_ntt_forward(s.h, sk.buf.ptr(), sk_ntt_.ptr(), 1, nullptr), "ntt");
+    }
+    void decrypt(const Ciphertext &ct, Plaintext &out) { int budget; run(ct, &out, budget); }
+    int invariant_noise_budget(const Ciphertext &ct) { int budget; run(ct, nullptr, budget); return budget; }
+private:
+    // phase = sum_j c_j s^j (Horner in s, NTT domain), then m = round(t*phase/q) mod t exactly
+    void run(const Ciphertext &ct, Plaintext *out, int &budget) {
+        const detail::CtxState &s = *st_;
+        if (ct.size() < 2 || ct.k() != s.k || ct.n() != s.n) throw std::invalid_argument("ciphertext does not match the context");
+        const size_t pw = s.poly_words();
+        detail::DevBuf all((size_t)ct.size() * pw), acc(pw);
+        detail::check(fhe_ntt_forward(s.h, ct.ptr(), all.ptr(), (uint64_t)ct.size(), nullptr), "ntt");
+        detail::check(fhe_copy(acc.ptr(), all.ptr() + (size_t)(ct.size() - 1) * pw, pw * 8, nullptr), "copy");
+        for (int j = ct.size() - 2; j >= 0; --j) {
+            detail::check(fhe_dyadic_multiply(s.h, acc.ptr(), sk_ntt_.ptr(), acc.ptr(), 1, nullptr), "dyadic");
+            detail::check(fhe_add(s.h, acc.ptr(), all.ptr() + (size_t)j * pw, acc.ptr(), 1, nullptr), "add");
+        }
+        detail::check(fhe_ntt_inverse(s.h, acc.ptr(), acc.ptr(), 1, nullptr), "intt");
+        std::vector<uint64_t> ph(pw);
+        acc.download(ph.data(), pw);
+        std::vector<uint64_t> plain(s.n, 0);
+        int worst = 0;
+        for (uint32_t c = 0; c < s.n; ++c) {
+            detail::Big x(0);
+            for (uint32_t i = 0; i < s.k; ++i) {
+                detail::Big term = s.punct[i];
+                term.mul_small(detail::mulmod(ph[(size_t)i * s.n + c], s.inv_punct[i], s.q[i]));
+                x.add(term);
+            }
+            while (x.cmp(s.Q) >= 0) x.sub(s.Q);
+            detail::Big tx = x;
+            tx.mul_small(s.t);
+            detail::Big num = tx;
+            num.add(s.Qhalf);
+            uint64_t lo = 0, hi = s.t;                    // quotient of num / Q lies in [0, t]
+            while (lo < hi) {
+                uint64_t mid = lo + (hi - lo + 1) / 2;
+                detail::Big prod = s.Q;
+                prod.mul_small(mid);
+                if (prod.cmp(num) <= 0) lo = mid; else hi = mid - 1;
+            }
+            plain[c] = lo % s.t;
+            detail::Big prod = s.Q, diff;
+            prod.mul_small(lo);
+            if (tx.cmp(prod) >= 0) { diff = tx; diff.sub(prod); } else { diff = prod; diff.sub(tx); }
+            worst = std::max(worst, diff.bits());
+        }
+        budget = std::max(0, s.Q.bits() - worst - 1);
+        if (out) *out = Plaintext(plain);
+    }
+    std::shared_ptr<detail::CtxState> st_;
+    detail::DevBuf sk_ntt_;
+};
+
+class FractionalEncoder {
+public:
+    FractionalEncoder(const SmallModulus &plain_modulus, const BigPoly &poly_modulus, int integer_coeff_count,
+                      int fraction_coeff_count, uint64_t base = 2)
+        : t_(plain_modulus.value()), n_((uint32_t)poly_modulus.degree()), ic_(integer_coeff_count), fc_(fraction_coeff_count) {
+        if (base != 2) throw std::invalid_argument("only base 2 is supported (the reference uses POLY_BASE = 2, homo/fhe_image.h:22)");
+        if (ic_ <= 0 || fc_ <= 0 || (uint32_t)(ic_ + fc_) > n_) throw std::invalid_argument("coefficient counts do not fit the polynomial");
+    }
+    Plaintext encode(double value) const {
+        std::vector<uint64_t> c(n_);
+        if (fhe_frac_encode(n_, t_, value, ic_, fc_, c.data()) < 0) throw std::invalid_argument(fhe_last_error());
+        return Plaintext(std::move(c));
+    }
+    double decode(const Plaintext &p) const {
+        std::vector<uint64_t> c(p.data());
+        c.resize(n_, 0);
+        return fhe_frac_decode(n_, t_, c.data(), ic_, fc_);
+    }
+private:
+    uint64_t t_;
+    uint32_t n_;
+    int ic_, fc_;
+};
+
+class Evaluator {
+public:
+    explicit Evaluator(const SEALContext &ctx) : st_(ctx.state()) {}
+
+    void add(Ciphertext &a, const Ciphertext &b) { addsub(a, b, false); }
+    void sub(Ciphertext &a, const Ciphertext &b) { addsub(a, b, true); }
+    void negate(Ciphertext &a) {
+        need(a);
+        detail::check(fhe_negate(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), nullptr), "negate");
+    }
+    void add_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, +1); }
+    void sub_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, -1); }
+    void multiply_plain(Ciphertext &a, const Plaintext &p) {
+        need(a);
+        const int len = p.significant_coeff_count();
+        if (len == 0) throw std::invalid_argument("plain cannot be zero");     // SEAL 2.3 rejects the zero plaintext
+        plain_ntt_.resize(fhe_plain_ntt_words(st_->h));
+        detail::check(fhe_plain_prepare(st_->h, p.data().data(), (uint32_t)len, plain_ntt_.ptr(), nullptr), "plain_prepare");
+        detail::check(fhe_multiply_plain(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), plain_ntt_.ptr(), nullptr), "multiply_plain");
+    }
+    void multiply(Ciphertext &a, const Ciphertext &b) {
+        need(a); need(b);
+        Ciphertext out;
+        out.shape((uint32_t)(a.size() + b.size() - 1), st_->k, st_->n);
+        const size_t bytes = fhe_multiply_scratch_bytes(st_->h, (uint32_t)a.size(), (uint32_t)b.size(), 1);
+        scratch_.resize((bytes + 7) / 8);
+        if (&a == &b || a.ptr() == b.ptr())
+            detail::check(fhe_square(st_->h, a.ptr(), (uint32_t)a.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "square");
+        else
+            detail::check(fhe_multiply(st_->h, a.ptr(), (uint32_t)a.size(), b.ptr(), (uint32_t)b.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "multiply");
+        a = std::move(out);
+    }
+    void square(Ciphertext &a) {
+        need(a);
+        Ciphertext out;
+        out.shape((uint32_t)(2 * a.size() - 1), st_->k, st_->n);
+        const size_t bytes = fhe_multiply_scratch_bytes(st_->h, (uint32_t)a.size(), (uint32_t)a.size(), 1);
+        scratch_.resize((bytes + 7) / 8);
+        detail::check(fhe_square(st_->h, a.ptr(), (uint32_t)a.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "square");
+        a = std::move(out);
+    }
+    // repeated until size 2, as SEAL does
+    void relinearize(Ciphertext &a, const EvaluationKeys &evk) {
+        need(a);
+        if (a.size() > 3) throw std::invalid_argument("relinearize: only size-3 ciphertexts are supported (keys for s^2)");
+        if (a.size() < 3) return;
+        const size_t bytes = fhe_relinearize_scratch_bytes(st_->h, evk.dbc, 1);
+        scratch_.resize((bytes + 7) / 8);
+        const size_t pw = st_->poly_words();
+        detail::check(fhe_relinearize(st_->h, a.ptr(), 3 * pw, 1, evk.buf.ptr(), evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
+        Ciphertext out;
+        out.shape(2, st_->k, st_->n);
+        detail::check(fhe_copy(out.ptr(), a.ptr(), 2 * pw * 8, nullptr), "copy");
+        a = std::move(out);
+    }
+private:
+    void need(const Ciphertext &c) const {
+        if (c.size() < 1 || c.k() != st_->k || c.n() != st_->n) throw std::invalid_argument("ciphertext is empty or does not match the context");
+    }
+    void addsub(Ciphertext &a, const Ciphertext &b, bool sub) {
+        need(a); need(b);
+        const size_t pw = st_->poly_words();
+        const int m = std::min(a.size(), b.size());
+        if (b.size() > a.size()) {            // destination grows; the tail is b (add) or -b (sub)
+            Ciphertext out;
+            out.shape((uint32_t)b.size(), st_->k, st_->n);
+            detail::check(fhe_copy(out.ptr(), a.ptr(), (size_t)a.size() * pw * 8, nullptr), "copy");
+            const uint64_t *tail = b.ptr() + (size_t)m * pw;
+            if (sub) detail::check(fhe_negate(st_->h, tail, out.ptr() + (size_t)m * pw, (uint64_t)(b.size() - m), nullptr), "negate");
+            else detail::check(fhe_copy(out.ptr() + (size_t)m * pw, tail, (size_t)(b.size() - m) * pw * 8, nullptr), "copy");
+            a = std::move(out);
+        }
+        detail::check((sub ? fhe_sub : fhe_add)(st_->h, a.ptr(), b.ptr(), a.ptr(), (uint64_t)m, nullptr), sub ? "sub" : "add");
+    }
+    void plain_addsub(Ciphertext &a, const Plaintext &p, int sign) {
+        need(a);
+        const int len = p.significant_coeff_count();
+        if (len) detail::check(fhe_add_plain(st_->h, a.ptr(), (uint64_t)a.size() * st_->poly_words(), 1, p.data().data(), (uint32_t)len, sign, nullptr), "add_plain");
+    }
+    std::shared_ptr<detail::CtxState> st_;
+    detail::DevBuf plain_ntt_, scratch_;
+};
+
+// ---- throughput helpers: the fused/batched C ABI behind SEAL-typed arguments ---------------------
+namespace hip {
+// encrypted_dct + quantize_fhe on whole blocks (64 ciphertexts each) in one call
+inline void dct8x8_quant(const SEALContext &ctx, std::vector<Ciphertext> &data, const std::vector<double> *quant,
+                         int int_coeffs = 100, int frac_coeffs = 100) {
+    const detail::CtxState &s = *ctx.state();
+    if (data.empty() || data.size() % 64) throw std::invalid_argument("dct8x8_quant needs a multiple of 64 ciphertexts");
+    const size_t ctw = 2 * s.poly_words(), blocks = data.size() / 64;
+    detail::DevBuf in(data.size() * ctw), out(data.size() * ctw);
+    for (size_t i = 0; i < data.size(); ++i) {
+        if (data[i].size() != 2) throw std::invalid_argument("dct8x8_quant needs size-2 ciphertexts");
+        detail::check(fhe_copy(in.ptr() + i * ctw, data[i].ptr(), ctw * 8, nullptr), "copy");
+    }
+    fhe_dct_plan *plan = nullptr;
+    detail::check(fhe_dct_plan_create(s.h, quant ? quant->data() : nullptr, int_coeffs, frac_coeffs, nullptr, &plan), "dct plan");
+    const size_t bytes = fhe_dct8x8_scratch_bytes(s.h, blocks);
+    detail::DevBuf scratch((bytes + 7) / 8);
+    int rc = fhe_dct8x8_quant(s.h, plan, in.ptr(), out.ptr(), blocks, scratch.ptr(), bytes, nullptr);
+    fhe_dct_plan_destroy(plan);
+    detail::check(rc, "dct8x8_quant");
+    for (size_t i = 0; i < data.size(); ++i) detail::check(fhe_copy(data[i].ptr(), out.ptr() + i * ctw, ctw * 8, nullptr), "copy");
+    detail::check(fhe_stream_sync(nullptr), "sync");
+}
+}  // namespace hip
+
+}  // namespace seal
+#endif
