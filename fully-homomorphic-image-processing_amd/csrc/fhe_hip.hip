@@ -338,15 +338,22 @@ extern "C" int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, ui
             vals[(size_t)i * len + j] = v;
         }
     }
+    // Host-sourced operand: staged through a private device buffer with fully synchronous
+    // semantics (allocate, blocking copy, launch, wait, free).  Stream-ordered pool allocations
+    // combined with pageable async copies were observed to let a later call's copy overtake an
+    // earlier call's kernel; this entry point is not on the throughput path.
     hipStream_t st = (hipStream_t)s;
     u64 *d_vals = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&d_vals, vals.size() * sizeof(u64), st));
-    HIP_TRY(hipMemcpyAsync(d_vals, vals.data(), vals.size() * sizeof(u64), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // vals is a stack-lifetime host buffer
-    dim3 grid((len + 255) / 256, c->k, (unsigned)(count < 16384 ? count : 16384));
-    k_add_plain<<<grid, 256, 0, st>>>((u64 *)ct, stride, count, d_vals, len, c->qb.d_mod, c->k, c->n, sign);
-    KERNEL_CHECK();
-    HIP_TRY(hipFreeAsync(d_vals, st));
+    HIP_TRY(hipMalloc((void **)&d_vals, vals.size() * sizeof(u64)));
+    hipError_t e = hipMemcpy(d_vals, vals.data(), vals.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        dim3 grid((len + 255) / 256, c->k, (unsigned)(count < 16384 ? count : 16384));
+        k_add_plain<<<grid, 256, 0, st>>>((u64 *)ct, stride, count, d_vals, len, c->qb.d_mod, c->k, c->n, sign);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_vals);
+    if (e != hipSuccess) return fail(FHE_ERR_HIP, "add_plain: %s", hipGetErrorString(e));
     return FHE_OK;
 }
 
@@ -478,15 +485,20 @@ extern "C" int fhe_plain_prepare(const fhe_ctx *c, const uint64_t *plain, uint32
     if (rc) return rc;
     hipStream_t st = (hipStream_t)s;
     const size_t words = (size_t)c->k * c->n;
-    u64 *tmp = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&tmp, 2 * words * sizeof(u64), st));
-    HIP_TRY(hipMemcpyAsync(tmp, lifted.data(), words * sizeof(u64), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    rc = fhe_ntt_launch(false, c, c->qb, tmp, tmp + words, c->k, st);
+    u64 *tmp = nullptr;                       // same synchronous staging discipline as fhe_add_plain
+    HIP_TRY(hipMalloc((void **)&tmp, 2 * words * sizeof(u64)));
+    hipError_t e = hipMemcpy(tmp, lifted.data(), words * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = fhe_ntt_launch(false, c, c->qb, tmp, tmp + words, c->k, st);
+        if (rc == FHE_OK) {
+            k_make_shoup<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(tmp + words, (ulonglong2 *)d_out, c->qb.d_mod, c->n, (u32)words);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(tmp);
     if (rc) return rc;
-    k_make_shoup<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(tmp + words, (ulonglong2 *)d_out, c->qb.d_mod, c->n, (u32)words);
-    KERNEL_CHECK();
-    HIP_TRY(hipFreeAsync(tmp, st));
+    if (e != hipSuccess) return fail(FHE_ERR_HIP, "plain_prepare: %s", hipGetErrorString(e));
     return FHE_OK;
 }
 
