@@ -23,9 +23,23 @@
 // evaluation order yields bit-identical ciphertexts.
 #include "internal.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace {
+
+// Register-pass geometry with 2^LE coefficients per thread (LE = 3: 512 threads per 4096-point
+// polynomial, 64 data VGPRs for four polynomials -> 4 waves/SIMD; LE = 4: 256 threads, 128 VGPRs).
+template <int L, int LE> struct Shape {
+    static constexpr int N = 1 << L, E = 1 << LE, TP = N >> LE, NP = (L + LE - 1) / LE, LDS_WORDS = N + (N >> LE);
+};
+__host__ __device__ constexpr int g_lo(int L, int LE, int p) { return (L - LE * p - LE) < 0 ? 0 : (L - LE * p - LE); }
+__host__ __device__ constexpr int g_stages(int L, int LE, int p) { return (L - LE * p) > LE ? LE : (L - LE * p); }
+template <int LO, int LE> __device__ __forceinline__ int g_index(int tid, int r) {
+    return ((tid >> LO) << (LO + LE)) | (r << LO) | (tid & ((1 << LO) - 1));
+}
+template <int LO, int LE> __device__ __forceinline__ int g_pad(int j) { return j + ((j >> (LO + LE)) << LO); }
 
 __device__ __forceinline__ double mm(double y, double w, double p, double pinv) {
     const double h = y * w;
@@ -60,32 +74,33 @@ __device__ __forceinline__ double u52_to_f64(u64 v) { return __longlong_as_doubl
 __device__ __forceinline__ u64 f64_to_u52(double v) { return (u64)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL; }
 
 // twiddles of one register pass, fetched ahead of use (before the preceding LDS barrier) so that
-// their L2 latency is hidden behind the previous pass: 2^(3-rb) values per stage, at most 15.
-template <int L, int P> struct PassTw {
-    static constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
-    static constexpr int rb(int u) { return (L - 1 - (4 * P + u)) - LO; }
-    static constexpr int count(int u) { return 1 << (3 - rb(u)); }
+// their L2 latency is hidden behind the previous pass: 2^(LE-1-rb) values per stage, < 2^LE in all.
+template <int L, int LE, int P> struct PassTw {
+    static constexpr int LO = g_lo(L, LE, P), S = g_stages(L, LE, P), NTW = (1 << LE) - 1;
+    static constexpr int rb(int u) { return (L - 1 - (LE * P + u)) - LO; }
+    static constexpr int count(int u) { return 1 << (LE - 1 - rb(u)); }
     static constexpr int offset(int u) { int o = 0; for (int v = 0; v < u; v++) o += count(v); return o; }
 };
-template <int L, int P>
-__device__ __forceinline__ void load_tw(double (&w)[15], const double *__restrict__ tw, int tid) {
-    using T = PassTw<L, P>;
+template <int L, int LE, int P>
+__device__ __forceinline__ void load_tw(double (&w)[(1 << LE) - 1], const double *__restrict__ tw, int tid) {
+    using T = PassTw<L, LE, P>;
     const int th = (P == 0) ? 0 : (tid >> T::LO);
 #pragma unroll
     for (int u = 0; u < T::S; u++) {
 #pragma unroll
-        for (int i = 0; i < T::count(u); i++) w[T::offset(u) + i] = tw[(1 << (4 * P + u)) + ((th << (3 - T::rb(u))) | i)];
+        for (int i = 0; i < T::count(u); i++) w[T::offset(u) + i] = tw[(1 << (LE * P + u)) + ((th << (LE - 1 - T::rb(u))) | i)];
     }
 }
 
-template <int L, int P, int M>
-__device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double (&w)[15], double p, double pinv) {
-    using T = PassTw<L, P>;
+template <int L, int LE, int P, int M>
+__device__ __forceinline__ void fwd_pass(double (&x)[M][1 << LE], const double (&w)[(1 << LE) - 1], double p, double pinv) {
+    using T = PassTw<L, LE, P>;
+    constexpr int E = 1 << LE;
 #pragma unroll
     for (int u = 0; u < T::S; u++) {
         const int rb = T::rb(u);
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0++) {
+        for (int r0 = 0; r0 < E; r0++) {
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
             const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
@@ -103,14 +118,15 @@ __device__ __forceinline__ void fwd_pass(double (&x)[M][16], const double (&w)[1
     }
 }
 
-template <int L, int P, int M>
-__device__ __forceinline__ void inv_pass(double (&x)[M][16], const double (&w)[15], double ninv, double p, double pinv) {
-    using T = PassTw<L, P>;
+template <int L, int LE, int P, int M>
+__device__ __forceinline__ void inv_pass(double (&x)[M][1 << LE], const double (&w)[(1 << LE) - 1], double ninv, double p, double pinv) {
+    using T = PassTw<L, LE, P>;
+    constexpr int E = 1 << LE;
 #pragma unroll
     for (int u = T::S - 1; u >= 0; u--) {
-        const int sigma = 4 * P + u, rb = T::rb(u);
+        const int sigma = LE * P + u, rb = T::rb(u);
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0++) {
+        for (int r0 = 0; r0 < E; r0++) {
             if (r0 & (1 << rb)) continue;
             const int r1 = r0 | (1 << rb);
             const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
@@ -142,54 +158,54 @@ __device__ __forceinline__ void inv_pass(double (&x)[M][16], const double (&w)[1
 }
 
 // M polynomials through two alternating LDS buffers: one barrier per polynomial
-template <int L, int LO_FROM, int LO_TO, int M>
-__device__ __forceinline__ void transpose(double (&x)[M][16], double *lds, int tid, int &phase) {
-    constexpr int PL = imin(LO_FROM, LO_TO);
+template <int L, int LE, int LO_FROM, int LO_TO, int M>
+__device__ __forceinline__ void transpose(double (&x)[M][1 << LE], double *lds, int tid, int &phase) {
+    constexpr int PL = imin(LO_FROM, LO_TO), E = 1 << LE;
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        double *buf = lds + (phase & 1) * NttShape<L>::LDS_WORDS;
+        double *buf = lds + (phase & 1) * Shape<L, LE>::LDS_WORDS;
         phase++;
 #pragma unroll
-        for (int r = 0; r < 16; r++) buf[lds_pad<PL>(elem_index<LO_FROM>(tid, r))] = x[m][r];
+        for (int r = 0; r < E; r++) buf[g_pad<PL, LE>(g_index<LO_FROM, LE>(tid, r))] = x[m][r];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[m][r] = buf[lds_pad<PL>(elem_index<LO_TO>(tid, r))];
+        for (int r = 0; r < E; r++) x[m][r] = buf[g_pad<PL, LE>(g_index<LO_TO, LE>(tid, r))];
     }
 }
 
 // forward transform; `w` holds the pass-0 twiddles on entry.  `pre()` is invoked once, right
 // before the last transpose, so that the caller can start fetching what it needs after the NTT.
-template <int L, int M, typename PRE, int P = 0>
-__device__ __forceinline__ void ntt_fwd(double (&x)[M][16], double (&w)[15], const double *__restrict__ tw, double p, double pinv,
+template <int L, int LE, int M, typename PRE, int P = 0>
+__device__ __forceinline__ void ntt_fwd(double (&x)[M][1 << LE], double (&w)[(1 << LE) - 1], const double *__restrict__ tw, double p, double pinv,
                                         double *lds, int tid, int &phase, PRE pre) {
-    if constexpr (P + 1 < NttShape<L>::NP) {
-        double wn[15];
-        load_tw<L, P + 1>(wn, tw, tid);          // in flight during this pass and the transpose
-        fwd_pass<L, P, M>(x, w, p, pinv);
-        if constexpr (P + 2 == NttShape<L>::NP) pre();
-        transpose<L, pass_lo(L, P), pass_lo(L, P + 1), M>(x, lds, tid, phase);
-        ntt_fwd<L, M, PRE, P + 1>(x, wn, tw, p, pinv, lds, tid, phase, pre);
+    if constexpr (P + 1 < Shape<L, LE>::NP) {
+        double wn[(1 << LE) - 1];
+        load_tw<L, LE, P + 1>(wn, tw, tid);          // in flight during this pass and the transpose
+        fwd_pass<L, LE, P, M>(x, w, p, pinv);
+        if constexpr (P + 2 == Shape<L, LE>::NP) pre();
+        transpose<L, LE, g_lo(L, LE, P), g_lo(L, LE, P + 1), M>(x, lds, tid, phase);
+        ntt_fwd<L, LE, M, PRE, P + 1>(x, wn, tw, p, pinv, lds, tid, phase, pre);
     } else {
-        fwd_pass<L, P, M>(x, w, p, pinv);
+        fwd_pass<L, LE, P, M>(x, w, p, pinv);
     }
 }
-template <int L, int M, bool BIG, int P = NttShape<L>::NP - 1>
-__device__ __forceinline__ void ntt_inv(double (&x)[M][16], double (&w)[15], const double *__restrict__ itw, double p, double pinv,
+template <int L, int LE, int M, bool BIG, int P = Shape<L, LE>::NP - 1>
+__device__ __forceinline__ void ntt_inv(double (&x)[M][1 << LE], double (&w)[(1 << LE) - 1], const double *__restrict__ itw, double p, double pinv,
                                         double *lds, int tid, int &phase) {
     if constexpr (P > 0) {
-        double wn[15];
-        load_tw<L, P - 1>(wn, itw, tid);
-        inv_pass<L, P, M>(x, w, 0.0, p, pinv);
+        double wn[(1 << LE) - 1];
+        load_tw<L, LE, P - 1>(wn, itw, tid);
+        inv_pass<L, LE, P, M>(x, w, 0.0, p, pinv);
         if constexpr (BIG) {
 #pragma unroll
             for (int m = 0; m < M; m++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) x[m][r] = red(x[m][r], p, pinv);
+                for (int r = 0; r < (1 << LE); r++) x[m][r] = red(x[m][r], p, pinv);
         }
-        transpose<L, pass_lo(L, P), pass_lo(L, P - 1), M>(x, lds, tid, phase);
-        ntt_inv<L, M, BIG, P - 1>(x, wn, itw, p, pinv, lds, tid, phase);
+        transpose<L, LE, g_lo(L, LE, P), g_lo(L, LE, P - 1), M>(x, lds, tid, phase);
+        ntt_inv<L, LE, M, BIG, P - 1>(x, wn, itw, p, pinv, lds, tid, phase);
     } else {
-        inv_pass<L, P, M>(x, w, itw[0], p, pinv);
+        inv_pass<L, LE, P, M>(x, w, itw[0], p, pinv);
     }
 }
 
@@ -210,9 +226,11 @@ __device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, do
     } else {
         const double tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
         const double z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
-        double y[9] = {z3 + z4, tmp4, tmp5, tmp6, tmp7, z1, z2, z3, z4};
-        const double w[9] = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
-        mmv<9>(y, w, p, pinv);
+        double ya[5] = {z3 + z4, tmp4, tmp5, tmp6, tmp7}, yb[4] = {z1, z2, z3, z4};
+        const double wa[5] = {c[0], c[1], c[2], c[3], c[4]}, wb[4] = {c[5], c[6], c[7], c[8]};
+        mmv<5>(ya, wa, p, pinv);
+        mmv<4>(yb, wb, p, pinv);
+        const double y[9] = {ya[0], ya[1], ya[2], ya[3], ya[4], yb[0], yb[1], yb[2], yb[3]};
         const double z3b = y[7] + y[0], z4b = y[8] + y[0];
         x0 = y[4] + y[5] + z4b;    // out 1 = tmp7' + z1' + z4
         x1 = y[3] + y[6] + z3b;    // out 3 = tmp6' + z2' + z3
@@ -223,13 +241,16 @@ __device__ __forceinline__ void line_half(double &x0, double &x1, double &x2, do
 template <int HALF> struct HalfC { static constexpr int NC = HALF ? 9 : 3, FIRST = HALF ? 3 : 0; };
 
 struct Work { u32 blk, line, poly, prime, half; };
-// blockIdx -> work item; the two halves of an item sit 8 apart so they land on the same XCD
+// blockIdx -> work item.  The two halves of an item sit 8 apart so they land on the same XCD, and the
+// prime is the SLOWEST index: workgroups resident at the same time share one prime, so its twiddles
+// and circuit constants (0.4 - 2.5 MB per prime) stay in the XCD L2s instead of thrashing them.
 __device__ __forceinline__ Work decode(u32 idx, u32 k) {
     const u32 w = ((idx >> 4) << 3) | (idx & 7);
+    const u32 per_prime = (gridDim.x >> 1) / k;
     Work o;
     o.half = (idx >> 3) & 1;
-    o.prime = w % k;
-    u32 t = w / k;
+    o.prime = w / per_prime;
+    u32 t = w - o.prime * per_prime;
     o.poly = t & 1;
     t >>= 1;
     o.line = t & 7;
@@ -237,63 +258,73 @@ __device__ __forceinline__ Work decode(u32 idx, u32 k) {
     return o;
 }
 
-template <int L, bool BIG, int HALF>
+template <int L, int LE, bool BIG, int HALF, int ABL>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__restrict__ mid, const double *__restrict__ consts,
                                           const double *__restrict__ tw, const Work &wk, double p, double pinv, u32 k, double *lds) {
-    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
+    using SH = Shape<L, LE>;
+    constexpr int N = SH::N, TP = SH::TP, E = SH::E, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
     const int tid = threadIdx.x;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + 8 * wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
-    double w0[15];
-    load_tw<L, 0>(w0, tw, tid);
-    double x[4][16];
+    double w0[E - 1];
+    load_tw<L, LE, 0>(w0, tw, tid);
+    double x[4][E];
     // d_m +- d_(7-m) in integers (inputs are < 2^47), then one exact move to double.  Two line
-    // pairs (64 loads per thread) are kept in flight; the compiler fences stop it from hoisting all
-    // 128 loads to the top, which would not fit the register file.
+    // pairs are kept in flight; the compiler fences stop it from hoisting every load to the top.
     constexpr u64 OFF = 1ULL << 48;
-    u64 ra[2][16], rb[2][16];
+    u64 ra[2][E], rb[2][E];
     auto issue = [&](int m) {
         const u64 *a = in + base + (size_t)m * ct_words + tid, *b = in + base + (size_t)(7 - m) * ct_words + tid;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {       // pass-0 mapping: coefficient r*TP + tid
+        for (int r = 0; r < E; r++) {       // pass-0 mapping: coefficient r*TP + tid
             ra[m & 1][r] = a[r * TP];
             rb[m & 1][r] = b[r * TP];
         }
     };
     auto combine = [&](int m) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < E; r++) {
             const u64 A = ra[m & 1][r], B = rb[m & 1][r];
             x[m][r] = HALF ? u52_to_f64(A + OFF - B) - (double)OFF : u52_to_f64(A + B);
         }
     };
-    issue(0);
-    issue(1);
-    asm volatile("" ::: "memory");
-    combine(0);
-    issue(2);
-    asm volatile("" ::: "memory");
-    combine(1);
-    issue(3);
-    asm volatile("" ::: "memory");
-    combine(2);
-    combine(3);
+    if constexpr (LE >= 4) {
+        issue(0);
+        issue(1);
+        asm volatile("" ::: "memory");
+        combine(0);
+        issue(2);
+        asm volatile("" ::: "memory");
+        combine(1);
+        issue(3);
+        asm volatile("" ::: "memory");
+        combine(2);
+        combine(3);
+    } else {   // four waves per SIMD hide the round trips; keep the staging registers small
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            issue(m);
+            combine(m);
+            asm volatile("" ::: "memory");
+        }
+    }
     const double *cp = consts + (size_t)FIRST * k * N + (size_t)wk.prime * N + tid;
     const size_t cstride = (size_t)k * N;
     double cn[9];
     auto fetch = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
+        for (int i = 0; i < NC; i++) cn[i] = (ABL == 1) ? 3.0 + i : cp[(size_t)i * cstride + r * TP];
     };
     int phase = 0;
-    ntt_fwd<L, 4>(x, w0, tw, p, pinv, lds, tid, phase, [&] { fetch(0); });
+    ntt_fwd<L, LE, 4>(x, w0, tw, p, pinv, lds, tid, phase, [&] { if (LE >= 4) fetch(0); });
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < E; r++) {
         double c[9];
+        if (LE < 4) fetch(r);               // four waves per SIMD: no software prefetch, fewer registers
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
-        if (r + 1 < 16) fetch(r + 1);
-        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+        if (LE >= 4 && r + 1 < E) fetch(r + 1);
+        if (ABL != 3) line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         if (BIG) {
 #pragma unroll
             for (int m = 0; m < 4; m++) x[m][r] = red(x[m][r], p, pinv);
@@ -303,27 +334,35 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
     for (int m = 0; m < 4; m++) {
         double *o = mid + base + (size_t)(2 * m + HALF) * ct_words + tid;
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[r * TP] = x[m][r];
+        for (int r = 0; r < E; r++) if (ABL != 4 || x[m][r] == 1.2345e300) o[r * TP] = x[m][r];
     }
 }
 
-template <int L, bool BIG>
-__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
+// waves per SIMD requested from the register allocator: two workgroups per CU
+// waves per SIMD requested from the register allocator = what LDS lets be resident (at most two workgroups)
+__host__ __device__ constexpr int occ_waves(int tp, int lds_words) {
+    return ((2 * lds_words * 16 <= 160 * 1024) ? 2 : 1) * tp / 256 < 1 ? 1 : ((2 * lds_words * 16 <= 160 * 1024) ? 2 : 1) * tp / 256;
+}
+template <int L, int LE> struct Occ { static constexpr int W = occ_waves(Shape<L, LE>::TP, Shape<L, LE>::LDS_WORDS); };
+
+template <int L, int LE, bool BIG, int ABL = 0>
+__global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
                                                                   const double *__restrict__ consts, const double *__restrict__ tw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
-    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+    __shared__ double lds[2 * Shape<L, LE>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
-    const double *tw = tw_all + (size_t)wk.prime * NttShape<L>::N;
-    if (wk.half) rows_body<L, BIG, 1>(in, mid, consts, tw, wk, p, pinv, k, lds);
-    else rows_body<L, BIG, 0>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    const double *tw = tw_all + (size_t)wk.prime * Shape<L, LE>::N;
+    if (wk.half) rows_body<L, LE, BIG, 1, ABL>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    else rows_body<L, LE, BIG, 0, ABL>(in, mid, consts, tw, wk, p, pinv, k, lds);
 }
 
-template <int L, bool BIG, int HALF>
+template <int L, int LE, bool BIG, int HALF, int ABL>
 __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *__restrict__ out, const double *__restrict__ consts,
                                           const double *__restrict__ itw, const Work &wk, double p, double pinv, u32 k, double *lds) {
-    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
-    constexpr int LASTP = NttShape<L>::NP - 1;
+    using SH = Shape<L, LE>;
+    constexpr int N = SH::N, TP = SH::TP, E = SH::E, NC = HalfC<HALF>::NC, FIRST = HalfC<HALF>::FIRST;
+    constexpr int LASTP = SH::NP - 1;
     const int tid = threadIdx.x;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
@@ -335,72 +374,84 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
     double cn[9], sn[4];
     auto fetch = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
+        for (int i = 0; i < NC; i++) cn[i] = (ABL == 1) ? 3.0 + i : cp[(size_t)i * cstride + r * TP];
 #pragma unroll
-        for (int m = 0; m < 4; m++) sn[m] = sp[(size_t)(16 * m) * cstride + r * TP];
+        for (int m = 0; m < 4; m++) sn[m] = (ABL == 1) ? 5.0 + m : sp[(size_t)(16 * m) * cstride + r * TP];
     };
-    fetch(0);
-    double wl[15];
-    load_tw<L, LASTP>(wl, itw, tid);
-    double x[4][16];
+    if (LE >= 4) fetch(0);
+    double wl[E - 1];
+    load_tw<L, LE, LASTP>(wl, itw, tid);
+    double x[4][E];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const double *a = mid + base + (size_t)m * row_stride + tid, *b = mid + base + (size_t)(7 - m) * row_stride + tid;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < E; r++) {
             const double A = a[r * TP], B = b[r * TP];
             x[m][r] = HALF ? A - B : A + B;
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < E; r++) {
         double c[9], sc[4];
+        if (LE < 4) fetch(r);
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
 #pragma unroll
         for (int m = 0; m < 4; m++) sc[m] = sn[m];
-        if (r + 1 < 16) fetch(r + 1);
-        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+        if (LE >= 4 && r + 1 < E) fetch(r + 1);
+        if (ABL != 3) line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         double y[4] = {x[0][r], x[1][r], x[2][r], x[3][r]};
         mmv<4>(y, sc, p, pinv);
 #pragma unroll
         for (int m = 0; m < 4; m++) x[m][r] = y[m];
     }
     int phase = 0;
-    ntt_inv<L, 4, BIG>(x, wl, itw, p, pinv, lds, tid, phase);
+    ntt_inv<L, LE, 4, BIG>(x, wl, itw, p, pinv, lds, tid, phase);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         u64 *o = out + base + (size_t)(2 * m + HALF) * row_stride + tid;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < E; r++) {
             double v = x[m][r];
             v = v < 0.0 ? v + p : v;
-            o[r * TP] = f64_to_u52(v);
+            if (ABL != 4 || v == 1.2345e300) o[r * TP] = f64_to_u52(v);
         }
     }
 }
 
-template <int L, bool BIG>
-__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
+template <int L, int LE, bool BIG, int ABL = 0>
+__global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
                                                                   const double *__restrict__ consts, const double *__restrict__ itw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
-    __shared__ double lds[2 * NttShape<L>::LDS_WORDS];
+    __shared__ double lds[2 * Shape<L, LE>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);   // line = column index
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
-    const double *itw = itw_all + (size_t)wk.prime * NttShape<L>::N;
-    if (wk.half) cols_body<L, BIG, 1>(mid, out, consts, itw, wk, p, pinv, k, lds);
-    else cols_body<L, BIG, 0>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    const double *itw = itw_all + (size_t)wk.prime * Shape<L, LE>::N;
+    if (wk.half) cols_body<L, LE, BIG, 1, ABL>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    else cols_body<L, LE, BIG, 0, ABL>(mid, out, consts, itw, wk, p, pinv, k, lds);
 }
 
-__global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n, u32 total) {
+// Shoup-pair table in the u64 kernels' slot order (16 slots per thread) -> centred doubles in the
+// fused kernels' slot order: bit-reversed index j = (t << LE) + r lives at r * (n >> LE) + t.
+__global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n, u32 le, u32 total) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    const u32 pos = i % n, rowbase = i - pos;          // destination position within its [n] row
+    const u32 tp = n >> le, r = pos / tp, t = pos % tp;
+    const u32 j = (t << le) + r;
+    const u32 src = (j & 15) * (n >> 4) + (j >> 4);
     const u64 q = mods[(i / n) % k].q;
-    const u64 w = in[i].x;
+    const u64 w = in[rowbase + src].x;
     out[i] = w > q / 2 ? -(double)(q - w) : (double)w;
 }
 
 }  // namespace
+
+static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves per SIMD resident
+    static int le = [] { const char *e = getenv("FHE_DCT_LE"); int v = e ? atoi(e) : 3; return (v == 4) ? 4 : 3; }();
+    return le;
+}
 
 bool fhe_dct_f64_supported(const fhe_ctx *c) {
     return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && (c->logn == 10 || c->logn == 12 || c->logn == 13);
@@ -409,9 +460,26 @@ bool fhe_dct_f64_supported(const fhe_ctx *c) {
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
     const u32 total = DCT_NCONST * c->k * c->n;
     HIP_TRY(hipMalloc(&plan->d_consts_f64, sizeof(double) * total));
-    k_consts_to_f64<<<(total + 255) / 256, 256, 0, st>>>(plan->d_consts, plan->d_consts_f64, c->qb.d_mod, c->k, c->n, total);
+    const u32 le = (dct_le() == 3 && c->logn == 12 && c->max_prime_bits <= 40) ? 3 : 4;
+    k_consts_to_f64<<<(total + 255) / 256, 256, 0, st>>>(plan->d_consts, plan->d_consts_f64, c->qb.d_mod, c->k, c->n, le, total);
     KERNEL_CHECK();
     return FHE_OK;
+}
+
+template <int L, int LE>
+static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st) {
+    constexpr int TP = Shape<L, LE>::TP;
+    if constexpr (LE == 4) {
+        if (big) {
+            k_dct_rows<L, LE, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            k_dct_cols<L, LE, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+            return;
+        }
+    }
+    {
+        k_dct_rows<L, LE, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+        k_dct_cols<L, LE, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+    }
 }
 
 int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st) {
@@ -419,18 +487,13 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     const u64 grid = items * 2;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const bool big = c->max_prime_bits > 40;
-#define LAUNCH(LL, BB)                                                                                                        \
-    do {                                                                                                                      \
-        k_dct_rows<LL, BB><<<(unsigned)grid, NttShape<LL>::TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);  \
-        k_dct_cols<LL, BB><<<(unsigned)grid, NttShape<LL>::TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k); \
-    } while (0)
-    switch (c->logn) {
-        case 10: if (big) LAUNCH(10, true); else LAUNCH(10, false); break;
-        case 12: if (big) LAUNCH(12, true); else LAUNCH(12, false); break;
-        case 13: if (big) LAUNCH(13, true); else LAUNCH(13, false); break;
-        default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in [1024, 8192]");
+    const int le = dct_le();
+    switch (c->logn) {   // LE = 3 is only built for the headline size
+        case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
+        case 12: if (le == 3 && !big) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
+        case 13: launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
+        default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 4096, 8192}");
     }
-#undef LAUNCH
     KERNEL_CHECK();
     return FHE_OK;
 }
