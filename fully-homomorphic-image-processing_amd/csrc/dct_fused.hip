@@ -378,7 +378,7 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
 #pragma unroll
         for (int m = 0; m < 4; m++) sn[m] = (ABL == 1) ? 5.0 + m : sp[(size_t)(16 * m) * cstride + r * TP];
     };
-    if (LE >= 4) fetch(0);
+    fetch(0);
     double wl[E - 1];
     load_tw<L, LE, LASTP>(wl, itw, tid);
     double x[4][E];
@@ -394,12 +394,11 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
 #pragma unroll
     for (int r = 0; r < E; r++) {
         double c[9], sc[4];
-        if (LE < 4) fetch(r);
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
 #pragma unroll
         for (int m = 0; m < 4; m++) sc[m] = sn[m];
-        if (LE >= 4 && r + 1 < E) fetch(r + 1);
+        if (r + 1 < E) fetch(r + 1);
         if (ABL != 3) line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         double y[4] = {x[0][r], x[1][r], x[2][r], x[3][r]};
         mmv<4>(y, sc, p, pinv);
