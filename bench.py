@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU per step")
-    ap.add_argument("--cpu-blocks", type=int, default=4, help="CPU baseline sample size (0 = skip)")
+    ap.add_argument("--cpu-blocks", type=int, default=16, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
@@ -119,13 +119,7 @@ def main():
         wall = float(tt.item())
 
     # ---- verification: sampled blocks against the CPU oracle, digest over everything -----------------
-    digest = ctx.digest(out.view(-1), index0=first_index)
-    if dist is not None:
-        dg = torch.tensor([digest & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device="cuda")
-        dist.all_reduce(dg, op=dist.ReduceOp.BXOR)
-        digest_all = int(dg.item())
-    else:
-        digest_all = digest & 0x7FFFFFFFFFFFFFFF
+    digest_all = fhe.parallel.combine_digests(ctx.digest(out.view(-1), index0=first_index))
     verified = None
     if rank == 0 and not args.no_verify:
         from oracle import oracle as om
@@ -142,18 +136,28 @@ def main():
         total_blocks = B * world * args.steps
         value = total_blocks / wall
         achieved = B * BYTES_PER_BLOCK / (dev_ms_per_step * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):       # written by tools/collect_traffic.py from separate rocprofv3 --pmc passes
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get("hbm_bytes_per_block", 0) * B or None
+            traffic_src = tj.get("source")
         res = {
             "metric": "encrypted 8x8 blocks/sec (homomorphic DCT+quant)",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=4096, 3 coeff moduli, t=2^14" % B,
                        "blocks_per_gpu": B, "poly_modulus_degree": 4096, "coeff_moduli": [hex(x) for x in ctx.q],
-                       "sharding": "blocks x%d, no data-path collective" % world},
+                       "sharding": "blocks x%d, no data-path collective" % world,
+                       "arithmetic": "exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fhe_dct8x8_quant (all launches of one step, HIP events on the launch stream)",
-                         "algorithmic_bytes_per_block": BYTES_PER_BLOCK, "ms_per_launch": dev_ms_per_step},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_dct_rows + k_dct_cols (the two launches of fhe_dct8x8_quant, all waves of one step; "
+                                   "HIP events on the launch stream)",
+                         "algorithmic_bytes_per_launch": B * BYTES_PER_BLOCK, "algorithmic_bytes_per_block": BYTES_PER_BLOCK,
+                         "ms_per_launch": dev_ms_per_step},
             "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
         }
         if world == 1 and args.cpu_blocks > 0:
