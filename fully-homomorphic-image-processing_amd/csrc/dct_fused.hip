@@ -95,24 +95,31 @@ __device__ __forceinline__ void load_tw(double (&w)[(1 << LE) - 1], const double
 template <int L, int LE, int P, int M>
 __device__ __forceinline__ void fwd_pass(double (&x)[M][1 << LE], const double (&w)[(1 << LE) - 1], double p, double pinv) {
     using T = PassTw<L, LE, P>;
-    constexpr int E = 1 << LE;
+    constexpr int E = 1 << LE, KB = (LE == 3) ? 2 : 1;     // butterflies batched per product group
 #pragma unroll
     for (int u = 0; u < T::S; u++) {
         const int rb = T::rb(u);
+        // enumerate the E/2 butterflies of this stage: index b -> r0 = b with a zero inserted at bit rb
 #pragma unroll
-        for (int r0 = 0; r0 < E; r0++) {
-            if (r0 & (1 << rb)) continue;
-            const int r1 = r0 | (1 << rb);
-            const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
-            double t[M], wm[M];
+        for (int b0 = 0; b0 < E / 2; b0 += KB) {
+            double t[KB * M], wm[KB * M];
 #pragma unroll
-            for (int m = 0; m < M; m++) { t[m] = x[m][r1]; wm[m] = wv; }
-            mmv<M>(t, wm, p, pinv);
+            for (int kb = 0; kb < KB; kb++) {
+                const int b = b0 + kb, r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+                const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const double X = x[m][r0];
-                x[m][r0] = X + t[m];
-                x[m][r1] = X - t[m];
+                for (int m = 0; m < M; m++) { t[kb * M + m] = x[m][r1]; wm[kb * M + m] = wv; }
+            }
+            mmv<KB * M>(t, wm, p, pinv);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) {
+                const int b = b0 + kb, r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const double X = x[m][r0];
+                    x[m][r0] = X + t[kb * M + m];
+                    x[m][r1] = X - t[kb * M + m];
+                }
             }
         }
     }
@@ -121,16 +128,15 @@ __device__ __forceinline__ void fwd_pass(double (&x)[M][1 << LE], const double (
 template <int L, int LE, int P, int M>
 __device__ __forceinline__ void inv_pass(double (&x)[M][1 << LE], const double (&w)[(1 << LE) - 1], double ninv, double p, double pinv) {
     using T = PassTw<L, LE, P>;
-    constexpr int E = 1 << LE;
+    constexpr int E = 1 << LE, KB = (LE == 3) ? 2 : 1;
 #pragma unroll
     for (int u = T::S - 1; u >= 0; u--) {
         const int sigma = LE * P + u, rb = T::rb(u);
+        if (sigma == 0) {          // last stage of the whole transform: both outputs carry n^-1
 #pragma unroll
-        for (int r0 = 0; r0 < E; r0++) {
-            if (r0 & (1 << rb)) continue;
-            const int r1 = r0 | (1 << rb);
-            const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
-            if (sigma == 0) {
+            for (int b = 0; b < E / 2; b++) {
+                const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+                const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
                 double t[2 * M], wm[2 * M];
 #pragma unroll
                 for (int m = 0; m < M; m++) {
@@ -141,17 +147,29 @@ __device__ __forceinline__ void inv_pass(double (&x)[M][1 << LE], const double (
                 mmv<2 * M>(t, wm, p, pinv);
 #pragma unroll
                 for (int m = 0; m < M; m++) { x[m][r0] = t[m]; x[m][r1] = t[M + m]; }
-            } else {
-                double t[M], wm[M];
+            }
+        } else {
 #pragma unroll
-                for (int m = 0; m < M; m++) {
-                    const double X = x[m][r0], Y = x[m][r1];
-                    x[m][r0] = X + Y;
-                    t[m] = X - Y; wm[m] = wv;
+            for (int b0 = 0; b0 < E / 2; b0 += KB) {
+                double t[KB * M], wm[KB * M];
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) {
+                    const int b = b0 + kb, r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+                    const double wv = w[T::offset(u) + (r0 >> (rb + 1))];
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const double X = x[m][r0], Y = x[m][r1];
+                        x[m][r0] = X + Y;
+                        t[kb * M + m] = X - Y; wm[kb * M + m] = wv;
+                    }
                 }
-                mmv<M>(t, wm, p, pinv);
+                mmv<KB * M>(t, wm, p, pinv);
 #pragma unroll
-                for (int m = 0; m < M; m++) x[m][r1] = t[m];
+                for (int kb = 0; kb < KB; kb++) {
+                    const int b = b0 + kb, r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+#pragma unroll
+                    for (int m = 0; m < M; m++) x[m][r1] = t[kb * M + m];
+                }
             }
         }
     }
@@ -180,8 +198,9 @@ __device__ __forceinline__ void ntt_fwd(double (&x)[M][1 << LE], double (&w)[(1 
                                         double *lds, int tid, int &phase, PRE pre) {
     if constexpr (P + 1 < Shape<L, LE>::NP) {
         double wn[(1 << LE) - 1];
-        load_tw<L, LE, P + 1>(wn, tw, tid);          // in flight during this pass and the transpose
+        if (LE >= 4) load_tw<L, LE, P + 1>(wn, tw, tid);   // in flight during this pass and the transpose
         fwd_pass<L, LE, P, M>(x, w, p, pinv);
+        if (LE < 4) load_tw<L, LE, P + 1>(wn, tw, tid);    // four waves/SIMD: the transpose alone hides it
         if constexpr (P + 2 == Shape<L, LE>::NP) pre();
         transpose<L, LE, g_lo(L, LE, P), g_lo(L, LE, P + 1), M>(x, lds, tid, phase);
         ntt_fwd<L, LE, M, PRE, P + 1>(x, wn, tw, p, pinv, lds, tid, phase, pre);
@@ -194,8 +213,9 @@ __device__ __forceinline__ void ntt_inv(double (&x)[M][1 << LE], double (&w)[(1 
                                         double *lds, int tid, int &phase) {
     if constexpr (P > 0) {
         double wn[(1 << LE) - 1];
-        load_tw<L, LE, P - 1>(wn, itw, tid);
+        if (LE >= 4) load_tw<L, LE, P - 1>(wn, itw, tid);
         inv_pass<L, LE, P, M>(x, w, 0.0, p, pinv);
+        if (LE < 4) load_tw<L, LE, P - 1>(wn, itw, tid);
         if constexpr (BIG) {
 #pragma unroll
             for (int m = 0; m < M; m++)
