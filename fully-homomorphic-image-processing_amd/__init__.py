@@ -5,10 +5,10 @@ The package directory name carries hyphens (it mirrors the reference's name), so
     import importlib; fhe = importlib.import_module("fully-homomorphic-image-processing_amd")
 or through the `fhip_amd` shim at the repository root.
 """
-from . import _lib, circuits, parallel
+from . import _lib, circuits, parallel, server
 from ._lib import FheError, LIB_PATH, HEADER_PATH
 from .evaluator import (PRESETS, SEED, YQT, DctPlan, Evaluator, FractionalEncoder, PreparedPlain, SEALContext,
                         to_device, to_host)
 
 __all__ = ["FheError", "LIB_PATH", "HEADER_PATH", "PRESETS", "SEED", "YQT", "DctPlan", "Evaluator",
-           "FractionalEncoder", "PreparedPlain", "SEALContext", "to_device", "to_host", "_lib", "parallel", "circuits"]
+           "FractionalEncoder", "PreparedPlain", "SEALContext", "to_device", "to_host", "_lib", "parallel", "circuits", "server"]

@@ -1,0 +1,69 @@
+"""GPU: the streaming server_jpeg loop (homo/server_jpeg.cpp:109-153) over a ciphertext stream file,
+and the bilinear sampler (homo/fhe_resize.h:222-252)."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(n=1024, q=[0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001], t=1 << 14)
+
+
+def _ctx(fhe, om):
+    return fhe.SEALContext(SMALL["n"], SMALL["q"], SMALL["t"]), om.Oracle(SMALL["n"], SMALL["q"], SMALL["t"])
+
+
+@pytest.mark.parametrize("wave_blocks", [2, 8])
+def test_server_jpeg_stream(fhe, oracle_mod, tmp_path, wave_blocks):
+    ctx, orc = _ctx(fhe, oracle_mod)
+    n_blocks = 3
+    cts = orc.random_ct(n_blocks * 3 * 64, seed=4711).reshape(n_blocks, 3, 64, 2, orc.k, orc.n)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for b in range(n_blocks):
+            for ch in range(3):
+                for i in range(64):
+                    fhe.server.write_ciphertext(f, cts[b, ch, i])
+    assert fhe.server.server_jpeg(ctx, str(fin), str(fout), n_blocks, wave_blocks=wave_blocks) == n_blocks
+    out = np.zeros((n_blocks, 64, 3, 2, orc.k, orc.n), dtype=np.uint64)
+    with open(fout, "rb") as f:
+        for b in range(n_blocks):
+            for i in range(64):
+                for ch in range(3):
+                    fhe.server.read_ciphertext_into(f, out[b, i, ch])
+        assert f.read(1) == b""
+    for b in (0, n_blocks - 1):
+        ycc = np.zeros((3, 64, 2, orc.k, orc.n), dtype=np.uint64)
+        for i in range(64):
+            y, u, v = orc.rgb_to_ycc(cts[b, 0, i], cts[b, 1, i], cts[b, 2, i])
+            ycc[0, i], ycc[1, i], ycc[2, i] = y, u, v
+        for ch in range(3):
+            ref = orc.encrypted_dct(ycc[ch])
+            assert np.array_equal(out[b, :, ch], ref), (b, ch)
+
+
+def test_stream_rejects_foreign_data(fhe, tmp_path):
+    buf = np.zeros((2, 3, 16), dtype=np.uint64)
+    with pytest.raises(ValueError):
+        fhe.server.read_ciphertext_into(io.BytesIO(b"NOTACIPHERTEXT" + bytes(64)), buf)
+    with pytest.raises(EOFError):
+        fhe.server.read_ciphertext_into(io.BytesIO(b""), buf)
+
+
+def test_sample_linear_vs_oracle(fhe, oracle_mod):
+    """bilinear: three Linear calls per pixel (size 2 -> 3 -> 4), batched, vs oracle Linear"""
+    ctx, orc = _ctx(fhe, oracle_mod)
+    ev = fhe.Evaluator(ctx)
+    pc = fhe.circuits.PlainCache(ctx)
+    W = H = 4
+    pix = ctx.random_ct(W * H, size=2, seed=31337)
+    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, 3, 3, bicubic=False)
+    xf, yf = ctx.random_ct(9, size=2, seed=1), ctx.random_ct(9, size=2, seed=2)
+    out = fhe.to_host(fhe.circuits.sample_linear(ev, pc, pix, taps, xf, yf))
+    assert out.shape[1] == 4
+    hp, hx, hy = fhe.to_host(pix), fhe.to_host(xf), fhe.to_host(yf)
+    for o in (0, 4, 8):
+        p00, p10, p01, p11 = (hp[i] for i in taps[o])
+        col0, col1 = orc.linear(p00, p10, hx[o]), orc.linear(p01, p11, hx[o])
+        assert np.array_equal(out[o], orc.linear(col0, col1, hy[o]))
