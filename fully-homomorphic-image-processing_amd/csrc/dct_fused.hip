@@ -408,31 +408,31 @@ int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st
 }
 
 template <int L, int LE>
-static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st) {
+static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st, int which) {
     constexpr int TP = Shape<L, LE>::TP;
     if constexpr (LE == 4) {
         if (big) {
-            k_dct_rows<L, LE, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
-            k_dct_cols<L, LE, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+            if (which & 1) k_dct_rows<L, LE, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 2) k_dct_cols<L, LE, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
     }
     {
-        k_dct_rows<L, LE, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
-        k_dct_cols<L, LE, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+        if (which & 1) k_dct_rows<L, LE, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+        if (which & 2) k_dct_cols<L, LE, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
     }
 }
 
-int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st) {
+int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st, int which) {
     const u64 items = n_blocks * 8 * 2 * c->k;   // (block, line, poly, prime), multiple of 8
     const u64 grid = items * 2;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const bool big = c->max_prime_bits > 40;
     const int le = dct_le();
     switch (c->logn) {   // LE = 3 is only built for the headline size
-        case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
-        case 12: if (le == 3 && !big) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
-        case 13: launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st); break;
+        case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
+        case 12: if (le == 3 && !big) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st, which); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
+        case 13: launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 4096, 8192}");
     }
     KERNEL_CHECK();

@@ -174,6 +174,10 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
 
 extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     if (!c) return FHE_OK;
+    if (c->aux_stream) {
+        (void)hipStreamDestroy(c->aux_stream);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_rows[i]); (void)hipEventDestroy(c->ev_cols[i]); }
+    }
     fhe_behz_free(c);
     fhe_free_base(c->qb);
     delete c;
@@ -686,14 +690,46 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
         const size_t per_block = (size_t)64 * 2 * c->k * c->n;
         const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(double)) : 0;
         if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
-        const u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
-        for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
-            const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
-            const bool wave_kernels = plan->d_consts_wave && fhe_dct_wave_supported(c) && getenv("FHE_DCT_WAVE");
-            int rc = wave_kernels ? fhe_dct_wave_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st)
-                                  : fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st);
-            if (rc) return rc;
+        const bool wave_kernels = plan->d_consts_wave && fhe_dct_wave_supported(c) && getenv("FHE_DCT_WAVE");
+        u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
+        // measured: 68.1k blocks/s pipelined vs 71.8k plain at 64-block waves, so this is opt-in
+        const bool pipelined = !wave_kernels && getenv("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
+        if (!pipelined) {
+            for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
+                const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
+                int rc = wave_kernels ? fhe_dct_wave_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st)
+                                      : fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st);
+                if (rc) return rc;
+            }
+            return FHE_OK;
         }
+        // Two half-size intermediates: the column kernel of wave w runs on a second stream while the
+        // row kernel of wave w+1 runs on the caller's stream, so workgroups of both kinds share the CUs
+        // (row work is FP64-issue heavy, column work waits more on memory) and launch tails overlap.
+        fhe_ctx *mc = const_cast<fhe_ctx *>(c);
+        if (!mc->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&mc->aux_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipEventCreateWithFlags(&mc->ev_rows[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&mc->ev_cols[i], hipEventDisableTiming));
+            }
+        }
+        wave = wave / 2 < 1 ? 1 : wave / 2;
+        double *midbuf[2] = {(double *)scratch, (double *)scratch + wave * per_block};
+        u64 w = 0;
+        for (u64 b0 = 0; b0 < n_blocks; b0 += wave, ++w) {
+            const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
+            const int s = (int)(w & 1);
+            if (w >= 2) HIP_TRY(hipStreamWaitEvent(st, mc->ev_cols[s], 0));            // mid[s] is free again
+            int rc = fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, midbuf[s], st, 1);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(mc->ev_rows[s], st));
+            HIP_TRY(hipStreamWaitEvent(mc->aux_stream, mc->ev_rows[s], 0));
+            rc = fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, midbuf[s], mc->aux_stream, 2);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(mc->ev_cols[s], mc->aux_stream));
+        }
+        for (int s = 0; s < 2 && (u64)s < w; ++s) HIP_TRY(hipStreamWaitEvent(st, mc->ev_cols[s], 0));   // join: out is complete on `st`
         return FHE_OK;
     }
     // general path (any prime below 2^61): three launches per chunk, u64 Shoup arithmetic

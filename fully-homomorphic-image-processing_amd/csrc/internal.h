@@ -45,6 +45,10 @@ struct fhe_ctx {
     u64 delta_mod[FHE_MAX_K] = {0};                    // floor(q/t) mod q_i
     u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
     struct BehzTables *behz = nullptr;                 // ct x ct tables (behz.hip)
+    // second stream + events for overlapping the column kernel of one wave of blocks with the row
+    // kernel of the next (fhe_dct8x8_quant); created on first use
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
 };
 
 #define DCT_NCONST 76
@@ -73,7 +77,8 @@ void fhe_free_base(BaseTables &B);
 void fhe_behz_free(fhe_ctx *c);
 // fused FP64 DCT path (dct_fused.hip)
 bool fhe_dct_f64_supported(const fhe_ctx *c);
-int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st);
+// which: bit 0 = row kernel, bit 1 = column kernel
+int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st, int which = 3);
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);
 // wave-synchronous variant (dct_wave.hip), n = 4096 and primes <= 40 bits
 bool fhe_dct_wave_supported(const fhe_ctx *c);

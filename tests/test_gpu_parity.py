@@ -498,4 +498,11 @@ def test_dct_wave_synchronous_variant(fhe, oracle_mod, monkeypatch):
     wave = fhe.to_host(ev.dct8x8_quant(plan, blocks))
     monkeypatch.delenv("FHE_DCT_WAVE")
     assert np.array_equal(default, wave)
+    # two-stream pipelining of the row and column kernels over waves of one block each
+    monkeypatch.setenv("FHE_DCT_PIPELINE", "1")
+    monkeypatch.setenv("FHE_DCT_WAVE_BLOCKS", "2")
+    piped = fhe.to_host(ev.dct8x8_quant(plan, blocks))
+    monkeypatch.delenv("FHE_DCT_PIPELINE")
+    monkeypatch.delenv("FHE_DCT_WAVE_BLOCKS")
+    assert np.array_equal(default, piped)
     assert np.array_equal(default[2], orc.dct_quant(fhe.to_host(blocks)[2], fhe.YQT))
