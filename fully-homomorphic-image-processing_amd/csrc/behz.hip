@@ -18,27 +18,29 @@
 
 #define BK FHE_MAX_K
 
-struct BehzDev {   // passed to kernels by value
+struct BehzDev {   // lives in device memory; every access is wave-uniform (scalar loads)
     u32 k;         // |q-base|; Bsk has k+1 primes, index k = m_sk
     Modulus q[BK], b[BK + 1];
-    u64 r64q[BK], r64b[BK + 1];            // floor(2^64 / modulus) for single-word reductions
-    u64 mt_inv_punct[BK], mt_inv_punct_s[BK];      // m~ * (q/q_i)^-1 mod q_i  (+ Shoup)
-    u64 inv_punct[BK], inv_punct_s[BK];            // (q/q_i)^-1 mod q_i
-    u64 punct_q_mod_b[BK][BK + 1];         // (q/q_i) mod b_j
+    u64 r64q[BK];                          // floor(2^64 / q_i) for single-word reductions
+    // every base-conversion multiplier is a context constant: (value, Shoup companion) pairs
+    ulonglong2 mt_inv_punct[BK];           // m~ * (q/q_i)^-1 mod q_i
+    ulonglong2 inv_punct[BK];              // (q/q_i)^-1 mod q_i
+    ulonglong2 punct_q_mod_b[BK][BK + 1];  // (q/q_i) mod b_j
     u64 punct_q_mod_mt[BK];                // (q/q_i) mod 2^32
     u64 neg_inv_q_mod_mt;                  // -q^-1 mod 2^32
-    u64 q_mod_b[BK + 1], inv_mt_mod_b[BK + 1], inv_q_mod_b[BK + 1];
-    u64 t_mod_q[BK], t_mod_b[BK + 1];
-    u64 inv_punct_B[BK];                   // (B/b_j)^-1 mod b_j
-    u64 punct_B_mod_q[BK][BK];             // (B/b_j) mod q_i
-    u64 punct_B_mod_msk[BK];
-    u64 inv_B_mod_msk;
-    u64 B_mod_q[BK];
+    ulonglong2 q_mod_b[BK + 1], inv_mt_mod_b[BK + 1], inv_q_mod_b[BK + 1];
+    ulonglong2 t_mod_q[BK], t_mod_b[BK + 1];
+    ulonglong2 inv_punct_B[BK];            // (B/b_j)^-1 mod b_j
+    ulonglong2 punct_B_mod_q[BK][BK];      // (B/b_j) mod q_i
+    ulonglong2 punct_B_mod_msk[BK];
+    ulonglong2 inv_B_mod_msk;
+    ulonglong2 B_mod_q[BK];
 };
 
 struct BehzTables {
     BaseTables aux;     // NTT tables of Bsk (k+1 primes)
-    BehzDev dev;
+    BehzDev host;       // host copy (k, moduli)
+    BehzDev *dev = nullptr;
 };
 
 namespace {
@@ -49,25 +51,30 @@ __device__ __forceinline__ u64 reduce64(u64 x, u64 q, u64 r64) {   // x mod q fo
     return csub(r, q);
 }
 
+// x * c mod m for a context constant c = (value, Shoup companion); any x < 2^64; result in [0, m)
+__device__ __forceinline__ u64 mulc(u64 x, const ulonglong2 c, u64 m) { return mul_shoup(x, c.x, c.y, m); }
+// lazy variant, result in [0, 2m)
+__device__ __forceinline__ u64 mulc_lazy(u64 x, const ulonglong2 c, u64 m) { return mul_shoup_lazy(x, c.x, c.y, m); }
+
 // steps 0+1 for every coefficient of every input polynomial: in [polys][k][n] -> out [polys][k+1][n]
-__global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in, u64 *__restrict__ out, BehzDev T, u32 n, u64 n_polys) {
+__global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in, u64 *__restrict__ out, const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzDev &T = *Tp;
     const u32 k = T.k;
     for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
         for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
             u64 y[BK];
             u64 xm = 0;
             for (u32 i = 0; i < k; i++) {
-                y[i] = mul_shoup(in[(p * k + i) * n + c], T.mt_inv_punct[i], T.mt_inv_punct_s[i], T.q[i].q);
+                y[i] = mulc(in[(p * k + i) * n + c], T.mt_inv_punct[i], T.q[i].q);      // canonical: used as an integer below
                 xm += (y[i] & 0xffffffffULL) * T.punct_q_mod_mt[i];
             }
             const u64 r = ((xm & 0xffffffffULL) * T.neg_inv_q_mod_mt) & 0xffffffffULL;
             for (u32 j = 0; j <= k; j++) {
-                const Modulus &m = T.b[j];
-                u64 acc = 0;
-                for (u32 i = 0; i < k; i++) acc = addmod(acc, mul_barrett(y[i], T.punct_q_mod_b[i][j], m), m.q);   // y_i < q_i < b_j
-                const u64 rb = r >= 0x80000000ULL ? r + m.q - 0x100000000ULL : r;       // centred remainder
-                acc = addmod(acc, mul_barrett(T.q_mod_b[j], rb, m), m.q);
-                out[(p * (k + 1) + j) * n + c] = mul_barrett(acc, T.inv_mt_mod_b[j], m);
+                const u64 bq = T.b[j].q, two = 2 * bq;
+                const u64 rb = r >= 0x80000000ULL ? r + bq - 0x100000000ULL : r;         // centred remainder
+                u64 acc = mulc_lazy(rb, T.q_mod_b[j], bq);
+                for (u32 i = 0; i < k; i++) acc = csub(acc + mulc_lazy(y[i], T.punct_q_mod_b[i][j], bq), two);
+                out[(p * (k + 1) + j) * n + c] = mulc(acc, T.inv_mt_mod_b[j], bq);
             }
         }
     }
@@ -97,37 +104,38 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
 
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
-                                                         BehzDev T, u32 n, u64 n_polys) {
+                                                         const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzDev &T = *Tp;
     const u32 k = T.k;
-    const Modulus &msk = T.b[k];
+    const u64 msk = T.b[k].q;
     for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
         for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
             u64 y[BK], f[BK + 1], z[BK];
             for (u32 i = 0; i < k; i++) {
-                const u64 td = mul_barrett(Dq[(p * k + i) * n + c], T.t_mod_q[i], T.q[i]);
-                y[i] = mul_shoup(td, T.inv_punct[i], T.inv_punct_s[i], T.q[i].q);
+                const u64 td = mulc_lazy(Dq[(p * k + i) * n + c], T.t_mod_q[i], T.q[i].q);
+                y[i] = mulc(td, T.inv_punct[i], T.q[i].q);                              // canonical integer in [0, q_i)
             }
             for (u32 j = 0; j <= k; j++) {     // fast floor
-                const Modulus &m = T.b[j];
+                const u64 bq = T.b[j].q, two = 2 * bq;
                 u64 conv = 0;
-                for (u32 i = 0; i < k; i++) conv = addmod(conv, mul_barrett(y[i], T.punct_q_mod_b[i][j], m), m.q);
-                const u64 td = mul_barrett(Db[(p * (k + 1) + j) * n + c], T.t_mod_b[j], m);
-                f[j] = mul_barrett(submod(td, conv, m.q), T.inv_q_mod_b[j], m);
+                for (u32 i = 0; i < k; i++) conv = csub(conv + mulc_lazy(y[i], T.punct_q_mod_b[i][j], bq), two);
+                const u64 td = mulc_lazy(Db[(p * (k + 1) + j) * n + c], T.t_mod_b[j], bq);   // [0, 2b)
+                f[j] = mulc(td + two - conv, T.inv_q_mod_b[j], bq);                          // (td - conv) mod b, canonical
             }
             u64 conv_sk = 0;
             for (u32 j = 0; j < k; j++) {
-                z[j] = mul_barrett(f[j], T.inv_punct_B[j], T.b[j]);
-                conv_sk = addmod(conv_sk, mul_barrett(reduce64(z[j], msk.q, T.r64b[k]), T.punct_B_mod_msk[j], msk), msk.q);
+                z[j] = mulc(f[j], T.inv_punct_B[j], T.b[j].q);                               // canonical integer in [0, b_j)
+                conv_sk = csub(conv_sk + mulc_lazy(z[j], T.punct_B_mod_msk[j], msk), 2 * msk);
             }
-            const u64 alpha = mul_barrett(submod(conv_sk, f[k], msk.q), T.inv_B_mod_msk, msk);
-            const bool neg = alpha > (msk.q >> 1);
+            const u64 alpha = mulc(conv_sk + 2 * msk - f[k], T.inv_B_mod_msk, msk);
+            const bool neg = alpha > (msk >> 1);
             for (u32 i = 0; i < k; i++) {
-                const Modulus &m = T.q[i];
+                const u64 qi = T.q[i].q, two = 2 * qi;
                 u64 conv = 0;
-                for (u32 j = 0; j < k; j++) conv = addmod(conv, mul_barrett(reduce64(z[j], m.q, T.r64q[i]), T.punct_B_mod_q[j][i], m), m.q);
-                const u64 a = reduce64(neg ? msk.q - alpha : alpha, m.q, T.r64q[i]);
-                const u64 corr = mul_barrett(a, T.B_mod_q[i], m);
-                out[(p * k + i) * n + c] = neg ? addmod(conv, corr, m.q) : submod(conv, corr, m.q);
+                for (u32 j = 0; j < k; j++) conv = csub(conv + mulc_lazy(z[j], T.punct_B_mod_q[j][i], qi), two);
+                const u64 corr = mulc_lazy(neg ? msk - alpha : alpha, T.B_mod_q[i], qi);    // [0, 2q)
+                const u64 r = neg ? conv + corr : conv + two - corr;                        // < 4q
+                out[(p * k + i) * n + c] = csub(csub(r, two), qi);
             }
         }
     }
@@ -135,8 +143,9 @@ __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__
 
 // relinearisation ------------------------------------------------------------------------------
 // digits: for ciphertext c, source prime i, digit d, target prime ii: ((c2_i >> (dbc d)) & mask) mod q_ii
-__global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, BehzDev T,
+__global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, const BehzDev *__restrict__ Tp,
                                                       u32 n, u32 nd, u32 dbc, u64 count) {
+    const BehzDev &T = *Tp;
     const u32 k = T.k;
     const u64 mask = dbc >= 64 ? ~0ULL : ((1ULL << dbc) - 1);
     const u64 units = count * k * nd;
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct
 }
 // acc[c][pp][ii][s] = sum_{i,d} dig[c][i][d][ii][s] * evk[i][d][pp][ii][s]
 __global__ __launch_bounds__(256) void k_relin_accum(const u64 *__restrict__ dig, const u64 *__restrict__ evk, u64 *__restrict__ acc,
-                                                     BehzDev T, u32 n, u32 nd, u64 count) {
+                                                     const BehzDev *__restrict__ Tp, u32 n, u32 nd, u64 count) {
+    const BehzDev &T = *Tp;
     const u32 k = T.k;
     for (u64 u = blockIdx.y; u < count * k; u += gridDim.y) {
         const u32 ii = (u32)(u % k);
@@ -173,7 +183,8 @@ __global__ __launch_bounds__(256) void k_relin_accum(const u64 *__restrict__ dig
         }
     }
 }
-__global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, BehzDev T, u32 n, u64 count) {
+__global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, const BehzDev *__restrict__ Tp, u32 n, u64 count) {
+    const BehzDev &T = *Tp;
     const u32 k = T.k;
     for (u64 u = blockIdx.y; u < count * 2 * k; u += gridDim.y) {
         const u32 ii = (u32)(u % k);
@@ -194,7 +205,7 @@ static int behz_build(fhe_ctx *c) {
     if (c->behz) return FHE_OK;
     const u32 k = c->k, n = c->n;
     BehzTables *T = new BehzTables();
-    BehzDev &D = T->dev;
+    BehzDev &D = T->host;
     memset(&D, 0, sizeof(D));
     D.k = k;
     const std::vector<u64> &q = c->qb.primes;
@@ -211,19 +222,18 @@ static int behz_build(fhe_ctx *c) {
     bsk[k] = found[0];
     int rc = fhe_build_base(T->aux, bsk, n, c->logn, false);
     if (rc) { delete T; return rc; }
+    auto pair = [](u64 v, u64 m) { return make_ulonglong2(v, shoup(v, m)); };
     const u64 mt = 1ULL << 32;
     for (u32 i = 0; i < k; ++i) {
         D.q[i] = c->qb.h_mod[i];
         D.r64q[i] = (u64)((((u128)1) << 64) / q[i]);
         const u64 ip = invmod(prod_mod(q.data(), (int)k, (int)i, q[i]), q[i]);
-        D.inv_punct[i] = ip;
-        D.inv_punct_s[i] = shoup(ip, q[i]);
-        D.mt_inv_punct[i] = mulmod(mt % q[i], ip, q[i]);
-        D.mt_inv_punct_s[i] = shoup(D.mt_inv_punct[i], q[i]);
-        for (u32 j = 0; j <= k; ++j) D.punct_q_mod_b[i][j] = prod_mod(q.data(), (int)k, (int)i, bsk[j]);
+        D.inv_punct[i] = pair(ip, q[i]);
+        D.mt_inv_punct[i] = pair(mulmod(mt % q[i], ip, q[i]), q[i]);
+        for (u32 j = 0; j <= k; ++j) D.punct_q_mod_b[i][j] = pair(prod_mod(q.data(), (int)k, (int)i, bsk[j]), bsk[j]);
         D.punct_q_mod_mt[i] = prod_mod(q.data(), (int)k, (int)i, mt);
-        D.t_mod_q[i] = c->t % q[i];
-        D.B_mod_q[i] = prod_mod(bsk.data(), (int)k, -1, q[i]);
+        D.t_mod_q[i] = pair(c->t % q[i], q[i]);
+        D.B_mod_q[i] = pair(prod_mod(bsk.data(), (int)k, -1, q[i]), q[i]);
     }
     {
         const u64 qm = prod_mod(q.data(), (int)k, -1, mt);   // odd
@@ -233,18 +243,24 @@ static int behz_build(fhe_ctx *c) {
     }
     for (u32 j = 0; j <= k; ++j) {
         D.b[j] = T->aux.h_mod[j];
-        D.r64b[j] = (u64)((((u128)1) << 64) / bsk[j]);
-        D.q_mod_b[j] = prod_mod(q.data(), (int)k, -1, bsk[j]);
-        D.inv_q_mod_b[j] = invmod(D.q_mod_b[j], bsk[j]);
-        D.inv_mt_mod_b[j] = invmod(mt % bsk[j], bsk[j]);
-        D.t_mod_b[j] = c->t % bsk[j];
+        const u64 qmb = prod_mod(q.data(), (int)k, -1, bsk[j]);
+        D.q_mod_b[j] = pair(qmb, bsk[j]);
+        D.inv_q_mod_b[j] = pair(invmod(qmb, bsk[j]), bsk[j]);
+        D.inv_mt_mod_b[j] = pair(invmod(mt % bsk[j], bsk[j]), bsk[j]);
+        D.t_mod_b[j] = pair(c->t % bsk[j], bsk[j]);
     }
     for (u32 j = 0; j < k; ++j) {
-        D.inv_punct_B[j] = invmod(prod_mod(bsk.data(), (int)k, (int)j, bsk[j]), bsk[j]);
-        for (u32 i = 0; i < k; ++i) D.punct_B_mod_q[j][i] = prod_mod(bsk.data(), (int)k, (int)j, q[i]);
-        D.punct_B_mod_msk[j] = prod_mod(bsk.data(), (int)k, (int)j, bsk[k]);
+        D.inv_punct_B[j] = pair(invmod(prod_mod(bsk.data(), (int)k, (int)j, bsk[j]), bsk[j]), bsk[j]);
+        for (u32 i = 0; i < k; ++i) D.punct_B_mod_q[j][i] = pair(prod_mod(bsk.data(), (int)k, (int)j, q[i]), q[i]);
+        D.punct_B_mod_msk[j] = pair(prod_mod(bsk.data(), (int)k, (int)j, bsk[k]), bsk[k]);
     }
-    D.inv_B_mod_msk = invmod(prod_mod(bsk.data(), (int)k, -1, bsk[k]), bsk[k]);
+    D.inv_B_mod_msk = pair(invmod(prod_mod(bsk.data(), (int)k, -1, bsk[k]), bsk[k]), bsk[k]);
+    if (hipMalloc((void **)&T->dev, sizeof(BehzDev)) != hipSuccess ||
+        hipMemcpy(T->dev, &D, sizeof(BehzDev), hipMemcpyHostToDevice) != hipSuccess) {
+        fhe_free_base(T->aux);
+        delete T;
+        return fail(FHE_ERR_HIP, "BEHZ table upload failed");
+    }
     c->behz = T;
     return FHE_OK;
 }
@@ -252,6 +268,7 @@ static int behz_build(fhe_ctx *c) {
 void fhe_behz_free(fhe_ctx *c) {
     if (c && c->behz) {
         fhe_free_base(c->behz->aux);
+        if (c->behz->dev) (void)hipFree(c->behz->dev);
         delete c->behz;
         c->behz = nullptr;
     }
@@ -280,7 +297,7 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, 
     const bool square = (a == b && sa == sb);
     if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
         return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
-    const BehzDev &T = c->behz->dev;
+    const BehzDev *T = c->behz->dev;
     const u32 k = c->k, n = c->n, so = sa + sb - 1;
     const size_t kn = (size_t)k * n, bn = (size_t)(k + 1) * n;
     u64 *Aq = (u64 *)scratch, *Ab = Aq + count * sa * kn;
@@ -337,7 +354,7 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
     hipStream_t st = (hipStream_t)s;
     const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
-    const BehzDev &T = c->behz->dev;
+    const BehzDev *T = c->behz->dev;
     u64 *dig = (u64 *)scratch, *acc = dig + count * k * nd * k * n;
     k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count);
     if ((rc = fhe_ntt_launch(false, c, c->qb, dig, dig, count * k * nd * k, st))) return rc;
