@@ -67,3 +67,46 @@ def test_sample_linear_vs_oracle(fhe, oracle_mod):
         p00, p10, p01, p11 = (hp[i] for i in taps[o])
         col0, col1 = orc.linear(p00, p10, hx[o]), orc.linear(p01, p11, hx[o])
         assert np.array_equal(out[o], orc.linear(col0, col1, hy[o]))
+
+
+def test_end_to_end_image_through_streaming_server(fhe, oracle_mod, tmp_path):
+    """BASELINE.json configs[0] shape on a synthetic image: client encrypts a 16x16 RGB image pixel by
+    pixel (homo/client_jpeg.cpp:129-165, block order of split_image_eight_block, homo/fhe_image.h:108-124),
+    the GPU server runs rgb_to_ycc_fhe + encrypted_dct over the ciphertext stream, the client decrypts
+    and decodes; the result must equal the plaintext pipeline (colour transform + dct() of
+    homo/fhe_image.h:400-484) -- the quantity behind the reference's RMSError line."""
+    from oracle import bigint_model as bm
+    p = oracle_mod.PRESETS["P4096"]
+    ctx, orc = fhe.SEALContext(p["n"], p["q"], p["t"]), oracle_mod.Oracle(p["n"], p["q"], p["t"])
+    sk, pk = orc.keygen(2026)
+    W = H = 16
+    img = np.array([[[(31 * x + 17 * y + 101 * c) % 256 for c in range(3)] for x in range(W)] for y in range(H)], dtype=np.float64)
+    blocks = []                                   # per 8x8 block: [channel][64] pixel values, row-major inside the block
+    for j in range(0, H, 8):
+        for i in range(0, W, 8):
+            blocks.append([[img[j + k, i + l, c] for k in range(8) for l in range(8)] for c in range(3)])
+    fin, fout = tmp_path / "image.ct", tmp_path / "result.ct"
+    seed = 0
+    with open(fin, "wb") as f:
+        for b in blocks:
+            for c in range(3):
+                for v in b[c]:
+                    seed += 1
+                    fhe.server.write_ciphertext(f, orc.encrypt(pk, orc.encode(v), seed=seed))
+    fhe.server.server_jpeg(ctx, str(fin), str(fout), len(blocks), wave_blocks=3)
+    ct = np.zeros((2, orc.k, orc.n), dtype=np.uint64)
+    worst, min_budget = 0.0, 1 << 30
+    with open(fout, "rb") as f:
+        for b in blocks:
+            r, g, bl = (np.array(b[c]) for c in range(3))
+            ycc = [0.299 * r + 0.587 * g + 0.114 * bl - 128.0, -0.168736 * r - 0.331264 * g + 0.5 * bl, 0.5 * r - 0.418688 * g - 0.081312 * bl]
+            expect = [bm.plain_dct(list(ch)) for ch in ycc]
+            for i in range(64):
+                for c in range(3):
+                    fhe.server.read_ciphertext_into(f, ct)
+                    if i % 9 == 0:                              # decrypt a sample of the 768 outputs
+                        plain, budget = orc.decrypt(sk, ct)
+                        worst = max(worst, abs(orc.decode(plain) - expect[c][i]))
+                        min_budget = min(min_budget, budget)
+    assert min_budget > 0
+    assert worst < 1e-6, worst      # decode is exact up to double rounding of the fractional digits
