@@ -506,3 +506,66 @@ def test_dct_wave_synchronous_variant(fhe, oracle_mod, monkeypatch):
     monkeypatch.delenv("FHE_DCT_WAVE_BLOCKS")
     assert np.array_equal(default, piped)
     assert np.array_equal(default[2], orc.dct_quant(fhe.to_host(blocks)[2], fhe.YQT))
+
+
+# ---------------------------------------------------------------------------------------------
+# empty / ragged inputs and error behaviour of the C ABI
+# ---------------------------------------------------------------------------------------------
+def test_empty_inputs_are_no_ops(fhe, oracle_mod):
+    import ctypes as C
+    import torch
+    ctx, _ = _pair(fhe, oracle_mod, "SMALL")
+    L = fhe._lib.load()
+    a = ctx.random_ct(1, seed=1)
+    before = fhe.to_host(a).copy()
+    p = C.c_void_p(a.data_ptr())
+    assert L.fhe_add(ctx.h, p, p, p, 0, None) == 0
+    assert L.fhe_negate(ctx.h, p, p, 0, None) == 0
+    assert L.fhe_ntt_forward(ctx.h, p, p, 0, None) == 0
+    assert L.fhe_multiply_plain(ctx.h, p, p, 0, p, None) == 0
+    assert L.fhe_add_plain(ctx.h, p, 2 * ctx.k * ctx.n, 1, None, 0, 1, None) == 0     # zero plaintext
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    assert L.fhe_dct8x8_quant(ctx.h, plan.h, p, p, 0, None, 0, None) == 0
+    assert L.fhe_fill_random(ctx.h, p, 0, 1, 0, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(fhe.to_host(a), before)
+
+
+def test_ragged_block_counts(fhe, oracle_mod, monkeypatch):
+    """block counts that do not divide the launch wave (7 blocks in waves of 3)"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    monkeypatch.setenv("FHE_DCT_WAVE_BLOCKS", "3")
+    blocks = ctx.random_ct(7, 64, seed=77)
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
+    for b in (0, 3, 6):
+        assert np.array_equal(out[b], orc.dct_quant(fhe.to_host(blocks)[b], fhe.YQT))
+
+
+def test_c_abi_error_codes(fhe, oracle_mod):
+    import ctypes as C
+    ctx, _ = _pair(fhe, oracle_mod, "SMALL")
+    other = fhe.SEALContext(4096, oracle_mod.PRESETS["P4096"]["q"], 1 << 14)
+    L = fhe._lib.load()
+    a = ctx.random_ct(64, seed=1)
+    p = C.c_void_p(a.data_ptr())
+    plan_other = fhe.DctPlan(other, fhe.YQT)
+    assert L.fhe_dct8x8_quant(ctx.h, plan_other.h, p, p, 1, None, 0, None) == -1        # plan of another context
+    assert b"another context" in L.fhe_last_error()
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    assert L.fhe_dct8x8_quant(ctx.h, plan.h, p, p, 1, None, 0, None) == -1              # missing scratch
+    assert b"scratch" in L.fhe_last_error()
+    assert L.fhe_add(ctx.h, None, p, p, 1, None) == -1                                  # null pointer
+    bad_plain = np.full(8, ctx.t, dtype=np.uint64)                                      # coefficient == t is out of range
+    assert L.fhe_add_plain(ctx.h, p, 2 * ctx.k * ctx.n, 1, bad_plain.ctypes.data_as(C.c_void_p), 8, 1, None) == -1
+    assert L.fhe_add_plain(ctx.h, p, 2 * ctx.k * ctx.n, 1, bad_plain.ctypes.data_as(C.c_void_p), 8, 0, None) == -1   # sign must be +-1
+    assert L.fhe_multiply(ctx.h, p, 2, p, 2, p, 1, None, 0, None) == -1                 # scratch too small
+    assert L.fhe_relinearize(ctx.h, p, 10, 1, p, 30, None, 0, None) == -1               # stride below a size-3 ciphertext
+    with pytest.raises(fhe.FheError):
+        fhe._lib.call("fhe_ntt_forward", ctx.h, None, None, 1, None)
+    h = C.c_void_p()
+    q = (C.c_uint64 * 1)(0xFFFFEE001)
+    assert L.fhe_ctx_create(4096, q, 1, 1 << 40, 0, C.byref(h)) == -1                   # t above the modulus
+    q2 = (C.c_uint64 * 1)(0xFFFFEE003)
+    assert L.fhe_ctx_create(4096, q2, 1, 1 << 14, 0, C.byref(h)) == -1                  # not an NTT prime
+    assert L.fhe_ctx_create(4096, q, 1, 1 << 14, 99, C.byref(h)) == -1                  # no such device
