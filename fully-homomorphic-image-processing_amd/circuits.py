@@ -54,18 +54,32 @@ def rgb_to_ycc(ev, pc, r, g, b):
 # ------------------------------------------------------------------------------------------------
 # resize path
 # ------------------------------------------------------------------------------------------------
-def cubic(ev, pc, A, B, C, D, t):
+def cubic(ev, pc, A, B, C, D, t, relin=None):
     """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189.  Note t3 = t*t exactly as the reference
-    computes it (:175), and t2/t3 are recomputed per call as there."""
+    computes it (:175), and t2/t3 are recomputed per call as there.
+
+    relin=(evk_ntt, dbc) switches on the relinearised mode (NOT what the
+    reference does): every product is brought back to size 2, so the result has size 2 instead of
+    s+2 and memory stays flat; ciphertext bits then differ from the reference path by construction
+    (key-switching noise), the decrypted value does not."""
     M, P = ev.multiply_plain, pc.prepared
+
+    def mul(x, y):
+        z = ev.multiply(x, y)
+        return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
+
+    def sq(x):
+        z = ev.square(x)
+        return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
+
     a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
     b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
     c = ev.sub(C, A)
-    t2 = ev.square(t)
-    t3 = ev.multiply(t, t)
-    a = ev.multiply(a, t3)
-    b = ev.multiply(b, t2)
-    c = ev.multiply(c, t)
+    t2 = sq(t)
+    t3 = mul(t, t)
+    a = mul(a, t3)
+    b = mul(b, t2)
+    c = mul(c, t)
     a = ev.add(ev.add(a, b), c)
     a = M(a, P(0.5))
     return ev.add(a, B)

@@ -1,0 +1,157 @@
+"""Client-side objects over the C ABI: KeyGenerator, Encryptor, Decryptor (seal:: names).
+
+The reference's clients (homo/client_jpeg.cpp:98-165,266-280) generate keys, encrypt every pixel and
+decrypt the results on the CPU through SEAL.  Here the ring arithmetic of those steps (NTT, dyadic
+products, additions) runs on the GPU through the same C ABI as the server path; sampling and the
+final exact rounding t*x/q (big integers) are host work.  Textbook BFV as in SURVEY.md App. A.7:
+  sk s <- ternary;  pk = (-(a s + e), a);  Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2)
+  Dec(c) = round(t/q [sum_j c_j s^j]_q) mod t;   evk[i][d] = (-(a s + e) + 2^(dbc d) s^2 E_i, a)
+"""
+import ctypes as C
+from functools import reduce
+
+import numpy as np
+import torch
+
+from . import _lib
+from .evaluator import _ptr, _stream, to_device, to_host
+
+
+class _Sampler:
+    def __init__(self, ctx, seed=None):
+        self.ctx = ctx
+        self.rng = np.random.default_rng(seed)
+
+    def ternary(self):
+        v = self.rng.integers(0, 3, size=self.ctx.n)
+        return np.stack([np.where(v == 2, q - 1, v).astype(np.uint64) for q in self.ctx.q])
+
+    def noise(self):
+        n = self.ctx.n
+        e = np.rint(self.rng.normal(0.0, 3.19, size=n))
+        bad = np.abs(e) > 19
+        while bad.any():                                   # clipped at 6 sigma
+            e[bad] = np.rint(self.rng.normal(0.0, 3.19, size=int(bad.sum())))
+            bad = np.abs(e) > 19
+        e = e.astype(np.int64)
+        return np.stack([np.where(e < 0, q + e, e).astype(np.uint64) for q in self.ctx.q])
+
+    def uniform(self):
+        return np.stack([self.rng.integers(0, q, size=self.ctx.n, dtype=np.uint64) for q in self.ctx.q])
+
+
+def _ntt(ctx, a):
+    out = torch.empty_like(a)
+    polys = a.numel() // (ctx.k * ctx.n)
+    _lib.call("fhe_ntt_forward", ctx.h, _ptr(a), _ptr(out), polys, _stream())
+    return out
+
+
+def _ring_mul(ctx, a, b_ntt):
+    """a: [polys, k, n] coefficient form (device), b_ntt: [k, n] NTT form -> a*b in R_q, coefficient form."""
+    fa = _ntt(ctx, a)
+    for j in range(a.shape[0]):
+        _lib.call("fhe_dyadic_multiply", ctx.h, _ptr(fa[j]), _ptr(b_ntt), _ptr(fa[j]), 1, _stream())
+    _lib.call("fhe_ntt_inverse", ctx.h, _ptr(fa), _ptr(fa), a.shape[0], _stream())
+    return fa
+
+
+class KeyGenerator:
+    def __init__(self, ctx, seed=None):
+        self.ctx = ctx
+        smp = _Sampler(ctx, seed)
+        self._sk = to_device(smp.ternary()[None], ctx.device)               # [1, k, n]
+        self._sk_ntt = _ntt(ctx, self._sk)[0]
+        a = to_device(smp.uniform()[None], ctx.device)
+        e = to_device(smp.noise()[None], ctx.device)
+        as_e = _ring_mul(ctx, a, self._sk_ntt)
+        _lib.call("fhe_add", ctx.h, _ptr(as_e), _ptr(e), _ptr(as_e), 1, _stream())
+        _lib.call("fhe_negate", ctx.h, _ptr(as_e), _ptr(as_e), 1, _stream())
+        self._pk = torch.cat([as_e, a], dim=0).contiguous()                  # [2, k, n]
+        self._smp = smp
+
+    def secret_key(self):
+        return self._sk[0]
+
+    def public_key(self):
+        return self._pk
+
+    def generate_evaluation_keys(self, dbc):
+        """[k][digits][2][k][n] in NTT form (library slot order), for Evaluator.relinearize."""
+        ctx = self.ctx
+        nd = int(_lib.load().fhe_evk_digits(ctx.h, dbc))
+        s2 = to_host(_ring_mul(ctx, self._sk, self._sk_ntt))[0]
+        evk = np.zeros((ctx.k, nd, 2, ctx.k, ctx.n), dtype=np.uint64)
+        for i in range(ctx.k):
+            for d in range(nd):
+                a = self._smp.uniform()
+                e = to_device(self._smp.noise()[None], ctx.device)
+                k0 = _ring_mul(ctx, to_device(a[None], ctx.device), self._sk_ntt)
+                _lib.call("fhe_add", ctx.h, _ptr(k0), _ptr(e), _ptr(k0), 1, _stream())
+                _lib.call("fhe_negate", ctx.h, _ptr(k0), _ptr(k0), 1, _stream())
+                h0 = to_host(k0)[0].copy()
+                qi = ctx.q[i]
+                wd = pow(2, dbc * d, qi)
+                h0[i] = np.array([(int(x) + int(s) * wd) % qi for x, s in zip(h0[i], s2[i])], dtype=np.uint64)
+                evk[i, d, 0], evk[i, d, 1] = h0, a
+        return _ntt(ctx, to_device(evk, ctx.device))
+
+
+class Encryptor:
+    def __init__(self, ctx, public_key, seed=None):
+        self.ctx = ctx
+        self._pk_ntt = _ntt(ctx, public_key.contiguous())
+        self._smp = _Sampler(ctx, seed)
+
+    def encrypt(self, plain):
+        ctx = self.ctx
+        u = _ntt(ctx, to_device(self._smp.ternary()[None], ctx.device))[0]
+        ct = torch.empty((2, ctx.k, ctx.n), dtype=torch.int64, device=ctx.device)
+        for j in range(2):
+            _lib.call("fhe_dyadic_multiply", ctx.h, _ptr(self._pk_ntt[j]), _ptr(u), _ptr(ct[j]), 1, _stream())
+        _lib.call("fhe_ntt_inverse", ctx.h, _ptr(ct), _ptr(ct), 2, _stream())
+        e = to_device(np.stack([self._smp.noise(), self._smp.noise()]), ctx.device)
+        _lib.call("fhe_add", ctx.h, _ptr(ct), _ptr(e), _ptr(ct), 2, _stream())
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        ln = len(p)
+        while ln > 0 and p[ln - 1] == 0:
+            ln -= 1
+        if ln:
+            _lib.call("fhe_add_plain", ctx.h, _ptr(ct), 2 * ctx.k * ctx.n, 1, p.ctypes.data_as(C.c_void_p), ln, 1, _stream())
+        return ct
+
+
+class Decryptor:
+    def __init__(self, ctx, secret_key):
+        self.ctx = ctx
+        self._sk_ntt = _ntt(ctx, secret_key[None].contiguous())[0]
+        self.Q = reduce(lambda a, b: a * b, ctx.q, 1)
+        self._crt = [(self.Q // q) * pow(self.Q // q, -1, q) for q in ctx.q]
+
+    def _phase(self, ct):
+        ctx = self.ctx
+        f = _ntt(ctx, ct.contiguous())
+        acc = f[-1].clone()
+        for j in range(ct.shape[0] - 2, -1, -1):
+            _lib.call("fhe_dyadic_multiply", ctx.h, _ptr(acc), _ptr(self._sk_ntt), _ptr(acc), 1, _stream())
+            _lib.call("fhe_add", ctx.h, _ptr(acc), _ptr(f[j]), _ptr(acc), 1, _stream())
+        out = acc[None].contiguous()
+        _lib.call("fhe_ntt_inverse", ctx.h, _ptr(out), _ptr(out), 1, _stream())
+        return to_host(out)[0]
+
+    def decrypt(self, ct, with_budget=False):
+        ph = self._phase(ct)
+        Q, t = self.Q, self.ctx.t
+        plain = np.zeros(self.ctx.n, dtype=np.uint64)
+        worst = 0
+        for c in range(self.ctx.n):
+            x = sum(int(ph[i, c]) * f for i, f in enumerate(self._crt)) % Q
+            m = (t * x + Q // 2) // Q
+            worst = max(worst, abs(t * x - m * Q))
+            plain[c] = m % t
+        if with_budget:
+            return plain, max(0, Q.bit_length() - worst.bit_length() - 1)
+        return plain
+
+    def invariant_noise_budget(self, ct):
+        return self.decrypt(ct, with_budget=True)[1]
