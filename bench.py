@@ -53,6 +53,29 @@ def cpu_baseline(n_blocks_sample):
     }
 
 
+def _cpu_worker(nb):
+    from oracle import oracle as om
+    orc = om.Oracle.preset("P4096")
+    blocks = orc.random_ct(nb * 64, seed=om.SEED).reshape(nb, 64, 2, orc.k, orc.n)
+    t0 = time.perf_counter()
+    for b in range(nb):
+        orc.dct_quant(blocks[b], om.YQT)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(blocks_per_proc=2, max_procs=64):
+    """Same oracle, one process per core over independent blocks (extra field, not the `cpu_baseline` object)."""
+    import multiprocessing as mp
+    procs = max(1, min(max_procs, (os.cpu_count() or 1) // 2))
+    with mp.get_context("spawn").Pool(procs) as pool:
+        pool.map(_cpu_worker, [1] * procs)                     # warm up: library load, page faults
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [blocks_per_proc] * procs)
+        dt = time.perf_counter() - t0
+    return {"value": procs * blocks_per_proc / dt, "unit": "blocks/s", "cores": procs, "kind": "port",
+            "sample": "%d processes x %d blocks, same oracle" % (procs, blocks_per_proc)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +185,10 @@ def main():
         }
         if world == 1 and args.cpu_blocks > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
+            try:
+                res["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            except Exception as exc:      # the extra field must never break the bench line
+                res["cpu_baseline_all_cores"] = {"error": str(exc)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
