@@ -27,6 +27,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <random>
 #include <sstream>
@@ -62,6 +63,28 @@ struct Big {
     int bits() const { for (size_t i = w.size(); i-- > 0;) if (w[i]) return (int)(64 * i) + 64 - __builtin_clzll(w[i]); return 0; }
     void shr1() { for (size_t i = 0; i < w.size(); ++i) w[i] = (w[i] >> 1) | (i + 1 < w.size() ? w[i + 1] << 63 : 0); }
 };
+// Size-class pool of device allocations.  The reference's circuits create and destroy a temporary
+// Ciphertext around every Evaluator call (homo/fhe_image.h:207 `Ciphertext boaz1(data[i])`), and
+// hipMalloc/hipFree synchronise the device; recycling buffers keeps the op-at-a-time mode asynchronous.
+// All facade work runs on the default stream, so a recycled buffer is only touched after the work
+// that used it before.  Single-threaded like the reference.
+class Pool {
+public:
+    static Pool &instance() { static Pool p; return p; }
+    uint64_t *get(size_t words) {
+        auto &fl = free_[words];
+        if (!fl.empty()) { uint64_t *p = fl.back(); fl.pop_back(); return p; }
+        void *q = nullptr;
+        check(fhe_dev_alloc(words * 8, &q), "device alloc");
+        return (uint64_t *)q;
+    }
+    void put(uint64_t *p, size_t words) { free_[words].push_back(p); }
+    // buffers are returned to the driver at process exit (the HIP runtime may already be gone when
+    // static destructors run, so nothing is freed explicitly here)
+private:
+    std::map<size_t, std::vector<uint64_t *>> free_;
+};
+
 // device buffer with value semantics
 class DevBuf {
 public:
@@ -76,12 +99,12 @@ public:
         return *this;
     }
     DevBuf &operator=(DevBuf &&o) noexcept { std::swap(p_, o.p_); std::swap(words_, o.words_); return *this; }
-    ~DevBuf() { if (p_) fhe_dev_free(p_); }
+    ~DevBuf() { if (p_) Pool::instance().put(p_, words_); }
     void resize(size_t words) {
         if (words == words_) return;
-        if (p_) { fhe_dev_free(p_); p_ = nullptr; }
+        if (p_) { Pool::instance().put(p_, words_); p_ = nullptr; }
         words_ = words;
-        if (words) { void *q = nullptr; check(fhe_dev_alloc(words * 8, &q), "device alloc"); p_ = (uint64_t *)q; }
+        if (words) p_ = Pool::instance().get(words);
     }
     uint64_t *ptr() { return p_; }
     const uint64_t *ptr() const { return p_; }
@@ -556,13 +579,14 @@ public:
     }
     void add_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, +1); }
     void sub_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, -1); }
+    // The reference re-encodes the same few constants on every call (13 for the DCT,
+    // homo/fhe_image.h:221-236); the lifted + transformed form of each distinct plaintext is cached.
     void multiply_plain(Ciphertext &a, const Plaintext &p) {
         need(a);
         const int len = p.significant_coeff_count();
         if (len == 0) throw std::invalid_argument("plain cannot be zero");     // SEAL 2.3 rejects the zero plaintext
-        plain_ntt_.resize(fhe_plain_ntt_words(st_->h));
-        detail::check(fhe_plain_prepare(st_->h, p.data().data(), (uint32_t)len, plain_ntt_.ptr(), nullptr), "plain_prepare");
-        detail::check(fhe_multiply_plain(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), plain_ntt_.ptr(), nullptr), "multiply_plain");
+        const detail::DevBuf &prepared = prepared_plain(p, len);
+        detail::check(fhe_multiply_plain(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), prepared.ptr(), nullptr), "multiply_plain");
     }
     void multiply(Ciphertext &a, const Ciphertext &b) {
         need(a); need(b);
@@ -623,8 +647,23 @@ private:
         const int len = p.significant_coeff_count();
         if (len) detail::check(fhe_add_plain(st_->h, a.ptr(), (uint64_t)a.size() * st_->poly_words(), 1, p.data().data(), (uint32_t)len, sign, nullptr), "add_plain");
     }
+    const detail::DevBuf &prepared_plain(const Plaintext &p, int len) {
+        uint64_t h = 1469598103934665603ULL;                               // FNV-1a over the significant coefficients
+        for (int i = 0; i < len; ++i) { h ^= p[i] + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1); h *= 1099511628211ULL; }
+        auto range = plain_cache_.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it) {
+            const std::vector<uint64_t> &key = it->second.first;
+            if ((int)key.size() == len && std::equal(key.begin(), key.end(), p.data().begin())) return it->second.second;
+        }
+        if (plain_cache_.size() > 4096) plain_cache_.clear();
+        auto it = plain_cache_.emplace(h, std::make_pair(std::vector<uint64_t>(p.data().begin(), p.data().begin() + len), detail::DevBuf()));
+        it->second.second.resize(fhe_plain_ntt_words(st_->h));
+        detail::check(fhe_plain_prepare(st_->h, p.data().data(), (uint32_t)len, it->second.second.ptr(), nullptr), "plain_prepare");
+        return it->second.second;
+    }
     std::shared_ptr<detail::CtxState> st_;
-    detail::DevBuf plain_ntt_, scratch_;
+    detail::DevBuf scratch_;
+    std::multimap<uint64_t, std::pair<std::vector<uint64_t>, detail::DevBuf>> plain_cache_;
 };
 
 // ---- throughput helpers: the fused/batched C ABI behind SEAL-typed arguments ---------------------
