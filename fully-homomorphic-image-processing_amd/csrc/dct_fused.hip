@@ -200,7 +200,7 @@ __device__ __forceinline__ void ntt_inv(double (&x)[M][1 << LE], double (&w)[(1 
     }
 }
 
-template <int L, int LE, bool BIG, int HALF, int ABL>
+template <int L, int LE, bool BIG, int HALF>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__restrict__ mid, const double *__restrict__ consts,
                                           const double *__restrict__ tw, const Work &wk, double p, double pinv, u32 k, double *lds) {
     using SH = Shape<L, LE>;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
     double cn[9];
     auto fetch = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) cn[i] = (ABL == 1) ? 3.0 + i : cp[(size_t)i * cstride + r * TP];
+        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
     };
     int phase = 0;
     ntt_fwd<L, LE, 4>(x, w0, tw, p, pinv, lds, tid, phase, [&] { if (LE >= 4) fetch(0); });
@@ -266,7 +266,7 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
         if (LE >= 4 && r + 1 < E) fetch(r + 1);
-        if (ABL != 3) line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         if (BIG) {
 #pragma unroll
             for (int m = 0; m < 4; m++) x[m][r] = red(x[m][r], p, pinv);
@@ -276,18 +276,17 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
     for (int m = 0; m < 4; m++) {
         double *o = mid + base + (size_t)(2 * m + HALF) * ct_words + tid;
 #pragma unroll
-        for (int r = 0; r < E; r++) if (ABL != 4 || x[m][r] == 1.2345e300) o[r * TP] = x[m][r];
+        for (int r = 0; r < E; r++) o[r * TP] = x[m][r];
     }
 }
 
-// waves per SIMD requested from the register allocator: two workgroups per CU
 // waves per SIMD requested from the register allocator = what LDS lets be resident (at most two workgroups)
 __host__ __device__ constexpr int occ_waves(int tp, int lds_words) {
     return ((2 * lds_words * 16 <= 160 * 1024) ? 2 : 1) * tp / 256 < 1 ? 1 : ((2 * lds_words * 16 <= 160 * 1024) ? 2 : 1) * tp / 256;
 }
 template <int L, int LE> struct Occ { static constexpr int W = occ_waves(Shape<L, LE>::TP, Shape<L, LE>::LDS_WORDS); };
 
-template <int L, int LE, bool BIG, int ABL = 0>
+template <int L, int LE, bool BIG>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
                                                                   const double *__restrict__ consts, const double *__restrict__ tw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
@@ -295,11 +294,11 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_row
     const Work wk = decode(blockIdx.x, k);
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const double *tw = tw_all + (size_t)wk.prime * Shape<L, LE>::N;
-    if (wk.half) rows_body<L, LE, BIG, 1, ABL>(in, mid, consts, tw, wk, p, pinv, k, lds);
-    else rows_body<L, LE, BIG, 0, ABL>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    if (wk.half) rows_body<L, LE, BIG, 1>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    else rows_body<L, LE, BIG, 0>(in, mid, consts, tw, wk, p, pinv, k, lds);
 }
 
-template <int L, int LE, bool BIG, int HALF, int ABL>
+template <int L, int LE, bool BIG, int HALF>
 __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *__restrict__ out, const double *__restrict__ consts,
                                           const double *__restrict__ itw, const Work &wk, double p, double pinv, u32 k, double *lds) {
     using SH = Shape<L, LE>;
@@ -316,9 +315,9 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
     double cn[9], sn[4];
     auto fetch = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) cn[i] = (ABL == 1) ? 3.0 + i : cp[(size_t)i * cstride + r * TP];
+        for (int i = 0; i < NC; i++) cn[i] = cp[(size_t)i * cstride + r * TP];
 #pragma unroll
-        for (int m = 0; m < 4; m++) sn[m] = (ABL == 1) ? 5.0 + m : sp[(size_t)(16 * m) * cstride + r * TP];
+        for (int m = 0; m < 4; m++) sn[m] = sp[(size_t)(16 * m) * cstride + r * TP];
     };
     fetch(0);
     double wl[E - 1];
@@ -341,7 +340,7 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
 #pragma unroll
         for (int m = 0; m < 4; m++) sc[m] = sn[m];
         if (r + 1 < E) fetch(r + 1);
-        if (ABL != 3) line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         double y[4] = {x[0][r], x[1][r], x[2][r], x[3][r]};
         mmv<4>(y, sc, p, pinv);
 #pragma unroll
@@ -356,12 +355,12 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
         for (int r = 0; r < E; r++) {
             double v = x[m][r];
             v = v < 0.0 ? v + p : v;
-            if (ABL != 4 || v == 1.2345e300) o[r * TP] = f64_to_u52(v);
+            o[r * TP] = f64_to_u52(v);
         }
     }
 }
 
-template <int L, int LE, bool BIG, int ABL = 0>
+template <int L, int LE, bool BIG>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
                                                                   const double *__restrict__ consts, const double *__restrict__ itw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
@@ -369,8 +368,8 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_col
     const Work wk = decode(blockIdx.x, k);   // line = column index
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const double *itw = itw_all + (size_t)wk.prime * Shape<L, LE>::N;
-    if (wk.half) cols_body<L, LE, BIG, 1, ABL>(mid, out, consts, itw, wk, p, pinv, k, lds);
-    else cols_body<L, LE, BIG, 0, ABL>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    if (wk.half) cols_body<L, LE, BIG, 1>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    else cols_body<L, LE, BIG, 0>(mid, out, consts, itw, wk, p, pinv, k, lds);
 }
 
 // Shoup-pair table in the u64 kernels' slot order (16 slots per thread) -> centred doubles in the
