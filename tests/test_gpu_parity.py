@@ -569,3 +569,24 @@ def test_c_abi_error_codes(fhe, oracle_mod):
     q2 = (C.c_uint64 * 1)(0xFFFFEE003)
     assert L.fhe_ctx_create(4096, q2, 1, 1 << 14, 0, C.byref(h)) == -1                  # not an NTT prime
     assert L.fhe_ctx_create(4096, q, 1, 1 << 14, 99, C.byref(h)) == -1                  # no such device
+
+
+# ---------------------------------------------------------------------------------------------
+# the other polynomial degrees the reference's benchmark grid uses (benchmark/benchmark.py:6): 2048, 16384
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,q", [(2048, [0x3FFFFFFF000001]),
+                                 (16384, [0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x3FFFFFFF000001])])
+def test_other_degrees(fhe, oracle_mod, n, q):
+    ctx, orc = fhe.SEALContext(n, q, 1 << 14), oracle_mod.Oracle(n, q, 1 << 14)
+    ev, enc = fhe.Evaluator(ctx), fhe.FractionalEncoder(ctx)
+    a, b = ctx.random_ct(2, seed=71), ctx.random_ct(2, seed=72)
+    ha, hb = fhe.to_host(a), fhe.to_host(b)
+    assert np.array_equal(fhe.to_host(ev.ntt_inverse(ev.ntt_forward(a))), ha)
+    assert np.array_equal(fhe.to_host(ev.add(a, b))[1], orc.add(ha[1], hb[1]))
+    for v in (0.541196100, -1.847759065, 3.0):
+        assert np.array_equal(fhe.to_host(ev.multiply_plain(a, enc.encode(v)))[0], orc.multiply_plain(ha[0], orc.encode(v)))
+    assert np.array_equal(fhe.to_host(ev.multiply(a, b))[0], orc.multiply(ha[0], hb[0]))
+    blk = ctx.random_ct(1, 64, seed=73)
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blk))[0]
+    ref = orc.dct_quant(fhe.to_host(blk)[0], fhe.YQT)
+    assert np.array_equal(out, ref)
