@@ -181,6 +181,10 @@ def main():
                                    "HIP events on the launch stream)",
                          "algorithmic_bytes_per_launch": B * BYTES_PER_BLOCK, "algorithmic_bytes_per_block": BYTES_PER_BLOCK,
                          "ms_per_launch": dev_ms_per_step},
+            # secondary view: the fused circuit needs ~213e6 FP64 lane-operations per block;
+            # 29.3e12/s is the densest v_fma_f64 rate measured on this chip (profiles/r01_ubench2_fp64_latency.txt)
+            "fp64_alu": {"ops_per_block": 213e6, "achieved_tops": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 1e12,
+                         "measured_peak_tops": 29.3, "frac": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 29.3e12},
             "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
         }
         if world == 1 and args.cpu_blocks > 0:
