@@ -35,3 +35,42 @@ def test_reference_circuit_code_through_facade_equals_oracle(oracle_mod, tmp_pat
     y, u, v = orc.rgb_to_ycc(cts[64], cts[65], cts[66])
     assert np.array_equal(out[64], y) and np.array_equal(out[65], u) and np.array_equal(out[66], v)
     assert "," in r.stdout          # the reference's own timing prints (homo/fhe_image.h:286)
+
+
+def test_reference_cli_pipeline_unmodified(tmp_path):
+    """BASELINE.json configs[0] end to end with the reference's OWN mains: homo/client_jpeg.cpp and
+    homo/server_jpeg.cpp compiled unchanged against the facade (oracle/Makefile, target `ref`).
+    client --send (keygen + encrypt every pixel) -> server (rgb_to_ycc_fhe + encrypted_dct on the GPU)
+    -> client --recieve (decrypt, quantise, Huffman-code, write the JPEG), then the reference's own
+    check (homo/fhe_image.h:508-521): RMS error of the FHE-produced JPEG against jo_jpeg's."""
+    client = os.path.join(ROOT, "oracle", "_ref", "ref_client_jpeg")
+    server = os.path.join(ROOT, "oracle", "_ref", "ref_server_jpeg")
+    if not (os.path.exists(client) and os.path.exists(server)):
+        pytest.skip("oracle/_ref/ref_client_jpeg / ref_server_jpeg not built (needs /root/reference at build time)")
+    Image = pytest.importorskip("PIL.Image")
+    (tmp_path / "keys").mkdir()
+    (tmp_path / "image").mkdir()
+    w, h = 16, 8                                       # 2 blocks x 3 channels x 64 ciphertexts
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([40 + 12 * xx, 200 - 20 * yy, 90 + 5 * xx + 7 * yy], axis=-1).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(str(tmp_path / "image" / "in.jpg"), quality=95, subsampling=0)
+
+    def run(argv):
+        r = subprocess.run(argv, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, " ".join(argv) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+
+    out = run([client, "--send", "-f", "image/in.jpg", "-c", "image/ct_in.txt", "--cmod", "4096"])
+    assert out.startswith("Encryption,")
+    out = run([server, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt", "--cmod", "4096"])
+    assert out.count("DCT,") == (w // 8) * (h // 8)
+    out = run([client, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg",
+               "--cmod", "4096"])
+    line = [ln for ln in out.splitlines() if ln.startswith("RMSError,")]
+    assert line, out[-2000:]
+    rms = float(line[0].split(",")[1])
+    # the FHE JPEG and jo_jpeg's differ only where a coefficient sits on a rounding boundary
+    assert rms < 6.0, rms
+    got = np.asarray(Image.open(str(tmp_path / "image" / "out.jpg")).convert("RGB"), dtype=np.int32)
+    assert got.shape == (h, w, 3)
+    assert np.sqrt(np.mean((got - rgb.astype(np.int32)) ** 2)) < 12.0
