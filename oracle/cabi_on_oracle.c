@@ -1,0 +1,265 @@
+/* TEST INFRASTRUCTURE ONLY -- never loaded, linked or imported by the package or by bench.py's timed path.
+ *
+ * The entry points of include/fhe_hip.h implemented on the CPU oracle (fhe_oracle.c), with "device"
+ * memory = malloc.  Purpose: pin the ORACLE against the reference's own golden outputs without a GPU.
+ * oracle/Makefile (target `ref`) links the reference's unmodified homo/client_jpeg.cpp and
+ * homo/server_jpeg.cpp against seal/seal.h + this library (oracle/_ref/ref_*_cpu); run on the
+ * reference's benchmark image they must print the RMSError values published in the reference's
+ * benchmark/results.txt (tests/test_oracle_golden.py, tests/golden/make_golden.py).  The same library
+ * lets seal/facade_test.cpp exercise the facade's host logic on a machine without a GPU.
+ *
+ * The product library (csrc/, libfhe_hip.so) has no CPU fallback and shares no code with this file.
+ * Plaintext / key material in "NTT form" uses the oracle's own slot order; it is opaque to callers,
+ * exactly like the product's (include/fhe_hip.h, layout note).
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/fhe_hip.h"
+#include "fhe_oracle.h"
+
+typedef unsigned __int128 u128;
+
+static __thread char g_err[256];
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct fhe_ctx {
+    fo_ctx *o;
+    uint32_t n, k;
+    uint64_t t, q[FHE_MAX_K];
+};
+struct fhe_dct_plan {
+    double quant[64];
+};
+
+const char *fhe_last_error(void) { return g_err; }
+uint32_t fhe_abi_version(void) { return 1; }
+
+int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out) {
+    /* the same published SEAL prime tables the product restates */
+    static const uint64_t s3_4096[] = {0xffffee001ULL, 0xffffc4001ULL, 0x1ffffe0001ULL};
+    static const uint64_t s3_8192[] = {0x7fffffd8001ULL, 0x7fffffc8001ULL, 0xfffffffc001ULL, 0xffffff6c001ULL,
+                                       0xfffffebc001ULL};
+    static const uint64_t s23_2048[] = {0x3fffffff000001ULL};
+    static const uint64_t s23_4096[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL};
+    static const uint64_t s23_8192[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x3fffffff000001ULL,
+                                        0x3ffffffef40001ULL};
+    const uint64_t *src = NULL;
+    int cnt = 0;
+    if (n == 2048 || n == 1024) { src = s23_2048; cnt = 1; }
+    else if (n == 4096) { src = preset ? s23_4096 : s3_4096; cnt = preset ? 2 : 3; }
+    else if (n == 8192) { src = preset ? s23_8192 : s3_8192; cnt = preset ? 4 : 5; }
+    if (!src || preset < 0 || preset > 1) return fail(FHE_ERR_PARAM, "no default coefficient modulus for n=%u", n);
+    memcpy(q_out, src, sizeof(uint64_t) * cnt);
+    return cnt;
+}
+
+int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int device, fhe_ctx **out) {
+    (void)device;
+    if (!out || !q || k == 0 || k > FHE_MAX_K) return fail(FHE_ERR_PARAM, "bad argument");
+    fo_ctx *o = fo_ctx_create(n, q, k, t);
+    if (!o) return fail(FHE_ERR_PARAM, "oracle rejected the parameter set");
+    fhe_ctx *c = (fhe_ctx *)calloc(1, sizeof *c);
+    c->o = o; c->n = n; c->k = k; c->t = t;
+    memcpy(c->q, q, sizeof(uint64_t) * k);
+    *out = c;
+    return FHE_OK;
+}
+int fhe_ctx_destroy(fhe_ctx *c) {
+    if (c) { fo_ctx_destroy(c->o); free(c); }
+    return FHE_OK;
+}
+uint32_t fhe_ctx_n(const fhe_ctx *c) { return c->n; }
+uint32_t fhe_ctx_k(const fhe_ctx *c) { return c->k; }
+uint64_t fhe_ctx_t(const fhe_ctx *c) { return c->t; }
+uint64_t fhe_ctx_q(const fhe_ctx *c, uint32_t i) { return i < c->k ? c->q[i] : 0; }
+
+int fhe_dev_alloc(size_t bytes, void **p) {
+    *p = malloc(bytes ? bytes : 8);
+    return *p ? FHE_OK : fail(FHE_ERR_NOMEM, "malloc(%zu)", bytes);
+}
+int fhe_dev_free(void *p) { free(p); return FHE_OK; }
+int fhe_upload(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
+int fhe_download(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
+int fhe_copy(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memmove(d, s, b); return FHE_OK; }
+int fhe_stream_sync(fhe_stream st) { (void)st; return FHE_OK; }
+
+/* encode/decode depend on (n, t) only; keep one small oracle context per pair */
+static fo_ctx *codec_ctx(uint32_t n, uint64_t t) {
+    static struct { uint32_t n; uint64_t t; fo_ctx *o; } cache[16];
+    static int used;
+    for (int i = 0; i < used; i++)
+        if (cache[i].n == n && cache[i].t == t) return cache[i].o;
+    uint64_t q[FHE_MAX_K];
+    if (fhe_default_coeff_modulus(8192, 1, q) <= 0) return NULL;          /* 0x7fffffff380001 = 1 mod 2^19 */
+    fo_ctx *o = fo_ctx_create(n, q, 1, t);
+    if (o && used < 16) { cache[used].n = n; cache[used].t = t; cache[used].o = o; used++; }
+    return o;
+}
+int fhe_frac_encode(uint32_t n, uint64_t t, double v, int ic, int fc, uint64_t *plain) {
+    fo_ctx *o = codec_ctx(n, t);
+    if (!o) return fail(FHE_ERR_PARAM, "no codec context for n=%u", n);
+    return (int)fo_frac_encode(o, v, ic, fc, plain);
+}
+double fhe_frac_decode(uint32_t n, uint64_t t, const uint64_t *plain, int ic, int fc) {
+    fo_ctx *o = codec_ctx(n, t);
+    return o ? fo_frac_decode(o, plain, ic, fc) : 0.0;
+}
+
+static size_t pw(const fhe_ctx *c) { return (size_t)c->k * c->n; }
+
+int fhe_add(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t np, fhe_stream s) {
+    (void)s;
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) {
+            const uint64_t q = c->q[i];
+            size_t o = p * pw(c) + (size_t)i * c->n;
+            for (uint32_t l = 0; l < c->n; l++) { uint64_t v = a[o + l] + b[o + l]; out[o + l] = v >= q ? v - q : v; }
+        }
+    return FHE_OK;
+}
+int fhe_sub(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t np, fhe_stream s) {
+    (void)s;
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) {
+            const uint64_t q = c->q[i];
+            size_t o = p * pw(c) + (size_t)i * c->n;
+            for (uint32_t l = 0; l < c->n; l++) out[o + l] = a[o + l] >= b[o + l] ? a[o + l] - b[o + l] : a[o + l] + q - b[o + l];
+        }
+    return FHE_OK;
+}
+int fhe_negate(const fhe_ctx *c, const uint64_t *a, uint64_t *out, uint64_t np, fhe_stream s) {
+    (void)s;
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) {
+            size_t o = p * pw(c) + (size_t)i * c->n;
+            for (uint32_t l = 0; l < c->n; l++) out[o + l] = a[o + l] ? c->q[i] - a[o + l] : 0;
+        }
+    return FHE_OK;
+}
+
+int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, fhe_stream s) {
+    (void)s;
+    if (in != out) memmove(out, in, np * pw(c) * 8);
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) fo_ntt_fwd(c->o, 0, i, out + p * pw(c) + (size_t)i * c->n);
+    return FHE_OK;
+}
+int fhe_ntt_inverse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, fhe_stream s) {
+    (void)s;
+    if (in != out) memmove(out, in, np * pw(c) * 8);
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) fo_ntt_inv(c->o, 0, i, out + p * pw(c) + (size_t)i * c->n);
+    return FHE_OK;
+}
+int fhe_dyadic_multiply(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t np,
+                        fhe_stream s) {
+    (void)s;
+    for (uint64_t p = 0; p < np; p++)
+        for (uint32_t i = 0; i < c->k; i++) {
+            size_t o = p * pw(c) + (size_t)i * c->n;
+            for (uint32_t l = 0; l < c->n; l++) out[o + l] = (uint64_t)(((u128)a[o + l] * b[o + l]) % c->q[i]);
+        }
+    return FHE_OK;
+}
+
+size_t fhe_plain_ntt_words(const fhe_ctx *c) { return pw(c); }
+int fhe_plain_prepare(const fhe_ctx *c, const uint64_t *plain, uint32_t len, uint64_t *d, fhe_stream s) {
+    fo_plain_lift(c->o, plain, len, d);
+    return fhe_ntt_forward(c, d, d, 1, s);
+}
+int fhe_plain_ntt_mul(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, fhe_stream s) {
+    return fhe_dyadic_multiply(c, a, b, out, 1, s);
+}
+int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, const uint64_t *d_plain,
+                       fhe_stream s) {
+    fhe_ntt_forward(c, in, out, np, s);
+    for (uint64_t p = 0; p < np; p++) fhe_dyadic_multiply(c, out + p * pw(c), d_plain, out + p * pw(c), 1, s);
+    return fhe_ntt_inverse(c, out, out, np, s);
+}
+int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, uint64_t count, const uint64_t *plain,
+                  uint32_t len, int sign, fhe_stream s) {
+    (void)s;
+    for (uint64_t b = 0; b < count; b++) {
+        if (sign >= 0) fo_add_plain(c->o, ct + b * stride, plain, len);
+        else fo_sub_plain(c->o, ct + b * stride, plain, len);
+    }
+    return FHE_OK;
+}
+
+size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint32_t sb, uint64_t count) {
+    (void)c; (void)sa; (void)sb; (void)count;
+    return 8;
+}
+int fhe_multiply(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out,
+                 uint64_t count, void *scr, size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    for (uint64_t i = 0; i < count; i++)
+        fo_multiply(c->o, a + i * sa * pw(c), sa, b + i * sb * pw(c), sb, out + i * (sa + sb - 1) * pw(c));
+    return FHE_OK;
+}
+int fhe_square(const fhe_ctx *c, const uint64_t *a, uint32_t sa, uint64_t *out, uint64_t count, void *scr,
+               size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    for (uint64_t i = 0; i < count; i++) fo_square(c->o, a + i * sa * pw(c), sa, out + i * (2 * sa - 1) * pw(c));
+    return FHE_OK;
+}
+uint32_t fhe_evk_digits(const fhe_ctx *c, uint32_t dbc) { return fo_evk_digits(c->o, dbc); }
+size_t fhe_relinearize_scratch_bytes(const fhe_ctx *c, uint32_t dbc, uint64_t count) {
+    (void)c; (void)dbc; (void)count;
+    return 8;
+}
+int fhe_relinearize(const fhe_ctx *c, uint64_t *ct3, uint64_t stride, uint64_t count, const uint64_t *evk,
+                    uint32_t dbc, void *scr, size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    for (uint64_t i = 0; i < count; i++) fo_relinearize3(c->o, ct3 + i * stride, evk, dbc);
+    return FHE_OK;
+}
+
+int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int ic, int fc, fhe_stream s, fhe_dct_plan **out) {
+    (void)c; (void)s;
+    if (ic != 100 || fc != 100) return fail(FHE_ERR_PARAM, "the oracle fixes 100/100 coefficients");
+    fhe_dct_plan *p = (fhe_dct_plan *)calloc(1, sizeof *p);
+    memcpy(p->quant, quant64, sizeof p->quant);
+    *out = p;
+    return FHE_OK;
+}
+int fhe_dct_plan_destroy(fhe_dct_plan *p) { free(p); return FHE_OK; }
+size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *c, uint64_t nb) { (void)c; (void)nb; return 8; }
+int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out, uint64_t nb,
+                     void *scr, size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    const size_t bw = 64 * 2 * pw(c);
+    if (in != out) memmove(out, in, nb * bw * 8);
+    for (uint64_t b = 0; b < nb; b++) {
+        fo_encrypted_dct(c->o, out + b * bw);
+        fo_quantize(c->o, out + b * bw, plan->quant);
+    }
+    return FHE_OK;
+}
+int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int ic, int fc,
+                   fhe_stream s) {
+    (void)s;
+    if (ic != 100 || fc != 100) return fail(FHE_ERR_PARAM, "the oracle fixes 100/100 coefficients");
+    for (uint64_t i = 0; i < count; i++) fo_rgb_to_ycc(c->o, r + i * 2 * pw(c), g + i * 2 * pw(c), b + i * 2 * pw(c));
+    return FHE_OK;
+}
+int fhe_fill_random(const fhe_ctx *c, uint64_t *ct, uint64_t np, uint64_t seed, uint64_t first, fhe_stream s) {
+    (void)s;
+    fo_fill_random_ct(c->o, ct, np, seed, first);
+    return FHE_OK;
+}
+int fhe_digest(const fhe_ctx *c, const uint64_t *data, uint64_t count, uint64_t index0, uint64_t *d_out,
+               fhe_stream s) {
+    (void)c; (void)s; (void)index0;
+    *d_out = fo_digest(data, count);          /* oracle digest; not the product's position-salted one */
+    return FHE_OK;
+}

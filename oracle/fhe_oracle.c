@@ -1,6 +1,6 @@
 /*
  * fhe_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
- * See fhe_oracle.h for scope, citations and the "PARITY UNPINNED" statement.
+ * See fhe_oracle.h for scope, citations and the PARITY STATUS statement.
  *
  * Deliberately simple: schoolbook-order loops, unsigned __int128 products with
  * a hardware remainder, one operation at a time, plaintexts re-lifted and

@@ -7,12 +7,22 @@
  * and homo/fhe_decode.h:48-242.
  *
  * SEAL itself is an un-vendored, unpinned git submodule of the reference
- * (.gitmodules:1-3, README.md:70; SEAL/ is empty) and the reference holds no
- * golden ciphertexts, so:
+ * (.gitmodules:1-3, README.md:70; SEAL/ is empty), so SEAL cannot be run here.
  *
- *        ***  PARITY UNPINNED at the SEAL boundary  ***
+ * PARITY STATUS
+ *   PINNED for the JPEG path (add, sub, negate, add_plain, sub_plain, multiply_plain, encoder,
+ *   encrypt/decrypt): the reference's own mains (homo/client_jpeg.cpp, homo/server_jpeg.cpp,
+ *   compiled unchanged) run on this oracle through oracle/cabi_on_oracle.c reproduce every
+ *   `RMSError` value the reference publishes for that pipeline in benchmark/results.txt
+ *   (36 runs = 9 plain moduli x 4 degrees; five plain moduli wrap around on purpose):
+ *   tests/test_reference_published_outputs.py, oracle/pin_against_reference.py.
+ *   That pin is at the level of decrypted values.
  *
- * What pins this oracle instead (see DESIGN.md "Oracle"):
+ *        ***  PARITY UNPINNED at the level of ciphertext bits, and for  ***
+ *        ***  multiply / square / relinearize (resize and decode paths) ***
+ *
+ *   The reference holds no golden ciphertexts, and its resize/decode mains need OpenCV, which
+ *   this image lacks (unbuildable here).  What checks those parts instead (DESIGN.md "Oracle"):
  *   - add/sub/negate/add_plain/sub_plain/multiply_plain are exact operations in
  *     R_q = Z_q[x]/(x^n+1); their fully reduced residues are mathematically
  *     unique.  oracle/bigint_model.py re-derives them with Python big integers

@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  The product package never imports this module.
-See oracle/fhe_oracle.h for what it restates and the "parity unpinned" statement.
+See oracle/fhe_oracle.h for what it restates and its PARITY STATUS (JPEG path pinned by the
+reference's published outputs; ciphertext bits and the ct x ct ops "parity unpinned").
 """
 import ctypes as C
 import os

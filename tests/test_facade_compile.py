@@ -44,3 +44,14 @@ def test_reference_mains_compile_unchanged(src):
 def test_reference_jpeg_circuit_links_against_facade():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "ref"])
     assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_jpeg_circuit"))
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_facade_self_test_on_oracle_backed_cabi(n):
+    """seal/facade_test.cpp (keygen, encrypt, every Evaluator method, relinearize, save/load, fused
+    DCT, decrypt) linked against oracle/cabi_on_oracle.c: the facade's host logic without a GPU."""
+    exe = os.path.join(ROOT, "oracle", "facade_test_cpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "facade_test_cpu"])
+    r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FACADE TEST OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,0 +1,58 @@
+"""The reference's own golden outputs: the `RMSError` lines of benchmark/results.txt for the JPEG
+pipeline (benchmark/benchmark.py:33-43 on image/boazbarak.jpg, committed here as the fixture
+tests/golden/boazbarak.jpg; nine plain moduli, five of which overflow on purpose).
+
+The reference's UNMODIFIED mains (homo/client_jpeg.cpp, homo/server_jpeg.cpp; built by oracle/Makefile
+target `ref` in the container that holds /root/reference, binaries in oracle/_ref/) are run
+  * on the CPU against the oracle (oracle/libfhe_cabi_oracle.so)   -> pins the ORACLE   (not gpu)
+  * on the MI355X against libfhe_hip.so                            -> pins the PRODUCT  (gpu)
+and must print exactly the published value for every parameter set."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from oracle.pin_against_reference import PUBLISHED, ROOT, run_set
+
+
+def _have(sfx):
+    return all(os.path.exists(os.path.join(ROOT, "oracle", "_ref", b + sfx)) for b in ("ref_client_jpeg", "ref_server_jpeg"))
+
+
+def test_published_table_is_the_references():
+    """guard the transcription when the reference tree is at hand"""
+    path = "/root/reference/benchmark/results.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    lines = open(path).read().splitlines()
+    seen = {}
+    for i, ln in enumerate(lines):
+        if "logs/jpg_boaz_" in ln:
+            n, t = ln.rsplit(".txt", 1)[0].split("_")[-2:]
+            rms = [x for x in lines[i + 1:i + 6] if x.startswith("RMSError,")][0].split(",")[1]
+            seen.setdefault(int(t), set()).add(rms)
+    assert {t: {v} for t, v in PUBLISHED.items()} == seen      # 36 runs, one value per plain modulus
+
+
+def test_oracle_reproduces_published_rms_on_cpu():
+    """three sets concurrently (about 45 s): a wrapped one, the borderline one, a clean one;
+    `python oracle/pin_against_reference.py` runs all nine (profiles/r01_oracle_pin_n2048.json)."""
+    if not _have("_cpu"):
+        pytest.skip("oracle/_ref/ref_*_jpeg_cpu not built (needs /root/reference at build time)")
+    sets = [101, 1009, 3001]
+    with ThreadPoolExecutor(len(sets)) as ex:
+        got = list(ex.map(lambda t: run_set(2048, t)[0], sets))
+    assert got == [PUBLISHED[t] for t in sets]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_product_reproduces_published_rms_on_gpu(n):
+    """all nine plain moduli; n = 2048 runs the general u64 kernels (54-bit prime), n = 4096 the
+    BASELINE.json configs[0] parameter set on the FP64 kernels."""
+    if not _have(""):
+        pytest.skip("oracle/_ref/ref_*_jpeg not built (needs /root/reference at build time)")
+    sets = sorted(PUBLISHED)
+    with ThreadPoolExecutor(3) as ex:
+        got = list(ex.map(lambda t: run_set(n, t, gpu=True)[0], sets))
+    assert got == [PUBLISHED[t] for t in sets]
