@@ -146,17 +146,28 @@ __device__ __forceinline__ void inv_pass(double (&x)[M][1 << LE], const double (
     }
 }
 
-// M polynomials through two alternating LDS buffers: one barrier per polynomial
+// M polynomials through two alternating LDS buffers: one barrier per polynomial.
+// When both layouts keep the wave bits of the thread id (tid >> 6) on the same index bits -- every
+// exchange except the one next to pass 0 -- a wave reads only what it wrote itself: no workgroup
+// barrier is needed (LDS operations of one wave complete in order), and the eight waves of a
+// workgroup are free to drift apart instead of meeting twelve times per transform.
 template <int L, int LE, int LO_FROM, int LO_TO, int M>
 __device__ __forceinline__ void transpose(double (&x)[M][1 << LE], double *lds, int tid, int &phase) {
     constexpr int PL = imin(LO_FROM, LO_TO), E = 1 << LE;
+    constexpr bool WAVE_LOCAL = (Shape<L, LE>::TP <= 64) || (LO_FROM <= 6 && LO_TO <= 6);
 #pragma unroll
     for (int m = 0; m < M; m++) {
         double *buf = lds + (phase & 1) * Shape<L, LE>::LDS_WORDS;
         phase++;
 #pragma unroll
         for (int r = 0; r < E; r++) buf[g_pad<PL, LE>(g_index<LO_FROM, LE>(tid, r))] = x[m][r];
-        __syncthreads();
+        if constexpr (WAVE_LOCAL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int r = 0; r < E; r++) x[m][r] = buf[g_pad<PL, LE>(g_index<LO_TO, LE>(tid, r))];
     }
