@@ -11,8 +11,8 @@ Stream format = the facade's Ciphertext::save records (seal/seal.h: "FHEHIP1" ma
 u32 k, u32 n, u32 reserved, raw little-endian u64).  SEAL 2.3's own wire format is not pinned by
 anything in the reference (no sample files).
 """
+import os
 import struct
-import threading
 
 import numpy as np
 import torch
@@ -45,63 +45,116 @@ def read_ciphertext_into(f, out):
         raise EOFError("truncated ciphertext record")
 
 
-def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=16, quant=None, do_dct=True):
+RECORD_HEADER = HEADER.size
+_IO_THREADS = 8
+_pinned_cache = {}
+
+
+def _pinned(tag, shape):
+    """pinned staging buffers are expensive to create (page locking): keep them between calls"""
+    key = (tag, shape)
+    if key not in _pinned_cache:
+        _pinned_cache[key] = torch.empty(shape, dtype=torch.int64).pin_memory()
+    return _pinned_cache[key]
+
+
+def _pread_records(fd, views, first_record, rec_bytes, expect):
+    """positional scatter reads (header -> scratch, payload -> straight into pinned memory); the
+    records are of fixed size, so any number of threads can read disjoint ranges concurrently"""
+    hdr = bytearray(RECORD_HEADER)
+    for j, v in enumerate(views):
+        mv = memoryview(v).cast("B")
+        got = os.preadv(fd, [hdr, mv], (first_record + j) * rec_bytes)
+        if got != rec_bytes:
+            raise EOFError("ciphertext stream ended")
+        magic, size, k, n, _ = HEADER.unpack(hdr)
+        if magic != MAGIC:
+            raise ValueError("not a ciphertext record")
+        if (size, k, n) != expect:
+            raise ValueError("ciphertext shape %r does not match the context %r" % ((size, k, n), expect))
+
+
+def _pwrite_records(fd, views, first_record, rec_bytes, hdr):
+    for j, v in enumerate(views):
+        mv = memoryview(v).cast("B")
+        if os.pwritev(fd, [hdr, mv], (first_record + j) * rec_bytes) != rec_bytes:
+            raise IOError("short write on the ciphertext stream")
+
+
+def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True):
     """Process `n_blocks` colour blocks.  Input order per block: 64 R, 64 G, 64 B ciphertexts
     (homo/server_jpeg.cpp:115-124).  Output order per block: for i in 0..63: Y[i], Cb[i], Cr[i]
     (homo/server_jpeg.cpp:150-152).  quant=None reproduces the reference server (no quantize_fhe call);
-    a 64-entry table applies quantize_fhe to every channel as well.  Returns blocks processed."""
+    a 64-entry table applies quantize_fhe to every channel as well.  Returns blocks processed.
+
+    Pipeline per wave of blocks: a pool of I/O threads reads the next wave's fixed-size records with
+    positional reads straight into a pinned buffer and writes the previous wave's results, while
+    the GPU converts and transforms the current one (file -> pinned -> HBM -> pinned -> file)."""
+    from concurrent.futures import ThreadPoolExecutor
     ev = Evaluator(ctx)
     plan = DctPlan(ctx, quant) if do_dct else None
     shape = (3, 64, 2, ctx.k, ctx.n)                       # one block: channel, pixel, poly, prime, coeff
     wave_blocks = max(1, min(wave_blocks, n_blocks))
-    host = [torch.empty((wave_blocks,) + shape, dtype=torch.int64).pin_memory() for _ in range(2)]
-    host_out = [torch.empty((wave_blocks,) + shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+    host = [_pinned(("in", i), (wave_blocks,) + shape) for i in range(2)]
+    host_out = [_pinned(("out", i), (wave_blocks,) + shape) for i in range(2)]
     copy_stream = torch.cuda.Stream()
+    rec_bytes = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+    expect = (2, ctx.k, ctx.n)
+    out_hdr = HEADER.pack(MAGIC, 2, ctx.k, ctx.n, 0)
+    if os.path.getsize(in_path) < n_blocks * 192 * rec_bytes:
+        raise EOFError("ciphertext stream ended")
 
-    def read_wave(f, buf, nb):
+    def read_wave(pool, fd, buf, first_block, nb):
         arr = buf.numpy().view(np.uint64)
-        for b in range(nb):
-            for ch in range(3):
-                for i in range(64):
-                    read_ciphertext_into(f, arr[b, ch, i])
+        # one task per (block, channel): 64 consecutive records
+        return [pool.submit(_pread_records, fd, [arr[b, ch, i] for i in range(64)],
+                            ((first_block + b) * 3 + ch) * 64, rec_bytes, expect)
+                for b in range(nb) for ch in range(3)]
 
-    def write_wave(f, buf, nb):
+    def write_wave(pool, fd, buf, first_block, nb):
         arr = buf.numpy().view(np.uint64)
-        for b in range(nb):
-            for i in range(64):
-                for ch in range(3):
-                    write_ciphertext(f, arr[b, ch, i])
+        # output order i-major, channel-minor: one task per (block, 16 coefficients)
+        return [pool.submit(_pwrite_records, fd, [arr[b, ch, i] for i in range(i0, i0 + 16) for ch in range(3)],
+                            (first_block + b) * 192 + i0 * 3, rec_bytes, out_hdr)
+                for b in range(nb) for i0 in range(0, 64, 16)]
+
+    def wait(futs):
+        for f in futs:
+            f.result()
 
     waves = [(s, min(s + wave_blocks, n_blocks)) for s in range(0, n_blocks, wave_blocks)]
-    with open(in_path, "rb") as fin, open(out_path, "wb") as fout:
-        read_wave(fin, host[0], waves[0][1] - waves[0][0])
-        writer = None
-        for wi, (s, e) in enumerate(waves):
-            nb = e - s
-            cur = host[wi & 1]
-            reader = None
-            if wi + 1 < len(waves):                         # prefetch the next wave from the file
-                ns, ne = waves[wi + 1]
-                reader = threading.Thread(target=read_wave, args=(fin, host[(wi + 1) & 1], ne - ns))
-                reader.start()
-            with torch.cuda.stream(copy_stream):
-                dev = cur[:nb].to(ctx.device, non_blocking=True)
-            torch.cuda.current_stream().wait_stream(copy_stream)
-            r, g, b = (dev[:, ch].reshape(nb * 64, 2, ctx.k, ctx.n).contiguous() for ch in range(3))
-            ev.rgb_to_ycc(r, g, b)                          # in place: r,g,b now hold Y, Cb, Cr
-            chans = []
-            for t in (r, g, b):
-                t = t.reshape(nb, 64, 2, ctx.k, ctx.n)
-                chans.append(ev.dct8x8_quant(plan, t) if do_dct else t)
-            res = torch.stack(chans, dim=1)                 # [nb, 3, 64, 2, k, n]
-            if writer is not None:
-                writer.join()                               # host_out[wi & 1] was written two waves ago
-            host_out[wi & 1][:nb].copy_(res, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            writer = threading.Thread(target=write_wave, args=(fout, host_out[wi & 1], nb))
-            writer.start()
-            if reader is not None:
-                reader.join()
-        if writer is not None:
-            writer.join()
+    fin = os.open(in_path, os.O_RDONLY)
+    fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fout, n_blocks * 192 * rec_bytes)
+        with ThreadPoolExecutor(_IO_THREADS) as pool:
+            wait(read_wave(pool, fin, host[0], 0, waves[0][1] - waves[0][0]))
+            pending = [[], []]
+            for wi, (s, e) in enumerate(waves):
+                nb = e - s
+                cur = host[wi & 1]
+                reading = []
+                if wi + 1 < len(waves):                     # prefetch the next wave from the file
+                    ns, ne = waves[wi + 1]
+                    reading = read_wave(pool, fin, host[(wi + 1) & 1], ns, ne - ns)
+                with torch.cuda.stream(copy_stream):
+                    dev = cur[:nb].to(ctx.device, non_blocking=True)
+                torch.cuda.current_stream().wait_stream(copy_stream)
+                r, g, b = (dev[:, ch].reshape(nb * 64, 2, ctx.k, ctx.n).contiguous() for ch in range(3))
+                ev.rgb_to_ycc(r, g, b)                      # in place: r,g,b now hold Y, Cb, Cr
+                chans = []
+                for t in (r, g, b):
+                    t = t.reshape(nb, 64, 2, ctx.k, ctx.n)
+                    chans.append(ev.dct8x8_quant(plan, t) if do_dct else t)
+                res = torch.stack(chans, dim=1)             # [nb, 3, 64, 2, k, n]
+                wait(pending[wi & 1])                       # host_out[wi & 1] was queued two waves ago
+                host_out[wi & 1][:nb].copy_(res, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                pending[wi & 1] = write_wave(pool, fout, host_out[wi & 1], s, nb)
+                wait(reading)
+            wait(pending[0])
+            wait(pending[1])
+    finally:
+        os.close(fin)
+        os.close(fout)
     return n_blocks
