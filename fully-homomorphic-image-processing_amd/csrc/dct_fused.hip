@@ -397,6 +397,70 @@ __global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__res
     out[i] = w > q / 2 ? -(double)(q - w) : (double)w;
 }
 
+// rgb_to_ycc_fhe (homo/fhe_image.h:310-325) for one residue polynomial of one pixel: three joint
+// forward transforms, the nine constant products per slot, three joint inverse transforms, in
+// place.  No intermediate leaves the workgroup: global traffic is the compulsory 3 in + 3 out.
+template <int L, int LE>
+__global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_rgb2ycc_f64(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc,
+                                                                     const double *__restrict__ consts, const double *__restrict__ tw_all,
+                                                                     const double *__restrict__ itw_all, const Modulus *__restrict__ mods,
+                                                                     const u64 *__restrict__ yoff, u32 yoff_len, u32 k) {
+    using SH = Shape<L, LE>;
+    constexpr int N = SH::N, TP = SH::TP, E = SH::E, LASTP = SH::NP - 1;
+    __shared__ double lds[2 * SH::LDS_WORDS];
+    const int tid = threadIdx.x;
+    // prime-major like the DCT kernels: resident workgroups share one prime's tables
+    const u32 per_prime = gridDim.x / k;
+    const u32 prime = blockIdx.x / per_prime;
+    const u32 pp = blockIdx.x - prime * per_prime;           // pixel * 2 + poly
+    const u32 poly = pp & 1;
+    const u64 q = mods[prime].q;
+    const double p = (double)q, pinv = 1.0 / p;
+    const double *tw = tw_all + (size_t)prime * N, *itw = itw_all + (size_t)prime * N;
+    const size_t off = ((size_t)pp * k + prime) * N + tid;
+    double w0[E - 1];
+    load_tw<L, LE, 0>(w0, tw, tid);
+    double x[3][E];
+    {
+        const u64 *src[3] = {R + off, G + off, Bc + off};
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int r = 0; r < E; r++) x[m][r] = u52_to_f64(src[m][r * TP]);
+    }
+    int phase = 0;
+    ntt_fwd<L, LE, 3>(x, w0, tw, p, pinv, lds, tid, phase, [] {});
+    double wl[E - 1];
+    load_tw<L, LE, LASTP>(wl, itw, tid);
+    const double *cp = consts + (size_t)prime * N + tid;
+    const size_t cstride = (size_t)k * N;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        double c[9], y[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { c[i] = cp[(size_t)i * cstride + r * TP]; y[i] = x[i % 3][r]; }
+        mmv<9>(y, c, p, pinv);
+        x[0][r] = y[0] + y[1] + y[2];          // Y  =  0.299 R + 0.587 G + 0.114 B      (- 128 below)
+        x[1][r] = y[3] - y[4] + y[5];          // Cb = (-0.168736) R - 0.331264 G + 0.5 B
+        x[2][r] = y[6] - y[7] - y[8];          // Cr =  0.5 R - 0.418688 G - 0.081312 B
+    }
+    ntt_inv<L, LE, 3, false>(x, wl, itw, p, pinv, lds, tid, phase);
+    u64 *dst[3] = {R + off, G + off, Bc + off};
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            double v = x[m][r];
+            v = v < 0.0 ? v + p : v;
+            u64 o = f64_to_u52(v);
+            if (m == 0 && poly == 0) {
+                const u32 j = (u32)(r * TP + tid);
+                if (j < yoff_len) o = submod(o, yoff[(size_t)prime * yoff_len + j], q);
+            }
+            dst[m][r * TP] = o;
+        }
+}
+
 }  // namespace
 
 static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves per SIMD resident
@@ -445,6 +509,29 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
         case 13: launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 4096, 8192}");
     }
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rgb_to_ycc_fhe on the FP64 kernels (n = 4096, primes <= 40 bits: the P4096 preset)
+// ------------------------------------------------------------------------------------------------
+bool fhe_rgb_f64_supported(const fhe_ctx *c) {
+    return fhe_dct_f64_supported(c) && c->logn == 12 && c->max_prime_bits <= 40;
+}
+
+int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **out, hipStream_t st) {
+    const u32 total = 9 * c->k * c->n;
+    HIP_TRY(hipMalloc(out, sizeof(double) * total));
+    k_consts_to_f64<<<(total + 255) / 256, 256, 0, st>>>(d_c, *out, c->qb.d_mod, c->k, c->n, 3, total);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st) {
+    const u64 grid = count * 2 * c->k;
+    if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
+    k_rgb2ycc_f64<12, 3><<<(unsigned)grid, Shape<12, 3>::TP, 0, st>>>(r, g, b, consts, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, yoff, yoff_len, c->k);
     KERNEL_CHECK();
     return FHE_OK;
 }

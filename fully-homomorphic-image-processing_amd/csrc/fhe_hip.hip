@@ -178,6 +178,9 @@ extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
         (void)hipStreamDestroy(c->aux_stream);
         for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_rows[i]); (void)hipEventDestroy(c->ev_cols[i]); }
     }
+    if (c->rgb.d_c) (void)hipFree(c->rgb.d_c);
+    if (c->rgb.d_c_f64) (void)hipFree(c->rgb.d_c_f64);
+    if (c->rgb.d_off) (void)hipFree(c->rgb.d_off);
     fhe_behz_free(c);
     fhe_free_base(c->qb);
     delete c;
@@ -802,26 +805,31 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_rgb2ycc(u64 *__restrict__ R
     store_coeff<L>(v, Bc + rp * N, tid);
 }
 
-extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int int_coeffs, int frac_coeffs, fhe_stream s) {
+// Encode, lift and transform the nine factors once per context (synchronous, first call only).
+static int rgb_consts(const fhe_ctx *c, int int_coeffs, int frac_coeffs, hipStream_t st, const fhe_ctx::RgbConsts **out) {
     using namespace hostmath;
-    if (!c || !r || !g || !b) return fail(FHE_ERR_PARAM, "null argument");
-    if (!count) return FHE_OK;
+    std::lock_guard<std::mutex> lock(c->rgb_mutex);
+    fhe_ctx::RgbConsts &rc_ = c->rgb;
+    if (rc_.d_c && rc_.int_coeffs == int_coeffs && rc_.frac_coeffs == frac_coeffs) { *out = &rc_; return FHE_OK; }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(FHE_ERR_HIP, "stream sync failed");   // earlier users of the old tables
+    if (rc_.d_c) (void)hipFree(rc_.d_c);
+    if (rc_.d_c_f64) (void)hipFree(rc_.d_c_f64);
+    if (rc_.d_off) (void)hipFree(rc_.d_off);
+    rc_ = fhe_ctx::RgbConsts();
     static const double cc[9] = {0.299, 0.587, 0.114, -0.168736, 0.331264, 0.5, 0.5, 0.418688, 0.081312};
-    hipStream_t st = (hipStream_t)s;
     const size_t pw = (size_t)c->k * c->n;
-    ulonglong2 *d_c = nullptr;
-    u64 *d_off = nullptr;
     std::vector<uint64_t> plain(c->n);
-    int rc = fhe_dev_alloc(sizeof(ulonglong2) * pw * 9, (void **)&d_c);
+    fhe_ctx::RgbConsts t;
+    auto drop = [&](int code) { if (t.d_c) (void)hipFree(t.d_c); if (t.d_c_f64) (void)hipFree(t.d_c_f64); if (t.d_off) (void)hipFree(t.d_off); return code; };
+    int rc = fhe_dev_alloc(sizeof(ulonglong2) * pw * 9, (void **)&t.d_c);
     if (rc) return rc;
-    auto done = [&](int code) { if (d_c) (void)hipFree(d_c); if (d_off) (void)hipFree(d_off); return code; };
     for (int i = 0; i < 9; ++i) {
         int len = fhe_frac_encode(c->n, c->t, cc[i], int_coeffs, frac_coeffs, plain.data());
-        if (len < 0) return done(len);
-        if ((rc = fhe_plain_prepare(c, plain.data(), (uint32_t)len, (uint64_t *)(d_c + pw * i), s))) return done(rc);
+        if (len < 0) return drop(len);
+        if ((rc = fhe_plain_prepare(c, plain.data(), (uint32_t)len, (uint64_t *)(t.d_c + pw * i), st))) return drop(rc);
     }
     int len = fhe_frac_encode(c->n, c->t, 128.0, int_coeffs, frac_coeffs, plain.data());
-    if (len < 0) return done(len);
+    if (len < 0) return drop(len);
     std::vector<u64> off((size_t)c->k * len);
     for (u32 i = 0; i < c->k; ++i)
         for (int j = 0; j < len; ++j) {
@@ -830,15 +838,33 @@ extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64
             if (m >= c->upper_half_threshold) v = addmod(v, c->upper_half_increment[i], qi);
             off[(size_t)i * len + j] = v;
         }
-    if ((rc = fhe_dev_alloc(off.size() * sizeof(u64) + 8, (void **)&d_off))) return done(rc);
-    if (hipMemcpy(d_off, off.data(), off.size() * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) return done(fail(FHE_ERR_HIP, "upload failed"));
+    if ((rc = fhe_dev_alloc(off.size() * sizeof(u64) + 8, (void **)&t.d_off))) return drop(rc);
+    if (hipMemcpy(t.d_off, off.data(), off.size() * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) return drop(fail(FHE_ERR_HIP, "upload failed"));
+    t.off_len = (u32)len;
+    if (fhe_rgb_f64_supported(c) && (rc = fhe_rgb_f64_make_consts(c, t.d_c, &t.d_c_f64, st))) return drop(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) return drop(fail(FHE_ERR_HIP, "stream sync failed"));
+    t.int_coeffs = int_coeffs;
+    t.frac_coeffs = frac_coeffs;
+    rc_ = t;
+    *out = &rc_;
+    return FHE_OK;
+}
+
+extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int int_coeffs, int frac_coeffs, fhe_stream s) {
+    if (!c || !r || !g || !b) return fail(FHE_ERR_PARAM, "null argument");
+    if (!count) return FHE_OK;
+    hipStream_t st = (hipStream_t)s;
+    const fhe_ctx::RgbConsts *k9 = nullptr;
+    int rc = rgb_consts(c, int_coeffs, frac_coeffs, st, &k9);
+    if (rc) return rc;
+    if (k9->d_c_f64 && !getenv("FHE_DCT_FORCE_U64"))
+        return fhe_rgb_f64_launch(c, (u64 *)r, (u64 *)g, (u64 *)b, count, k9->d_c_f64, k9->d_off, k9->off_len, st);
     const u64 nrp = count * 2 * c->k;
-    if (nrp > 0x7fffffffULL) return done(fail(FHE_ERR_PARAM, "too many pixels for one launch"));
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
     const RnsBase base = c->qb.dev();
-    DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((u64 *)r, (u64 *)g, (u64 *)b, d_c, d_off, (u32)len, base)));
-    if (hipGetLastError() != hipSuccess) return done(fail(FHE_ERR_HIP, "kernel launch failed"));
-    if (hipStreamSynchronize(st) != hipSuccess) return done(fail(FHE_ERR_HIP, "stream sync failed"));
-    return done(FHE_OK);
+    DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((u64 *)r, (u64 *)g, (u64 *)b, k9->d_c, k9->d_off, k9->off_len, base)));
+    KERNEL_CHECK();
+    return FHE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

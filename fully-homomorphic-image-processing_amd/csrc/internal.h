@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,17 @@ struct fhe_ctx {
     // kernel of the next (fhe_dct8x8_quant); created on first use
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
+    // rgb_to_ycc_fhe constants (nine encoded factors + Delta*encode(128)), built on first use for one
+    // (int_coeffs, frac_coeffs) pair and kept: the reference re-encodes them on every call
+    struct RgbConsts {
+        int int_coeffs = -1, frac_coeffs = -1;
+        ulonglong2 *d_c = nullptr;      // [9][k][n] Shoup pairs, u64 kernels' slot order
+        double *d_c_f64 = nullptr;      // [9][k][n] centred doubles, fused kernels' slot order (or null)
+        u64 *d_off = nullptr;           // [k][off_len]
+        u32 off_len = 0;
+    };
+    mutable RgbConsts rgb;
+    mutable std::mutex rgb_mutex;
 };
 
 #define DCT_NCONST 76
@@ -80,6 +92,9 @@ bool fhe_dct_f64_supported(const fhe_ctx *c);
 // which: bit 0 = row kernel, bit 1 = column kernel
 int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st, int which = 3);
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);
+bool fhe_rgb_f64_supported(const fhe_ctx *c);
+int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **out, hipStream_t st);
+int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st);
 // wave-synchronous variant (dct_wave.hip), n = 4096 and primes <= 40 bits
 bool fhe_dct_wave_supported(const fhe_ctx *c);
 int fhe_dct_wave_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st);

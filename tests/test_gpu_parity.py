@@ -199,8 +199,10 @@ def test_dct_via_evaluator_calls_matches_fused(fhe, oracle_mod):
     assert np.array_equal(fused[1], orc.dct_quant(fhe.to_host(blocks)[1], fhe.YQT))
 
 
-def test_rgb_to_ycc(fhe, oracle_mod):
-    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192"])
+def test_rgb_to_ycc(fhe, oracle_mod, preset):
+    """SMALL / P8192 run the general u64 kernel, P4096 the fused FP64 kernel (csrc/dct_fused.hip)."""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
     r, g, b = ctx.random_ct(3, seed=31), ctx.random_ct(3, seed=32), ctx.random_ct(3, seed=33)
     hr, hg, hb = fhe.to_host(r).copy(), fhe.to_host(g).copy(), fhe.to_host(b).copy()
@@ -210,6 +212,35 @@ def test_rgb_to_ycc(fhe, oracle_mod):
         assert np.array_equal(fhe.to_host(r)[i], y)
         assert np.array_equal(fhe.to_host(g)[i], u)
         assert np.array_equal(fhe.to_host(b)[i], v)
+
+
+def test_rgb_to_ycc_fp64_path_equals_u64_path_and_extremes(fhe, oracle_mod, monkeypatch):
+    """P4096: the FP64 kernel against the u64 kernel on 40 pixels, including all-(q-1) and all-zero
+    residues (largest magnitudes the exact FP64 products see), and repeated calls (cached constants)."""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    ev = fhe.Evaluator(ctx)
+    base = [ctx.random_ct(40, seed=71 + i) for i in range(3)]
+    qm1 = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=base[0].device).view(1, ctx.k, 1)
+    for t in base:
+        t[0] = qm1.expand(2, ctx.k, ctx.n)
+        t[1] = 0
+    base[1][2] = qm1.expand(2, ctx.k, ctx.n)
+    fast = [t.clone() for t in base]
+    ev.rgb_to_ycc(*fast)
+    again = [t.clone() for t in base]
+    ev.rgb_to_ycc(*again)
+    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
+    slow = [t.clone() for t in base]
+    ev.rgb_to_ycc(*slow)
+    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    for a, b, c in zip(fast, slow, again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for i in (0, 1, 2):
+        y, u, v = orc.rgb_to_ycc(*(fhe.to_host(t)[i] for t in base))
+        assert np.array_equal(fhe.to_host(fast[0])[i], y)
+        assert np.array_equal(fhe.to_host(fast[1])[i], u)
+        assert np.array_equal(fhe.to_host(fast[2])[i], v)
 
 
 def test_dct_known_answer_through_decrypt(fhe, oracle_mod):
