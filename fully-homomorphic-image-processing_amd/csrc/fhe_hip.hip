@@ -101,6 +101,9 @@ void fhe_free_base(BaseTables &B) {
     B.d_mod = nullptr;
 }
 
+// experiment switches: set and not "0"
+static bool env_on(const char *name) { const char *e = getenv(name); return e && *e && !(e[0] == '0' && !e[1]); }
+
 extern "C" int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out) {
     // preset 0: small (36..44-bit) prime sets, 109/218 bits total (BASELINE.json "3 coeff moduli" at 4096)
     // preset 1: SEAL 2.3.1 coeff_modulus_128 defaults
@@ -689,14 +692,14 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
     if (plan->k != c->k || plan->n != c->n) return fail(FHE_ERR_PARAM, "plan was built for another context");
     if (n_blocks == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)s;
-    if (plan->d_consts_f64 && fhe_dct_f64_supported(c) && !getenv("FHE_DCT_FORCE_U64")) {
+    if (plan->d_consts_f64 && fhe_dct_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) {
         const size_t per_block = (size_t)64 * 2 * c->k * c->n;
         const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(double)) : 0;
         if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
-        const bool wave_kernels = plan->d_consts_wave && fhe_dct_wave_supported(c) && getenv("FHE_DCT_WAVE");
+        const bool wave_kernels = plan->d_consts_wave && fhe_dct_wave_supported(c) && env_on("FHE_DCT_WAVE");
         u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
         // measured: 68.1k blocks/s pipelined vs 71.8k plain at 64-block waves, so this is opt-in
-        const bool pipelined = !wave_kernels && getenv("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
+        const bool pipelined = !wave_kernels && env_on("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
         if (!pipelined) {
             for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
                 const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
@@ -857,7 +860,7 @@ extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64
     const fhe_ctx::RgbConsts *k9 = nullptr;
     int rc = rgb_consts(c, int_coeffs, frac_coeffs, st, &k9);
     if (rc) return rc;
-    if (k9->d_c_f64 && !getenv("FHE_DCT_FORCE_U64"))
+    if (k9->d_c_f64 && !env_on("FHE_DCT_FORCE_U64"))
         return fhe_rgb_f64_launch(c, (u64 *)r, (u64 *)g, (u64 *)b, count, k9->d_c_f64, k9->d_off, k9->off_len, st);
     const u64 nrp = count * 2 * c->k;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");

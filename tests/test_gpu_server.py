@@ -43,6 +43,30 @@ def test_server_jpeg_stream(fhe, oracle_mod, tmp_path, wave_blocks):
             assert np.array_equal(out[b, :, ch], ref), (b, ch)
 
 
+def test_server_jpeg_stream_n4096_fused_fp64_kernels(fhe, oracle_mod, tmp_path):
+    """one colour block at the BASELINE parameter set: the streaming loop over the FP64 kernels
+    (k_rgb2ycc_f64, k_dct_rows/cols) with quantisation, against the oracle op by op"""
+    ctx = fhe.SEALContext.preset("P4096")
+    orc = oracle_mod.Oracle.preset("P4096")
+    cts = orc.random_ct(3 * 64, seed=99).reshape(3, 64, 2, orc.k, orc.n)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for ch in range(3):
+            for i in range(64):
+                fhe.server.write_ciphertext(f, cts[ch, i])
+    assert fhe.server.server_jpeg(ctx, str(fin), str(fout), 1, quant=list(fhe.YQT)) == 1
+    out = np.zeros((64, 3, 2, orc.k, orc.n), dtype=np.uint64)
+    with open(fout, "rb") as f:
+        for i in range(64):
+            for ch in range(3):
+                fhe.server.read_ciphertext_into(f, out[i, ch])
+    ycc = np.zeros((3, 64, 2, orc.k, orc.n), dtype=np.uint64)
+    for i in range(64):
+        ycc[0, i], ycc[1, i], ycc[2, i] = orc.rgb_to_ycc(cts[0, i], cts[1, i], cts[2, i])
+    for ch in range(3):
+        assert np.array_equal(out[:, ch], orc.dct_quant(ycc[ch], oracle_mod.YQT)), ch
+
+
 def test_stream_rejects_foreign_data(fhe, tmp_path):
     buf = np.zeros((2, 3, 16), dtype=np.uint64)
     with pytest.raises(ValueError):
