@@ -211,7 +211,35 @@ __device__ __forceinline__ void ntt_inv(double (&x)[M][1 << LE], double (&w)[(1 
     }
 }
 
-template <int L, int LE, bool BIG, int HALF>
+// Packed intermediate (primes <= 37 bits): a row output is an integer |v| < 2^39, so it travels as
+// its low 32 bits plus one signed high byte -- 40 bytes per thread and polynomial instead of 64.
+// t = v + (2^52 + 2^51) has bits(t) = (0x43380000 + floor(v / 2^32)) : (v mod 2^32), so packing is one
+// FP64 add and byte picks, unpacking (cols_body) rebuilds t from (low word, 0x43380000 + sign-extended byte),
+// and the column kernel's first butterfly works on the biased values directly:
+//   t_a - t_b = a - b,   t_a + (t_b - 2 (2^52 + 2^51)) = a + b      (all exact).
+constexpr double PACK_BIAS = 6755399441055744.0;
+template <int E, int TP>
+__device__ __forceinline__ void store_packed(u64 *__restrict__ o, const double (&x)[E]) {
+    static_assert(E == 8, "packed layout is defined for 8 values per thread");
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double t = x[r] + PACK_BIAS;
+        lo[r] = (u32)__double2loint(t);
+        hi[r] = (u32)__double2hiint(t);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[q * TP] = (u64)lo[2 * q] | ((u64)lo[2 * q + 1] << 32);
+    u32 h[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const u32 p01 = __builtin_amdgcn_perm(hi[4 * g + 1], hi[4 * g + 0], 0x0c0c0400u);
+        const u32 p23 = __builtin_amdgcn_perm(hi[4 * g + 3], hi[4 * g + 2], 0x0c0c0400u);
+        h[g] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    }
+    o[4 * TP] = (u64)h[0] | ((u64)h[1] << 32);
+}
+template <int L, int LE, bool BIG, int HALF, bool PACK>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__restrict__ mid, const double *__restrict__ consts,
                                           const double *__restrict__ tw, const Work &wk, double p, double pinv, u32 k, double *lds) {
     using SH = Shape<L, LE>;
@@ -281,13 +309,20 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
         if (BIG) {
 #pragma unroll
             for (int m = 0; m < 4; m++) x[m][r] = red(x[m][r], p, pinv);
+        } else if (PACK && HALF == 0) {   // outputs 0 and 4 carry no product: bring them below 2^39 too
+            x[0][r] = red(x[0][r], p, pinv);
+            x[2][r] = red(x[2][r], p, pinv);
         }
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         double *o = mid + base + (size_t)(2 * m + HALF) * ct_words + tid;
+        if constexpr (PACK) {
+            store_packed<E, TP>((u64 *)o, x[m]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < E; r++) o[r * TP] = x[m][r];
+            for (int r = 0; r < E; r++) o[r * TP] = x[m][r];
+        }
     }
 }
 
@@ -297,7 +332,7 @@ __host__ __device__ constexpr int occ_waves(int tp, int lds_words) {
 }
 template <int L, int LE> struct Occ { static constexpr int W = occ_waves(Shape<L, LE>::TP, Shape<L, LE>::LDS_WORDS); };
 
-template <int L, int LE, bool BIG>
+template <int L, int LE, bool BIG, bool PACK>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
                                                                   const double *__restrict__ consts, const double *__restrict__ tw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
@@ -305,11 +340,11 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_row
     const Work wk = decode(blockIdx.x, k);
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const double *tw = tw_all + (size_t)wk.prime * Shape<L, LE>::N;
-    if (wk.half) rows_body<L, LE, BIG, 1>(in, mid, consts, tw, wk, p, pinv, k, lds);
-    else rows_body<L, LE, BIG, 0>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    if (wk.half) rows_body<L, LE, BIG, 1, PACK>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    else rows_body<L, LE, BIG, 0, PACK>(in, mid, consts, tw, wk, p, pinv, k, lds);
 }
 
-template <int L, int LE, bool BIG, int HALF>
+template <int L, int LE, bool BIG, int HALF, bool PACK>
 __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *__restrict__ out, const double *__restrict__ consts,
                                           const double *__restrict__ itw, const Work &wk, double p, double pinv, u32 k, double *lds) {
     using SH = Shape<L, LE>;
@@ -330,27 +365,56 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
 #pragma unroll
         for (int m = 0; m < 4; m++) sn[m] = sp[(size_t)(16 * m) * cstride + r * TP];
     };
-    fetch(0);
     double wl[E - 1];
-    load_tw<L, LE, LASTP>(wl, itw, tid);
+    if constexpr (!PACK) {           // in flight behind the bulk loads
+        fetch(0);
+        load_tw<L, LE, LASTP>(wl, itw, tid);
+    }
     double x[4][E];
+    if constexpr (PACK) {
+        // rebuild the biased doubles t = 2^52 + 2^51 + v from (0x43380000 + sign-extended byte : low
+        // word) and let the first butterfly remove the bias.  All 80 packed words are requested
+        // before the first is used (x is not live yet).
+        u64 wa[4][5], wb[4][5];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const double *a = mid + base + (size_t)m * row_stride + tid, *b = mid + base + (size_t)(7 - m) * row_stride + tid;
+        for (int m = 0; m < 4; m++) {
+            const u64 *a = (const u64 *)(mid + base + (size_t)m * row_stride) + tid, *b = (const u64 *)(mid + base + (size_t)(7 - m) * row_stride) + tid;
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-            const double A = a[r * TP], B = b[r * TP];
-            x[m][r] = HALF ? A - B : A + B;
+            for (int q = 0; q < 5; q++) { wa[m][q] = a[q * TP]; wb[m][q] = b[q * TP]; }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const u32 la = (r & 1) ? (u32)(wa[m][r >> 1] >> 32) : (u32)wa[m][r >> 1];
+                const u32 lb = (r & 1) ? (u32)(wb[m][r >> 1] >> 32) : (u32)wb[m][r >> 1];
+                const u32 hwa = (r & 4) ? (u32)(wa[m][4] >> 32) : (u32)wa[m][4], hwb = (r & 4) ? (u32)(wb[m][4] >> 32) : (u32)wb[m][4];
+                const double ta = __hiloint2double((int)(0x43380000u + (u32)(int)(signed char)(hwa >> (8 * (r & 3)))), (int)la);
+                const double tb = __hiloint2double((int)(0x43380000u + (u32)(int)(signed char)(hwb >> (8 * (r & 3)))), (int)lb);
+                x[m][r] = HALF ? ta - tb : ta + (tb - 2.0 * PACK_BIAS);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const double *a = mid + base + (size_t)m * row_stride + tid, *b = mid + base + (size_t)(7 - m) * row_stride + tid;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const double A = a[r * TP], B = b[r * TP];
+                x[m][r] = HALF ? A - B : A + B;
+            }
         }
     }
+    if constexpr (PACK) load_tw<L, LE, LASTP>(wl, itw, tid);   // the unpacking needs the registers first
 #pragma unroll
     for (int r = 0; r < E; r++) {
         double c[9], sc[4];
+        if (PACK) fetch(r);
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
 #pragma unroll
         for (int m = 0; m < 4; m++) sc[m] = sn[m];
-        if (r + 1 < E) fetch(r + 1);
+        if (!PACK && r + 1 < E) fetch(r + 1);
         line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         double y[4] = {x[0][r], x[1][r], x[2][r], x[3][r]};
         mmv<4>(y, sc, p, pinv);
@@ -371,7 +435,7 @@ __device__ __forceinline__ void cols_body(const double *__restrict__ mid, u64 *_
     }
 }
 
-template <int L, int LE, bool BIG>
+template <int L, int LE, bool BIG, bool PACK>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_cols(const double *__restrict__ mid, u64 *__restrict__ out,
                                                                   const double *__restrict__ consts, const double *__restrict__ itw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
@@ -379,8 +443,8 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_col
     const Work wk = decode(blockIdx.x, k);   // line = column index
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const double *itw = itw_all + (size_t)wk.prime * Shape<L, LE>::N;
-    if (wk.half) cols_body<L, LE, BIG, 1>(mid, out, consts, itw, wk, p, pinv, k, lds);
-    else cols_body<L, LE, BIG, 0>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    if (wk.half) cols_body<L, LE, BIG, 1, PACK>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    else cols_body<L, LE, BIG, 0, PACK>(mid, out, consts, itw, wk, p, pinv, k, lds);
 }
 
 // Shoup-pair table in the u64 kernels' slot order (16 slots per thread) -> centred doubles in the
@@ -481,19 +545,31 @@ int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st
     return FHE_OK;
 }
 
+static bool dct_pack_enabled() {
+    static const bool on = [] { const char *e = getenv("FHE_DCT_PACK"); return !(e && e[0] == '0' && !e[1]); }();
+    return on;
+}
+
 template <int L, int LE>
 static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st, int which) {
     constexpr int TP = Shape<L, LE>::TP;
     if constexpr (LE == 4) {
         if (big) {
-            if (which & 1) k_dct_rows<L, LE, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
-            if (which & 2) k_dct_cols<L, LE, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+            if (which & 1) k_dct_rows<L, LE, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 2) k_dct_cols<L, LE, true, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+            return;
+        }
+    }
+    if constexpr (LE == 3) {
+        if (c->max_prime_bits <= 37 && dct_pack_enabled()) {      // packed intermediate, 40 instead of 64 bytes
+            if (which & 1) k_dct_rows<L, LE, false, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 2) k_dct_cols<L, LE, false, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
     }
     {
-        if (which & 1) k_dct_rows<L, LE, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
-        if (which & 2) k_dct_cols<L, LE, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+        if (which & 1) k_dct_rows<L, LE, false, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+        if (which & 2) k_dct_cols<L, LE, false, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
     }
 }
 
