@@ -15,7 +15,7 @@ import collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BLOCKS = 128
-WAVE = 64        # default FHE_DCT_WAVE_BLOCKS: blocks per dispatch
+WAVE = 128       # blocks per dispatch here: min(default FHE_DCT_WAVE_BLOCKS = 256, BLOCKS)
 CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", str(BLOCKS), "--cpu-blocks", "0", "--no-verify"]
 
 
