@@ -525,6 +525,87 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_rgb2ycc
         }
 }
 
+// Standalone transforms and multiply_plain on the FP64 machinery, reading and writing the library's
+// NTT-form order (the u64 kernels' 16-slots-per-thread order, include/fhe_hip.h layout note):
+// bit-reversed index j = (t << LE) + r lives at (j & 15) * (n / 16) + (j >> 4).
+// MODE 0: forward NTT; 1: inverse NTT; 2: multiply_plain (NTT, product with the prepared plaintext,
+// inverse NTT).  M polynomials of one prime per workgroup share every twiddle.
+template <int L, int LE, int M, int MODE>
+__global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_poly_f64(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                                  const ulonglong2 *__restrict__ plain, const double *__restrict__ tw_all,
+                                                                  const double *__restrict__ itw_all, const Modulus *__restrict__ mods, u32 k) {
+    using SH = Shape<L, LE>;
+    constexpr int N = SH::N, TP = SH::TP, E = SH::E, LASTP = SH::NP - 1;
+    static_assert(LE == 3, "slot-order mapping below is written for 8 values per thread");
+    __shared__ double lds[2 * SH::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const u32 per_prime = gridDim.x / k;
+    const u32 prime = blockIdx.x / per_prime;
+    const u32 g = blockIdx.x - prime * per_prime;
+    const double p = (double)mods[prime].q, pinv = 1.0 / p;
+    const double *tw = tw_all + (size_t)prime * N, *itw = itw_all + (size_t)prime * N;
+    const int slot0 = ((tid & 1) << 3) * (N >> 4) + (tid >> 1);        // + r * (N >> 4)
+    double x[M][E];
+    int phase = 0;
+    if constexpr (MODE != 1) {
+        double w0[E - 1];
+        load_tw<L, LE, 0>(w0, tw, tid);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const u64 *src = in + ((size_t)(g * M + m) * k + prime) * N + tid;
+#pragma unroll
+            for (int r = 0; r < E; r++) x[m][r] = u52_to_f64(src[r * TP]);
+        }
+        ntt_fwd<L, LE, M>(x, w0, tw, p, pinv, lds, tid, phase, [] {});
+    } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const u64 *src = in + ((size_t)(g * M + m) * k + prime) * N + slot0;
+#pragma unroll
+            for (int r = 0; r < E; r++) x[m][r] = u52_to_f64(src[r * (N >> 4)]);
+        }
+    }
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            u64 *dst = out + ((size_t)(g * M + m) * k + prime) * N + slot0;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                double v = red(x[m][r], p, pinv);
+                v = v < 0.0 ? v + p : v;
+                dst[r * (N >> 4)] = f64_to_u52(v);
+            }
+        }
+        return;
+    }
+    double wl[E - 1];
+    load_tw<L, LE, LASTP>(wl, itw, tid);
+    if constexpr (MODE == 2) {
+        const ulonglong2 *pp = plain + (size_t)prime * N + slot0;
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const double w = u52_to_f64(pp[r * (N >> 4)].x);
+            double y[M], wm[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) { y[m] = x[m][r]; wm[m] = w; }
+            mmv<M>(y, wm, p, pinv);
+#pragma unroll
+            for (int m = 0; m < M; m++) x[m][r] = y[m];
+        }
+    }
+    ntt_inv<L, LE, M, false>(x, wl, itw, p, pinv, lds, tid, phase);
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        u64 *dst = out + ((size_t)(g * M + m) * k + prime) * N + tid;
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            double v = x[m][r];
+            v = v < 0.0 ? v + p : v;
+            dst[r * TP] = f64_to_u52(v);
+        }
+    }
+}
+
 }  // namespace
 
 static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves per SIMD resident
@@ -608,6 +689,23 @@ int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, cons
     const u64 grid = count * 2 * c->k;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
     k_rgb2ycc_f64<12, 3><<<(unsigned)grid, Shape<12, 3>::TP, 0, st>>>(r, g, b, consts, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, yoff, yoff_len, c->k);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// mode 0 forward NTT, 1 inverse NTT, 2 multiply_plain; n_polys RNS polynomials of k residues each
+int fhe_poly_f64_launch(int mode, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_polys, const ulonglong2 *plain, hipStream_t st) {
+    const u64 grid2 = (n_polys / 2) * c->k, grid1 = n_polys * c->k;
+    if (grid1 > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    constexpr int TP = Shape<12, 3>::TP;
+#define LAUNCH_POLY(M, GRID)                                                                                                          \
+    switch (mode) {                                                                                                                   \
+        case 0: k_poly_f64<12, 3, M, 0><<<(unsigned)(GRID), TP, 0, st>>>(in, out, plain, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k); break; \
+        case 1: k_poly_f64<12, 3, M, 1><<<(unsigned)(GRID), TP, 0, st>>>(in, out, plain, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k); break; \
+        default: k_poly_f64<12, 3, M, 2><<<(unsigned)(GRID), TP, 0, st>>>(in, out, plain, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k); break; \
+    }
+    if (n_polys % 2 == 0) { LAUNCH_POLY(2, grid2) } else { LAUNCH_POLY(1, grid1) }
+#undef LAUNCH_POLY
     KERNEL_CHECK();
     return FHE_OK;
 }

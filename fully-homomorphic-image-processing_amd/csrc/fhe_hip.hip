@@ -439,10 +439,12 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
 
 extern "C" int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (n_polys && fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) return fhe_poly_f64_launch(0, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
     return fhe_ntt_launch(false, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 extern "C" int fhe_ntt_inverse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (n_polys && fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) return fhe_poly_f64_launch(1, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
     return fhe_ntt_launch(true, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 
@@ -452,6 +454,8 @@ extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t
     const u64 nrp = n_polys * c->k;
     if (nrp == 0) return FHE_OK;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    if (fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64"))
+        return fhe_poly_f64_launch(2, c, (const u64 *)in, (u64 *)out, n_polys, (const ulonglong2 *)d_plain_ntt, (hipStream_t)s);
     const RnsBase base = c->qb.dev();
     hipStream_t st = (hipStream_t)s;
     DISPATCH_L(c->logn, (k_mulplain<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));

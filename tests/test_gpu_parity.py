@@ -621,3 +621,33 @@ def test_other_degrees(fhe, oracle_mod, n, q):
     out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blk))[0]
     ref = orc.dct_quant(fhe.to_host(blk)[0], fhe.YQT)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("n_ct", [3, 4])
+def test_fp64_transforms_and_multiply_plain_equal_u64_kernels(fhe, oracle_mod, monkeypatch, n_ct):
+    """P4096: fhe_ntt_forward / fhe_ntt_inverse / fhe_multiply_plain on the FP64 kernels write the same
+    words (same NTT-form order, canonical residues) as the u64 kernels; odd and even polynomial counts
+    take the one- and two-polynomial workgroups.  multiply_plain also against the oracle."""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    ev = fhe.Evaluator(ctx)
+    enc = fhe.FractionalEncoder(ctx)
+    a = ctx.random_ct(n_ct, seed=5)
+    if n_ct == 3:
+        a = a.reshape(-1, ctx.k, ctx.n)[:5].contiguous()          # five RNS polynomials: odd count
+    a.view(-1, ctx.k, ctx.n)[0] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=a.device).view(ctx.k, 1)
+    plain = enc.encode(-0.168736)
+    pp = fhe.PreparedPlain(ctx, plain)
+
+    def run():
+        f = ev.ntt_forward(a)
+        return f, ev.ntt_inverse(f), (ev.multiply_plain(a, pp) if n_ct == 4 else None)
+
+    fast = run()
+    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
+    slow = run()
+    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1]) and torch.equal(fast[1], a)
+    if n_ct == 4:
+        assert torch.equal(fast[2], slow[2])
+        assert np.array_equal(fhe.to_host(fast[2])[1], orc.multiply_plain(fhe.to_host(a)[1], plain))
