@@ -286,6 +286,14 @@ extern "C" size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint
     return mul_words(c, sa, sb, count, false) * sizeof(u64);
 }
 
+// q-base transforms of `n_rns` RNS polynomials: the FP64 kernels where the context supports them (same
+// NTT-form order and canonical residues as the u64 kernels), the u64 kernels otherwise
+static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_rns, hipStream_t st) {
+    static const bool force_u64 = [] { const char *e = getenv("FHE_DCT_FORCE_U64"); return e && *e && !(e[0] == '0' && !e[1]); }();
+    if (n_rns && fhe_rgb_f64_supported(c) && !force_u64) return fhe_poly_f64_launch(inverse ? 1 : 0, c, in, out, n_rns, nullptr, st);
+    return fhe_ntt_launch(inverse, c, c->qb, in, out, n_rns * c->k, st);
+}
+
 static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, u32 sb, u64 *out, u64 count, void *scratch,
                          size_t scratch_bytes, hipStream_t st) {
     if (!cc || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
@@ -309,13 +317,13 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, 
         k_behz_to_bsk<<<grid2(n, count * s), 256, 0, st>>>(src, xb, T, n, count * s);
         int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
         if (r) return r;
-        return fhe_ntt_launch(false, c, c->qb, src, xq, count * s * k, st);
+        return qbase_ntt(false, c, src, xq, count * s, st);
     };
     if ((rc = prep(a, sa, Aq, Ab))) return rc;
     if (!square && (rc = prep(b, sb, Bq, Bb))) return rc;
     k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, k, n, sa, sb, count);
     k_behz_tensor<<<grid2(n, count * (k + 1)), 256, 0, st>>>(Ab, Bb, Db, c->behz->aux.d_mod, k + 1, n, sa, sb, count);
-    if ((rc = fhe_ntt_launch(true, c, c->qb, Dq, Dq, count * so * k, st))) return rc;
+    if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     if ((rc = fhe_ntt_launch(true, c, c->behz->aux, Db, Db, count * so * (k + 1), st))) return rc;
     k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, T, n, count * so);
     KERNEL_CHECK();
@@ -357,9 +365,9 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     const BehzDev *T = c->behz->dev;
     u64 *dig = (u64 *)scratch, *acc = dig + count * k * nd * k * n;
     k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count);
-    if ((rc = fhe_ntt_launch(false, c, c->qb, dig, dig, count * k * nd * k, st))) return rc;
+    if ((rc = qbase_ntt(false, c, dig, dig, count * k * nd, st))) return rc;
     k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);
-    if ((rc = fhe_ntt_launch(true, c, c->qb, acc, acc, count * 2 * k, st))) return rc;
+    if ((rc = qbase_ntt(true, c, acc, acc, count * 2, st))) return rc;
     k_relin_add<<<grid2(n, count * 2 * k), 256, 0, st>>>((u64 *)ct3, stride, acc, T, n, count);
     KERNEL_CHECK();
     return FHE_OK;
