@@ -54,9 +54,20 @@ def rgb_to_ycc(ev, pc, r, g, b):
 # ------------------------------------------------------------------------------------------------
 # resize path
 # ------------------------------------------------------------------------------------------------
-def cubic(ev, pc, A, B, C, D, t, relin=None):
+def cubic_powers(ev, t, relin=None):
+    """t2 = square(t) and t3 = multiply(t, t) of Cubic (homo/fhe_resize.h:174-175).  Both are the same
+    ring tensor (the library's square IS multiply(t, t)), so one product serves both, and a caller
+    that evaluates several Cubics at the same t (SampleBicubic: four rows share xfract) passes the
+    pair in instead of recomputing it -- the ciphertext bits are the same either way."""
+    t2 = ev.square(t)
+    if relin is not None and t2.shape[-3] == 3:
+        t2 = ev.relinearize(t2, relin[0], relin[1])
+    return t2, t2
+
+
+def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None):
     """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189.  Note t3 = t*t exactly as the reference
-    computes it (:175), and t2/t3 are recomputed per call as there.
+    computes it (:175).  powers = cubic_powers(ev, t) may be shared between calls with the same t.
 
     relin=(evk_ntt, dbc) switches on the relinearised mode (NOT what the
     reference does): every product is brought back to size 2, so the result has size 2 instead of
@@ -68,15 +79,10 @@ def cubic(ev, pc, A, B, C, D, t, relin=None):
         z = ev.multiply(x, y)
         return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
 
-    def sq(x):
-        z = ev.square(x)
-        return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
-
     a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
     b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
     c = ev.sub(C, A)
-    t2 = sq(t)
-    t3 = mul(t, t)
+    t2, t3 = powers if powers is not None else cubic_powers(ev, t, relin)
     a = mul(a, t3)
     b = mul(b, t2)
     c = mul(c, t)
@@ -123,7 +129,8 @@ def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
     ciphertexts of the fractional offsets.  Returns [B, 6, k, n]."""
     idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 16]
     p = [pixels[idx[:, i]].contiguous() for i in range(16)]
-    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract) for r in range(4)]
+    px = cubic_powers(ev, xfract)                       # shared by the four row Cubics
+    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract, powers=px) for r in range(4)]
     return cubic(ev, pc, cols[0], cols[1], cols[2], cols[3], yfract)
 
 
@@ -139,33 +146,45 @@ def sample_linear(ev, pc, pixels, taps, xfract, yfract):
 # ------------------------------------------------------------------------------------------------
 # decode path
 # ------------------------------------------------------------------------------------------------
-def _taylor(ev, pc, x, zero, coeffs, constant):
-    """shared body of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:56-119 / :136-199):
-    even Taylor polynomial of degree 10 in (x - 3 pi / 2); only the five coefficients differ."""
+def _taylor_terms(ev, pc, x, coeffs):
+    """the five power terms of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:56-113 / :136-193):
+    even Taylor polynomial of degree 10 in (x - 3 pi / 2); only the coefficients differ."""
     M, P = ev.multiply_plain, pc.prepared
     sx = ev.add_plain(x, pc.plain(-3 * math.pi / 2.0))
-    p2 = M(ev.square(sx), P(coeffs[0]))
-    p4 = M(ev.square(ev.square(sx)), P(coeffs[1]))
-    p6 = ev.square(ev.square(sx))
-    p6 = M(ev.multiply(ev.multiply(p6, sx), sx), P(coeffs[2]))
-    p8 = M(ev.square(ev.square(ev.square(sx))), P(coeffs[3]))
-    p10 = ev.square(ev.square(ev.square(sx)))
-    p10 = M(ev.multiply(ev.multiply(p10, sx), sx), P(coeffs[4]))
+    # The reference rebuilds every power from a fresh copy of sx (11 squares, 4 multiplies); the
+    # repeated squares are the same ring elements bit for bit, so each is formed once here.
+    s2 = ev.square(sx)
+    s4 = ev.square(s2)
+    s8 = ev.square(s4)
+    p2 = M(s2, P(coeffs[0]))
+    p4 = M(s4, P(coeffs[1]))
+    p6 = M(ev.multiply(ev.multiply(s4, sx), sx), P(coeffs[2]))
+    p8 = M(s8, P(coeffs[3]))
+    p10 = M(ev.multiply(ev.multiply(s8, sx), sx), P(coeffs[4]))
+    return (p2, p4, p6, p8, p10)
+
+
+def _taylor_sum(ev, pc, zero, constant, terms):
+    """res = Enc(0) + constant, then the terms in the reference's order (homo/fhe_decode.h:114-119)."""
     res = ev.add_plain(zero, pc.plain(constant))
-    for term in (p2, p4, p6, p8, p10):
+    for term in terms:
         res = ev.add(res, term)
     return res
 
 
+SIN_COEFFS = (0.5, -1.0 / 24.0, 1.0 / 720.0, -1.0 / 40320.0, 1.0 / 3628800.0)
+COS_COEFFS = (-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0)
+
+
 def homomorphic_sin(ev, pc, x, zero):
     """homo/fhe_decode.h:48-120; `zero` plays the role of encrypt(encode(0.0)) (:54)."""
-    return _taylor(ev, pc, x, zero, (0.5, -1.0 / 24.0, 1.0 / 720.0, -1.0 / 40320.0, 1.0 / 3628800.0), -1.0)
+    return _taylor_sum(ev, pc, zero, -1.0, _taylor_terms(ev, pc, x, SIN_COEFFS))
 
 
 def homomorphic_cos(ev, pc, x, zero):
     """homo/fhe_decode.h:128-200 (the reference shifts by -3pi/2 here too, :137, and falls off the end
     without a return statement, :200; the value it leaves in `res` is what is returned here)."""
-    return _taylor(ev, pc, x, zero, (-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0), 1.0)
+    return _taylor_sum(ev, pc, zero, 1.0, _taylor_terms(ev, pc, x, COS_COEFFS))
 
 
 def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros):
@@ -175,22 +194,26 @@ def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, wid
     ciphertexts [1, 22, k, n].
 
     Faithful to the reference's quirk: `offset` is advanced by add_plain(offset, encode(i)) INSIDE
-    the harmonic loop (:229), after cos_arg was copied from it."""
+    the harmonic loop (:229), after cos_arg was copied from it.  The sine argument b * f_j does not
+    depend on the position, so its five Taylor terms are evaluated once per harmonic and reused
+    for all positions (the reference re-evaluates them width*height times; same bits)."""
     M, P = ev.multiply_plain, pc.prepared
     b = M(count, P(0.5))
     offset = ev.negate(ev.add_plain(ev.add(index, b), pc.plain(-0.5)))
     b = ev.add_plain(b, pc.plain(delta - 0.5))
     run = []
+    sin_terms = {}
     for i in range(width * height):
         c = M(b, P(1.0 / float(order)))
         for j in range(1, degree + 1):
             import numpy as np
             arg_factor = float(np.float32(j)) * math.pi / float(order)
-            sin_arg = M(b, P(arg_factor))
+            if j not in sin_terms:      # sin_arg = b * f_j is the same for every position i
+                sin_terms[j] = _taylor_terms(ev, pc, M(b, P(arg_factor)), SIN_COEFFS)
             cos_arg = offset
             offset = ev.add_plain(offset, pc.plain(float(i)))
             cos_arg = M(cos_arg, P(arg_factor))
-            s = homomorphic_sin(ev, pc, sin_arg, zeros(i, j, "sin"))
+            s = _taylor_sum(ev, pc, zeros(i, j, "sin"), -1.0, sin_terms[j])
             co = homomorphic_cos(ev, pc, cos_arg, zeros(i, j, "cos"))
             term = M(ev.multiply(s, co), P(2.0 / (math.pi * float(np.float32(j)))))
             c = ev.add(c, term)
