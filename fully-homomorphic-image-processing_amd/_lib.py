@@ -49,6 +49,7 @@ SIGNATURES = {
     "fhe_plain_prepare": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "fhe_plain_ntt_mul": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "fhe_multiply_plain": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "fhe_multiply_plain_sparse": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp]),
     "fhe_add_plain": (_i, [_vp, _vp, _u64, _u64, _vp, _u32, _i, _vp]),
     "fhe_ntt_forward": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "fhe_ntt_inverse": (_i, [_vp, _vp, _vp, _u64, _vp]),

@@ -464,6 +464,73 @@ extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// multiply_plain by a sparse plaintext: sum of signed rotations, no transform
+// ------------------------------------------------------------------------------------------------
+struct SparseTerms {
+    u32 count;
+    u32 exp[FHE_SPARSE_MAX_TERMS];
+    u64 w[FHE_SPARSE_MAX_TERMS][FHE_MAX_K], ws[FHE_SPARSE_MAX_TERMS][FHE_MAX_K];   // lifted coefficient mod q_i, Shoup companion
+};
+template <int L>
+__global__ __launch_bounds__(256) void k_mulplain_sparse(const u64 *__restrict__ in, u64 *__restrict__ out, const Modulus *__restrict__ mods,
+                                                         u32 k, const SparseTerms T) {
+    constexpr int N = 1 << L;
+    __shared__ u64 buf[N];                       // staged so that out may alias in
+    const u64 rp = blockIdx.x;
+    const u32 prime = (u32)(rp % k);
+    const u64 q = mods[prime].q;
+    for (int j = threadIdx.x; j < N; j += 256) buf[j] = in[rp * N + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += 256) {
+        u64 acc = 0;
+        for (u32 t = 0; t < T.count; t++) {
+            int idx = j - (int)T.exp[t];
+            const bool wrap = idx < 0;            // x^n = -1
+            idx += wrap ? N : 0;
+            const u64 prod = mul_shoup(buf[idx], T.w[t][prime], T.ws[t][prime], q);
+            acc = wrap ? submod(acc, prod, q) : addmod(acc, prod, q);
+        }
+        out[rp * N + j] = acc;
+    }
+}
+
+extern "C" int fhe_multiply_plain_sparse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                                         const uint64_t *plain_host, uint32_t plain_len, fhe_stream s) {
+    using namespace hostmath;
+    if (!c || !in || !out || !plain_host) return fail(FHE_ERR_PARAM, "null argument");
+    if (c->logn > 13) return fail(FHE_ERR_PARAM, "sparse multiply_plain supports n <= 8192");
+    SparseTerms T;
+    T.count = 0;
+    for (u32 j = 0; j < plain_len && j < c->n; ++j) {
+        const u64 m = plain_host[j];
+        if (!m) continue;
+        if (m >= c->t) return fail(FHE_ERR_PARAM, "plaintext coefficient not below the plain modulus");
+        if (T.count == FHE_SPARSE_MAX_TERMS) return fail(FHE_ERR_PARAM, "plaintext has more than %d non-zero coefficients", FHE_SPARSE_MAX_TERMS);
+        T.exp[T.count] = j;
+        for (u32 i = 0; i < c->k; ++i) {
+            const u64 qi = c->qb.primes[i];
+            const u64 w = m >= c->upper_half_threshold ? (m + c->plain_upper_half_increment[i]) % qi : m % qi;
+            T.w[T.count][i] = w;
+            T.ws[T.count][i] = shoup(w, qi);
+        }
+        ++T.count;
+    }
+    if (!T.count) return fail(FHE_ERR_PARAM, "plain cannot be zero");
+    const u64 nrp = n_polys * c->k;
+    if (nrp == 0) return FHE_OK;
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    hipStream_t st = (hipStream_t)s;
+    switch (c->logn) {
+        case 10: k_mulplain_sparse<10><<<(unsigned)nrp, 256, 0, st>>>((const u64 *)in, (u64 *)out, c->qb.d_mod, c->k, T); break;
+        case 11: k_mulplain_sparse<11><<<(unsigned)nrp, 256, 0, st>>>((const u64 *)in, (u64 *)out, c->qb.d_mod, c->k, T); break;
+        case 12: k_mulplain_sparse<12><<<(unsigned)nrp, 256, 0, st>>>((const u64 *)in, (u64 *)out, c->qb.d_mod, c->k, T); break;
+        default: k_mulplain_sparse<13><<<(unsigned)nrp, 256, 0, st>>>((const u64 *)in, (u64 *)out, c->qb.d_mod, c->k, T); break;
+    }
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // plaintext preparation
 // ------------------------------------------------------------------------------------------------
 // in: [k][n] NTT-form values; out: [k][n] (value, Shoup companion) pairs.  in may alias the first

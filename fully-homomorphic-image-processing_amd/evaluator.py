@@ -110,6 +110,9 @@ class FractionalEncoder:
                                                  self.int_coeffs, self.frac_coeffs))
 
 
+SPARSE_MAX_TERMS = 8       # FHE_SPARSE_MAX_TERMS in include/fhe_hip.h
+
+
 class PreparedPlain:
     """A Plaintext lifted to the q-base and transformed once (the reference redoes this per call)."""
 
@@ -121,6 +124,10 @@ class PreparedPlain:
             ln -= 1
         self.buf = torch.empty(2 * ctx.k * ctx.n, dtype=torch.int64, device=ctx.device)
         _lib.call("fhe_plain_prepare", ctx.h, p.ctypes.data_as(C.c_void_p), ln, _ptr(self.buf), _stream())
+        # few non-zero coefficients (encode(3) = x+1, encode(0.5) = -x^(n-1), ...): the product is a sum
+        # of signed rotations, done without any transform (fhe_multiply_plain_sparse)
+        self.plain = p[:ln].copy()
+        self.sparse = 0 < int(np.count_nonzero(self.plain)) <= SPARSE_MAX_TERMS and ctx.n <= 8192
 
 
 class DctPlan:
@@ -203,7 +210,11 @@ class Evaluator:
         if not isinstance(plain, PreparedPlain):
             plain = PreparedPlain(self.ctx, plain)
         out = torch.empty_like(a) if out is None else out
-        _lib.call("fhe_multiply_plain", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _ptr(plain.buf), _stream())
+        if plain.sparse:
+            _lib.call("fhe_multiply_plain_sparse", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a),
+                      plain.plain.ctypes.data_as(C.c_void_p), len(plain.plain), _stream())
+        else:
+            _lib.call("fhe_multiply_plain", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _ptr(plain.buf), _stream())
         return out
 
     def _plain_addsub(self, a, plain, sign):

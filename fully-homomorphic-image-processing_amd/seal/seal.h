@@ -585,6 +585,12 @@ public:
         need(a);
         const int len = p.significant_coeff_count();
         if (len == 0) throw std::invalid_argument("plain cannot be zero");     // SEAL 2.3 rejects the zero plaintext
+        int nnz = 0;
+        for (int i = 0; i < len && nnz <= FHE_SPARSE_MAX_TERMS; ++i) nnz += p[i] != 0;
+        if (nnz <= FHE_SPARSE_MAX_TERMS && st_->n <= 8192) {      // x+1, x^2+1, -x^(n-1), ...: signed rotations, no transform
+            detail::check(fhe_multiply_plain_sparse(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), p.data().data(), (uint32_t)len, nullptr), "multiply_plain");
+            return;
+        }
         const detail::DevBuf &prepared = prepared_plain(p, len);
         detail::check(fhe_multiply_plain(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), prepared.ptr(), nullptr), "multiply_plain");
     }

@@ -105,6 +105,16 @@ int fhe_plain_ntt_mul(const fhe_ctx *ctx, const uint64_t *d_a, const uint64_t *d
  * n_polys must be a multiple of k (whole RNS polynomials).  out may alias in. */
 int fhe_multiply_plain(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
                        const uint64_t *d_plain_ntt, fhe_stream stream);
+/* multiply_plain for a plaintext with at most FHE_SPARSE_MAX_TERMS non-zero coefficients (host
+ * memory, coefficients in [0,t)): the ring product is formed directly as a sum of signed rotations
+ * in coefficient form -- no transform.  The integer and power-of-two constants of Cubic
+ * (encode(3) = x+1, encode(5) = x^2+1, encode(0.5) = -x^(n-1); homo/fhe_resize.h:150-163,186) are of
+ * this kind.  Same result as fhe_multiply_plain (exact ring arithmetic, canonical residues).
+ * out may alias in.  n <= 8192.  Returns FHE_ERR_PARAM if the plaintext has more terms or is zero. */
+#define FHE_SPARSE_MAX_TERMS 8
+int fhe_multiply_plain_sparse(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
+                              const uint64_t *plain_host, uint32_t plain_len, fhe_stream stream);
+
 /* seal::Evaluator::add_plain / sub_plain (homo/fhe_image.h:317 sub_plain(128.0); fhe_resize.h:196;
  * fhe_decode.h:57,113,218,220,229): c_0 += sign * Delta * m' for `count` ciphertexts whose first
  * polynomial starts every ct_stride_words u64. sign = +1 / -1. */

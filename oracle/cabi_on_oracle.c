@@ -185,6 +185,13 @@ int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint
     for (uint64_t p = 0; p < np; p++) fhe_dyadic_multiply(c, out + p * pw(c), d_plain, out + p * pw(c), 1, s);
     return fhe_ntt_inverse(c, out, out, np, s);
 }
+int fhe_multiply_plain_sparse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, const uint64_t *plain,
+                              uint32_t len, fhe_stream s) {
+    (void)s;
+    if (in != out) memmove(out, in, np * pw(c) * 8);
+    fo_multiply_plain(c->o, out, (uint32_t)np, plain, len);
+    return FHE_OK;
+}
 int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, uint64_t count, const uint64_t *plain,
                   uint32_t len, int sign, fhe_stream s) {
     (void)s;

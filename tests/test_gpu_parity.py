@@ -651,3 +651,30 @@ def test_fp64_transforms_and_multiply_plain_equal_u64_kernels(fhe, oracle_mod, m
     if n_ct == 4:
         assert torch.equal(fast[2], slow[2])
         assert np.array_equal(fhe.to_host(fast[2])[1], orc.multiply_plain(fhe.to_host(a)[1], plain))
+
+
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192"])
+def test_sparse_multiply_plain_equals_transform_path_and_oracle(fhe, oracle_mod, preset):
+    """Plaintexts with few non-zero coefficients (the constants of Cubic: encode(3) = x+1, encode(5) =
+    x^2+1, encode(4) = x^2, encode(0.5) = -x^(n-1), and -1) go through fhe_multiply_plain_sparse:
+    same words as the NTT path and the oracle, also in place; dense plaintexts keep the NTT path."""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    enc = fhe.FractionalEncoder(ctx)
+    a = ctx.random_ct(3, seed=77)
+    a[0, 0] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=a.device).view(ctx.k, 1)
+    for v in (3.0, 5.0, 4.0, 2.0, 0.5, -1.0, 0.375):
+        plain = enc.encode(v)
+        pp = fhe.PreparedPlain(ctx, plain)
+        assert pp.sparse
+        got = ev.multiply_plain(a, pp)
+        pp.sparse = False
+        ref = ev.multiply_plain(a, pp)
+        assert torch.equal(got, ref), v
+        assert np.array_equal(fhe.to_host(got)[1], orc.multiply_plain(fhe.to_host(a)[1], plain)), v
+        pp.sparse = True
+        b = a.clone()
+        ev.multiply_plain(b, pp, out=b)                      # in place
+        assert torch.equal(b, ref), v
+    assert not fhe.PreparedPlain(ctx, enc.encode(0.299)).sparse
