@@ -194,28 +194,40 @@ def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, wid
     ciphertexts [1, 22, k, n].
 
     Faithful to the reference's quirk: `offset` is advanced by add_plain(offset, encode(i)) INSIDE
-    the harmonic loop (:229), after cos_arg was copied from it.  The sine argument b * f_j does not
-    depend on the position, so its five Taylor terms are evaluated once per harmonic and reused
-    for all positions (the reference re-evaluates them width*height times; same bits)."""
+    the harmonic loop (:229), after cos_arg was copied from it.
+
+    The reference walks positions x harmonics serially with one ciphertext per call; here only the
+    (cheap) offset chain is serial.  All width*height*degree cosine polynomials are evaluated as ONE
+    batch, the sine polynomial once per harmonic (its argument b * f_j does not depend on the
+    position) -- the same ring operations on the same operands, so the same bits, but launches that
+    fill the GPU."""
+    import numpy as np
     M, P = ev.multiply_plain, pc.prepared
+    npos = width * height
     b = M(count, P(0.5))
     offset = ev.negate(ev.add_plain(ev.add(index, b), pc.plain(-0.5)))
     b = ev.add_plain(b, pc.plain(delta - 0.5))
-    run = []
-    sin_terms = {}
-    for i in range(width * height):
-        c = M(b, P(1.0 / float(order)))
-        for j in range(1, degree + 1):
-            import numpy as np
-            arg_factor = float(np.float32(j)) * math.pi / float(order)
-            if j not in sin_terms:      # sin_arg = b * f_j is the same for every position i
-                sin_terms[j] = _taylor_terms(ev, pc, M(b, P(arg_factor)), SIN_COEFFS)
-            cos_arg = offset
+    factors = [float(np.float32(j)) * math.pi / float(order) for j in range(1, degree + 1)]
+    pre = []                                    # pre[i][j-1] = offset as copied into cos_arg (:226)
+    for i in range(npos):
+        row = []
+        for _ in range(degree):
+            row.append(offset)
             offset = ev.add_plain(offset, pc.plain(float(i)))
-            cos_arg = M(cos_arg, P(arg_factor))
-            s = _taylor_sum(ev, pc, zeros(i, j, "sin"), -1.0, sin_terms[j])
-            co = homomorphic_cos(ev, pc, cos_arg, zeros(i, j, "cos"))
-            term = M(ev.multiply(s, co), P(2.0 / (math.pi * float(np.float32(j)))))
-            c = ev.add(c, term)
-        run.append(ev.multiply(c, amplitude))
-    return run
+        pre.append(row)
+    # batch index = (j-1) * npos + i
+    cos_arg = torch.cat([M(torch.cat([pre[i][j] for i in range(npos)]), P(factors[j])) for j in range(degree)])
+    zc = torch.cat([zeros(i, j + 1, "cos") for j in range(degree) for i in range(npos)])
+    zs = torch.cat([zeros(i, j + 1, "sin") for j in range(degree) for i in range(npos)])
+    co = _taylor_sum(ev, pc, zc, 1.0, _taylor_terms(ev, pc, cos_arg, COS_COEFFS))
+    sin_arg = torch.cat([M(b, P(factors[j])) for j in range(degree)])                  # [degree, 2, k, n]
+    sin_terms = [t.repeat_interleave(npos, dim=0) for t in _taylor_terms(ev, pc, sin_arg, SIN_COEFFS)]
+    s = _taylor_sum(ev, pc, zs, -1.0, sin_terms)
+    del sin_terms
+    prod = ev.multiply(s, co)                                                           # [degree * npos, 21, k, n]
+    c = M(b, P(1.0 / float(order))).repeat(npos, 1, 1, 1)
+    for j in range(degree):
+        term = M(prod[j * npos:(j + 1) * npos], P(2.0 / (math.pi * float(np.float32(j + 1)))))
+        c = ev.add(c, term)
+    out = ev.multiply(c, amplitude.repeat(npos, 1, 1, 1))
+    return [out[i:i + 1] for i in range(npos)]

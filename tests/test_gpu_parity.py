@@ -496,7 +496,8 @@ def test_homomorphic_sin_cos_vs_oracle(fhe, oracle_mod):
 
 
 def test_approximated_step_vs_oracle(fhe, oracle_mod):
-    """the deepest circuit (sizes up to 22) at a reduced harmonic count: W*H = 2, degree 2"""
+    """the deepest circuit (sizes up to 22) at a reduced size: W*H = 3 positions, 2 harmonics (unequal
+    on purpose: the GPU path evaluates all position x harmonic pairs as one batch, the oracle serially)"""
     ctx, orc = _pair(fhe, oracle_mod, "SMALL")
     ev = fhe.Evaluator(ctx)
     pc = fhe.circuits.PlainCache(ctx)
@@ -509,9 +510,9 @@ def test_approximated_step_vs_oracle(fhe, oracle_mod):
     def zeros_host(i, j, which):
         return fhe.to_host(zeros_dev(i, j, which))[0]
 
-    run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=2, delta=0.5, width=2, height=1, zeros=zeros_dev)
-    ref = oracle_mod.oracle_approximated_step(orc, fhe.to_host(amp)[0], fhe.to_host(idx)[0], fhe.to_host(cnt)[0], 64, 2, 0.5, 2, 1, zeros_host)
-    assert len(run) == 2
+    run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=2, delta=0.5, width=3, height=1, zeros=zeros_dev)
+    ref = oracle_mod.oracle_approximated_step(orc, fhe.to_host(amp)[0], fhe.to_host(idx)[0], fhe.to_host(cnt)[0], 64, 2, 0.5, 3, 1, zeros_host)
+    assert len(run) == 3
     for g, r in zip(run, ref):
         assert g.shape[-3] == 22
         assert np.array_equal(fhe.to_host(g)[0], r)
