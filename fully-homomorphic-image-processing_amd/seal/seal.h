@@ -20,6 +20,7 @@
 #define FHE_HIP_SEAL_FACADE_H
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -52,9 +53,10 @@ inline uint64_t powmod(uint64_t a, uint64_t e, uint64_t m) {
     return r;
 }
 // little-endian multi-word unsigned integer: enough for CRT composition and t*x/q rounding
-struct Big {
-    std::vector<uint64_t> w;
-    explicit Big(uint64_t v = 0, size_t words = 12) : w(words, 0) { w[0] = v; }
+struct Big {                                  // fixed 768-bit unsigned integer (no heap traffic: decrypt uses it per coefficient)
+    std::array<uint64_t, 12> w;
+    explicit Big(uint64_t v = 0) { w.fill(0); w[0] = v; }
+    long double to_ld() const { long double r = 0; for (size_t i = w.size(); i-- > 0;) r = r * 18446744073709551616.0L + (long double)w[i]; return r; }
     void mul_small(uint64_t s) { u128 c = 0; for (auto &x : w) { c += (u128)x * s; x = (uint64_t)c; c >>= 64; } }
     void add(const Big &o) { u128 c = 0; for (size_t i = 0; i < w.size(); ++i) { c += (u128)w[i] + o.w[i]; w[i] = (uint64_t)c; c >>= 64; } }
     void sub(const Big &o) { uint64_t br = 0; for (size_t i = 0; i < w.size(); ++i) { u128 d = (u128)w[i] - o.w[i] - br; w[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
@@ -511,6 +513,7 @@ private:
         acc.download(ph.data(), pw);
         std::vector<uint64_t> plain(s.n, 0);
         int worst = 0;
+        const long double Qld = s.Q.to_ld();
         for (uint32_t c = 0; c < s.n; ++c) {
             detail::Big x(0);
             for (uint32_t i = 0; i < s.k; ++i) {
@@ -523,12 +526,19 @@ private:
             tx.mul_small(s.t);
             detail::Big num = tx;
             num.add(s.Qhalf);
-            uint64_t lo = 0, hi = s.t;                    // quotient of num / Q lies in [0, t]
-            while (lo < hi) {
-                uint64_t mid = lo + (hi - lo + 1) / 2;
+            // quotient of num / Q lies in [0, t]: 64-bit-mantissa estimate, then exact correction
+            uint64_t lo = (uint64_t)std::min<long double>((long double)s.t, std::floor(num.to_ld() / Qld));
+            {
                 detail::Big prod = s.Q;
-                prod.mul_small(mid);
-                if (prod.cmp(num) <= 0) lo = mid; else hi = mid - 1;
+                prod.mul_small(lo);
+                while (prod.cmp(num) > 0) { prod.sub(s.Q); --lo; }
+                for (;;) {
+                    detail::Big next = prod;
+                    next.add(s.Q);
+                    if (next.cmp(num) > 0) break;
+                    prod = next;
+                    ++lo;
+                }
             }
             plain[c] = lo % s.t;
             detail::Big prod = s.Q, diff;
