@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU per step")
     ap.add_argument("--cpu-blocks", type=int, default=16, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--preset", default="P4096", help="parameter set (default: the BASELINE.json configuration)")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,7 +103,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    ctx = fhe.SEALContext.preset("P4096", device=local_rank)
+    ctx = fhe.SEALContext.preset(args.preset, device=local_rank)
     ev = fhe.Evaluator(ctx)
     plan = fhe.DctPlan(ctx, fhe.YQT)
     B = args.blocks
@@ -147,7 +148,7 @@ def main():
     if rank == 0 and not args.no_verify:
         from oracle import oracle as om
         om.build()
-        orc = om.Oracle.preset("P4096")
+        orc = om.Oracle.preset(args.preset)
         sample = [0, B - 1] if B > 1 else [0]
         ok = True
         for b in sample:
@@ -158,10 +159,11 @@ def main():
     if rank == 0:
         total_blocks = B * world * args.steps
         value = total_blocks / wall
-        achieved = B * BYTES_PER_BLOCK / (dev_ms_per_step * 1e-3) / 1e9
+        bytes_per_block = 128 * 2 * ctx.k * ctx.n * 8          # = BYTES_PER_BLOCK for the default preset
+        achieved = B * bytes_per_block / (dev_ms_per_step * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):       # written by tools/collect_traffic.py from separate rocprofv3 --pmc passes
+        if os.path.exists(tpath) and args.preset == "P4096":       # written by tools/collect_traffic.py from separate rocprofv3 --pmc passes
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get("hbm_bytes_per_block", 0) * B or None
@@ -171,15 +173,16 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=4096, 3 coeff moduli, t=2^14" % B,
-                       "blocks_per_gpu": B, "poly_modulus_degree": 4096, "coeff_moduli": [hex(x) for x in ctx.q],
+            "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=%d, %d coeff moduli, t=2^14" % (B, ctx.n, ctx.k),
+                       "blocks_per_gpu": B, "poly_modulus_degree": ctx.n, "coeff_moduli": [hex(x) for x in ctx.q],
                        "sharding": "blocks x%d, no data-path collective" % world,
-                       "arithmetic": "exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out"},
+                       "arithmetic": ("exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out"
+                                      if max(ctx.q) < (1 << 47) else "u64 Shoup/Barrett modular arithmetic (general path)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_dct_rows + k_dct_cols (the two launches of fhe_dct8x8_quant, all waves of one step; "
                                    "HIP events on the launch stream)",
-                         "algorithmic_bytes_per_launch": B * BYTES_PER_BLOCK, "algorithmic_bytes_per_block": BYTES_PER_BLOCK,
+                         "algorithmic_bytes_per_launch": B * bytes_per_block, "algorithmic_bytes_per_block": bytes_per_block,
                          "ms_per_launch": dev_ms_per_step},
             # secondary view: the fused circuit needs ~213e6 FP64 lane-operations per block;
             # 29.3e12/s is the densest v_fma_f64 rate measured on this chip (profiles/r01_ubench2_fp64_latency.txt)
@@ -187,7 +190,7 @@ def main():
                          "measured_peak_tops": 29.3, "frac": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 29.3e12},
             "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
         }
-        if world == 1 and args.cpu_blocks > 0:
+        if world == 1 and args.cpu_blocks > 0 and args.preset == "P4096":
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
             try:
                 res["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
