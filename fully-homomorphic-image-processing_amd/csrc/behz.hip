@@ -102,6 +102,40 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
     }
 }
 
+// tensor product fused into the inverse transform: one workgroup forms output polynomial o of
+// ciphertext pair c at base prime j from the NTT-form operands and transforms it back, so the
+// NTT-form product never goes to memory.  A [count][sa][nb][n], Bm [count][sb][nb][n] (NTT order)
+// -> D [count][sa+sb-1][nb][n] (coefficient form, canonical).
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
+                                                                       RnsBase base, u32 sa, u32 sb) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 nb = base.count, so = sa + sb - 1;
+    const u64 id = blockIdx.x;                         // (c * so + o) * nb + j
+    const u32 j = (u32)(id % nb);
+    const u64 co = id / nb;
+    const u32 o = (u32)(co % so);
+    const u64 c = co / so;
+    const Modulus m = base.mod[j];
+    u64 acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0;
+    const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
+    for (u32 ja = lo; ja <= hi; ja++) {
+        u64 xa[16], xb[16];
+        load_slots<L>(xa, A + ((c * sa + ja) * nb + j) * N, tid);
+        load_slots<L>(xb, Bm + ((c * sb + (o - ja)) * nb + j) * N, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
+    }
+    ntt_inv_regs<L>(acc, base.itw + (size_t)j * N, m.q, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = csub(acc[r], m.q);
+    store_coeff<L>(acc, D + id * N, tid);
+}
+
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
                                                          const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
@@ -321,10 +355,19 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, 
     };
     if ((rc = prep(a, sa, Aq, Ab))) return rc;
     if (!square && (rc = prep(b, sb, Bq, Bb))) return rc;
-    k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, k, n, sa, sb, count);
-    k_behz_tensor<<<grid2(n, count * (k + 1)), 256, 0, st>>>(Ab, Bb, Db, c->behz->aux.d_mod, k + 1, n, sa, sb, count);
-    if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
-    if ((rc = fhe_ntt_launch(true, c, c->behz->aux, Db, Db, count * so * (k + 1), st))) return rc;
+    if (count * so * (u64)(k + 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    const bool q_f64 = fhe_rgb_f64_supported(c);      // FP64 inverse transforms beat the fused u64 kernel there
+    if (q_f64) {
+        k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, k, n, sa, sb, count);
+        if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
+    } else {
+        const RnsBase qb = c->qb.dev();
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * k), NttShape<L>::TP, 0, st>>>(Aq, Bq, Dq, qb, sa, sb)));
+    }
+    {
+        const RnsBase ab = c->behz->aux.dev();
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * (k + 1)), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb)));
+    }
     k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, T, n, count * so);
     KERNEL_CHECK();
     return FHE_OK;
