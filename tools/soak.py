@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Soak test: repeat the fused kernels on the same inputs and compare output digests every time
+(would expose a rare ordering hazard in the barrier-free in-wave LDS exchanges or the packed
+intermediate).  usage: python tools/soak.py [iterations]"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fhip_amd as fhe
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+ctx = fhe.SEALContext.preset("P4096")
+ev = fhe.Evaluator(ctx)
+plan = fhe.DctPlan(ctx, fhe.YQT)
+blocks = ctx.random_ct(1024, 64, seed=fhe.SEED)
+out = torch.empty_like(blocks)
+ev.dct8x8_quant(plan, blocks, out=out)
+ref = ctx.digest(out.view(-1))
+r0, g0, b0 = (ctx.random_ct(4096, seed=11 + i) for i in range(3))
+r, g, b = r0.clone(), g0.clone(), b0.clone()
+ev.rgb_to_ycc(r, g, b)
+ref_rgb = ctx.digest(torch.cat([r, g, b]).view(-1))
+a = ctx.random_ct(4096, seed=5)
+ref_ntt = ctx.digest(ev.ntt_inverse(ev.ntt_forward(a)).view(-1))
+assert ref_ntt == ctx.digest(a.view(-1))
+bad = 0
+t0 = time.time()
+for i in range(iters):
+    out.zero_()
+    ev.dct8x8_quant(plan, blocks, out=out)
+    if ctx.digest(out.view(-1)) != ref:
+        bad += 1
+        print("DCT digest mismatch at iteration", i, flush=True)
+    if i % 4 == 0:
+        r.copy_(r0); g.copy_(g0); b.copy_(b0)
+        ev.rgb_to_ycc(r, g, b)
+        if ctx.digest(torch.cat([r, g, b]).view(-1)) != ref_rgb:
+            bad += 1
+            print("rgb digest mismatch at iteration", i, flush=True)
+        if ctx.digest(ev.ntt_inverse(ev.ntt_forward(a)).view(-1)) != ref_ntt:
+            bad += 1
+            print("ntt digest mismatch at iteration", i, flush=True)
+print("soak: %d iterations, %d mismatches, %.1f s" % (iters, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
