@@ -50,6 +50,8 @@ SIGNATURES = {
     "fhe_plain_ntt_mul": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "fhe_multiply_plain": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "fhe_multiply_plain_sparse": (_i, [_vp, _vp, _vp, _u64, _vp, _u32, _vp]),
+    "fhe_cubic_coeffs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u64, _vp]),
+    "fhe_cubic_combine": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _u64, _vp]),
     "fhe_add_plain": (_i, [_vp, _vp, _u64, _u64, _vp, _u32, _i, _vp]),
     "fhe_ntt_forward": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "fhe_ntt_inverse": (_i, [_vp, _vp, _vp, _u64, _vp]),

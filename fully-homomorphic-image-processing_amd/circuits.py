@@ -54,6 +54,22 @@ def rgb_to_ycc(ev, pc, r, g, b):
 # ------------------------------------------------------------------------------------------------
 # resize path
 # ------------------------------------------------------------------------------------------------
+def _base2_cubic_constants(pc):
+    """True if the encoder writes Cubic's constants the way the fused passes assume (base 2):
+    encode(3) = x+1, encode(2) = x, encode(5) = x^2+1, encode(4) = x^2, encode(0.5) = -x^(n-1)."""
+    if getattr(pc, "_cubic_ok", None) is None:
+        import numpy as np
+        t, n = pc.ctx.t, pc.ctx.n
+
+        def nz(v):
+            p = np.asarray(pc.plain(v), dtype=np.uint64)
+            return {int(i): int(p[i]) for i in np.nonzero(p)[0]}
+
+        pc._cubic_ok = (nz(3) == {0: 1, 1: 1} and nz(2) == {1: 1} and nz(5) == {0: 1, 2: 1} and nz(4) == {2: 1}
+                        and nz(0.5) == {n - 1: t - 1})
+    return pc._cubic_ok
+
+
 def cubic_powers(ev, t, relin=None):
     """t2 = square(t) and t3 = multiply(t, t) of Cubic (homo/fhe_resize.h:174-175).  Both are the same
     ring tensor (the library's square IS multiply(t, t)), so one product serves both, and a caller
@@ -79,13 +95,21 @@ def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None):
         z = ev.multiply(x, y)
         return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
 
-    a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
-    b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
-    c = ev.sub(C, A)
+    fused = _base2_cubic_constants(pc) and A.shape == B.shape == C.shape == D.shape
+    if fused:       # the linear parts in one pass each (same ring elements as the calls below)
+        a, b, c = ev.cubic_coeffs(A.contiguous(), B.contiguous(), C.contiguous(), D.contiguous())
+    else:
+        a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
+        b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
+        c = ev.sub(C, A)
     t2, t3 = powers if powers is not None else cubic_powers(ev, t, relin)
     a = mul(a, t3)
     b = mul(b, t2)
     c = mul(c, t)
+    if fused and a.shape == b.shape and c.shape[-3] <= a.shape[-3] and B.shape[-3] <= a.shape[-3]:
+        if c.shape[-3] < a.shape[-3]:                # c * t is one polynomial shorter than a * t3: pad with zeros
+            c = torch.cat([c, torch.zeros_like(a[..., c.shape[-3]:, :, :])], dim=-3)
+        return ev.cubic_combine(a.contiguous(), b.contiguous(), c.contiguous(), B.contiguous())
     a = ev.add(ev.add(a, b), c)
     a = M(a, P(0.5))
     return ev.add(a, B)

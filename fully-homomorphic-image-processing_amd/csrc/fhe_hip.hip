@@ -531,6 +531,83 @@ extern "C" int fhe_multiply_plain_sparse(const fhe_ctx *c, const uint64_t *in, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cubic's linear parts (homo/fhe_resize.h:150-172, 181-188) as single passes
+// ------------------------------------------------------------------------------------------------
+// x^e * P at coefficient j of a negacyclic polynomial: +-P[j - e]; returns the value to ADD
+__device__ __forceinline__ u64 rot_term(const u64 *__restrict__ p, int j, int e, int n, u64 q) {
+    const int idx = j - e;
+    if (idx >= 0) return p[idx];
+    const u64 v = p[idx + n];
+    return v ? q - v : 0;
+}
+__global__ __launch_bounds__(256) void k_cubic_coeffs(const u64 *__restrict__ A, const u64 *__restrict__ B, const u64 *__restrict__ C,
+                                                      const u64 *__restrict__ D, u64 *__restrict__ a, u64 *__restrict__ b, u64 *__restrict__ c,
+                                                      const Modulus *__restrict__ mods, u32 k, u32 n) {
+    const u64 rp = blockIdx.x;
+    const u64 q = mods[rp % k].q;
+    const u64 *pa = A + rp * n, *pb = B + rp * n, *pc = C + rp * n, *pd = D + rp * n;
+    for (int j = threadIdx.x; j < (int)n; j += 256) {
+        const u64 Aj = pa[j], Bj = pb[j], Cj = pc[j], Dj = pd[j];
+        // a = B (x+1) - A - C (x+1) + D
+        u64 va = addmod(Bj, rot_term(pb, j, 1, n, q), q);
+        va = submod(va, Aj, q);
+        va = submod(va, addmod(Cj, rot_term(pc, j, 1, n, q), q), q);
+        va = addmod(va, Dj, q);
+        // b = A x - B (x^2+1) + C x^2 - D
+        u64 vb = rot_term(pa, j, 1, n, q);
+        vb = submod(vb, addmod(Bj, rot_term(pb, j, 2, n, q), q), q);
+        vb = addmod(vb, rot_term(pc, j, 2, n, q), q);
+        vb = submod(vb, Dj, q);
+        a[rp * n + j] = va;
+        b[rp * n + j] = vb;
+        c[rp * n + j] = submod(Cj, Aj, q);
+    }
+}
+// out = (a + b + c) * (-x^(n-1)) + B:  -x^(n-1) = x^(-1), so coefficient j takes S[j+1], the last one -S[0]
+__global__ __launch_bounds__(256) void k_cubic_combine(const u64 *__restrict__ a, const u64 *__restrict__ b, const u64 *__restrict__ c,
+                                                       const u64 *__restrict__ B, u64 *__restrict__ out, const Modulus *__restrict__ mods,
+                                                       u32 k, u32 n, u32 size_abc, u32 size_b) {
+    const u64 rp = blockIdx.x;                       // (ct * size_abc + poly) * k + prime
+    const u32 prime = (u32)(rp % k);
+    const u64 cp = rp / k;
+    const u32 poly = (u32)(cp % size_abc);
+    const u64 ct = cp / size_abc;
+    const u64 q = mods[prime].q;
+    const u64 *pa = a + rp * n, *pb = b + rp * n, *pc = c + rp * n;
+    const u64 *pB = poly < size_b ? B + ((ct * size_b + poly) * k + prime) * n : nullptr;
+    for (int j = threadIdx.x; j < (int)n; j += 256) {
+        const int src = j + 1 < (int)n ? j + 1 : 0;
+        u64 s = addmod(addmod(pa[src], pb[src], q), pc[src], q);
+        if (j + 1 == (int)n) s = s ? q - s : 0;
+        out[rp * n + j] = pB ? addmod(s, pB[j], q) : s;
+    }
+}
+
+extern "C" int fhe_cubic_coeffs(const fhe_ctx *c, const uint64_t *A, const uint64_t *B, const uint64_t *C, const uint64_t *D,
+                                uint64_t *a, uint64_t *b, uint64_t *cc, uint32_t size, uint64_t count, fhe_stream s) {
+    if (!c || !A || !B || !C || !D || !a || !b || !cc) return fail(FHE_ERR_PARAM, "null argument");
+    const u64 nrp = count * size * c->k;
+    if (!nrp) return FHE_OK;
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    k_cubic_coeffs<<<(unsigned)nrp, 256, 0, (hipStream_t)s>>>((const u64 *)A, (const u64 *)B, (const u64 *)C, (const u64 *)D, (u64 *)a, (u64 *)b,
+                                                               (u64 *)cc, c->qb.d_mod, c->k, c->n);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+extern "C" int fhe_cubic_combine(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, const uint64_t *cc, uint32_t size_abc,
+                                 const uint64_t *B, uint32_t size_b, uint64_t *out, uint64_t count, fhe_stream s) {
+    if (!c || !a || !b || !cc || !B || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (size_b > size_abc) return fail(FHE_ERR_PARAM, "B is larger than the products");
+    const u64 nrp = count * size_abc * c->k;
+    if (!nrp) return FHE_OK;
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    k_cubic_combine<<<(unsigned)nrp, 256, 0, (hipStream_t)s>>>((const u64 *)a, (const u64 *)b, (const u64 *)cc, (const u64 *)B, (u64 *)out,
+                                                                c->qb.d_mod, c->k, c->n, size_abc, size_b);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // plaintext preparation
 // ------------------------------------------------------------------------------------------------
 // in: [k][n] NTT-form values; out: [k][n] (value, Shoup companion) pairs.  in may alias the first

@@ -271,6 +271,23 @@ class Evaluator:
         return work[..., :2, :, :].contiguous()
 
     # -- primitives named by the north star ---------------------------------------------------------
+    def cubic_coeffs(self, A, B, C, D):
+        """a = 3B - A - 3C + D, b = 2A - 5B + 4C - D, c = C - A of Cubic (homo/fhe_resize.h:150-172) in one
+        pass; valid for the base-2 FractionalEncoder (encode(3) = x+1, ...), which the caller checks."""
+        size = A.shape[-3]
+        count = A.numel() // (size * self.ctx.k * self.ctx.n)
+        a, b, c = torch.empty_like(A), torch.empty_like(A), torch.empty_like(A)
+        _lib.call("fhe_cubic_coeffs", self.ctx.h, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(a), _ptr(b), _ptr(c), size, count, _stream())
+        return a, b, c
+
+    def cubic_combine(self, a, b, c, B):
+        """0.5 (a + b + c) + B of Cubic (homo/fhe_resize.h:181-188); a, b, c of equal size >= size of B."""
+        size_abc, size_b = a.shape[-3], B.shape[-3]
+        count = a.numel() // (size_abc * self.ctx.k * self.ctx.n)
+        out = torch.empty_like(a)
+        _lib.call("fhe_cubic_combine", self.ctx.h, _ptr(a), _ptr(b), _ptr(c), size_abc, _ptr(B), size_b, _ptr(out), count, _stream())
+        return out
+
     def ntt_forward(self, a, out=None):
         out = torch.empty_like(a) if out is None else out
         _lib.call("fhe_ntt_forward", self.ctx.h, _ptr(a), _ptr(out), self._npolys(a), _stream())

@@ -115,6 +115,19 @@ int fhe_multiply_plain(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, ui
 int fhe_multiply_plain_sparse(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n_polys,
                               const uint64_t *plain_host, uint32_t plain_len, fhe_stream stream);
 
+/* Cubic (homo/fhe_resize.h:143-189) outside its four ciphertext products, for FractionalEncoder base 2
+ * where encode(3) = x+1, encode(2) = x, encode(5) = x^2+1, encode(4) = x^2, encode(0.5) = -x^(n-1):
+ *   fhe_cubic_coeffs:  a = 3B - A - 3C + D,  b = 2A - 5B + 4C - D,  c = C - A      (:150-172; one pass
+ *                      over A..D instead of six multiply_plain and eight add/sub calls)
+ *   fhe_cubic_combine: out = 0.5 (a + b + c) + B                                   (:181-188)
+ * exactly as the Evaluator calls compose (same ring elements, canonical residues).  Operands are
+ * batches of `count` ciphertexts; A..D, a, b, c have `size` polynomials each; in combine a, b, c have
+ * `size_abc` polynomials, B has `size_b` <= size_abc, out has size_abc.  Outputs must not alias inputs. */
+int fhe_cubic_coeffs(const fhe_ctx *ctx, const uint64_t *A, const uint64_t *B, const uint64_t *C, const uint64_t *D,
+                     uint64_t *a, uint64_t *b, uint64_t *c, uint32_t size, uint64_t count, fhe_stream stream);
+int fhe_cubic_combine(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint32_t size_abc,
+                      const uint64_t *B, uint32_t size_b, uint64_t *out, uint64_t count, fhe_stream stream);
+
 /* seal::Evaluator::add_plain / sub_plain (homo/fhe_image.h:317 sub_plain(128.0); fhe_resize.h:196;
  * fhe_decode.h:57,113,218,220,229): c_0 += sign * Delta * m' for `count` ciphertexts whose first
  * polynomial starts every ct_stride_words u64. sign = +1 / -1. */

@@ -185,6 +185,48 @@ int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint
     for (uint64_t p = 0; p < np; p++) fhe_dyadic_multiply(c, out + p * pw(c), d_plain, out + p * pw(c), 1, s);
     return fhe_ntt_inverse(c, out, out, np, s);
 }
+/* Cubic's linear parts, composed from the oracle's Evaluator-level calls exactly as homo/fhe_resize.h does */
+static void enc_small(const fhe_ctx *c, double v, uint64_t *plain, uint32_t *len) { *len = fo_frac_encode(c->o, v, 100, 100, plain); }
+int fhe_cubic_coeffs(const fhe_ctx *c, const uint64_t *A, const uint64_t *B, const uint64_t *C, const uint64_t *D, uint64_t *a,
+                     uint64_t *b, uint64_t *cc, uint32_t size, uint64_t count, fhe_stream s) {
+    (void)s;
+    const size_t w = (size_t)size * pw(c);
+    uint64_t *pl = (uint64_t *)calloc(c->n, 8), *t1 = (uint64_t *)malloc(w * 8);
+    uint32_t len;
+    for (uint64_t i = 0; i < count; i++) {
+        const uint64_t *Ai = A + i * w, *Bi = B + i * w, *Ci = C + i * w, *Di = D + i * w;
+        uint64_t *ai = a + i * w, *bi = b + i * w, *ci = cc + i * w;
+        memcpy(ai, Bi, w * 8); enc_small(c, 3.0, pl, &len); fo_multiply_plain(c->o, ai, size, pl, len);
+        fo_sub(c->o, ai, size, Ai, size);
+        memcpy(t1, Ci, w * 8); fo_multiply_plain(c->o, t1, size, pl, len); fo_sub(c->o, ai, size, t1, size);
+        fo_add(c->o, ai, size, Di, size);
+        memcpy(bi, Ai, w * 8); enc_small(c, 2.0, pl, &len); fo_multiply_plain(c->o, bi, size, pl, len);
+        memcpy(t1, Bi, w * 8); enc_small(c, 5.0, pl, &len); fo_multiply_plain(c->o, t1, size, pl, len); fo_sub(c->o, bi, size, t1, size);
+        memcpy(t1, Ci, w * 8); enc_small(c, 4.0, pl, &len); fo_multiply_plain(c->o, t1, size, pl, len); fo_add(c->o, bi, size, t1, size);
+        fo_sub(c->o, bi, size, Di, size);
+        memcpy(ci, Ci, w * 8); fo_sub(c->o, ci, size, Ai, size);
+    }
+    free(pl); free(t1);
+    return FHE_OK;
+}
+int fhe_cubic_combine(const fhe_ctx *c, const uint64_t *a, const uint64_t *b, const uint64_t *cc, uint32_t size_abc, const uint64_t *B,
+                      uint32_t size_b, uint64_t *out, uint64_t count, fhe_stream s) {
+    (void)s;
+    const size_t w = (size_t)size_abc * pw(c), wb = (size_t)size_b * pw(c);
+    uint64_t *pl = (uint64_t *)calloc(c->n, 8);
+    uint32_t len;
+    enc_small(c, 0.5, pl, &len);
+    for (uint64_t i = 0; i < count; i++) {
+        uint64_t *o = out + i * w;
+        memcpy(o, a + i * w, w * 8);
+        fo_add(c->o, o, size_abc, b + i * w, size_abc);
+        fo_add(c->o, o, size_abc, cc + i * w, size_abc);
+        fo_multiply_plain(c->o, o, size_abc, pl, len);
+        fo_add(c->o, o, size_abc, B + i * wb, size_b);
+    }
+    free(pl);
+    return FHE_OK;
+}
 int fhe_multiply_plain_sparse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, const uint64_t *plain,
                               uint32_t len, fhe_stream s) {
     (void)s;
