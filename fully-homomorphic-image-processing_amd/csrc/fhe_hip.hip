@@ -330,6 +330,26 @@ __global__ void k_add_plain(u64 *ct, u64 stride_words, u64 count, const u64 *__r
     }
 }
 
+// the same for a plaintext with few non-zero coefficients: the scaled terms travel in the kernel
+// arguments, so nothing is staged and the call is fully asynchronous
+#define ADD_PLAIN_MAX_TERMS 24
+struct PlainTerms {
+    u32 count;
+    u32 idx[ADD_PLAIN_MAX_TERMS];
+    u64 v[ADD_PLAIN_MAX_TERMS][FHE_MAX_K];
+};
+__global__ void k_add_plain_terms(u64 *ct, u64 stride_words, u64 count, const Modulus *__restrict__ mods, u32 k, u32 n, int sign, const PlainTerms T) {
+    const u64 total = count * k * T.count;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u32 t = (u32)(i % T.count);
+        const u32 prime = (u32)((i / T.count) % k);
+        const u64 cidx = i / ((u64)T.count * k);
+        const u64 q = mods[prime].q;
+        u64 *p = ct + cidx * stride_words + (u64)prime * n + T.idx[t];
+        *p = sign > 0 ? addmod(*p, T.v[t][prime], q) : submod(*p, T.v[t][prime], q);
+    }
+}
+
 extern "C" int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, uint64_t count, const uint64_t *plain,
                              uint32_t len, int sign, fhe_stream s) {
     using namespace hostmath;
@@ -337,6 +357,33 @@ extern "C" int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, ui
     if (len > c->n) return fail(FHE_ERR_PARAM, "plaintext longer than the polynomial");
     if (sign != 1 && sign != -1) return fail(FHE_ERR_PARAM, "sign must be +1 or -1");
     if (len == 0 || count == 0) return FHE_OK;
+    {
+        PlainTerms T;
+        T.count = 0;
+        bool sparse = true;
+        for (u32 j = 0; j < len; ++j) {
+            const u64 m = plain[j];
+            if (!m) continue;
+            if (m >= c->t) return fail(FHE_ERR_PARAM, "plaintext coefficient %u not below the plain modulus", j);
+            if (T.count == ADD_PLAIN_MAX_TERMS) { sparse = false; break; }
+            T.idx[T.count] = j;
+            for (u32 i = 0; i < c->k; ++i) {
+                const u64 qi = c->qb.primes[i];
+                u64 v = mulmod(c->delta_mod[i], m % qi, qi);
+                if (m >= c->upper_half_threshold) v = addmod(v, c->upper_half_increment[i], qi);
+                T.v[T.count][i] = v;
+            }
+            ++T.count;
+        }
+        if (sparse) {
+            if (!T.count) return FHE_OK;
+            const u64 total = count * c->k * T.count;
+            const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+            k_add_plain_terms<<<blocks, 256, 0, (hipStream_t)s>>>((u64 *)ct, stride, count, c->qb.d_mod, c->k, c->n, sign, T);
+            KERNEL_CHECK();
+            return FHE_OK;
+        }
+    }
     std::vector<u64> vals((size_t)c->k * len);
     for (u32 i = 0; i < c->k; ++i) {
         const u64 qi = c->qb.primes[i];

@@ -119,9 +119,8 @@ class PreparedPlain:
     def __init__(self, ctx, plain):
         self.ctx = ctx
         p = np.ascontiguousarray(plain, dtype=np.uint64)
-        ln = len(p)
-        while ln > 0 and p[ln - 1] == 0:
-            ln -= 1
+        nz = np.flatnonzero(p)
+        ln = int(nz[-1]) + 1 if nz.size else 0     # significant coefficient count
         self.buf = torch.empty(2 * ctx.k * ctx.n, dtype=torch.int64, device=ctx.device)
         _lib.call("fhe_plain_prepare", ctx.h, p.ctypes.data_as(C.c_void_p), ln, _ptr(self.buf), _stream())
         # few non-zero coefficients (encode(3) = x+1, encode(0.5) = -x^(n-1), ...): the product is a sum
@@ -220,9 +219,8 @@ class Evaluator:
     def _plain_addsub(self, a, plain, sign):
         out = a.clone()
         p = np.ascontiguousarray(plain, dtype=np.uint64)
-        ln = len(p)
-        while ln > 0 and p[ln - 1] == 0:
-            ln -= 1
+        nz = np.flatnonzero(p)
+        ln = int(nz[-1]) + 1 if nz.size else 0     # significant coefficient count
         size = a.shape[-3]
         stride = size * self.ctx.k * self.ctx.n
         count = out.numel() // stride

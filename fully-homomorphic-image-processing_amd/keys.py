@@ -113,9 +113,8 @@ class Encryptor:
         e = to_device(np.stack([self._smp.noise(), self._smp.noise()]), ctx.device)
         _lib.call("fhe_add", ctx.h, _ptr(ct), _ptr(e), _ptr(ct), 2, _stream())
         p = np.ascontiguousarray(plain, dtype=np.uint64)
-        ln = len(p)
-        while ln > 0 and p[ln - 1] == 0:
-            ln -= 1
+        nz = np.flatnonzero(p)
+        ln = int(nz[-1]) + 1 if nz.size else 0     # significant coefficient count
         if ln:
             _lib.call("fhe_add_plain", ctx.h, _ptr(ct), 2 * ctx.k * ctx.n, 1, p.ctypes.data_as(C.c_void_p), ln, 1, _stream())
         return ct
