@@ -81,9 +81,11 @@ def cubic_powers(ev, t, relin=None):
     return t2, t2
 
 
-def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None):
+def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None, prepared=None):
     """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189.  Note t3 = t*t exactly as the reference
-    computes it (:175).  powers = cubic_powers(ev, t) may be shared between calls with the same t.
+    computes it (:175).  powers = cubic_powers(ev, t) may be shared between calls with the same t, and
+    prepared = (prepare_operand(t3), prepare_operand(t2), prepare_operand(t)) for the same batch shape
+    saves their base extension and transforms in every call.
 
     relin=(evk_ntt, dbc) switches on the relinearised mode (NOT what the
     reference does): every product is brought back to size 2, so the result has size 2 instead of
@@ -103,9 +105,10 @@ def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None):
         b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
         c = ev.sub(C, A)
     t2, t3 = powers if powers is not None else cubic_powers(ev, t, relin)
-    a = mul(a, t3)
-    b = mul(b, t2)
-    c = mul(c, t)
+    if prepared is not None:
+        a, b, c = mul(a, prepared[0]), mul(b, prepared[1]), mul(c, prepared[2])
+    else:
+        a, b, c = mul(a, t3), mul(b, t2), mul(c, t)
     if fused and a.shape == b.shape and c.shape[-3] <= a.shape[-3] and B.shape[-3] <= a.shape[-3]:
         if c.shape[-3] < a.shape[-3]:                # c * t is one polynomial shorter than a * t3: pad with zeros
             c = torch.cat([c, torch.zeros_like(a[..., c.shape[-3]:, :, :])], dim=-3)
@@ -153,8 +156,10 @@ def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
     ciphertexts of the fractional offsets.  Returns [B, 6, k, n]."""
     idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 16]
     p = [pixels[idx[:, i]].contiguous() for i in range(16)]
-    px = cubic_powers(ev, xfract)                       # shared by the four row Cubics
-    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract, powers=px) for r in range(4)]
+    px = cubic_powers(ev, xfract)                       # shared by the four row Cubics, prepared once
+    p2 = ev.prepare_operand(px[0])
+    prep = (p2, p2, ev.prepare_operand(xfract.contiguous()))
+    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract, powers=px, prepared=prep) for r in range(4)]
     return cubic(ev, pc, cols[0], cols[1], cols[2], cols[3], yfract)
 
 
@@ -182,9 +187,10 @@ def _taylor_terms(ev, pc, x, coeffs):
     s8 = ev.square(s4)
     p2 = M(s2, P(coeffs[0]))
     p4 = M(s4, P(coeffs[1]))
-    p6 = M(ev.multiply(ev.multiply(s4, sx), sx), P(coeffs[2]))
+    psx = ev.prepare_operand(sx.contiguous())            # the four products below share this operand
+    p6 = M(ev.multiply(ev.multiply(s4, psx), psx), P(coeffs[2]))
     p8 = M(s8, P(coeffs[3]))
-    p10 = M(ev.multiply(ev.multiply(s8, sx), sx), P(coeffs[4]))
+    p10 = M(ev.multiply(ev.multiply(s8, psx), psx), P(coeffs[4]))
     return (p2, p4, p6, p8, p10)
 
 

@@ -328,33 +328,20 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
     return fhe_ntt_launch(inverse, c, c->qb, in, out, n_rns * c->k, st);
 }
 
-static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, u32 sb, u64 *out, u64 count, void *scratch,
-                         size_t scratch_bytes, hipStream_t st) {
-    if (!cc || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
-    if (sa < 1 || sb < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
-    if (!count) return FHE_OK;
-    fhe_ctx *c = const_cast<fhe_ctx *>(cc);   // lazily built tables; contexts are not shared across threads during creation
-    int rc = behz_build(c);
-    if (rc) return rc;
-    const bool square = (a == b && sa == sb);
-    if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
-        return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
-    const BehzDev *T = c->behz->dev;
+// operand preparation (steps 0-2 up to the forward transforms): src [count][s][k][n] -> xq [count][s][k][n] (NTT),
+// xb [count][s][k+1][n] (NTT)
+static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
+    const u32 k = c->k, n = c->n;
+    k_behz_to_bsk<<<grid2(n, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s);
+    int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
+    if (r) return r;
+    return qbase_ntt(false, c, src, xq, count * s, st);
+}
+// tensor product + inverse transforms + floor/back-conversion from prepared operands; D = scratch for so polynomials
+static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, const u64 *Bq, const u64 *Bb, u32 sb, u64 *out, u64 count,
+                       u64 *Dq, u64 *Db, hipStream_t st) {
     const u32 k = c->k, n = c->n, so = sa + sb - 1;
-    const size_t kn = (size_t)k * n, bn = (size_t)(k + 1) * n;
-    u64 *Aq = (u64 *)scratch, *Ab = Aq + count * sa * kn;
-    u64 *p = Ab + count * sa * bn;
-    u64 *Bq = Aq, *Bb = Ab;
-    if (!square) { Bq = p; Bb = Bq + count * sb * kn; p = Bb + count * sb * bn; }
-    u64 *Dq = p, *Db = Dq + count * so * kn;
-    auto prep = [&](const u64 *src, u32 s, u64 *xq, u64 *xb) -> int {
-        k_behz_to_bsk<<<grid2(n, count * s), 256, 0, st>>>(src, xb, T, n, count * s);
-        int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
-        if (r) return r;
-        return qbase_ntt(false, c, src, xq, count * s, st);
-    };
-    if ((rc = prep(a, sa, Aq, Ab))) return rc;
-    if (!square && (rc = prep(b, sb, Bq, Bb))) return rc;
+    int rc;
     if (count * so * (u64)(k + 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const bool q_f64 = fhe_rgb_f64_supported(c);      // FP64 inverse transforms beat the fused u64 kernel there
     if (q_f64) {
@@ -368,20 +355,75 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, u32 sa, const u64 *b, 
         const RnsBase ab = c->behz->aux.dev();
         DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * (k + 1)), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb)));
     }
-    k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, T, n, count * so);
+    k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so);
     KERNEL_CHECK();
     return FHE_OK;
 }
 
+// a / b: plain ciphertexts (used when the matching prepared pointer is null); ap / bp: prepared operands
+static int behz_multiply(const fhe_ctx *cc, const u64 *a, const u64 *ap, u32 sa, const u64 *b, const u64 *bp, u32 sb, u64 *out, u64 count,
+                         void *scratch, size_t scratch_bytes, hipStream_t st) {
+    if (!cc || (!a && !ap) || (!b && !bp) || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (sa < 1 || sb < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
+    if (!count) return FHE_OK;
+    fhe_ctx *c = const_cast<fhe_ctx *>(cc);   // lazily built tables; contexts are not shared across threads during creation
+    int rc = behz_build(c);
+    if (rc) return rc;
+    const bool square = !ap && !bp && a == b && sa == sb;
+    if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
+        return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
+    const u32 k = c->k, n = c->n, so = sa + sb - 1;
+    const size_t kn = (size_t)k * n, bn = (size_t)(k + 1) * n;
+    u64 *p = (u64 *)scratch;
+    const u64 *Aq, *Ab, *Bq, *Bb;
+    if (ap) { Aq = ap; Ab = ap + count * sa * kn; }
+    else {
+        u64 *xq = p, *xb = xq + count * sa * kn;
+        p = xb + count * sa * bn;
+        if ((rc = behz_prepare(c, a, sa, count, xq, xb, st))) return rc;
+        Aq = xq; Ab = xb;
+    }
+    if (square) { Bq = Aq; Bb = Ab; }
+    else if (bp) { Bq = bp; Bb = bp + count * sb * kn; }
+    else {
+        u64 *xq = p, *xb = xq + count * sb * kn;
+        p = xb + count * sb * bn;
+        if ((rc = behz_prepare(c, b, sb, count, xq, xb, st))) return rc;
+        Bq = xq; Bb = xb;
+    }
+    u64 *Dq = p, *Db = Dq + count * so * kn;
+    return behz_finish(c, Aq, Ab, sa, Bq, Bb, sb, out, count, Dq, Db, st);
+}
+
+extern "C" size_t fhe_multiply_operand_words(const fhe_ctx *c, uint32_t size, uint64_t count) {
+    if (!c) return 0;
+    return (size_t)count * size * (2 * (size_t)c->k + 1) * c->n;
+}
+extern "C" int fhe_multiply_prepare(const fhe_ctx *cc, const uint64_t *a, uint32_t size, uint64_t count, uint64_t *prepared, fhe_stream s) {
+    if (!cc || !a || !prepared) return fail(FHE_ERR_PARAM, "null argument");
+    if (!size) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
+    if (!count) return FHE_OK;
+    fhe_ctx *c = const_cast<fhe_ctx *>(cc);
+    int rc = behz_build(c);
+    if (rc) return rc;
+    u64 *xq = (u64 *)prepared, *xb = xq + count * size * (size_t)c->k * c->n;
+    return behz_prepare(c, (const u64 *)a, size, count, xq, xb, (hipStream_t)s);
+}
+extern "C" int fhe_multiply_prepared(const fhe_ctx *c, const uint64_t *a, const uint64_t *ap, uint32_t sa, const uint64_t *b, const uint64_t *bp,
+                                     uint32_t sb, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    return behz_multiply(c, (const u64 *)a, (const u64 *)ap, sa, (const u64 *)b, (const u64 *)bp, sb, (u64 *)out, count, scratch, scratch_bytes,
+                         (hipStream_t)s);
+}
+
 extern "C" int fhe_multiply(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out,
                             uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream s) {
-    return behz_multiply(c, (const u64 *)a, sa, (const u64 *)b, sb, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
+    return behz_multiply(c, (const u64 *)a, nullptr, sa, (const u64 *)b, nullptr, sb, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
 }
 // SEAL special-cases size 2 as (c0^2, 2 c0 c1, c1^2); that is the same ring tensor the generic
 // product forms, so square shares the multiply path (transforming the operand once).
 extern "C" int fhe_square(const fhe_ctx *c, const uint64_t *a, uint32_t sa, uint64_t *out, uint64_t count, void *scratch,
                           size_t scratch_bytes, fhe_stream s) {
-    return behz_multiply(c, (const u64 *)a, sa, (const u64 *)a, sa, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
+    return behz_multiply(c, (const u64 *)a, nullptr, sa, (const u64 *)a, nullptr, sa, (u64 *)out, count, scratch, scratch_bytes, (hipStream_t)s);
 }
 
 extern "C" uint32_t fhe_evk_digits(const fhe_ctx *c, uint32_t dbc) {

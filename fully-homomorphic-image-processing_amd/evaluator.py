@@ -129,6 +129,13 @@ class PreparedPlain:
         self.sparse = 0 < int(np.count_nonzero(self.plain)) <= SPARSE_MAX_TERMS and ctx.n <= 8192
 
 
+class PreparedCt:
+    """A multiply() operand in prepared form (Evaluator.prepare_operand); opaque device words."""
+
+    def __init__(self, buf, size, lead):
+        self.buf, self.size, self.lead = buf, size, lead
+
+
 class DctPlan:
     def __init__(self, ctx, quant=YQT, int_coeffs=100, frac_coeffs=100):
         self.ctx = ctx
@@ -233,17 +240,38 @@ class Evaluator:
     def sub_plain(self, a, plain):
         return self._plain_addsub(a, plain, -1)
 
+    def prepare_operand(self, a):
+        """Extend a ciphertext batch to the auxiliary base and transform it once, for several multiply()
+        calls with the same operand (fhe_multiply_prepare); multiply() accepts the result on either side."""
+        size = a.shape[-3]
+        lead = tuple(a.shape[:-3])
+        count = 1
+        for d in lead:
+            count *= d
+        words = _lib.load().fhe_multiply_operand_words(self.ctx.h, size, count)
+        buf = torch.empty(words, dtype=torch.int64, device=self.ctx.device)
+        _lib.call("fhe_multiply_prepare", self.ctx.h, _ptr(a), size, count, _ptr(buf), _stream())
+        return PreparedCt(buf, size, lead)
+
     def multiply(self, a, b):
-        sa, sb = a.shape[-3], b.shape[-3]
-        lead = a.shape[:-3]
-        assert b.shape[:-3] == lead
+        pa = a if isinstance(a, PreparedCt) else None
+        pb = b if isinstance(b, PreparedCt) else None
+        sa = pa.size if pa else a.shape[-3]
+        sb = pb.size if pb else b.shape[-3]
+        lead = pa.lead if pa else tuple(a.shape[:-3])
+        assert (pb.lead if pb else tuple(b.shape[:-3])) == lead
         count = 1
         for d in lead:
             count *= d
         out = self.ctx.empty(*lead, size=sa + sb - 1)
         nbytes = _lib.load().fhe_multiply_scratch_bytes(self.ctx.h, sa, sb, count)
         scr = self._scratch_buf(nbytes)
-        _lib.call("fhe_multiply", self.ctx.h, _ptr(a), sa, _ptr(b), sb, _ptr(out), count, _ptr(scr), nbytes, _stream())
+        if pa is None and pb is None:
+            _lib.call("fhe_multiply", self.ctx.h, _ptr(a), sa, _ptr(b), sb, _ptr(out), count, _ptr(scr), nbytes, _stream())
+        else:
+            null = C.c_void_p(None)
+            _lib.call("fhe_multiply_prepared", self.ctx.h, null if pa else _ptr(a), _ptr(pa.buf) if pa else null, sa,
+                      null if pb else _ptr(b), _ptr(pb.buf) if pb else null, sb, _ptr(out), count, _ptr(scr), nbytes, _stream())
         return out
 
     def square(self, a):

@@ -154,6 +154,18 @@ int fhe_multiply(const fhe_ctx *ctx, const uint64_t *a, uint32_t size_a, const u
                  fhe_stream stream);
 int fhe_square(const fhe_ctx *ctx, const uint64_t *a, uint32_t size_a, uint64_t *out, uint64_t count,
                void *scratch, size_t scratch_bytes, fhe_stream stream);
+/* An operand of fhe_multiply extended to the auxiliary base and transformed ONCE, for circuits that
+ * multiply several ciphertexts by the same one (Cubic: t and t^2 enter every row of a pixel,
+ * homo/fhe_resize.h:176-179,296-303).  fhe_multiply(a, b) == fhe_multiply_prepared(prepare(a), prepare(b))
+ * bit for bit.  A prepared operand holds fhe_multiply_operand_words() u64 words in device memory and is
+ * opaque.  Pass NULL for a_prepared (b_prepared) together with the plain ciphertext a (b) to prepare that
+ * side inside the call. */
+size_t fhe_multiply_operand_words(const fhe_ctx *ctx, uint32_t size, uint64_t count);
+int fhe_multiply_prepare(const fhe_ctx *ctx, const uint64_t *a, uint32_t size, uint64_t count, uint64_t *prepared,
+                         fhe_stream stream);
+int fhe_multiply_prepared(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *a_prepared, uint32_t size_a,
+                          const uint64_t *b, const uint64_t *b_prepared, uint32_t size_b, uint64_t *out, uint64_t count,
+                          void *scratch, size_t scratch_bytes, fhe_stream stream);
 
 /* ---- seal::Evaluator::relinearize (north_star API surface; the reference never calls it, only
  * tests/parameters.cpp:112 touches evaluation keys).  Key-switch inner product for `count`

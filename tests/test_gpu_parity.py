@@ -698,3 +698,21 @@ def test_fused_cubic_linear_parts_equal_evaluator_calls(fhe, oracle_mod, preset,
     plain = fhe.circuits.cubic(ev, pc, A, B, C, D, t)
     assert fused.shape == plain.shape and fused.shape[-3] == size + 2
     assert torch.equal(fused, plain)
+
+
+@pytest.mark.parametrize("preset", ["SMALL", "P4096"])
+def test_multiply_with_prepared_operands(fhe, oracle_mod, preset):
+    """fhe_multiply_prepared with either or both sides prepared equals fhe_multiply bit for bit
+    (sizes 2x3 and 4x2), and a prepared operand can be reused."""
+    import torch
+    ctx, _ = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    for sa, sb in ((2, 3), (4, 2)):
+        a, b = ctx.random_ct(3, size=sa, seed=500 + sa), ctx.random_ct(3, size=sb, seed=600 + sb)
+        ref = ev.multiply(a, b)
+        pa, pb = ev.prepare_operand(a), ev.prepare_operand(b)
+        assert torch.equal(ev.multiply(pa, b), ref)
+        assert torch.equal(ev.multiply(a, pb), ref)
+        assert torch.equal(ev.multiply(pa, pb), ref)
+        a2 = ctx.random_ct(3, size=sa, seed=700 + sa)
+        assert torch.equal(ev.multiply(a2, pb), ev.multiply(a2, b))
