@@ -81,7 +81,8 @@ def decode(args):
     def zeros(i, j, which):
         return bank[(i, j, which)]
 
-    fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, 64, 1, 0.5, 1, 1, zeros)   # warm-up
+    # warm-up at full size: scratch buffers and the allocator cache reach their steady state
+    fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=args.degree, delta=0.5, width=args.positions, height=1, zeros=zeros)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=args.degree, delta=0.5,
