@@ -127,7 +127,8 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
     fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     try:
         os.ftruncate(fout, n_blocks * 192 * rec_bytes)
-        with ThreadPoolExecutor(_IO_THREADS) as pool:
+        # separate pools: reads of the next wave must not queue behind the writes of the previous one
+        with ThreadPoolExecutor(_IO_THREADS) as pool, ThreadPoolExecutor(_IO_THREADS) as wpool:
             wait(read_wave(pool, fin, host[0], 0, waves[0][1] - waves[0][0]))
             pending = [[], []]
             for wi, (s, e) in enumerate(waves):
@@ -150,7 +151,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                 wait(pending[wi & 1])                       # host_out[wi & 1] was queued two waves ago
                 host_out[wi & 1][:nb].copy_(res, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-                pending[wi & 1] = write_wave(pool, fout, host_out[wi & 1], s, nb)
+                pending[wi & 1] = write_wave(wpool, fout, host_out[wi & 1], s, nb)
                 wait(reading)
             wait(pending[0])
             wait(pending[1])
