@@ -13,12 +13,14 @@
 // Dataflow per (block, polynomial j, prime i):
 //   kernel A (rows):    for each row: x_m = d_m +- d_(7-m) on coefficients, forward NTT of the
 //                       four sums (even half) or differences (odd half), the even/odd part of the
-//                       LL&M row pass per NTT slot, store the four row outputs (NTT form, FP64)
+//                       LL&M row pass per NTT slot, store the four row outputs (NTT form; packed to
+//                       40 bytes per thread and polynomial for primes <= 37 bits, FP64 otherwise)
 //   kernel B (columns): same for columns on the NTT-form intermediates, per-output scale
 //                       encode(0.125)*encode(1/quant) folded into one product, inverse NTT, store.
-// Each workgroup (256 threads at n=4096) carries 4 polynomials x 16 coefficients per thread in
-// registers and shares every twiddle across the four; the even and odd workgroup of a line read the
-// same eight inputs and are placed on the same XCD (blockIdx = 16g+u and 16g+8+u) so the second
+// Each workgroup carries 4 polynomials x 2^LE coefficients per thread in registers (n = 4096: LE = 3,
+// 512 threads, 64 data VGPRs, two workgroups = four waves per SIMD) and shares every twiddle across
+// the four; the even and odd workgroup of a line read the same eight inputs and are placed on the
+// same XCD (blockIdx = 16g+u and 16g+8+u) so the second
 // read is an L2 hit.  All 832 Evaluator calls of the reference are exact ring operations, so this
 // evaluation order yields bit-identical ciphertexts.
 #include "internal.h"
