@@ -716,3 +716,43 @@ def test_multiply_with_prepared_operands(fhe, oracle_mod, preset):
         assert torch.equal(ev.multiply(pa, pb), ref)
         a2 = ctx.random_ct(3, size=sa, seed=700 + sa)
         assert torch.equal(ev.multiply(a2, pb), ev.multiply(a2, b))
+
+
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "SEAL23_4096"])
+def test_randomised_op_sequences_vs_oracle(fhe, oracle_mod, preset):
+    """seeded random sequences of Evaluator calls on small batches (odd and even counts, sparse and
+    dense plaintexts, mixed sizes) replayed on the oracle: every intermediate must match bit for bit"""
+    import random
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    enc = fhe.FractionalEncoder(ctx)
+    rng = random.Random(20260929 + len(preset))
+    consts = [3.0, -2.0, 0.5, 0.299, -1.847759065, 128.0, 1.0 / 16, 0.587]
+    for trial in range(6):
+        count = rng.choice([1, 2, 3, 5])
+        dev = [ctx.random_ct(count, size=2, seed=rng.randrange(1 << 30)) for _ in range(3)]
+        host = [fhe.to_host(d).copy() for d in dev]            # [count, size, k, n]
+        for step in range(5):
+            op = rng.choice(["add", "sub", "negate", "mulplain", "addplain", "subplain", "multiply"])
+            i, j = rng.randrange(3), rng.randrange(3)
+            if op in ("add", "sub"):
+                dev[i] = getattr(ev, op)(dev[i], dev[j])
+                host[i] = np.stack([getattr(orc, op)(host[i][c], host[j][c]) for c in range(count)])
+            elif op == "negate":
+                dev[i] = ev.negate(dev[i])
+                host[i] = np.stack([orc.negate(host[i][c]) for c in range(count)])
+            elif op == "mulplain":
+                p = enc.encode(rng.choice(consts))
+                dev[i] = ev.multiply_plain(dev[i], p)
+                host[i] = np.stack([orc.multiply_plain(host[i][c], p) for c in range(count)])
+            elif op in ("addplain", "subplain"):
+                p = enc.encode(rng.choice(consts))
+                name = "add_plain" if op == "addplain" else "sub_plain"
+                dev[i] = getattr(ev, name)(dev[i], p)
+                host[i] = np.stack([getattr(orc, name)(host[i][c], p) for c in range(count)])
+            else:
+                if host[i].shape[1] + host[j].shape[1] > 5:
+                    continue
+                dev[i] = ev.multiply(dev[i], dev[j])
+                host[i] = np.stack([orc.multiply(host[i][c], host[j][c]) for c in range(count)])
+            assert np.array_equal(fhe.to_host(dev[i]), host[i]), (preset, trial, step, op)
