@@ -234,7 +234,7 @@ inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(row
 
 }  // namespace
 
-static int behz_build(fhe_ctx *c) {
+int fhe_behz_build(fhe_ctx *c) {
     using namespace hostmath;
     if (c->behz) return FHE_OK;
     const u32 k = c->k, n = c->n;
@@ -366,9 +366,9 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, const u64 *ap, u32 sa,
     if (!cc || (!a && !ap) || (!b && !bp) || !out) return fail(FHE_ERR_PARAM, "null argument");
     if (sa < 1 || sb < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
     if (!count) return FHE_OK;
-    fhe_ctx *c = const_cast<fhe_ctx *>(cc);   // lazily built tables; contexts are not shared across threads during creation
-    int rc = behz_build(c);
-    if (rc) return rc;
+    const fhe_ctx *c = cc;
+    int rc;
+    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
     const bool square = !ap && !bp && a == b && sa == sb;
     if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
         return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
@@ -403,9 +403,8 @@ extern "C" int fhe_multiply_prepare(const fhe_ctx *cc, const uint64_t *a, uint32
     if (!cc || !a || !prepared) return fail(FHE_ERR_PARAM, "null argument");
     if (!size) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
     if (!count) return FHE_OK;
-    fhe_ctx *c = const_cast<fhe_ctx *>(cc);
-    int rc = behz_build(c);
-    if (rc) return rc;
+    const fhe_ctx *c = cc;
+    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
     u64 *xq = (u64 *)prepared, *xb = xq + count * size * (size_t)c->k * c->n;
     return behz_prepare(c, (const u64 *)a, size, count, xq, xb, (hipStream_t)s);
 }
@@ -440,9 +439,9 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     if (!cc || !ct3 || !evk) return fail(FHE_ERR_PARAM, "null argument");
     if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (!count) return FHE_OK;
-    fhe_ctx *c = const_cast<fhe_ctx *>(cc);
-    int rc = behz_build(c);
-    if (rc) return rc;
+    const fhe_ctx *c = cc;
+    int rc;
+    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
     if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
     hipStream_t st = (hipStream_t)s;

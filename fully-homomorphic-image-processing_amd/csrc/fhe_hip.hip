@@ -171,19 +171,32 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         c->upper_half_increment[i] = q_mod_t % qi;
         c->delta_mod[i] = mulmod(submod(0, q_mod_t % qi, qi), invmod(t % qi, qi), qi);
     }
+    // everything a compute entry point needs is built here, so that a context is immutable afterwards
+    // (apart from the mutex-guarded rgb constant cache) and may be shared by threads: the ct x ct
+    // tables (auxiliary base, conversion constants) and the second stream of the pipelined DCT path
+    if ((rc = fhe_behz_build(c))) { fhe_ctx_destroy(c); return rc; }
+    bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_cols[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { fhe_ctx_destroy(c); return fail(FHE_ERR_HIP, "stream/event creation failed"); }
     *out = c;
     return FHE_OK;
 }
 
 extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     if (!c) return FHE_OK;
-    if (c->aux_stream) {
-        (void)hipStreamDestroy(c->aux_stream);
-        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_rows[i]); (void)hipEventDestroy(c->ev_cols[i]); }
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
+        if (c->ev_cols[i]) (void)hipEventDestroy(c->ev_cols[i]);
     }
-    if (c->rgb.d_c) (void)hipFree(c->rgb.d_c);
-    if (c->rgb.d_c_f64) (void)hipFree(c->rgb.d_c_f64);
-    if (c->rgb.d_off) (void)hipFree(c->rgb.d_off);
+    for (fhe_ctx::RgbConsts *r : c->rgb) {
+        if (r->d_c) (void)hipFree(r->d_c);
+        if (r->d_c_f64) (void)hipFree(r->d_c_f64);
+        if (r->d_off) (void)hipFree(r->d_off);
+        delete r;
+    }
     fhe_behz_free(c);
     fhe_free_base(c->qb);
     delete c;
@@ -907,14 +920,7 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
         // Two half-size intermediates: the column kernel of wave w runs on a second stream while the
         // row kernel of wave w+1 runs on the caller's stream, so workgroups of both kinds share the CUs
         // (row work is FP64-issue heavy, column work waits more on memory) and launch tails overlap.
-        fhe_ctx *mc = const_cast<fhe_ctx *>(c);
-        if (!mc->aux_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&mc->aux_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
-                HIP_TRY(hipEventCreateWithFlags(&mc->ev_rows[i], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&mc->ev_cols[i], hipEventDisableTiming));
-            }
-        }
+        const fhe_ctx *mc = c;      // stream and events belong to the context: one pipelined call per context at a time
         wave = wave / 2 < 1 ? 1 : wave / 2;
         double *midbuf[2] = {(double *)scratch, (double *)scratch + wave * per_block};
         u64 w = 0;
@@ -1007,13 +1013,8 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_rgb2ycc(u64 *__restrict__ R
 static int rgb_consts(const fhe_ctx *c, int int_coeffs, int frac_coeffs, hipStream_t st, const fhe_ctx::RgbConsts **out) {
     using namespace hostmath;
     std::lock_guard<std::mutex> lock(c->rgb_mutex);
-    fhe_ctx::RgbConsts &rc_ = c->rgb;
-    if (rc_.d_c && rc_.int_coeffs == int_coeffs && rc_.frac_coeffs == frac_coeffs) { *out = &rc_; return FHE_OK; }
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(FHE_ERR_HIP, "stream sync failed");   // earlier users of the old tables
-    if (rc_.d_c) (void)hipFree(rc_.d_c);
-    if (rc_.d_c_f64) (void)hipFree(rc_.d_c_f64);
-    if (rc_.d_off) (void)hipFree(rc_.d_off);
-    rc_ = fhe_ctx::RgbConsts();
+    for (const fhe_ctx::RgbConsts *r : c->rgb)
+        if (r->int_coeffs == int_coeffs && r->frac_coeffs == frac_coeffs) { *out = r; return FHE_OK; }
     static const double cc[9] = {0.299, 0.587, 0.114, -0.168736, 0.331264, 0.5, 0.5, 0.418688, 0.081312};
     const size_t pw = (size_t)c->k * c->n;
     std::vector<uint64_t> plain(c->n);
@@ -1043,8 +1044,8 @@ static int rgb_consts(const fhe_ctx *c, int int_coeffs, int frac_coeffs, hipStre
     if (hipStreamSynchronize(st) != hipSuccess) return drop(fail(FHE_ERR_HIP, "stream sync failed"));
     t.int_coeffs = int_coeffs;
     t.frac_coeffs = frac_coeffs;
-    rc_ = t;
-    *out = &rc_;
+    c->rgb.push_back(new fhe_ctx::RgbConsts(t));
+    *out = c->rgb.back();
     return FHE_OK;
 }
 

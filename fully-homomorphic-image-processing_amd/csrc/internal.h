@@ -47,11 +47,13 @@ struct fhe_ctx {
     u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
     struct BehzTables *behz = nullptr;                 // ct x ct tables (behz.hip)
     // second stream + events for overlapping the column kernel of one wave of blocks with the row
-    // kernel of the next (fhe_dct8x8_quant); created on first use
+    // kernel of the next (fhe_dct8x8_quant); created with the context
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
-    // rgb_to_ycc_fhe constants (nine encoded factors + Delta*encode(128)), built on first use for one
-    // (int_coeffs, frac_coeffs) pair and kept: the reference re-encodes them on every call
+    // rgb_to_ycc_fhe constants (nine encoded factors + Delta*encode(128)), built on first use of each
+    // (int_coeffs, frac_coeffs) pair under rgb_mutex and kept until the context is destroyed (entries are
+    // never freed or moved while the context lives, so a pointer handed to an in-flight launch stays valid):
+    // the reference re-encodes them on every call
     struct RgbConsts {
         int int_coeffs = -1, frac_coeffs = -1;
         ulonglong2 *d_c = nullptr;      // [9][k][n] Shoup pairs, u64 kernels' slot order
@@ -59,7 +61,7 @@ struct fhe_ctx {
         u64 *d_off = nullptr;           // [k][off_len]
         u32 off_len = 0;
     };
-    mutable RgbConsts rgb;
+    mutable std::vector<RgbConsts *> rgb;
     mutable std::mutex rgb_mutex;
 };
 
@@ -86,6 +88,7 @@ struct fhe_dct_plan {
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
 int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
 void fhe_free_base(BaseTables &B);
+int fhe_behz_build(fhe_ctx *c);   // called once from fhe_ctx_create
 void fhe_behz_free(fhe_ctx *c);
 // fused FP64 DCT path (dct_fused.hip)
 bool fhe_dct_f64_supported(const fhe_ctx *c);

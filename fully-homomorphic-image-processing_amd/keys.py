@@ -8,6 +8,7 @@ final exact rounding t*x/q (big integers) are host work.  Textbook BFV as in SUR
   Dec(c) = round(t/q [sum_j c_j s^j]_q) mod t;   evk[i][d] = (-(a s + e) + 2^(dbc d) s^2 E_i, a)
 """
 import ctypes as C
+import os
 from functools import reduce
 
 import numpy as np
@@ -17,10 +18,41 @@ from . import _lib
 from .evaluator import _ptr, _stream, to_device, to_host
 
 
+class _OsRandom:
+    """numpy-Generator-shaped sampling backed by the operating system's CSPRNG (os.urandom):
+    rejection sampling for the integers (no modulo bias), Box-Muller for the clipped normal."""
+
+    @staticmethod
+    def _words(count):
+        return np.frombuffer(os.urandom(8 * count), dtype=np.uint64)
+
+    def integers(self, low, high, size, dtype=np.int64):
+        bound = int(high) - int(low)
+        limit = ((1 << 64) // bound) * bound
+        out = np.empty(size, dtype=np.uint64)
+        filled = 0
+        while filled < size:
+            w = self._words(size - filled + 16)
+            if limit < (1 << 64):
+                w = w[w < np.uint64(limit)]
+            take = min(len(w), size - filled)
+            out[filled:filled + take] = w[:take] % np.uint64(bound)
+            filled += take
+        return (out + np.uint64(low)).astype(dtype)
+
+    def normal(self, mean, sigma, size):
+        u1 = ((self._words(size) >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740993.0
+        u2 = ((self._words(size) >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740993.0
+        return mean + sigma * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
 class _Sampler:
+    """seed=None (the default): every draw comes from the OS CSPRNG.  An explicit seed selects a
+    reproducible numpy PCG64 stream -- tests only; never pass a seed for keys that protect data."""
+
     def __init__(self, ctx, seed=None):
         self.ctx = ctx
-        self.rng = np.random.default_rng(seed)
+        self.rng = _OsRandom() if seed is None else np.random.default_rng(seed)
 
     def ternary(self):
         v = self.rng.integers(0, 3, size=self.ctx.n)

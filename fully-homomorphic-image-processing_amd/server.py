@@ -2,8 +2,9 @@
 
 The reference reads one 8x8 block of R, G and B ciphertexts at a time from ./image/nothingpersonnel.txt
 (3 x 64 Ciphertext::load calls, :115-124), runs rgb_to_ycc_fhe on the 64 pixels and encrypted_dct on
-the three channels (:127-135) and appends Y, Cb, Cr interleaved per coefficient to ./image/zoop.txt
-(:146-153).  Here the same stream is processed in waves of many blocks: a reader thread fills pinned
+the three channels (:127-135) and appends the block's 64 Y, then 64 Cb, then 64 Cr ciphertexts to
+./image/zoop.txt (save_three_blocks_interleaved_ycc, :146-153: "interleaved by block", channel-major
+inside a block -- the order homo/client_jpeg.cpp:266-271 reads back: for k<3, for j<64).  Here the same stream is processed in waves of many blocks: a reader thread fills pinned
 host buffers while the GPU works on the previous wave (file -> pinned -> HBM overlap), the colour
 conversion and the block transform are the fused kernels, and the writer drains the previous wave.
 
@@ -83,8 +84,8 @@ def _pwrite_records(fd, views, first_record, rec_bytes, hdr):
 
 def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True):
     """Process `n_blocks` colour blocks.  Input order per block: 64 R, 64 G, 64 B ciphertexts
-    (homo/server_jpeg.cpp:115-124).  Output order per block: for i in 0..63: Y[i], Cb[i], Cr[i]
-    (homo/server_jpeg.cpp:150-152).  quant=None reproduces the reference server (no quantize_fhe call);
+    (homo/server_jpeg.cpp:115-124).  Output order per block: 64 Y, 64 Cb, 64 Cr
+    (homo/server_jpeg.cpp:146-153; read back channel-major by homo/client_jpeg.cpp:266-271).  quant=None reproduces the reference server (no quantize_fhe call);
     a 64-entry table applies quantize_fhe to every channel as well.  Returns blocks processed.
 
     Pipeline per wave of blocks: a pool of I/O threads reads the next wave's fixed-size records with
@@ -113,10 +114,10 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
 
     def write_wave(pool, fd, buf, first_block, nb):
         arr = buf.numpy().view(np.uint64)
-        # output order i-major, channel-minor: one task per (block, 16 coefficients)
-        return [pool.submit(_pwrite_records, fd, [arr[b, ch, i] for i in range(i0, i0 + 16) for ch in range(3)],
-                            (first_block + b) * 192 + i0 * 3, rec_bytes, out_hdr)
-                for b in range(nb) for i0 in range(0, 64, 16)]
+        # record index (first_block + b) * 192 + ch * 64 + i: one task per (block, channel)
+        return [pool.submit(_pwrite_records, fd, [arr[b, ch, i] for i in range(64)],
+                            ((first_block + b) * 3 + ch) * 64, rec_bytes, out_hdr)
+                for b in range(nb) for ch in range(3)]
 
     def wait(futs):
         for f in futs:

@@ -18,6 +18,13 @@
  *    compute entry point fails with FHE_ERR_HIP.
  *  - ciphertext layout (SEAL-logical): u64 [ciphertext][poly j][prime i][coeff c], every residue
  *    fully reduced to [0, q_i).  "n_polys" counts RNS polynomials, i.e. size * number of cts.
+ *  - threading: a context is immutable after fhe_ctx_create (every table, including the ct x ct
+ *    auxiliary base, is built there) and may be shared by any number of host threads issuing calls on
+ *    their own streams; the only state created later is the rgb_to_ycc constant cache, which is
+ *    mutex-guarded and never frees an entry while the context lives.  Two restrictions: (1) the
+ *    pipelined DCT mode (FHE_DCT_PIPELINE=1) uses one second stream owned by the context, so at most
+ *    one fhe_dct8x8_quant call per context may be in flight in that mode; (2) fhe_ctx_destroy must not
+ *    race with any other call on the same context.  Plans and scratch buffers belong to their caller.
  *  - "NTT form" buffers use a library-internal slot order; they are only meaningful to this
  *    library (produced by fhe_plain_prepare / fhe_ntt_forward, consumed by the matching calls).
  */

@@ -11,6 +11,23 @@ This script runs the reference's UNMODIFIED mains, compiled by oracle/Makefile a
 the oracle-backed C ABI (oracle/libfhe_cabi_oracle.so), on tests/golden/boazbarak.jpg and compares.
 usage: python oracle/pin_against_reference.py [--n 2048] [--pmod 11 31 ...] [--jobs 3] [--gpu]
   --gpu uses oracle/_ref/ref_*_jpeg (libfhe_hip.so, needs an MI355X) instead of the *_cpu builds.
+  --resize bilinear|bicubic runs the resize pipeline instead (see PUBLISHED_RESIZE below).
+
+Resize pipeline (benchmark/benchmark.py:18-29: client_resize --send, server_resize [--bicubic],
+client_resize --recieve, 48x48 -> 17x17).  These runs go through Evaluator::multiply / square (BEHZ):
+Linear has two ciphertext products, Cubic five, and the decrypted pixels -- hence the RMSError against
+cv::resize(cv::imread(file), INTER_LINEAR), homo/fhe_resize.h:35-68 -- are right only if those products
+are.  (benchmark.py never passes --bicubic to the receiving client, so both modes are compared with
+INTER_LINEAR.)  OpenCV is absent from this image; the compare step uses the validated stand-in
+tests/stubs/opencv2/opencv.hpp.  Only the deterministic entries of the reference's table are listed:
+  17.9597  bilinear, noise budget intact            19.8048  bicubic (t3 = t*t quirk included), budget intact
+  34.4     bicubic at t = 11: the plaintext wraps mod t, deterministically.  NOT reproduced here: oracle, GPU
+           and the exact plaintext-ring model tools/plain_ring_model.py all give 29.715
+  113.692  budget exhausted: every pixel decodes to garbage, `int pixel = decode()` saturates and
+           CLAMP gives 0 -- the RMS of the INTER_LINEAR image against black; pins the stand-in alone
+The reference also recorded 67.2706 (bilinear 2048/307) and 20.004 / 30.8092 / 113.438 (bicubic 4096 at
+t = 3001 / 10007 / 30011): runs on the edge of the noise budget whose value depends on the random
+noise; they cannot be reproduced by any implementation and are left out.
 """
 import argparse, json, os, shutil, subprocess, sys, tempfile, time
 from concurrent.futures import ThreadPoolExecutor
@@ -19,6 +36,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # benchmark/results.txt: jpg_boaz_<n>_<t>.txt -> RMSError (same for n = 2048, 4096, 8192, 16384)
 PUBLISHED = {11: "72.7491", 31: "77.6639", 101: "114.663", 307: "35.672", 1009: "1.71783",
              3001: "1.71767", 10007: "1.71767", 30011: "1.71767", 100003: "1.71767"}
+
+
+# benchmark/results.txt: resize_boaz_<inter>_17_17_<n>_<t>.txt -> RMSError, deterministic entries only
+PUBLISHED_RESIZE = {}
+for _n in (2048, 4096, 8192, 16384):
+    for _t in (11, 31, 101, 307, 1009, 3001, 10007, 30011, 100003):
+        if _n >= 4096 or _t <= 101:
+            PUBLISHED_RESIZE[("bilinear", _n, _t)] = "17.9597"
+        elif _t >= 1009:
+            PUBLISHED_RESIZE[("bilinear", _n, _t)] = "113.692"
+        if _n == 2048:
+            PUBLISHED_RESIZE[("bicubic", _n, _t)] = "113.692"
+        elif _t == 11:
+            PUBLISHED_RESIZE[("bicubic", _n, _t)] = "34.4"
+        elif _n >= 8192 or _t <= 1009:
+            PUBLISHED_RESIZE[("bicubic", _n, _t)] = "19.8048"
+        elif _n == 4096 and _t == 100003:
+            PUBLISHED_RESIZE[("bicubic", _n, _t)] = "113.692"
+
+
+def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17):
+    """client_resize --send / server_resize / client_resize --recieve exactly as benchmark/benchmark.py:18-29
+    runs them; returns (RMSError string, seconds, the reference's own per-call timer values of the server)."""
+    sfx = "" if gpu else "_cpu"
+    cl = os.path.join(ROOT, "oracle", "_ref", "ref_client_resize" + sfx)
+    sv = os.path.join(ROOT, "oracle", "_ref", "ref_server_resize" + sfx)
+    image = image or os.path.join(ROOT, "tests", "golden", "boazbarak.jpg")
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        os.makedirs(d + "/keys"); os.makedirs(d + "/image")
+        shutil.copy(image, d + "/image/in.jpg")
+        par = ["--width", str(width), "--height", str(height), "--cmod", str(n), "--pmod", str(t)]
+        timers = []
+        for argv in ([cl, "--send", "-f", "image/in.jpg", "-o", "image/ct_in.txt"] + par,
+                     [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt"] + par + (["--bicubic"] if inter == "bicubic" else []),
+                     [cl, "--recieve", "-f", "image/in.jpg", "-c", "image/ct_out.txt", "-o", "image/out.png"] + par):
+            r = subprocess.run(argv, cwd=d, capture_output=True, text=True)
+            if r.returncode:
+                raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-1000:])
+            if argv[0] == sv:
+                timers = [float(x) for ln in r.stdout.splitlines() if ln.startswith(("Linear,", "Cubic,")) for x in ln.split(",")[1:] if x.strip()]
+        rms = [ln.split(",")[1] for ln in r.stdout.splitlines() if ln.startswith("RMSError,")]
+    return rms[0] if rms else None, time.time() - t0, timers
 
 
 def run_set(n, t, gpu=False, image=None):
@@ -48,7 +108,22 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=3)
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--resize", choices=["bilinear", "bicubic"], default=None)
     a = ap.parse_args()
+    if a.resize:
+        sets = [t for t in a.pmod if (a.resize, a.n, t) in PUBLISHED_RESIZE]
+        with ThreadPoolExecutor(a.jobs) as ex:
+            res = list(ex.map(lambda t: (t,) + run_resize_set(a.resize, a.n, t, a.gpu), sets))
+        rows, ok = [], True
+        for t, rms, dt, timers in res:
+            want = PUBLISHED_RESIZE[(a.resize, a.n, t)]
+            ok &= rms == want
+            rows.append({"inter": a.resize, "n": a.n, "plain_modulus": t, "rms": rms, "published": want, "match": rms == want,
+                         "seconds": round(dt, 1), "ms_per_call": round(sum(timers) / max(1, len(timers)), 3), "calls": len(timers)})
+            print(rows[-1], flush=True)
+        if a.out:
+            json.dump({"backend": "libfhe_hip.so (MI355X)" if a.gpu else "CPU oracle (libfhe_cabi_oracle.so)", "rows": rows}, open(a.out, "w"), indent=1)
+        sys.exit(0 if ok else 1)
     with ThreadPoolExecutor(a.jobs) as ex:
         res = list(ex.map(lambda t: (t,) + run_set(a.n, t, a.gpu), a.pmod))
     rows, ok = [], True

@@ -1,28 +1,426 @@
-// SYNTAX PROBE ONLY -- not a build of the reference and not an OpenCV replacement.
-// tests/test_facade_compile.py runs `g++ -fsyntax-only` over the reference's homo/fhe_resize.h and
-// homo/fhe_decode.h (which include <opencv2/opencv.hpp> for debug/compare helpers unrelated to the
-// ciphertext path) to show that seal/seal.h declares every SEAL name those headers use.  Nothing
-// is linked or executed; the declarations below only name what the reference's helper code mentions.
+// tests/stubs/opencv2/opencv.hpp -- TEST INFRASTRUCTURE: a stand-in for the four OpenCV calls behind the
+// reference's `RMSError` check of the resize pipeline (homo/fhe_resize.h:35-68 compare_resize_opencv:
+// cv::imread + cv::resize(INTER_LINEAR) + Mat::at<Vec3b>), plus names-only stubs for the display helpers.
+// OpenCV is not installed in this image.  Nothing here is part of the product or of the ciphertext path:
+// homo/fhe_resize.h and homo/fhe_decode.h include <opencv2/opencv.hpp> only for debug/compare helpers.
+//
+// Why it has to be bit-faithful: the reference's published bilinear/bicubic RMSError values
+// (benchmark/results.txt: 17.9597, 19.8048, 34.4, and 113.692 for exhausted noise budgets) compare the
+// decrypted image with cv::resize(cv::imread(file), INTER_LINEAR).  Reproducing them to all printed
+// digits pins the oracle and the GPU path for multiply/square-based circuits (tests/
+// test_reference_published_resize.py), which needs the same decoded pixels and the same fixed-point
+// resampling:
+//   imread  = baseline JPEG decode as libjpeg / libjpeg-turbo do it by default: Huffman, dequantise,
+//             jidctint.c "islow" inverse DCT (CONST_BITS 13, PASS1_BITS 2), h2v1/h2v2 "fancy" triangle
+//             upsampling, jdcolor.c YCbCr->RGB tables (SCALEBITS 16); output BGR like OpenCV.
+//   resize  = OpenCV's 8-bit path: float coefficients -> short at 11 fractional bits, horizontal pass
+//             in int, vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2 (INTER_LINEAR);
+//             (sum + 2^21) >> 22 (INTER_CUBIC, A = -0.75).
+// Validation of the stand-in itself: (a) tests/test_opencv_standin.py compares imread with Pillow's
+// libjpeg-turbo decode on generated JPEGs (4:4:4, 4:2:2, 4:2:0, odd sizes, restart markers);
+// (b) RMS(resize(imread(boazbarak.jpg),17x17), all-zero image) = 113.692, the value the reference
+// recorded for every run whose noise budget was exhausted -- independent of any FHE code.
 #pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
+
 namespace cv {
 typedef std::string String;
-struct Size { Size(int, int) {} };
-struct Vec3b { unsigned char val[3]; unsigned char &operator[](int i) { return val[i]; } };
-struct Mat {
-    int rows, cols;
-    unsigned char *data;
-    Mat() : rows(0), cols(0), data(0) {}
-    Mat(int, int, int) : rows(0), cols(0), data(0) {}
-    Mat(int, int, int, void *p) : rows(0), cols(0), data((unsigned char *)p) {}
-    template <class T> T &at(int, int) { static T t; return t; }
-    Mat clone() const { return *this; }
-};
+typedef unsigned char uchar;
+struct Size { int width, height; Size(int w = 0, int h = 0) : width(w), height(h) {} };
+struct Vec3b { uchar val[3]; uchar &operator[](int i) { return val[i]; } const uchar &operator[](int i) const { return val[i]; } };
 enum { IMREAD_COLOR = 1, INTER_LINEAR = 1, INTER_CUBIC = 2, WINDOW_AUTOSIZE = 1, CV_8UC3 = 16, CV_IMWRITE_PNG_COMPRESSION = 16 };
-inline Mat imread(const String &, int = 1) { return Mat(); }
-template <class V> inline bool imwrite(const String &, const Mat &, const V &) { return true; }
-inline bool imwrite(const String &, const Mat &) { return true; }
-inline void resize(const Mat &, Mat &, Size, double = 0, double = 0, int = 1) {}
+
+struct Mat {   // 8UC3 only
+    int rows, cols;
+    uchar *data;
+    std::shared_ptr<std::vector<uchar>> own;
+    Mat() : rows(0), cols(0), data(0) {}
+    Mat(int r, int c, int) : rows(r), cols(c), own(std::make_shared<std::vector<uchar>>((size_t)r * c * 3)) { data = own->data(); }
+    Mat(int r, int c, int, void *p) : rows(r), cols(c), data((uchar *)p) {}
+    template <class T> T &at(int i, int j) { return *(T *)(data + ((size_t)i * cols + j) * 3); }
+    template <class T> const T &at(int i, int j) const { return *(const T *)(data + ((size_t)i * cols + j) * 3); }
+    Mat clone() const { Mat m(rows, cols, CV_8UC3); if (rows > 0 && cols > 0) std::memcpy(m.data, data, (size_t)rows * cols * 3); return m; }
+    bool empty() const { return !data || !rows || !cols; }
+};
+
+namespace standin {
+// ---------------------------------------------------------------------------------------------------
+// baseline JPEG decoder, arithmetic as in libjpeg 6b / libjpeg-turbo defaults
+// ---------------------------------------------------------------------------------------------------
+struct Huff { uint8_t bits[17]; uint8_t vals[256]; int mincode[17], maxcode[18], valptr[17]; bool set; Huff() : set(false) {} };
+struct Comp { int id, h, v, tq, td, ta, pred, bw, bh; std::vector<uchar> plane; Comp() : id(0), h(1), v(1), tq(0), td(0), ta(0), pred(0), bw(0), bh(0) {} };
+struct BitReader {
+    const uchar *p, *end; uint32_t acc; int cnt; bool marker;
+    BitReader(const uchar *b, const uchar *e) : p(b), end(e), acc(0), cnt(0), marker(false) {}
+    void fill() {
+        while (cnt <= 24) {
+            int c = 0;
+            if (!marker && p < end) {
+                c = *p;
+                if (c == 0xFF) {
+                    if (p + 1 < end && p[1] == 0) p += 2;
+                    else { marker = true; c = 0; }
+                } else ++p;
+            }
+            acc |= (uint32_t)c << (24 - cnt);
+            cnt += 8;
+        }
+    }
+    int bit() { if (cnt < 1) fill(); int b = acc >> 31; acc <<= 1; --cnt; return b; }
+    int bits(int n) { if (!n) return 0; if (cnt < n) fill(); int v = (int)(acc >> (32 - n)); acc <<= n; cnt -= n; return v; }
+    void reset() { acc = 0; cnt = 0; marker = false; }
+};
+inline void build(Huff &h) {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        h.valptr[l] = k; h.mincode[l] = code;
+        code += h.bits[l]; k += h.bits[l];
+        h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    h.maxcode[17] = 0x7fffffff; h.set = true;
+}
+inline int decode_sym(BitReader &br, const Huff &h) {
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code = (code << 1) | br.bit();
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return 0;
+}
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+static const uchar kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+inline uchar clamp8(int v) { return (uchar)(v < 0 ? 0 : v > 255 ? 255 : v); }
+inline long descale(long x, int n) { return (x + (1L << (n - 1))) >> n; }
+// jidctint.c jpeg_idct_islow: coef[64] (natural order, already dequantised) -> 8x8 samples
+inline void idct_islow(const int *in, uchar *out, int stride) {
+    const long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069,
+               F2053 = 16819, F2562 = 20995, F3072 = 25172;
+    long ws[64];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < 8; ++i) {
+            long d[8];
+            for (int j = 0; j < 8; ++j) d[j] = pass == 0 ? in[j * 8 + i] : ws[i * 8 + j];
+            long z2 = d[2], z3 = d[6];
+            long z1 = (z2 + z3) * F0541;
+            long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+            z2 = d[0]; z3 = d[4];
+            long tmp0 = (z2 + z3) * 8192, tmp1 = (z2 - z3) * 8192;
+            const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            tmp0 = d[7]; tmp1 = d[5]; tmp2 = d[3]; tmp3 = d[1];
+            z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+            long z4 = tmp1 + tmp3;
+            const long z5 = (z3 + z4) * F1175;
+            tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+            z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+            z3 += z5; z4 += z5;
+            tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+            const long o[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+            if (pass == 0) for (int j = 0; j < 8; ++j) ws[j * 8 + i] = descale(o[j], 11);
+            else for (int j = 0; j < 8; ++j) {
+                // range_limit[(x) & 1023] centred at 128 (jdmaster.c prepare_range_limit_table)
+                const int x = (int)descale(o[j], 18) & 1023;
+                out[i * stride + j] = (uchar)(x < 128 ? x + 128 : x < 512 ? 255 : x < 896 ? 0 : x - 896);
+            }
+        }
+    }
+}
+// jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample on whole planes (edges replicate the last real row)
+inline void upsample_h2(const uchar *in, int w, uchar *out) {      // one row, w -> 2w (h2v1 fancy)
+    if (w == 1) { out[0] = out[1] = in[0]; return; }
+    out[0] = in[0]; out[1] = (uchar)((in[0] * 3 + in[1] + 2) >> 2);
+    for (int x = 1; x < w - 1; ++x) { const int v = in[x] * 3; out[2 * x] = (uchar)((v + in[x - 1] + 1) >> 2); out[2 * x + 1] = (uchar)((v + in[x + 1] + 2) >> 2); }
+    out[2 * w - 2] = (uchar)((in[w - 1] * 3 + in[w - 2] + 1) >> 2); out[2 * w - 1] = in[w - 1];
+}
+inline void upsample_h2v2_row(const uchar *near, const uchar *far, int w, uchar *out) {   // near/far input rows -> one output row of 2w
+    std::vector<int> cs(w);
+    for (int x = 0; x < w; ++x) cs[x] = near[x] * 3 + far[x];
+    if (w == 1) { out[0] = (uchar)((cs[0] * 4 + 8) >> 4); out[1] = (uchar)((cs[0] * 4 + 7) >> 4); return; }
+    out[0] = (uchar)((cs[0] * 4 + 8) >> 4); out[1] = (uchar)((cs[0] * 3 + cs[1] + 7) >> 4);
+    for (int x = 1; x < w - 1; ++x) { out[2 * x] = (uchar)((cs[x] * 3 + cs[x - 1] + 8) >> 4); out[2 * x + 1] = (uchar)((cs[x] * 3 + cs[x + 1] + 7) >> 4); }
+    out[2 * w - 2] = (uchar)((cs[w - 1] * 3 + cs[w - 2] + 8) >> 4); out[2 * w - 1] = (uchar)((cs[w - 1] * 4 + 7) >> 4);
+}
+
+inline bool decode_jpeg(const std::vector<uchar> &f, int &W, int &H, std::vector<uchar> &bgr) {
+    if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) return false;
+    uint16_t qt[4][64]; bool qset[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    std::vector<Comp> comps;
+    int restart = 0, hmax = 1, vmax = 1;
+    size_t pos = 2;
+    bool have_sof = false;
+    while (pos + 4 <= f.size()) {
+        if (f[pos] != 0xFF) return false;
+        const int m = f[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD9) break;
+        const size_t len = ((size_t)f[pos] << 8) | f[pos + 1];
+        if (pos + len > f.size()) return false;
+        const uchar *s = &f[pos + 2], *e = &f[pos + len];
+        if (m == 0xDB) {
+            while (s < e) {
+                const int pq = *s >> 4, tq = *s & 15; ++s;
+                if (tq > 3) return false;
+                for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = pq ? (uint16_t)((s[0] << 8) | s[1]) : s[0]; s += pq ? 2 : 1; }
+                qset[tq] = true;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (s[0] != 8) return false;
+            H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
+            const int nc = s[5];
+            if ((nc != 1 && nc != 3) || !W || !H) return false;
+            for (int i = 0; i < nc; ++i) { Comp c; c.id = s[6 + 3 * i]; c.h = s[7 + 3 * i] >> 4; c.v = s[7 + 3 * i] & 15; c.tq = s[8 + 3 * i]; c.pred = 0; comps.push_back(c); if (c.h > hmax) hmax = c.h; if (c.v > vmax) vmax = c.v; }
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            return false;                                   // progressive / lossless / arithmetic: not needed here
+        } else if (m == 0xC4) {
+            while (s < e) {
+                const int tc = *s >> 4, th = *s & 15; ++s;
+                if (th > 3) return false;
+                Huff &h = tc ? ac[th] : dc[th];
+                int total = 0;
+                h.bits[0] = 0;
+                for (int i = 1; i <= 16; ++i) { h.bits[i] = *s++; total += h.bits[i]; }
+                if (total > 256) return false;
+                for (int i = 0; i < total; ++i) h.vals[i] = *s++;
+                build(h);
+            }
+        } else if (m == 0xDD) {
+            restart = (s[0] << 8) | s[1];
+        } else if (m == 0xDA) {
+            if (!have_sof) return false;
+            const int ns = s[0];
+            if (ns != (int)comps.size()) return false;      // baseline interleaved scan only
+            for (int i = 0; i < ns; ++i)
+                for (auto &c : comps) if (c.id == s[1 + 2 * i]) { c.td = s[2 + 2 * i] >> 4; c.ta = s[2 + 2 * i] & 15; }
+            pos += len;
+            if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }    // single-component scan: MCU = one block
+            const int mcuw = 8 * hmax, mcuh = 8 * vmax, mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
+            for (auto &c : comps) {
+                c.bw = mx * c.h; c.bh = my * c.v;
+                c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+                if (!qset[c.tq] || !dc[c.td].set || !ac[c.ta].set) return false;
+            }
+            BitReader br(&f[pos], f.data() + f.size());
+            int togo = restart;
+            for (int row = 0; row < my; ++row)
+                for (int col = 0; col < mx; ++col) {
+                    if (restart && togo == 0) {             // expect RSTn
+                        br.reset();
+                        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+                        br.p += 2;
+                        for (auto &c : comps) c.pred = 0;
+                        togo = restart;
+                    }
+                    for (auto &c : comps)
+                        for (int by = 0; by < c.v; ++by)
+                            for (int bx = 0; bx < c.h; ++bx) {
+                                int blk[64];
+                                std::memset(blk, 0, sizeof blk);
+                                int s0 = decode_sym(br, dc[c.td]);
+                                int diff = s0 ? extend(br.bits(s0), s0) : 0;
+                                c.pred += diff;
+                                blk[0] = c.pred * qt[c.tq][0];
+                                for (int k = 1; k < 64;) {
+                                    const int rs = decode_sym(br, ac[c.ta]), r = rs >> 4, sz = rs & 15;
+                                    if (!sz) { if (r == 15) { k += 16; continue; } break; }
+                                    k += r;
+                                    if (k > 63) break;
+                                    blk[kZigzag[k]] = extend(br.bits(sz), sz) * qt[c.tq][kZigzag[k]];
+                                    ++k;
+                                }
+                                const int X = (col * c.h + bx) * 8, Y = (row * c.v + by) * 8;
+                                if (X + 8 <= c.bw * 8 && Y + 8 <= c.bh * 8) idct_islow(blk, &c.plane[(size_t)Y * c.bw * 8 + X], c.bw * 8);
+                            }
+                    --togo;
+                }
+            break;
+        }
+        if (m != 0xDA) pos += len;
+    }
+    if (comps.empty() || comps[0].plane.empty()) return false;
+    // upsample chroma to full resolution
+    std::vector<std::vector<uchar>> full(comps.size());
+    for (size_t ci = 0; ci < comps.size(); ++ci) {
+        Comp &c = comps[ci];
+        const int stride = c.bw * 8;
+        const int dw = (W * c.h + hmax - 1) / hmax, dh = (H * c.v + vmax - 1) / vmax;     // downsampled_width / height
+        std::vector<uchar> &o = full[ci];
+        if (c.h == hmax && c.v == vmax) {
+            o.resize((size_t)W * H);
+            for (int y = 0; y < H; ++y) std::memcpy(&o[(size_t)y * W], &c.plane[(size_t)y * stride], W);
+        } else if (c.h * 2 == hmax && c.v == vmax) {
+            o.resize((size_t)2 * dw * H);
+            for (int y = 0; y < H; ++y) upsample_h2(&c.plane[(size_t)y * stride], dw, &o[(size_t)y * 2 * dw]);
+            std::vector<uchar> t((size_t)W * H);
+            for (int y = 0; y < H; ++y) std::memcpy(&t[(size_t)y * W], &o[(size_t)y * 2 * dw], W);
+            o.swap(t);
+        } else if (c.h * 2 == hmax && c.v * 2 == vmax) {
+            std::vector<uchar> t((size_t)2 * dw * 2 * dh);
+            for (int y = 0; y < dh; ++y) {
+                const uchar *cur = &c.plane[(size_t)y * stride], *up = &c.plane[(size_t)(y ? y - 1 : 0) * stride], *dn = &c.plane[(size_t)(y + 1 < dh ? y + 1 : dh - 1) * stride];
+                upsample_h2v2_row(cur, up, dw, &t[(size_t)(2 * y) * 2 * dw]);
+                upsample_h2v2_row(cur, dn, dw, &t[(size_t)(2 * y + 1) * 2 * dw]);
+            }
+            o.resize((size_t)W * H);
+            for (int y = 0; y < H; ++y) std::memcpy(&o[(size_t)y * W], &t[(size_t)y * 2 * dw], W);
+        } else return false;
+    }
+    bgr.resize((size_t)W * H * 3);
+    if (comps.size() == 1) {
+        for (size_t i = 0; i < (size_t)W * H; ++i) bgr[3 * i] = bgr[3 * i + 1] = bgr[3 * i + 2] = full[0][i];
+        return true;
+    }
+    // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert
+    int crr[256], cbb[256]; long crg[256], cbg[256];
+    for (int i = 0; i < 256; ++i) {
+        const long x = i - 128;
+        crr[i] = (int)((91881L * x + 32768) >> 16);     // FIX(1.40200)
+        cbb[i] = (int)((116130L * x + 32768) >> 16);    // FIX(1.77200)
+        crg[i] = -46802L * x;                           // FIX(0.71414)
+        cbg[i] = -22554L * x + 32768;                   // FIX(0.34414)
+    }
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+        const int y = full[0][i], cb = full[1][i], cr = full[2][i];
+        bgr[3 * i + 2] = clamp8(y + crr[cr]);
+        bgr[3 * i + 1] = clamp8(y + (int)((cbg[cb] + crg[cr]) >> 16));
+        bgr[3 * i + 0] = clamp8(y + cbb[cb]);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cv::resize for 8UC3 (imgproc/src/resize.cpp: resizeGeneric_ with HResizeLinear / VResizeLinear,
+// HResizeCubic / VResizeCubic; INTER_RESIZE_COEF_BITS = 11)
+// ---------------------------------------------------------------------------------------------------
+inline int cv_round(double v) { return (int)std::nearbyint(v); }     // cvRound: round half to even
+inline short sat_short(float v) { int r = cv_round(v); return (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r); }
+inline void resize8u(const Mat &src, Mat &dst, int dw, int dh, int interp) {
+    const int sw = src.cols, sh = src.rows, cn = 3, ksize = interp == INTER_CUBIC ? 4 : 2, ksize2 = ksize / 2;
+    dst = Mat(dh, dw, CV_8UC3);
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> alpha((size_t)dw * ksize), beta((size_t)dh * ksize);
+    auto coeffs = [&](float fx, float *cb) {
+        if (interp == INTER_CUBIC) {
+            const float A = -0.75f;
+            cb[0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A;
+            cb[1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1;
+            cb[2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1;
+            cb[3] = 1.f - cb[0] - cb[1] - cb[2];
+        } else { cb[0] = 1.f - fx; cb[1] = fx; }
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        const int dn = pass ? dh : dw, sn = pass ? sh : sw;
+        const double scale = pass ? scale_y : scale_x;
+        for (int d = 0; d < dn; ++d) {
+            float fx = (float)((d + 0.5) * scale - 0.5);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (interp != INTER_CUBIC) {
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sn - 1) { fx = 0; sx = sn - 1; }
+            }
+            float cb[4];
+            coeffs(fx, cb);
+            (pass ? yofs : xofs)[d] = sx;
+            for (int k = 0; k < ksize; ++k) (pass ? beta : alpha)[(size_t)d * ksize + k] = sat_short(cb[k] * 2048.f);
+        }
+    }
+    auto clip = [](int v, int n) { return v < 0 ? 0 : v >= n ? n - 1 : v; };
+    std::vector<int> rows((size_t)sh * dw * cn);                       // horizontal pass of every source row
+    for (int y = 0; y < sh; ++y)
+        for (int d = 0; d < dw; ++d)
+            for (int c = 0; c < cn; ++c) {
+                int v = 0;
+                for (int k = 0; k < ksize; ++k) v += src.data[((size_t)y * sw + clip(xofs[d] - ksize2 + 1 + k, sw)) * cn + c] * alpha[(size_t)d * ksize + k];
+                rows[((size_t)y * dw + d) * cn + c] = v;
+            }
+    for (int d = 0; d < dh; ++d)
+        for (int x = 0; x < dw * cn; ++x) {
+            const short *b = &beta[(size_t)d * ksize];
+            int S[4];
+            for (int k = 0; k < ksize; ++k) S[k] = rows[(size_t)clip(yofs[d] - ksize2 + 1 + k, sh) * dw * cn + x];
+            int v;
+            if (interp == INTER_CUBIC) v = (int)(((long)S[0] * b[0] + (long)S[1] * b[1] + (long)S[2] * b[2] + (long)S[3] * b[3] + (1L << 21)) >> 22);
+            else v = (((b[0] * (S[0] >> 4)) >> 16) + ((b[1] * (S[1] >> 4)) >> 16) + 2) >> 2;
+            dst.data[(size_t)d * dw * cn + x] = clamp8(v);
+        }
+}
+
+// minimal PNG writer (stored deflate blocks) for save_image_rgb (homo/fhe_resize.h:104-121)
+inline uint32_t crc32(const uchar *p, size_t n, uint32_t c = 0) {
+    c = ~c;
+    for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1))); }
+    return ~c;
+}
+inline void png_chunk(FILE *f, const char *tag, const std::vector<uchar> &d) {
+    std::vector<uchar> b(tag, tag + 4);
+    b.insert(b.end(), d.begin(), d.end());
+    const uint32_t len = (uint32_t)d.size(), crc = crc32(b.data(), b.size());
+    const uchar L[4] = {(uchar)(len >> 24), (uchar)(len >> 16), (uchar)(len >> 8), (uchar)len}, C[4] = {(uchar)(crc >> 24), (uchar)(crc >> 16), (uchar)(crc >> 8), (uchar)crc};
+    std::fwrite(L, 1, 4, f); std::fwrite(b.data(), 1, b.size(), f); std::fwrite(C, 1, 4, f);
+}
+inline bool write_png(const String &name, const Mat &m) {
+    FILE *f = std::fopen(name.c_str(), "wb");
+    if (!f) return false;
+    static const uchar sig[8] = {0x89, 'P', 'N', 'G', 13, 10, 26, 10};
+    std::fwrite(sig, 1, 8, f);
+    std::vector<uchar> ihdr = {(uchar)(m.cols >> 24), (uchar)(m.cols >> 16), (uchar)(m.cols >> 8), (uchar)m.cols,
+                               (uchar)(m.rows >> 24), (uchar)(m.rows >> 16), (uchar)(m.rows >> 8), (uchar)m.rows, 8, 2, 0, 0, 0};
+    png_chunk(f, "IHDR", ihdr);
+    std::vector<uchar> raw;
+    for (int y = 0; y < m.rows; ++y) {
+        raw.push_back(0);
+        for (int x = 0; x < m.cols; ++x) { const uchar *p = m.data + ((size_t)y * m.cols + x) * 3; raw.push_back(p[2]); raw.push_back(p[1]); raw.push_back(p[0]); }
+    }
+    std::vector<uchar> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uchar c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    for (size_t o = 0; o < raw.size() || o == 0; o += 65535) {
+        const size_t n = raw.size() - o < 65535 ? raw.size() - o : 65535;
+        z.push_back(o + n >= raw.size()); z.push_back((uchar)n); z.push_back((uchar)(n >> 8)); z.push_back((uchar)~n); z.push_back((uchar)(~n >> 8));
+        z.insert(z.end(), raw.begin() + o, raw.begin() + o + n);
+        if (raw.empty()) break;
+    }
+    const uint32_t ad = (b << 16) | a;
+    z.push_back((uchar)(ad >> 24)); z.push_back((uchar)(ad >> 16)); z.push_back((uchar)(ad >> 8)); z.push_back((uchar)ad);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", std::vector<uchar>());
+    std::fclose(f);
+    return true;
+}
+}  // namespace standin
+
+inline Mat imread(const String &name, int = IMREAD_COLOR) {
+    FILE *f = std::fopen(name.c_str(), "rb");
+    if (!f) return Mat();
+    std::vector<uchar> buf;
+    uchar tmp[65536];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    std::fclose(f);
+    int W = 0, H = 0;
+    std::vector<uchar> bgr;
+    if (!standin::decode_jpeg(buf, W, H, bgr)) return Mat();
+    Mat m(H, W, CV_8UC3);
+    std::memcpy(m.data, bgr.data(), bgr.size());
+    return m;
+}
+inline void resize(const Mat &src, Mat &dst, Size sz, double = 0, double = 0, int interpolation = INTER_LINEAR) {
+    if (src.empty() || sz.width <= 0 || sz.height <= 0) { dst = Mat(); return; }
+    standin::resize8u(src, dst, sz.width, sz.height, interpolation);
+}
+template <class V> inline bool imwrite(const String &name, const Mat &m, const V &) { return standin::write_png(name, m); }
+inline bool imwrite(const String &name, const Mat &m) { return standin::write_png(name, m); }
 inline void namedWindow(const String &, int = 1) {}
 inline void imshow(const String &, const Mat &) {}
 inline int waitKey(int = 0) { return 0; }

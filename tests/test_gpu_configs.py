@@ -1,0 +1,106 @@
+"""GPU: BASELINE.json configs[2] and configs[3] at their STATED parameters -- n = 8192, the four 54/55-bit
+SEAL 2.3 moduli (preset P8192: general u64 kernels + 61-bit auxiliary base, a different kernel path from
+the 36-bit sets the small circuit tests use) -- checked, not just timed.
+
+configs[2]  bicubic resize 128x128 -> 64x64 (homo/fhe_resize.h:254-392), one colour channel: the full sample
+            plan in batches; sampled output pixels bit-equal to the oracle; the whole 4096-pixel output
+            independent of how it is batched (order-independent digest over all 18 GiB of results).
+configs[3]  approximated_step (homo/fhe_decode.h:202-242), W*H = 16, degree 12, size-22 results: one
+            position bit-equal to the oracle (24 Taylor polynomials + 12 products of sizes 11x11 on the
+            host, ~1 min), all 16 positions bit-equal to the REFERENCE's own code run op by op through the
+            facade (oracle/_ref/ref_decode_circuit), when that binary was built."""
+import numpy as np
+import pytest
+
+from refrun import oracle_sample, ref_bin, run_decode_circuit, sample_origins
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_bicubic_128_to_64_at_n8192(fhe, oracle_mod):
+    import torch
+    ctx = fhe.SEALContext.preset("P8192")
+    orc = oracle_mod.Oracle.preset("P8192")
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    W = H = 128
+    w = h = 64
+    taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+    pixels = ctx.random_ct(W * H, size=2, seed=fhe.SEED)                     # 8 GiB, resident
+    n_out = w * h
+    xf_all, yf_all = ctx.random_ct(n_out, size=2, seed=11), ctx.random_ct(n_out, size=2, seed=12)
+    origins = sample_origins(W, H, w, h)
+    picks = {0: None, 63: None, 64 * 31 + 17: None, n_out - 1: None}           # corners (clamped taps) and an interior pixel
+
+    def run(batch):
+        total = 0
+        for s in range(0, n_out, batch):
+            e = min(s + batch, n_out)
+            out = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf_all[s:e].contiguous(), yf_all[s:e].contiguous())
+            assert out.shape == (e - s, 6, ctx.k, ctx.n)
+            total = (total + ev.digest(out, index0=s * 6 * ctx.k * ctx.n)) % (1 << 64)
+            for o in picks:
+                if s <= o < e and picks[o] is None:
+                    picks[o] = fhe.to_host(out[o - s:o - s + 1])[0]
+            del out
+        torch.cuda.synchronize()
+        return total
+
+    d256 = run(256)
+    d192 = run(192)                                                            # other chunk boundaries, other batch shapes
+    assert d256 == d192
+    hp = {}
+    for o, got in picks.items():
+        xi, yi = origins[o]
+        need = sorted({min(max(yi + dy, 0), H - 1) * W + min(max(xi + dx, 0), W - 1) for dx in (-1, 0, 1, 2) for dy in (-1, 0, 1, 2)})
+        for i in need:
+            if i not in hp:
+                hp[i] = fhe.to_host(pixels[i:i + 1])[0]
+        pix = {i: hp[i][None] for i in need}                                   # oracle_sample indexes pix[idx, ch]
+
+        class View:
+            def __getitem__(self, key):
+                return pix[key[0]][key[1]]
+        ref = oracle_sample(orc, View(), W, H, xi, yi, 0, fhe.to_host(xf_all[o:o + 1])[0], fhe.to_host(yf_all[o:o + 1])[0], True)
+        assert np.array_equal(got, ref), o
+
+
+def test_config3_approximated_step_16_positions_degree_12_at_n8192(fhe, oracle_mod, tmp_path):
+    ctx = fhe.SEALContext.preset("P8192")
+    orc = oracle_mod.Oracle.preset("P8192")
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    npos, deg, order, delta = 16, 12, 64, 0.5                                  # homo/server_decode.cpp:37-39
+    run_in = orc.random_ct(3, seed=900)
+    zs = orc.random_ct(npos * deg * 2, seed=1000)                              # Enc(0) accumulators in the reference's call order
+    pick = lambda i, j, which: zs[(i * deg + j - 1) * 2 + (which == "cos")]
+    mine = fhe.circuits.approximated_step(ev, pc, *(fhe.to_device(run_in[i:i + 1]) for i in range(3)), order=order, degree=deg, delta=delta,
+                                          width=npos, height=1, zeros=lambda i, j, which: fhe.to_device(pick(i, j, which)[None]))
+    assert len(mine) == npos and all(m.shape == (1, 22, ctx.k, ctx.n) for m in mine)
+    mine = [fhe.to_host(m)[0] for m in mine]
+
+    # one position against the oracle: the offset chain (add_plain only) is walked for every position, the
+    # polynomial evaluation only for `probe`
+    probe = 5
+    import math
+    b = orc.multiply_plain(run_in[2], orc.encode(0.5))
+    offset = orc.negate(orc.add_plain(orc.add(run_in[1], b), orc.encode(-0.5)))
+    b = orc.add_plain(b, orc.encode(delta - 0.5))
+    c = None
+    for i in range(probe + 1):
+        if i == probe:
+            c = orc.multiply_plain(b, orc.encode(1.0 / float(order)))
+        for j in range(1, deg + 1):
+            f = float(np.float32(j)) * math.pi / float(order)
+            cos_arg = offset.copy()
+            offset = orc.add_plain(offset, orc.encode(float(i)))               # homo/fhe_decode.h:229 (inside the j loop)
+            if i == probe:
+                s = oracle_mod.oracle_homomorphic_sin(orc, orc.multiply_plain(b, orc.encode(f)), pick(i, j, "sin"))
+                co = oracle_mod.oracle_homomorphic_cos(orc, orc.multiply_plain(cos_arg, orc.encode(f)), pick(i, j, "cos"))
+                term = orc.multiply_plain(orc.multiply(s, co), orc.encode(2.0 / (math.pi * float(np.float32(j)))))
+                c = orc.add(c, term)
+    assert np.array_equal(mine[probe], orc.multiply(c, run_in[0]))
+
+    if ref_bin("ref_decode_circuit", True):
+        got = run_decode_circuit(str(tmp_path), orc, "step", run_in, zs, gpu=True, n_arg=8192, extra=(order, deg, delta, npos, 1),
+                                 env_extra={"FHE_SEAL23_MODULI": "1"}, sizes=(22,) * npos)
+        for i in range(npos):
+            assert np.array_equal(got[i], mine[i]), i

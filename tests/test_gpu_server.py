@@ -26,12 +26,12 @@ def test_server_jpeg_stream(fhe, oracle_mod, tmp_path, wave_blocks):
                 for i in range(64):
                     fhe.server.write_ciphertext(f, cts[b, ch, i])
     assert fhe.server.server_jpeg(ctx, str(fin), str(fout), n_blocks, wave_blocks=wave_blocks) == n_blocks
-    out = np.zeros((n_blocks, 64, 3, 2, orc.k, orc.n), dtype=np.uint64)
+    out = np.zeros((n_blocks, 3, 64, 2, orc.k, orc.n), dtype=np.uint64)
     with open(fout, "rb") as f:
         for b in range(n_blocks):
-            for i in range(64):
-                for ch in range(3):
-                    fhe.server.read_ciphertext_into(f, out[b, i, ch])
+            for ch in range(3):              # the order homo/client_jpeg.cpp:266-271 reads: for k<3, for j<64
+                for i in range(64):
+                    fhe.server.read_ciphertext_into(f, out[b, ch, i])
         assert f.read(1) == b""
     for b in (0, n_blocks - 1):
         ycc = np.zeros((3, 64, 2, orc.k, orc.n), dtype=np.uint64)
@@ -40,7 +40,7 @@ def test_server_jpeg_stream(fhe, oracle_mod, tmp_path, wave_blocks):
             ycc[0, i], ycc[1, i], ycc[2, i] = y, u, v
         for ch in range(3):
             ref = orc.encrypted_dct(ycc[ch])
-            assert np.array_equal(out[b, :, ch], ref), (b, ch)
+            assert np.array_equal(out[b, ch], ref), (b, ch)
 
 
 def test_server_jpeg_stream_n4096_fused_fp64_kernels(fhe, oracle_mod, tmp_path):
@@ -55,16 +55,16 @@ def test_server_jpeg_stream_n4096_fused_fp64_kernels(fhe, oracle_mod, tmp_path):
             for i in range(64):
                 fhe.server.write_ciphertext(f, cts[ch, i])
     assert fhe.server.server_jpeg(ctx, str(fin), str(fout), 1, quant=list(fhe.YQT)) == 1
-    out = np.zeros((64, 3, 2, orc.k, orc.n), dtype=np.uint64)
+    out = np.zeros((3, 64, 2, orc.k, orc.n), dtype=np.uint64)
     with open(fout, "rb") as f:
-        for i in range(64):
-            for ch in range(3):
-                fhe.server.read_ciphertext_into(f, out[i, ch])
+        for ch in range(3):
+            for i in range(64):
+                fhe.server.read_ciphertext_into(f, out[ch, i])
     ycc = np.zeros((3, 64, 2, orc.k, orc.n), dtype=np.uint64)
     for i in range(64):
         ycc[0, i], ycc[1, i], ycc[2, i] = orc.rgb_to_ycc(cts[0, i], cts[1, i], cts[2, i])
     for ch in range(3):
-        assert np.array_equal(out[:, ch], orc.dct_quant(ycc[ch], oracle_mod.YQT)), ch
+        assert np.array_equal(out[ch], orc.dct_quant(ycc[ch], oracle_mod.YQT)), ch
 
 
 def test_stream_rejects_foreign_data(fhe, tmp_path):
@@ -125,8 +125,8 @@ def test_end_to_end_image_through_streaming_server(fhe, oracle_mod, tmp_path):
             r, g, bl = (np.array(b[c]) for c in range(3))
             ycc = [0.299 * r + 0.587 * g + 0.114 * bl - 128.0, -0.168736 * r - 0.331264 * g + 0.5 * bl, 0.5 * r - 0.418688 * g - 0.081312 * bl]
             expect = [bm.plain_dct(list(ch)) for ch in ycc]
-            for i in range(64):
-                for c in range(3):
+            for c in range(3):
+                for i in range(64):
                     fhe.server.read_ciphertext_into(f, ct)
                     if i % 9 == 0:                              # decrypt a sample of the 768 outputs
                         plain, budget = orc.decrypt(sk, ct)
@@ -134,3 +134,35 @@ def test_end_to_end_image_through_streaming_server(fhe, oracle_mod, tmp_path):
                         min_budget = min(min_budget, budget)
     assert min_budget > 0
     assert worst < 1e-6, worst      # decode is exact up to double rounding of the fractional digits
+
+
+def test_streaming_server_output_feeds_the_reference_client(fhe, tmp_path):
+    """The record order contract end to end: the reference's own client (homo/client_jpeg.cpp, compiled
+    unchanged against the facade) encrypts the benchmark image, THIS package's streaming server
+    (server.server_jpeg, fused kernels) processes the ciphertext stream, and the reference client's
+    --recieve half (decrypt, zig-zag, Huffman, compare with jo_jpeg) must print the RMSError the
+    reference recorded for that parameter set (benchmark/results.txt: 1.71767 at t = 3001).  A wrong
+    channel/coefficient order in the output stream (homo/server_jpeg.cpp:146-153) gives a garbage JPEG."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    client = os.path.join(root, "oracle", "_ref", "ref_client_jpeg")
+    if not os.path.exists(client):
+        pytest.skip("oracle/_ref/ref_client_jpeg not built (needs /root/reference at build time)")
+    (tmp_path / "keys").mkdir()
+    (tmp_path / "image").mkdir()
+    shutil.copy(os.path.join(root, "tests", "golden", "boazbarak.jpg"), str(tmp_path / "image" / "in.jpg"))
+    par = ["--cmod", "4096", "--pmod", "3001"]
+
+    def run(argv):
+        r = subprocess.run(argv, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, " ".join(argv) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+
+    run([client, "--send", "-f", "image/in.jpg", "-c", "image/ct_in.txt"] + par)
+    ctx = fhe.SEALContext(4096, fhe.PRESETS["P4096"]["q"], 3001)
+    n_blocks = (48 // 8) * (48 // 8)
+    assert fhe.server.server_jpeg(ctx, str(tmp_path / "image" / "ct_in.txt"), str(tmp_path / "image" / "ct_out.txt"), n_blocks, wave_blocks=8) == n_blocks
+    out = run([client, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg"] + par)
+    line = [ln for ln in out.splitlines() if ln.startswith("RMSError,")]
+    assert line and line[0].split(",")[1] == "1.71767", out[-500:]
