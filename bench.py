@@ -26,6 +26,18 @@ BYTES_PER_BLOCK = 128 * 2 * 3 * 4096 * 8   # read 64 ct + write 64 ct, ct = 2*3*
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def kernel_source_hash():
+    """identifies the kernel sources a PMC record belongs to (git is not available on the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(n_blocks_sample):
     """The CPU oracle (op-at-a-time port of the SEAL path) timed on this host, 1 thread."""
     from oracle import oracle as om
@@ -48,32 +60,26 @@ def cpu_baseline(n_blocks_sample):
         pass
     return {
         "value": n_blocks_sample / dt, "unit": "blocks/s", "cores": 1, "kind": "port",
+        # context only: the reference's own published timings (benchmark/results.txt:41, n=4096, unknown CPU, one
+        # thread): 199 ms per encrypted_dct call + 64 multiply_plain for quantize_fhe at ~0.75 ms => ~4.0 blocks/s
+        "reference_published_blocks_per_s": 4.0,
         "sample": "%d blocks of the same workload (n=4096,k=3), oracle/libfhe_oracle.so op-at-a-time, 1 thread of %d on %s"
                   % (n_blocks_sample, os.cpu_count() or 0, cpu),
     }
 
 
-def _cpu_worker(nb):
+def cpu_baseline_all_cores(blocks_per_thread=1):
+    """Same oracle, OpenMP over independent blocks (extra field, not the `cpu_baseline` object)."""
     from oracle import oracle as om
     orc = om.Oracle.preset("P4096")
+    nb = max(1, (os.cpu_count() or 1) * blocks_per_thread)
+    nb = min(nb, 256)                                              # 12 MiB per block
     blocks = orc.random_ct(nb * 64, seed=om.SEED).reshape(nb, 64, 2, orc.k, orc.n)
     t0 = time.perf_counter()
-    for b in range(nb):
-        orc.dct_quant(blocks[b], om.YQT)
-    return time.perf_counter() - t0
-
-
-def cpu_baseline_all_cores(blocks_per_proc=2, max_procs=64):
-    """Same oracle, one process per core over independent blocks (extra field, not the `cpu_baseline` object)."""
-    import multiprocessing as mp
-    procs = max(1, min(max_procs, (os.cpu_count() or 1) // 2))
-    with mp.get_context("spawn").Pool(procs) as pool:
-        pool.map(_cpu_worker, [1] * procs)                     # warm up: library load, page faults
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, [blocks_per_proc] * procs)
-        dt = time.perf_counter() - t0
-    return {"value": procs * blocks_per_proc / dt, "unit": "blocks/s", "cores": procs, "kind": "port",
-            "sample": "%d processes x %d blocks, same oracle" % (procs, blocks_per_proc)}
+    _, threads = orc.dct_quant_blocks(blocks, om.YQT)
+    dt = time.perf_counter() - t0
+    return {"value": nb / dt, "unit": "blocks/s", "cores": threads, "kind": "port",
+            "sample": "%d blocks, OpenMP over blocks, %d threads, same oracle" % (nb, threads)}
 
 
 def main():
@@ -161,13 +167,18 @@ def main():
         value = total_blocks / wall
         bytes_per_block = 128 * 2 * ctx.k * ctx.n * 8          # = BYTES_PER_BLOCK for the default preset
         achieved = B * bytes_per_block / (dev_ms_per_step * 1e-3) / 1e9
+        # HBM-side traffic: profiles/pmc_traffic.json, written by tools/collect_traffic.py from separate rocprofv3
+        # --pmc passes.  It is only quoted when it was measured on the kernel sources that are running now.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.preset == "P4096":       # written by tools/collect_traffic.py from separate rocprofv3 --pmc passes
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and args.preset == "P4096":
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get("hbm_bytes_per_block", 0) * B or None
-            traffic_src = tj.get("source")
+            if tj.get("kernel_source_hash") == kernel_source_hash():
+                traffic = tj.get("hbm_bytes_per_block", 0) * B or None
+                traffic_src = tj.get("source")
+            else:
+                traffic_src = "profiles/pmc_traffic.json was measured on other kernel sources (%s); re-run tools/collect_traffic.py" % tj.get("kernel_source_hash")
         res = {
             "metric": "encrypted 8x8 blocks/sec (homomorphic DCT+quant)",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

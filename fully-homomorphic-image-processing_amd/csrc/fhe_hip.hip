@@ -843,7 +843,7 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
     auto cleanup = [&](int code) {
         if (d_eighth) (void)hipFree(d_eighth);
         if (d_tmp) (void)hipFree(d_tmp);
-        if (code) { (void)hipFree(p->d_consts); if (p->d_consts_f64) (void)hipFree(p->d_consts_f64); if (p->d_consts_wave) (void)hipFree(p->d_consts_wave); delete p; }
+        if (code) { (void)hipFree(p->d_consts); if (p->d_consts_f64) (void)hipFree(p->d_consts_f64); delete p; }
         return code;
     };
     auto prep = [&](double v, ulonglong2 *dst) -> int {
@@ -868,7 +868,6 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
         }
     }
     if (fhe_dct_f64_supported(c) && (rc = fhe_dct_f64_make_consts(c, p, (hipStream_t)s))) return cleanup(rc);
-    if (fhe_dct_wave_supported(c) && (rc = fhe_dct_wave_make_consts(c, p, (hipStream_t)s))) return cleanup(rc);
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return cleanup(fail(FHE_ERR_HIP, "stream sync failed"));
     *out = p;
     return cleanup(FHE_OK);
@@ -877,7 +876,6 @@ extern "C" int fhe_dct_plan_destroy(fhe_dct_plan *p) {
     if (!p) return FHE_OK;
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_consts_f64) (void)hipFree(p->d_consts_f64);
-    if (p->d_consts_wave) (void)hipFree(p->d_consts_wave);
     delete p;
     return FHE_OK;
 }
@@ -904,15 +902,13 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
         const size_t per_block = (size_t)64 * 2 * c->k * c->n;
         const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(double)) : 0;
         if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
-        const bool wave_kernels = plan->d_consts_wave && fhe_dct_wave_supported(c) && env_on("FHE_DCT_WAVE");
         u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
         // measured: 68.1k blocks/s pipelined vs 71.8k plain at 64-block waves, so this is opt-in
-        const bool pipelined = !wave_kernels && env_on("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
+        const bool pipelined = env_on("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
         if (!pipelined) {
             for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
                 const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
-                int rc = wave_kernels ? fhe_dct_wave_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st)
-                                      : fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st);
+                int rc = fhe_dct_f64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (double *)scratch, st);
                 if (rc) return rc;
             }
             return FHE_OK;

@@ -1,5 +1,5 @@
 // fp64_core.h -- exact FP64-FMA modular arithmetic and the LL&M half-line circuit, shared by the
-// fused DCT kernels (dct_fused.hip: workgroup-cooperative NTT; dct_wave.hip: wave-synchronous NTT).
+// fused DCT kernels (dct_fused.hip).
 #pragma once
 #include "internal.h"
 

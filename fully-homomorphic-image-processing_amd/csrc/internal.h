@@ -69,7 +69,6 @@ struct fhe_ctx {
 struct fhe_dct_plan {
     ulonglong2 *d_consts = nullptr;   // [DCT_NCONST][k][n] Shoup pairs, slot order
     double *d_consts_f64 = nullptr;   // [DCT_NCONST][k][n] centred doubles (FP64 path), or null
-    double *d_consts_wave = nullptr;  // same constants in the wave-synchronous kernels' order, or null
     u32 k = 0, n = 0;
     bool has_quant = false;
 };
@@ -99,7 +98,3 @@ bool fhe_rgb_f64_supported(const fhe_ctx *c);
 int fhe_poly_f64_launch(int mode, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_polys, const ulonglong2 *plain, hipStream_t st);
 int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **out, hipStream_t st);
 int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st);
-// wave-synchronous variant (dct_wave.hip), n = 4096 and primes <= 40 bits
-bool fhe_dct_wave_supported(const fhe_ctx *c);
-int fhe_dct_wave_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st);
-int fhe_dct_wave_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);

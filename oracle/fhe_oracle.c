@@ -13,6 +13,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -903,6 +906,23 @@ void fo_encrypted_dct(const fo_ctx *c, uint64_t *data) {
 void fo_quantize(const fo_ctx *c, uint64_t *data, const double *quant) {
     size_t ctw = (size_t)2 * c->k * c->n;
     for (int i = 0; i < 64; i++) mp_const(c, data + ctw * (size_t)i, 2, 1 / quant[i]);
+}
+
+/* encrypted_dct + quantize_fhe on n_blocks independent blocks, OpenMP over blocks: the "all cores" CPU
+ * baseline of bench.py (the reference's loop, homo/server_jpeg.cpp:113, is serial; blocks are independent).
+ * Returns the number of threads used. */
+int fo_dct_quant_blocks(const fo_ctx *c, uint64_t *data, uint32_t n_blocks, const double *quant) {
+    const size_t blk = (size_t)64 * 2 * c->k * c->n;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        fo_encrypted_dct(c, data + blk * b);
+        fo_quantize(c, data + blk * b, quant);
+    }
+    return threads;
 }
 
 void fo_rgb_to_ycc(const fo_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b) {

@@ -123,6 +123,7 @@ void fo_relinearize3(const fo_ctx *c, uint64_t *ct, const uint64_t *evk, uint32_
 void fo_encrypted_dct(const fo_ctx *c, uint64_t *data64);
 /* data[i] *= encode(1/quant[i])  (homo/fhe_image.h:294-305) */
 void fo_quantize(const fo_ctx *c, uint64_t *data64, const double *quant64);
+int fo_dct_quant_blocks(const fo_ctx *c, uint64_t *data, uint32_t n_blocks, const double *quant64);
 /* (r,g,b) -> (y,cb,cr) in place (homo/fhe_image.h:310-325) */
 void fo_rgb_to_ycc(const fo_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b);
 /* Cubic (homo/fhe_resize.h:143-189): A..D size s, t size 2, result size s+2 */

@@ -86,6 +86,8 @@ def lib():
         L.fo_relinearize3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.fo_encrypted_dct.argtypes = [C.c_void_p, C.c_void_p]
         L.fo_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fo_dct_quant_blocks.restype = C.c_int
+        L.fo_dct_quant_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.fo_rgb_to_ycc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_cubic.restype = C.c_uint32
         L.fo_cubic.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p]
@@ -277,6 +279,13 @@ class Oracle:
 
     def dct_quant(self, block, quant=YQT):
         return self.quantize(self.encrypted_dct(block), quant)
+
+    def dct_quant_blocks(self, blocks, quant=YQT):
+        """dct_quant on [n_blocks, 64, 2, k, n], OpenMP over blocks; returns (result, threads used)"""
+        out = np.ascontiguousarray(blocks).copy()
+        qv = (C.c_double * 64)(*[float(x) for x in quant])
+        threads = lib().fo_dct_quant_blocks(self.h, _p(out), out.shape[0], qv)
+        return out, int(threads)
 
     def rgb_to_ycc(self, r, g, b):
         r, g, b = (np.ascontiguousarray(x).copy() for x in (r, g, b))

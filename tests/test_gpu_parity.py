@@ -518,28 +518,6 @@ def test_approximated_step_vs_oracle(fhe, oracle_mod):
         assert np.array_equal(fhe.to_host(g)[0], r)
 
 
-def test_dct_wave_synchronous_variant(fhe, oracle_mod, monkeypatch):
-    """the experimental wave-synchronous NTT kernels (csrc/dct_wave.hip, FHE_DCT_WAVE=1) give the
-    same bytes as the default kernels"""
-    ctx, orc = _pair(fhe, oracle_mod, "P4096")
-    ev = fhe.Evaluator(ctx)
-    blocks = ctx.random_ct(3, 64, seed=4242)
-    plan = fhe.DctPlan(ctx, fhe.YQT)
-    default = fhe.to_host(ev.dct8x8_quant(plan, blocks))
-    monkeypatch.setenv("FHE_DCT_WAVE", "1")
-    wave = fhe.to_host(ev.dct8x8_quant(plan, blocks))
-    monkeypatch.delenv("FHE_DCT_WAVE")
-    assert np.array_equal(default, wave)
-    # two-stream pipelining of the row and column kernels over waves of one block each
-    monkeypatch.setenv("FHE_DCT_PIPELINE", "1")
-    monkeypatch.setenv("FHE_DCT_WAVE_BLOCKS", "2")
-    piped = fhe.to_host(ev.dct8x8_quant(plan, blocks))
-    monkeypatch.delenv("FHE_DCT_PIPELINE")
-    monkeypatch.delenv("FHE_DCT_WAVE_BLOCKS")
-    assert np.array_equal(default, piped)
-    assert np.array_equal(default[2], orc.dct_quant(fhe.to_host(blocks)[2], fhe.YQT))
-
-
 # ---------------------------------------------------------------------------------------------
 # empty / ragged inputs and error behaviour of the C ABI
 # ---------------------------------------------------------------------------------------------

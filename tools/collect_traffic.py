@@ -1,54 +1,86 @@
 #!/usr/bin/env python3
 """Measure HBM-side traffic of the fused DCT kernels with rocprofv3 PMC counters (run on the GPU box).
 
-Separate --pmc passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2);
-gfx950 correction: FETCH_SIZE tallies 128-byte read requests at 64 bytes, so reads are doubled;
-WRITE_SIZE matched the known output byte count of k_dct_cols within 2% and is taken as is.
-Both counters are in KiB.  Writes profiles/r01_pmc_traffic.json (read by bench.py).
-"""
+Separate --pmc passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2); both
+counters are in KiB.  The guide's gfx950 note (FETCH_SIZE reports half of the bytes of a 16 B/lane streaming
+read) is calibrated for 16-byte accesses; these kernels issue 8 B/lane, so the factor is CALIBRATED here on
+a kernel with the same access pattern and a known byte count: k_poly_f64<MODE 0> (the standalone FP64
+forward NTT, `src[r * TP + tid]` u64 loads like k_dct_rows) over a buffer far larger than the Infinity
+Cache, which must read exactly its input and write exactly its output.
+
+Writes profiles/pmc_traffic.json (tracked; read by bench.py) with the kernel names it saw and the hash of the
+kernel sources it measured: bench.py prints `traffic: null` when the running sources differ."""
+import collections
 import csv
+import hashlib
 import json
 import os
 import subprocess
 import sys
-import collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BLOCKS = 128
-WAVE = 128       # blocks per dispatch here: min(default FHE_DCT_WAVE_BLOCKS = 256, BLOCKS)
+BLOCKS = 256
 CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", str(BLOCKS), "--cpu-blocks", "0", "--no-verify"]
+CAL_CTS = 8192        # 8192 cts x 192 KiB = 1.5 GiB in, 1.5 GiB out
+CAL = [sys.executable, "-c",
+       "import sys; sys.path.insert(0, %r); import torch, fhip_amd as fhe; ctx = fhe.SEALContext.preset('P4096'); ev = fhe.Evaluator(ctx); "
+       "a = ctx.random_ct(%d, seed=1); o = torch.empty_like(a); [ev.ntt_forward(a, out=o) for _ in range(3)]; torch.cuda.synchronize()" % (ROOT, CAL_CTS)]
 
 
-def run_pass(counters, tag):
+def kernel_source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_pass(counters, tag, cmd, match):
     out = os.path.join(ROOT, "gpurun_out", "traffic_" + tag)
     env = dict(os.environ, TMPDIR="/tmp")
-    subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--pmc", *counters, "--"] + CMD,
+    subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--pmc", *counters, "--"] + cmd,
                    check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = {}
     with open(os.path.join(out, "p_counter_collection.csv")) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            name = "k_dct_rows" if "k_dct_rows" in k else "k_dct_cols" if "k_dct_cols" in k else None
-            if name:
-                acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+            for m in match:
+                if m in k:
+                    acc[m][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    names[m] = k
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, names
 
 
 def main():
-    rd = run_pass(["FETCH_SIZE"], "fetch")
-    wr = run_pass(["WRITE_SIZE"], "write")
+    cal_bytes = CAL_CTS * 2 * 3 * 4096 * 8
+    crd, cnames = run_pass(["FETCH_SIZE"], "cal_fetch", CAL, ["k_poly_f64"])
+    cwr, _ = run_pass(["WRITE_SIZE"], "cal_write", CAL, ["k_poly_f64"])
+    f_read = cal_bytes / (crd["k_poly_f64"]["FETCH_SIZE"] * 1024)
+    f_write = cal_bytes / (cwr["k_poly_f64"]["WRITE_SIZE"] * 1024)
+    rd, names = run_pass(["FETCH_SIZE"], "fetch", CMD, ["k_dct_rows", "k_dct_cols"])
+    wr, _ = run_pass(["WRITE_SIZE"], "write", CMD, ["k_dct_rows", "k_dct_cols"])
     per_kernel, total = {}, 0.0
     for k in ("k_dct_rows", "k_dct_cols"):
-        fetch = rd[k]["FETCH_SIZE"] * 1024 * 2 / WAVE      # bytes per block, gfx950 x2 read correction
-        write = wr[k]["WRITE_SIZE"] * 1024 / WAVE
-        per_kernel[k] = {"read_bytes_per_block": fetch, "write_bytes_per_block": write,
+        fetch = rd[k]["FETCH_SIZE"] * 1024 * f_read / BLOCKS
+        write = wr[k]["WRITE_SIZE"] * 1024 * f_write / BLOCKS
+        per_kernel[k] = {"read_bytes_per_block": fetch, "write_bytes_per_block": write, "kernel_name": names[k],
                          "FETCH_SIZE_KiB_per_dispatch": rd[k]["FETCH_SIZE"], "WRITE_SIZE_KiB_per_dispatch": wr[k]["WRITE_SIZE"]}
         total += fetch + write
     res = {"hbm_bytes_per_block": total, "algorithmic_bytes_per_block": 25165824, "ratio_to_algorithmic": total / 25165824,
-           "per_kernel": per_kernel, "blocks_per_dispatch": WAVE,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --blocks 128 --steps 2`, "
-                     "FETCH_SIZE x2 (gfx950), per block; tools/collect_traffic.py"}
-    with open(os.path.join(ROOT, "gpurun_out", "r01_pmc_traffic.json"), "w") as f:
+           "per_kernel": per_kernel, "blocks_per_dispatch": BLOCKS, "kernel_source_hash": kernel_source_hash(),
+           "calibration": {"kernel": cnames.get("k_poly_f64"), "known_bytes_each_way": cal_bytes,
+                           "FETCH_SIZE_KiB": crd["k_poly_f64"]["FETCH_SIZE"], "WRITE_SIZE_KiB": cwr["k_poly_f64"]["WRITE_SIZE"],
+                           "read_factor": f_read, "write_factor": f_write},
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --blocks %d --steps 2`, per block; "
+                     "KiB -> bytes factors calibrated on the FP64 forward-NTT kernel over 1.5 GiB (same 8 B/lane access pattern, "
+                     "known byte count); tools/collect_traffic.py" % BLOCKS}
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w") as f:     # profiles/ is not merged back by gpurun
         json.dump(res, f, indent=1)
     print(json.dumps(res))
 
