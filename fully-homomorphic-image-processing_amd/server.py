@@ -160,3 +160,165 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         os.close(fin)
         os.close(fout)
     return n_blocks
+
+
+# ------------------------------------------------------------------------------------------------
+# server_resize: ResizeImage (homo/fhe_resize.h:308-392) over a ciphertext stream
+# ------------------------------------------------------------------------------------------------
+def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None):
+    """The circuit's server-side encryptions (homo/fhe_resize.h:230,234,262,266): a callable
+    values -> [len(values), 2, k, n] of fresh encryptions of encode(v) under `public_key`
+    ([2, k, n] device tensor).  seed=None draws from the OS CSPRNG."""
+    from .evaluator import FractionalEncoder
+    from .keys import Encryptor
+    enc = encoder or FractionalEncoder(ctx)
+    er = Encryptor(ctx, public_key, seed=seed)
+
+    def encrypt(values):
+        return torch.stack([er.encrypt(enc.encode(float(v))) for v in values])
+    return encrypt
+
+
+def _row_windows(H, h, init_rows):
+    """Per destination row: v (float32, homo/fhe_resize.h:351) and the first source row of the
+    reference's sliding window (:352; the window never moves backwards)."""
+    f32 = np.float32
+    start, out = 0, []
+    for y in range(h):
+        v = f32(f32(y) / f32(h - 1) * f32(H)) - f32(0.5)
+        new_start = min(int(v) - init_rows // 2 + 1, H - init_rows)
+        if new_start > start:
+            start = new_start
+        out.append((v, start))
+    return out
+
+
+def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4):
+    """homo/server_resize.cpp:127-146 + ResizeImage (homo/fhe_resize.h:308-392) on the GPU.
+
+    Input stream: src_w * src_h pixels, row by row, three ciphertext records (R, G, B) per pixel
+    (homo/client_resize.cpp:141-150).  Output stream: dst_w * dst_h pixels, row by row, three
+    records of size 4 (bilinear) or 6 (bicubic) per pixel (homo/server_resize.cpp:141-146).
+
+    The reference keeps a sliding window of init_rows = 2 / 4 source rows resident (`for memory
+    reasons`, :324-379), walks the destination rows serially and samples one pixel at a time
+    (SampleLinear / SampleBicubic, :381-388).  Here the same window logic decides which source rows
+    are resident in HBM (rows below the window's start are dropped, rows are read from the file
+    exactly once, in order); a step takes up to `rows_per_step` destination rows whose windows are
+    loaded, samples ALL their pixels and channels as one batch per channel through the batched
+    circuits (circuits.sample_bicubic / sample_linear), and a writer pool drains the previous
+    step's results from a pinned buffer while the GPU works on the next.
+
+    encrypt_fractions(values) -> [len, 2, k, n] supplies the circuit's server-side encryptions in
+    the reference's call order (per destination pixel: frac(x), then frac(y))."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import circuits
+    ev = Evaluator(ctx)
+    pc = circuits.PlainCache(ctx)
+    init_rows = 4 if bicubic else 2
+    out_size = 6 if bicubic else 4
+    if dst_w < 2 or dst_h < 2 or src_h < init_rows or src_w < 1:
+        raise ValueError("image too small for the sampler")
+    rec_in = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+    rec_out = RECORD_HEADER + out_size * ctx.k * ctx.n * 8
+    if os.path.getsize(in_path) < src_w * src_h * 3 * rec_in:
+        raise EOFError("ciphertext stream ended")
+    expect = (2, ctx.k, ctx.n)
+    out_hdr = HEADER.pack(MAGIC, out_size, ctx.k, ctx.n, 0)
+    windows = _row_windows(src_h, dst_h, init_rows)
+    f32 = np.float32
+    us = [f32(f32(x) / f32(dst_w - 1) * f32(src_w)) - f32(0.5) for x in range(dst_w)]
+    row_shape = (src_w, 3, 2, ctx.k, ctx.n)
+    resident = {}                                   # source row index -> device tensor [src_w, 3, 2, k, n]
+    next_row = 0                                    # rows are consumed from the stream in order, once
+    staging = [_pinned(("rs_in", i), (init_rows + rows_per_step,) + row_shape) for i in range(2)]
+    host_out = [_pinned(("rs_out", i, out_size), (rows_per_step * dst_w, 3, out_size, ctx.k, ctx.n)) for i in range(2)]
+    copy_stream = torch.cuda.Stream()
+
+    def read_rows(pool, fd, buf, first_row, count):
+        arr = buf.numpy().view(np.uint64)
+        return [pool.submit(_pread_records, fd, [arr[r, x, c] for x in range(src_w) for c in range(3)],
+                            (first_row + r) * src_w * 3, rec_in, expect) for r in range(count)]
+
+    def write_rows(pool, fd, buf, first_pixel, count):
+        arr = buf.numpy().view(np.uint64)
+        step = max(1, count // _IO_THREADS)
+        return [pool.submit(_pwrite_records, fd, [arr[p, c] for p in range(s, min(s + step, count)) for c in range(3)],
+                            (first_pixel + s) * 3, rec_out, out_hdr) for s in range(0, count, step)]
+
+    def wait(futs):
+        for f in futs:
+            f.result()
+
+    # steps: consecutive destination rows whose source rows fit `init_rows + rows_per_step` resident rows
+    steps, y = [], 0
+    while y < dst_h:
+        e = y + 1
+        while e < dst_h and e - y < rows_per_step and windows[e][1] + init_rows - windows[y][1] <= init_rows + rows_per_step:
+            e += 1
+        steps.append((y, e))
+        y = e
+    fin = os.open(in_path, os.O_RDONLY)
+    fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fout, dst_w * dst_h * 3 * rec_out)
+        with ThreadPoolExecutor(_IO_THREADS) as rpool, ThreadPoolExecutor(_IO_THREADS) as wpool:
+            def rows_needed(step):
+                lo, hi = windows[step[0]][1], windows[step[1] - 1][1] + init_rows
+                return lo, hi
+
+            def start_read(si, first_new):
+                lo, hi = rows_needed(steps[si])
+                cnt = hi - max(first_new, lo)
+                skip_to = max(first_new, lo)            # rows between first_new and lo are skipped like :353-357
+                return (skip_to, cnt, read_rows(rpool, fin, staging[si & 1], skip_to, cnt)) if cnt > 0 else (skip_to, 0, [])
+
+            pending_w = [[], []]
+            reading = start_read(0, next_row)
+            for si, (y0, y1) in enumerate(steps):
+                first, cnt, futs = reading
+                wait(futs)
+                if cnt:
+                    with torch.cuda.stream(copy_stream):
+                        dev = staging[si & 1][:cnt].to(ctx.device, non_blocking=True)
+                    torch.cuda.current_stream().wait_stream(copy_stream)
+                    copy_stream.synchronize()            # staging[si & 1] may be refilled two steps later
+                    for r in range(cnt):
+                        resident[first + r] = dev[r]
+                    next_row = first + cnt
+                lo, hi = rows_needed((y0, y1))
+                for r in [r for r in resident if r < lo]:
+                    del resident[r]
+                if si + 1 < len(steps):                  # prefetch the next step's new rows from the file
+                    reading = start_read(si + 1, next_row)
+                # sample plan of these destination rows, in terms of the resident window
+                base = lo
+                window = torch.stack([resident[r] for r in range(lo, hi)])           # [rows, src_w, 3, 2, k, n]
+                taps, fracs = [], []
+                for yy in range(y0, y1):
+                    v = windows[yy][0]
+                    yi = int(v)
+                    for xx in range(dst_w):
+                        u = us[xx]
+                        xi = int(u)
+                        offs = ([(dx, dy) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)] if bicubic
+                                else [(0, 0), (1, 0), (0, 1), (1, 1)])
+                        taps.append([(min(max(yi + dy, 0), src_h - 1) - base) * src_w + min(max(xi + dx, 0), src_w - 1) for dx, dy in offs])
+                        fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
+                fr = encrypt_fractions(fracs)                                        # xfract, yfract per pixel, in order
+                xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
+                npx = (y1 - y0) * dst_w
+                sampler = circuits.sample_bicubic if bicubic else circuits.sample_linear
+                wait(pending_w[si & 1])
+                for ch in range(3):
+                    pix = window[:, :, ch].reshape(-1, 2, ctx.k, ctx.n)
+                    res = sampler(ev, pc, pix, taps, xf, yf)                         # [npx, out_size, k, n]
+                    host_out[si & 1][:npx, ch].copy_(res, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                pending_w[si & 1] = write_rows(wpool, fout, host_out[si & 1], y0 * dst_w, npx)
+            wait(pending_w[0])
+            wait(pending_w[1])
+    finally:
+        os.close(fin)
+        os.close(fout)
+    return dst_w * dst_h

@@ -166,3 +166,91 @@ def test_streaming_server_output_feeds_the_reference_client(fhe, tmp_path):
     out = run([client, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg"] + par)
     line = [ln for ln in out.splitlines() if ln.startswith("RMSError,")]
     assert line and line[0].split(",")[1] == "1.71767", out[-500:]
+
+
+# ---------------------------------------------------------------------------------------------
+# server_resize: ResizeImage's sliding row window over a ciphertext stream (homo/fhe_resize.h:308-392)
+# ---------------------------------------------------------------------------------------------
+def _fraction_bank(fhe, bank):
+    """encrypt_fractions stand-in: hands out pre-made ciphertexts in call order (xfract, yfract per pixel)"""
+    pos = [0]
+
+    def encrypt(values):
+        out = bank[pos[0]:pos[0] + len(values)]
+        assert len(out) == len(values)
+        pos[0] += len(values)
+        return fhe.to_device(np.ascontiguousarray(out))
+    return encrypt
+
+
+@pytest.mark.parametrize("bicubic,rows_per_step", [(True, 3), (False, 1), (True, 8)])
+def test_server_resize_stream_16x16_to_8x8_vs_oracle(fhe, oracle_mod, tmp_path, bicubic, rows_per_step):
+    from refrun import oracle_sample, read_records, sample_origins, write_record
+    ctx, orc = _ctx(fhe, oracle_mod)
+    W = H = 16
+    w = h = 8
+    pix = orc.random_ct(W * H * 3, seed=21).reshape(W * H, 3, 2, orc.k, orc.n)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for p in range(W * H):
+            for c in range(3):
+                write_record(f, pix[p, c])
+    bank = orc.random_ct(w * h * 2, seed=22)
+    n = fhe.server.server_resize(ctx, str(fin), str(fout), W, H, w, h, bicubic, _fraction_bank(fhe, bank), rows_per_step=rows_per_step)
+    assert n == w * h
+    out = read_records(str(fout), 6 if bicubic else 4, orc.k, orc.n, w * h * 3)
+    origins = sample_origins(W, H, w, h)
+    for o in range(0, w * h, 5 if bicubic else 3):
+        xi, yi = origins[o]
+        for ch in range(3):
+            assert np.array_equal(out[o * 3 + ch], oracle_sample(orc, pix, W, H, xi, yi, ch, bank[2 * o], bank[2 * o + 1], bicubic)), (o, ch)
+
+
+@pytest.mark.parametrize("bicubic", [False, True])
+def test_server_resize_stream_equals_the_reference_server_byte_for_byte(fhe, oracle_mod, tmp_path, bicubic):
+    """the same ciphertext stream through homo/server_resize.cpp (unchanged, facade, op at a time) and through
+    server.server_resize (batched circuits): identical output files"""
+    from refrun import ref_bin, run_server_resize
+    if not ref_bin("ref_server_resize", True):
+        pytest.skip("oracle/_ref/ref_server_resize not built (needs /root/reference at build time)")
+    orc = oracle_mod.Oracle.preset("P4096")
+    ctx = fhe.SEALContext.preset("P4096")
+    W, H, w, h = 7, 9, 5, 6
+    pix = orc.random_ct(W * H * 3, seed=31).reshape(W * H, 3, 2, orc.k, orc.n)
+    bank = orc.random_ct(w * h * 2, seed=32)
+    ref = run_server_resize(str(tmp_path), orc, pix, W, H, w, h, bicubic, bank, gpu=True, n_arg=4096)
+    ref_bytes = open(tmp_path / "image" / "out.ct", "rb").read()
+    mine = tmp_path / "mine.ct"
+    fhe.server.server_resize(ctx, str(tmp_path / "image" / "in.ct"), str(mine), W, H, w, h, bicubic, _fraction_bank(fhe, bank), rows_per_step=2)
+    assert open(mine, "rb").read() == ref_bytes
+    assert ref.shape[0] == w * h * 3
+
+
+def test_server_resize_with_real_encryptions_decrypts_to_the_plain_sampler(fhe, oracle_mod, tmp_path):
+    """keys + fresh server-side encryptions of the fractions (make_fraction_encryptor, OS CSPRNG); decrypt and
+    compare with the closed form of Linear (homo/fhe_resize.h:191-204)"""
+    from refrun import read_records, sample_origins, write_record
+    p = oracle_mod.PRESETS["P4096"]
+    ctx, orc = fhe.SEALContext(p["n"], p["q"], p["t"]), oracle_mod.Oracle(p["n"], p["q"], p["t"])
+    sk, pk = orc.keygen(5)
+    W, H, w, h = 5, 4, 3, 3
+    vals = np.array([[(37 * x + 11 * y + 50 * c) % 256 for c in range(3)] for y in range(H) for x in range(W)], dtype=np.float64)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for i in range(W * H):
+            for c in range(3):
+                write_record(f, orc.encrypt(pk, orc.encode(vals[i, c]), seed=100 + 3 * i + c))
+    enc = fhe.server.make_fraction_encryptor(ctx, fhe.to_device(pk))
+    fhe.server.server_resize(ctx, str(fin), str(fout), W, H, w, h, False, enc, rows_per_step=2)
+    out = read_records(str(fout), 4, orc.k, orc.n, w * h * 3)
+    f32 = np.float32
+    for o, (xi, yi) in enumerate(sample_origins(W, H, w, h)):
+        y, x = divmod(o, w)
+        u = f32(f32(x) / f32(w - 1) * f32(W)) - f32(0.5)
+        v = f32(f32(y) / f32(h - 1) * f32(H)) - f32(0.5)
+        fx, fy = float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))
+        P = lambda dx, dy, c: vals[min(max(yi + dy, 0), H - 1) * W + min(max(xi + dx, 0), W - 1), c]
+        for c in range(3):
+            expect = (1 - fy) * ((1 - fx) * P(0, 0, c) + fx * P(1, 0, c)) + fy * ((1 - fx) * P(0, 1, c) + fx * P(1, 1, c))
+            plain, budget = orc.decrypt(sk, out[o * 3 + c])
+            assert budget > 0 and abs(orc.decode(plain) - expect) < 1e-6, (o, c)
