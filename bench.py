@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--cpu-blocks", type=int, default=16, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--preset", default="P4096", help="parameter set (default: the BASELINE.json configuration)")
+    ap.add_argument("--gather", choices=["none", "wave"], default="none",
+                    help="wave: every wave of output ciphertexts is sent to rank 0 (RCCL send/recv over xGMI, overlapped with the "
+                         "next wave's compute) and drained there by digest; none (default): outputs stay sharded (SURVEY.md 8e)")
+    ap.add_argument("--gather-wave-blocks", type=int, default=64)
     args = ap.parse_args()
 
     import numpy as np
@@ -120,8 +124,36 @@ def main():
     out = torch.empty_like(blocks)
     torch.cuda.synchronize()
 
+    gather = None
+    if args.gather == "wave":
+        if B % args.gather_wave_blocks:
+            raise SystemExit("--blocks must be a multiple of --gather-wave-blocks")
+        wave, n_waves = args.gather_wave_blocks, B // args.gather_wave_blocks
+        # rank 0 drains every wave (its own and the peers') by digest: one u64 per (source rank, wave)
+        wave_digests = torch.zeros(world * n_waves, dtype=torch.int64, device=blocks.device)
+
+        def consume(src, w, t):
+            ctx.digest_into(t.view(-1), wave_digests[src * n_waves + w:src * n_waves + w + 1],
+                            index0=(src * B + w * wave) * words_per_block)
+        if world > 1:
+            gather = fhe.parallel.WaveGather((wave,) + tuple(blocks.shape[1:]), blocks.dtype, blocks.device, n_waves, consume=consume)
+
     def step():
-        ev.dct8x8_quant(plan, blocks, out=out)
+        if args.gather != "wave":
+            ev.dct8x8_quant(plan, blocks, out=out)
+            return
+        for w in range(n_waves):
+            src = blocks[w * wave:(w + 1) * wave]
+            if gather is None:                                   # one GPU: nothing to move, drain in place
+                ev.dct8x8_quant(plan, src, out=out[w * wave:(w + 1) * wave])
+                consume(0, w, out[w * wave:(w + 1) * wave])
+            else:
+                buf = gather.acquire()
+                ev.dct8x8_quant(plan, src, out=buf)
+                gather.commit(w)
+        if gather is not None:
+            gather.finish()
+            gather.reset()
 
     for _ in range(args.warmup):
         step()
@@ -149,7 +181,14 @@ def main():
         wall = float(tt.item())
 
     # ---- verification: sampled blocks against the CPU oracle, digest over everything -----------------
-    digest_all = fhe.parallel.combine_digests(ctx.digest(out.view(-1), index0=first_index))
+    if args.gather == "wave":       # the root holds the digest of every rank's last step; the ciphertexts were not kept
+        digest_all = int(wave_digests.cpu().numpy().view(np.uint64).sum(dtype=np.uint64)) if rank == 0 else 0
+        if gather is not None:
+            out = None
+        if dist is not None:
+            dist.barrier()
+    else:
+        digest_all = fhe.parallel.combine_digests(ctx.digest(out.view(-1), index0=first_index))
     verified = None
     if rank == 0 and not args.no_verify:
         from oracle import oracle as om
@@ -157,6 +196,8 @@ def main():
         orc = om.Oracle.preset(args.preset)
         sample = [0, B - 1] if B > 1 else [0]
         ok = True
+        if out is None:                                      # gathered run: recompute the sampled blocks locally
+            out = ev.dct8x8_quant(plan, blocks)
         for b in sample:
             ref = orc.dct_quant(fhe.to_host(blocks[b]), om.YQT)
             ok &= bool(np.array_equal(fhe.to_host(out[b]), ref))
@@ -186,7 +227,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=%d, %d coeff moduli, t=2^14" % (B, ctx.n, ctx.k),
                        "blocks_per_gpu": B, "poly_modulus_degree": ctx.n, "coeff_moduli": [hex(x) for x in ctx.q],
-                       "sharding": "blocks x%d, no data-path collective" % world,
+                       "sharding": ("blocks x%d, no data-path collective" % world) if args.gather == "none" else
+                                   ("blocks x%d, every %d-block wave of outputs sent to rank 0 (RCCL send/recv) and drained by digest" % (world, args.gather_wave_blocks)),
+                       "gather": args.gather,
                        "arithmetic": ("exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out"
                                       if max(ctx.q) < (1 << 47) else "u64 Shoup/Barrett modular arithmetic (general path)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -92,6 +92,11 @@ class SEALContext:
         return int(out.cpu().numpy().view(np.uint64)[0])
 
 
+    def digest_into(self, t, out_elem, index0=0):
+        """asynchronous form: the digest of `t` is written to the one-element int64 device tensor `out_elem`"""
+        _lib.call("fhe_digest", self.h, _ptr(t), t.numel(), index0, _ptr(out_elem), _stream())
+
+
 class FractionalEncoder:
     """seal::FractionalEncoder(t, poly_modulus, 100, 100, 2) (homo/server_jpeg.cpp:100)."""
 

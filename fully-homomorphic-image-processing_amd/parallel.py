@@ -4,7 +4,8 @@ The reference is a single-threaded loop over blocks (homo/server_jpeg.cpp:113); 
 independent, so rank r of R owns the contiguous range [r*N/R, (r+1)*N/R) and no collective is
 needed on the data path.  The only exchanges are a barrier, an all-reduce of 64-bit output digests
 (cheap verification that every shard was produced) and -- when the caller asks for the ciphertexts
-on one rank -- a gather of the output shards (RCCL over xGMI on GPUs, gloo on CPU in the tests).
+on one rank -- a per-wave point-to-point gather of the output shards (WaveGather: RCCL send/recv over xGMI on
+GPUs, gloo on CPU in the tests).
 
 Everything here is backend-agnostic: `compute(blocks)` is any callable mapping a shard of input
 blocks to output blocks (the HIP evaluator on GPUs).
@@ -38,28 +39,145 @@ def combine_digests(local_digest, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_digest & 0xFFFFFFFFFFFFFFFF
     # two 32-bit halves in int64 so that the SUM all-reduce cannot overflow
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     parts = torch.tensor([local_digest & 0xFFFFFFFF, (local_digest >> 32) & 0xFFFFFFFF], dtype=torch.int64, device=dev)
     dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)
     lo, hi = int(parts[0].item()), int(parts[1].item())
     return (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
 
 
-def gather_outputs(local_out, n_blocks, dst=0, group=None):
-    """Gather the output shards on rank `dst` in global block order.  Shards may differ in size by
-    one block, so they are exchanged as padded equal-size tensors."""
+class WaveGather:
+    """The final ciphertext gather (BASELINE.json north_star: "RCCL over xGMI only for the final ciphertext
+    gather"), done per WAVE of blocks with point-to-point transfers instead of one collective at the end.
+
+    Why per wave and point to point: one step leaves 12 MiB of output per block (n = 4096, k = 3); config[4]'s
+    shard is 96 GiB per GPU and cannot be gathered in one piece, and xGMI is point-to-point (each peer reaches
+    the root over its own link, ~153 GB/s; the root takes in at most 7 links at once), so a ring collective would
+    be bound by a single link.  Each non-root rank sends wave w to the root (ncclSend on RCCL / gloo send in the
+    CPU tests) from a ring of `slots` output buffers while it computes wave w + 1 into the next slot; the root
+    posts the matching receives (grouped, one per peer) into its own ring and hands every received wave -- and
+    its own -- to `consume(src_rank, wave_index, tensor)`, e.g. a digest or a stream writer.  Sends and receives
+    of a pair are issued in wave order on both sides, which is what NCCL/RCCL p2p matching requires.
+
+    Usage on every rank:
+        g = WaveGather(wave_shape, dtype, device, n_waves, consume=...)
+        for w in range(n_waves):
+            buf = g.acquire()            # an output buffer that is free again (its send has completed)
+            compute wave w into buf
+            g.commit(w)                  # non-root: isend;  root: consume own wave, receive + consume the peers'
+        g.finish()
+    """
+
+    def __init__(self, wave_shape, dtype, device, n_waves, dst=0, group=None, slots=2, consume=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.dst = dist, group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.n_waves, self.slots = n_waves, max(2, slots)
+        self.consume = consume or (lambda src, w, t: None)
+        self.ring = [torch.empty(wave_shape, dtype=dtype, device=device) for _ in range(self.slots)]
+        self.sends = [None] * self.slots                   # in-flight send per slot (non-root)
+        self.peers = [r for r in range(self.world) if r != dst]
+        self.is_cuda = torch.device(device).type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if self.is_cuda else None
+        # root: receive ring, `slots` waves deep per peer; receives for wave w are posted as soon as slot w % slots is free
+        self.rx = {r: [torch.empty(wave_shape, dtype=dtype, device=device) for _ in range(self.slots)] for r in self.peers} if self.rank == dst else {}
+        self.rx_work = {}                                   # wave -> list of (src, work)
+        self.next, self.posted, self.consumed = 0, 0, 0
+        if self.rank == dst:
+            self._post_receives()
+
+    def reset(self):
+        """start another pass of n_waves waves with the same buffers (call after finish())"""
+        assert not self.rx_work and all(w is None for w in self.sends)
+        self.next, self.posted, self.consumed = 0, 0, 0
+        if self.rank == self.dst:
+            self._post_receives()
+
+    def _global(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def _post_receives(self):
+        """keep up to `slots` waves of receives in flight (each slot is reposted once its wave was consumed)"""
+        while self.posted < self.n_waves and self.posted - self.consumed < self.slots and self.peers:
+            w = self.posted
+            ops = [self.dist.P2POp(self.dist.irecv, self.rx[r][w % self.slots], self._global(r), self.group) for r in self.peers]
+            works = self.dist.batch_isend_irecv(ops)
+            self.rx_work[w] = list(zip(self.peers, works if len(works) == len(ops) else [works[0]] * len(ops)))
+            self.posted += 1
+
+    def acquire(self):
+        slot = self.next % self.slots
+        if self.sends[slot] is not None:                    # the buffer is free once its send has completed
+            self.sends[slot].wait()
+            self.sends[slot] = None
+        return self.ring[slot]
+
+    def commit(self, wave_index):
+        slot = self.next % self.slots
+        assert wave_index == self.next
+        buf = self.ring[slot]
+        if self.rank != self.dst:
+            if self.is_cuda:                                # the transfer waits for the compute of this wave only;
+                self.side.wait_stream(torch.cuda.current_stream())   # the caller's stream goes on with the next wave
+                with torch.cuda.stream(self.side):
+                    self.sends[slot] = self.dist.isend(buf, self._global(self.dst), self.group)
+            else:
+                self.sends[slot] = self.dist.isend(buf, self._global(self.dst), self.group)
+        else:
+            self.consume(self.dst, wave_index, buf)
+            self._drain(wave_index)
+        self.next += 1
+
+    def _drain(self, upto):
+        while self.consumed <= upto and self.consumed < self.n_waves and self.peers:
+            w = self.consumed
+            for src, work in self.rx_work.pop(w):
+                work.wait()
+                self.consume(src, w, self.rx[src][w % self.slots])
+            self.consumed += 1
+            self._post_receives()
+
+    def finish(self):
+        if self.rank == self.dst:
+            self._drain(self.n_waves - 1)
+        for i, wk in enumerate(self.sends):
+            if wk is not None:
+                wk.wait()
+                self.sends[i] = None
+        if self.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def gather_outputs(local_out, n_blocks, dst=0, group=None, wave_blocks=64):
+    """The output shards on rank `dst` in global block order (None elsewhere), moved in waves of `wave_blocks`
+    blocks through WaveGather.  Meant for results that fit one device; larger jobs pass their own `consume`
+    to WaveGather (digest, stream writer) instead of materialising everything."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = [block_range(r, world, n_blocks) for r in range(world)]
     longest = max(e - s for s, e in per)
-    pad = torch.zeros((longest,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
-    pad[: local_out.shape[0]] = local_out
-    if rank == dst:
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.gather(pad, bufs, dst=dst, group=group)
-        return torch.cat([b[: e - s] for b, (s, e) in zip(bufs, per)], dim=0)
-    dist.gather(pad, None, dst=dst, group=group)
-    return None
+    wave_blocks = max(1, min(wave_blocks, max(1, longest)))
+    n_waves = (longest + wave_blocks - 1) // wave_blocks
+    shape = (wave_blocks,) + tuple(local_out.shape[1:])
+    result = torch.empty((n_blocks,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device) if rank == dst else None
+
+    def consume(src, w, t):
+        s, e = per[src]
+        lo = s + w * wave_blocks
+        cnt = max(0, min(wave_blocks, e - lo))
+        if cnt:
+            result[lo:lo + cnt].copy_(t[:cnt])
+
+    g = WaveGather(shape, local_out.dtype, local_out.device, n_waves, dst=dst, group=group, consume=consume)
+    for w in range(n_waves):
+        buf = g.acquire()
+        lo = w * wave_blocks
+        cnt = max(0, min(wave_blocks, local_out.shape[0] - lo))
+        if cnt:
+            buf[:cnt].copy_(local_out[lo:lo + cnt])
+        g.commit(w)
+    g.finish()
+    return result
 
 
 def run_sharded(compute, make_inputs, n_blocks, digest, gather=False, group=None):

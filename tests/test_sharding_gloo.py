@@ -101,3 +101,82 @@ def test_two_ranks_equal_one_rank():
     assert res[0][2] == res[1][2] == ref_digest               # combined digest == single-process digest
     assert res[1][3] is None
     assert np.array_equal(res[0][3], ref_gather.numpy().view(np.uint64))
+
+
+def _wave_worker(rank, world, port, q, n_waves, slots):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import fhip_amd as fhe
+    seen = []
+    g = fhe.parallel.WaveGather((4, 3), torch.int64, "cpu", n_waves, slots=slots,
+                                consume=lambda src, w, t: seen.append((src, w, t.clone())))
+    for rep in range(2):                                    # two passes over the same rings (reset)
+        for w in range(n_waves):
+            buf = g.acquire()
+            buf.copy_(torch.arange(12).reshape(4, 3) + 1000 * rank + 100 * w + 7 * rep)
+            g.commit(w)
+        g.finish()
+        g.reset() if rep == 0 else None
+    q.put((rank, [(s, w, t.numpy().copy()) for s, w, t in seen]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_waves,slots", [(1, 2), (5, 2), (4, 3)])
+def test_wave_gather_delivers_every_wave_in_order(n_waves, slots):
+    """WaveGather over gloo, world size 2: the root consumes its own and the peer's waves, each exactly once per
+    pass, in wave order per source, with the bytes the sender wrote (also when there are more waves than ring slots)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wave_worker, args=(r, 2, port, q, n_waves, slots)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] == []                                       # only the root consumes
+    for src in (0, 1):
+        got = [(w, t) for s_, w, t in res[0] if s_ == src]
+        assert [w for w, _ in got] == list(range(n_waves)) * 2
+        for i, (w, t) in enumerate(got):
+            rep = i // n_waves
+            assert np.array_equal(t, np.arange(12).reshape(4, 3) + 1000 * src + 100 * w + 7 * rep)
+
+
+def test_gather_outputs_in_single_block_waves():
+    """ragged shards (3 + 2 blocks) moved one block per wave"""
+    fhe, om, orc = _setup()
+    make_inputs, compute, digest = _pipeline(fhe, om, orc)
+    ref = compute(make_inputs(0, NB))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None and np.array_equal(res[0], ref.numpy())
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fhe, om, orc = _setup()
+    make_inputs, compute, _ = _pipeline(fhe, om, orc)
+    s, e = fhe.parallel.block_range(rank, world, NB)
+    g = fhe.parallel.gather_outputs(compute(make_inputs(s, e)), NB, wave_blocks=1)
+    q.put((rank, None if g is None else g.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
