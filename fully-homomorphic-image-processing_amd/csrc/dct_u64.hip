@@ -1,0 +1,342 @@
+// dct_u64.hip -- encrypted_dct + quantize_fhe (homo/fhe_image.h:196-305) as TWO fused launches in 64-bit
+// integer (Shoup / Harvey) arithmetic, for coefficient moduli the exact-FP64 kernels of dct_fused.hip cannot
+// take: primes of 48..57 bits -- in particular the moduli SEAL 2.3's coeff_modulus_128 really returns
+// (54/55-bit, homo/server_jpeg.cpp:78).  Same dataflow as the FP64 pair:
+//   kernel A (rows):    x_m = d_m +- d_(7-m) on coefficients, four joint forward NTTs (every twiddle shared
+//                       by the four polynomials), the even / odd half of the LL&M row pass per NTT slot,
+//                       four NTT-form row outputs to the intermediate
+//   kernel B (columns): the same on the intermediates for a column, per-output scale
+//                       encode(0.125)*encode(1/quant) folded into one product, four joint inverse NTTs
+// instead of the general path's NTT -> 64-values-per-slot kernel -> inverse NTT (three launches, every
+// polynomial through HBM three times each way).
+//
+// Lazy ranges (q < 2^57 so that 128 q < 2^64): forward butterflies keep values in [0, 4q) (Harvey); a Shoup
+// product accepts ANY 64-bit operand and returns [0, 2q); sums inside the per-slot circuit are left
+// unreduced (bounds in the comments of line_half); the scale product brings column outputs to [0, 2q),
+// which is what the Gentleman-Sande inverse butterflies expect; one conditional subtraction at the store
+// gives canonical residues.  The ciphertexts are bit-identical to the op-at-a-time evaluation (exact ring
+// arithmetic); tests/test_gpu_parity.py compares with the oracle.
+#include "internal.h"
+
+#include <cstdlib>
+
+namespace {
+
+struct Work { u32 blk, line, poly, prime, half; };
+// the two halves of a line sit 8 apart in blockIdx (same XCD: the partner's re-read of the eight inputs is an
+// L2 hit) and the prime is the slowest index (resident workgroups share one prime's twiddles and constants)
+__device__ __forceinline__ Work decode(u32 idx, u32 k) {
+    const u32 w = ((idx >> 4) << 3) | (idx & 7);
+    const u32 per_prime = (gridDim.x >> 1) / k;
+    Work o;
+    o.half = (idx >> 3) & 1;
+    o.prime = w / per_prime;
+    u32 t = w - o.prime * per_prime;
+    o.poly = t & 1;
+    t >>= 1;
+    o.line = t & 7;
+    o.blk = t >> 3;
+    return o;
+}
+
+constexpr int LE = 3, E = 8;                     // coefficients per thread
+template <int L> struct Sh { static constexpr int N = 1 << L, TP = N >> LE, NP = (L + LE - 1) / LE, LDS_WORDS = N + (N >> LE); };
+__host__ __device__ constexpr int p_lo(int L, int p) { return (L - LE * p - LE) < 0 ? 0 : (L - LE * p - LE); }
+__host__ __device__ constexpr int p_stages(int L, int p) { return (L - LE * p) > LE ? LE : (L - LE * p); }
+template <int LO> __device__ __forceinline__ int e_index(int tid, int r) { return ((tid >> LO) << (LO + LE)) | (r << LO) | (tid & ((1 << LO) - 1)); }
+template <int LO> __device__ __forceinline__ int e_pad(int j) { return j + ((j >> (LO + LE)) << LO); }
+
+// twiddles of one register pass: 2^(LE-1-rb) per stage, 7 in all, each a (value, Shoup companion) pair
+template <int L, int P> struct Tw {
+    static constexpr int LO = p_lo(L, P), S = p_stages(L, P);
+    static constexpr int rb(int u) { return (L - 1 - (LE * P + u)) - LO; }
+    static constexpr int count(int u) { return 1 << (LE - 1 - rb(u)); }
+    static constexpr int offset(int u) { int o = 0; for (int v = 0; v < u; v++) o += count(v); return o; }
+};
+// twiddles of ONE stage (1, 2 or 4 pairs): fetched one stage ahead of their use, so that at most eight pairs
+// are live (a whole pass's seven pairs plus the next pass's would not fit the 128-VGPR budget next to the data)
+template <int L, int P, int U>
+__device__ __forceinline__ void load_stage(ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, int tid) {
+    using T = Tw<L, P>;
+    const int th = (P == 0) ? 0 : (tid >> T::LO);
+#pragma unroll
+    for (int i = 0; i < T::count(U); i++) w[i] = tw[(1 << (LE * P + U)) + ((th << (LE - 1 - T::rb(U))) | i)];
+}
+
+// Cooley-Tukey stage U of pass P on four polynomials; values in [0, 4q) in and out
+template <int L, int P, int U>
+__device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], u64 q) {
+    using T = Tw<L, P>;
+    const u64 twoq = 2 * q;
+    constexpr int rb = T::rb(U);
+#pragma unroll
+    for (int b = 0; b < E / 2; b++) {
+        const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+        const ulonglong2 wv = w[r0 >> (rb + 1)];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const u64 X = csub(x[m][r0], twoq);
+            const u64 Tm = mul_shoup_lazy(x[m][r1], wv.x, wv.y, q);
+            x[m][r0] = X + Tm;
+            x[m][r1] = X - Tm + twoq;
+        }
+    }
+}
+template <int L, int P, int U = 0>
+__device__ __forceinline__ void fwd_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, u64 q, int tid) {
+    if constexpr (U + 1 < Tw<L, P>::S) {
+        ulonglong2 wn[4];
+        load_stage<L, P, U + 1>(wn, tw, tid);
+        fwd_stage<L, P, U>(x, w, q);
+        fwd_pass<L, P, U + 1>(x, wn, tw, q, tid);
+    } else {
+        fwd_stage<L, P, U>(x, w, q);
+    }
+}
+// Gentleman-Sande stage U of pass P; values in [0, 2q) in and out; n^-1 merged into the last stage of the transform
+template <int L, int P, int U>
+__device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, u64 q) {
+    using T = Tw<L, P>;
+    const u64 twoq = 2 * q;
+    constexpr int sigma = LE * P + U, rb = T::rb(U);
+#pragma unroll
+    for (int b = 0; b < E / 2; b++) {
+        const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+        const ulonglong2 wv = w[r0 >> (rb + 1)];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const u64 X = x[m][r0], Y = x[m][r1];
+            const u64 Tm = csub(X + Y, twoq);
+            const u64 D = X - Y + twoq;
+            x[m][r0] = (sigma == 0) ? mul_shoup_lazy(Tm, ninv.x, ninv.y, q) : Tm;
+            x[m][r1] = mul_shoup_lazy(D, wv.x, wv.y, q);
+        }
+    }
+}
+template <int L, int P, int U = Tw<L, P>::S - 1>
+__device__ __forceinline__ void inv_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, u64 q, int tid) {
+    if constexpr (U > 0) {
+        ulonglong2 wn[4];
+        load_stage<L, P, U - 1>(wn, itw, tid);
+        inv_stage<L, P, U>(x, w, ninv, q);
+        inv_pass<L, P, U - 1>(x, wn, itw, ninv, q, tid);
+    } else {
+        inv_stage<L, P, U>(x, w, ninv, q);
+    }
+}
+
+// four polynomials through two alternating LDS buffers; exchanges whose lane-to-index maps keep the wave bits
+// of the thread id fixed (both LO <= 6) need no workgroup barrier: a wave only reads what it wrote itself
+template <int L, int LO_FROM, int LO_TO>
+__device__ __forceinline__ void transpose(u64 (&x)[4][E], u64 *lds, int tid, int &phase) {
+    constexpr int PL = LO_FROM < LO_TO ? LO_FROM : LO_TO;
+    constexpr bool WAVE_LOCAL = (Sh<L>::TP <= 64) || (LO_FROM <= 6 && LO_TO <= 6);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        u64 *buf = lds + (phase & 1) * Sh<L>::LDS_WORDS;
+        phase++;
+#pragma unroll
+        for (int r = 0; r < E; r++) buf[e_pad<PL>(e_index<LO_FROM>(tid, r))] = x[m][r];
+        if constexpr (WAVE_LOCAL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < E; r++) x[m][r] = buf[e_pad<PL>(e_index<LO_TO>(tid, r))];
+    }
+}
+
+// `w` holds the twiddles of the first stage of pass P; the first stage of the next pass is fetched before the
+// LDS exchange so that its latency hides behind it
+template <int L, int P = 0>
+__device__ __forceinline__ void ntt_fwd(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, u64 q, u64 *lds, int tid, int &phase) {
+    fwd_pass<L, P>(x, w, tw, q, tid);
+    if constexpr (P + 1 < Sh<L>::NP) {
+        ulonglong2 wn[4];
+        load_stage<L, P + 1, 0>(wn, tw, tid);
+        transpose<L, p_lo(L, P), p_lo(L, P + 1)>(x, lds, tid, phase);
+        ntt_fwd<L, P + 1>(x, wn, tw, q, lds, tid, phase);
+    }
+}
+template <int L, int P = Sh<L>::NP - 1>
+__device__ __forceinline__ void ntt_inv(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, u64 q, u64 *lds, int tid, int &phase) {
+    inv_pass<L, P>(x, w, itw, ninv, q, tid);
+    if constexpr (P > 0) {
+        ulonglong2 wn[4];
+        load_stage<L, P - 1, Tw<L, P - 1>::S - 1>(wn, itw, tid);
+        transpose<L, p_lo(L, P), p_lo(L, P - 1)>(x, lds, tid, phase);
+        ntt_inv<L, P - 1>(x, wn, itw, ninv, q, lds, tid, phase);
+    }
+}
+
+// Even / odd half of one LL&M line (homo/fhe_image.h:215-242) on one NTT slot.  In: x[m] < B q (B = 4 in the row
+// kernel, 32 in the column kernel).  Out: x[m] = line output 2m + HALF, below 4B q (even: outputs 0 and 4) or
+// below 8q.  `sub` = B q, the multiple of q added before a subtraction.  128 q < 2^64 covers B = 32.
+template <int HALF, typename CF>
+__device__ __forceinline__ void line_half(u64 &x0, u64 &x1, u64 &x2, u64 &x3, u64 q, u64 sub, CF C) {
+    auto MUL = [&](u64 v, int cid) { const ulonglong2 w = C(cid); return mul_shoup_lazy(v, w.x, w.y, q); };    // any v -> [0, 2q)
+    if constexpr (HALF == 0) {                       // x = tmp0..tmp3
+        const u64 tmp10 = x0 + x3, tmp13 = x0 - x3 + sub, tmp11 = x1 + x2, tmp12 = x1 - x2 + sub;      // < 2B q
+        const u64 z1 = MUL(tmp12 + tmp13, 0);
+        x0 = tmp10 + tmp11;                          // out 0, < 4B q
+        x2 = tmp10 - tmp11 + 2 * sub;                // out 4, < 4B q
+        x1 = z1 + MUL(tmp13, 1);                     // out 2, < 4q
+        x3 = z1 + MUL(tmp12, 2);                     // out 6
+    } else {                                         // x = tmp7, tmp6, tmp5, tmp4
+        const u64 tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
+        const u64 z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;              // < 2B q
+        const u64 z5 = MUL(z3 + z4, 3);              // operand < 4B q
+        const u64 t4 = MUL(tmp4, 4), t5 = MUL(tmp5, 5), t6 = MUL(tmp6, 6), t7 = MUL(tmp7, 7);
+        const u64 m1 = MUL(z1, 8), m2 = MUL(z2, 9), m3 = MUL(z3, 10) + z5, m4 = MUL(z4, 11) + z5;      // m3, m4 < 4q
+        x0 = t7 + m1 + m4;                           // out 1, < 8q
+        x1 = t6 + m2 + m3;                           // out 3
+        x2 = t5 + m2 + m4;                           // out 5
+        x3 = t4 + m1 + m3;                           // out 7
+    }
+}
+
+template <int L, int HALF>
+__device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__restrict__ mid, const ulonglong2 *__restrict__ consts,
+                                          const ulonglong2 *__restrict__ tw, const Work &wk, u64 q, u32 k, u64 *lds) {
+    constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
+    const int tid = threadIdx.x;
+    const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
+    const size_t base = ((size_t)wk.blk * 64 + 8 * wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
+    ulonglong2 w0[4];
+    load_stage<L, 0, 0>(w0, tw, tid);
+    u64 x[4][E];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const u64 *a = in + base + (size_t)m * ct_words + tid, *b = in + base + (size_t)(7 - m) * ct_words + tid;
+#pragma unroll
+        for (int r = 0; r < E; r++) {                // pass-0 mapping: coefficient r*TP + tid; canonical inputs
+            const u64 A = a[r * TP], B = b[r * TP];
+            x[m][r] = HALF ? A - B + q : A + B;      // [0, 2q)
+        }
+    }
+    int phase = 0;
+    ntt_fwd<L>(x, w0, tw, q, lds, tid, phase);       // [0, 4q), slot j = (tid << 3) + r at position r*TP + tid
+    const ulonglong2 *cp = consts + (size_t)wk.prime * N + tid;
+    const size_t cstride = (size_t)k * N;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], q, 4 * q, C);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {                    // row outputs below 16 q
+        u64 *o = mid + base + (size_t)(2 * m + HALF) * ct_words + tid;
+#pragma unroll
+        for (int r = 0; r < E; r++) o[r * TP] = x[m][r];
+    }
+}
+
+template <int L, int HALF>
+__device__ __forceinline__ void cols_body(const u64 *__restrict__ mid, u64 *__restrict__ out, const ulonglong2 *__restrict__ consts,
+                                          const ulonglong2 *__restrict__ itw, const Work &wk, u64 q, u32 k, u64 *lds) {
+    constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
+    const int tid = threadIdx.x;
+    const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
+    const size_t base = ((size_t)wk.blk * 64 + wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
+    const size_t row_stride = 8 * ct_words, cstride = (size_t)k * N;
+    const u64 sub16 = 16 * q;
+    u64 x[4][E];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const u64 *a = mid + base + (size_t)m * row_stride + tid, *b = mid + base + (size_t)(7 - m) * row_stride + tid;
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const u64 A = a[r * TP], B = b[r * TP];  // < 16 q each
+            x[m][r] = HALF ? A - B + sub16 : A + B;  // < 32 q
+        }
+    }
+    const ulonglong2 *cp = consts + (size_t)wk.prime * N + tid;
+    // per-output scale: row 2m+HALF, column wk.line -> constant 12 + 8*row + col
+    const ulonglong2 *sp = consts + (size_t)(12 + 8 * HALF + wk.line) * cstride + (size_t)wk.prime * N + tid;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
+        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], q, 32 * q, C);       // outputs below 128 q
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const ulonglong2 s = sp[(size_t)(16 * m) * cstride + r * TP];
+            x[m][r] = mul_shoup_lazy(x[m][r], s.x, s.y, q);                      // [0, 2q)
+        }
+    }
+    int phase = 0;
+    ulonglong2 wl[4];
+    load_stage<L, Sh<L>::NP - 1, Tw<L, Sh<L>::NP - 1>::S - 1>(wl, itw, tid);
+    ntt_inv<L>(x, wl, itw, itw[0], q, lds, tid, phase);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        u64 *o = out + base + (size_t)(2 * m + HALF) * row_stride + tid;
+#pragma unroll
+        for (int r = 0; r < E; r++) o[r * TP] = csub(x[m][r], q);
+    }
+}
+
+__host__ __device__ constexpr int occ_w(int tp, int lds_words) { return ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256 < 1 ? 1 : ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256; }
+
+template <int L>
+__global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_rows_u64(const u64 *__restrict__ in, u64 *__restrict__ mid,
+                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
+    __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
+    const Work wk = decode(blockIdx.x, k);
+    const u64 q = base.mod[wk.prime].q;
+    const ulonglong2 *tw = base.tw + (size_t)wk.prime * Sh<L>::N;
+    if (wk.half) rows_body<L, 1>(in, mid, consts, tw, wk, q, k, lds);
+    else rows_body<L, 0>(in, mid, consts, tw, wk, q, k, lds);
+}
+template <int L>
+__global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_cols_u64(const u64 *__restrict__ mid, u64 *__restrict__ out,
+                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
+    __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
+    const Work wk = decode(blockIdx.x, k);
+    const u64 q = base.mod[wk.prime].q;
+    const ulonglong2 *itw = base.itw + (size_t)wk.prime * Sh<L>::N;
+    if (wk.half) cols_body<L, 1>(mid, out, consts, itw, wk, q, k, lds);
+    else cols_body<L, 0>(mid, out, consts, itw, wk, q, k, lds);
+}
+
+// constants from the u64 kernels' slot order (16 slots per thread) to this file's (8 per thread):
+// bit-reversed index j = (t << 3) + r lives at r * (n >> 3) + t here, at (j & 15) * (n >> 4) + (j >> 4) there
+__global__ void k_consts_to_le3(const ulonglong2 *__restrict__ in, ulonglong2 *__restrict__ out, u32 n, u32 total) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u32 pos = i % n, rowbase = i - pos, tp = n >> 3, r = pos / tp, t = pos % tp;
+    const u32 j = (t << 3) + r;
+    out[i] = in[rowbase + (j & 15) * (n >> 4) + (j >> 4)];
+}
+
+}  // namespace
+
+bool fhe_dct_u64_supported(const fhe_ctx *c) {
+    static const bool off = [] { const char *e = getenv("FHE_DCT_U64_FUSED"); return e && e[0] == '0' && !e[1]; }();
+    return c && !off && c->max_prime_bits <= 57 && (c->logn == 11 || c->logn == 12 || c->logn == 13);
+}
+
+int fhe_dct_u64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
+    const u32 total = DCT_NCONST * c->k * c->n;
+    HIP_TRY(hipMalloc(&plan->d_consts_le3, sizeof(ulonglong2) * total));
+    k_consts_to_le3<<<(total + 255) / 256, 256, 0, st>>>(plan->d_consts, plan->d_consts_le3, c->n, total);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+int fhe_dct_u64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, u64 *mid, hipStream_t st) {
+    const u64 grid = n_blocks * 8 * 2 * c->k * 2;      // (block, line, poly, prime) x two halves
+    if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
+    const RnsBase base = c->qb.dev();
+    switch (c->logn) {
+#define GO(LL) case LL: k_dct_rows_u64<LL><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
+                        k_dct_cols_u64<LL><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(mid, out, plan->d_consts_le3, base, c->k); break;
+        GO(11) GO(12) GO(13)
+#undef GO
+        default: return fail(FHE_ERR_PARAM, "fused u64 path supports n in {2048, 4096, 8192}");
+    }
+    KERNEL_CHECK();
+    return FHE_OK;
+}

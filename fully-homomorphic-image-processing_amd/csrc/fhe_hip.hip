@@ -843,7 +843,7 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
     auto cleanup = [&](int code) {
         if (d_eighth) (void)hipFree(d_eighth);
         if (d_tmp) (void)hipFree(d_tmp);
-        if (code) { (void)hipFree(p->d_consts); if (p->d_consts_f64) (void)hipFree(p->d_consts_f64); delete p; }
+        if (code) { (void)hipFree(p->d_consts); if (p->d_consts_f64) (void)hipFree(p->d_consts_f64); if (p->d_consts_le3) (void)hipFree(p->d_consts_le3); delete p; }
         return code;
     };
     auto prep = [&](double v, ulonglong2 *dst) -> int {
@@ -868,6 +868,7 @@ extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int 
         }
     }
     if (fhe_dct_f64_supported(c) && (rc = fhe_dct_f64_make_consts(c, p, (hipStream_t)s))) return cleanup(rc);
+    if (!fhe_dct_f64_supported(c) && fhe_dct_u64_supported(c) && (rc = fhe_dct_u64_make_consts(c, p, (hipStream_t)s))) return cleanup(rc);
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return cleanup(fail(FHE_ERR_HIP, "stream sync failed"));
     *out = p;
     return cleanup(FHE_OK);
@@ -876,6 +877,7 @@ extern "C" int fhe_dct_plan_destroy(fhe_dct_plan *p) {
     if (!p) return FHE_OK;
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_consts_f64) (void)hipFree(p->d_consts_f64);
+    if (p->d_consts_le3) (void)hipFree(p->d_consts_le3);
     delete p;
     return FHE_OK;
 }
@@ -887,7 +889,7 @@ static u64 dct_wave_blocks() {
     return 256;
 }
 extern "C" size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *c, uint64_t n_blocks) {
-    if (!c || !fhe_dct_f64_supported(c)) return 0;
+    if (!c || !(fhe_dct_f64_supported(c) || fhe_dct_u64_supported(c))) return 0;
     const u64 wave = dct_wave_blocks() < n_blocks ? dct_wave_blocks() : n_blocks;
     return (size_t)wave * 64 * 2 * c->k * c->n * sizeof(double);
 }
@@ -933,6 +935,19 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
             HIP_TRY(hipEventRecord(mc->ev_cols[s], mc->aux_stream));
         }
         for (int s = 0; s < 2 && (u64)s < w; ++s) HIP_TRY(hipStreamWaitEvent(st, mc->ev_cols[s], 0));   // join: out is complete on `st`
+        return FHE_OK;
+    }
+    // primes of 48..57 bits (SEAL 2.3's own coeff_modulus_128 tables): the same two-launch structure in u64 Shoup arithmetic
+    if (plan->d_consts_le3 && fhe_dct_u64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) {
+        const size_t per_block = (size_t)64 * 2 * c->k * c->n;
+        const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(u64)) : 0;
+        if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
+        const u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
+        for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
+            const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
+            int rc = fhe_dct_u64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (u64 *)scratch, st);
+            if (rc) return rc;
+        }
         return FHE_OK;
     }
     // general path (any prime below 2^61): three launches per chunk, u64 Shoup arithmetic

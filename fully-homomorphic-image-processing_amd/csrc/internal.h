@@ -69,6 +69,7 @@ struct fhe_ctx {
 struct fhe_dct_plan {
     ulonglong2 *d_consts = nullptr;   // [DCT_NCONST][k][n] Shoup pairs, slot order
     double *d_consts_f64 = nullptr;   // [DCT_NCONST][k][n] centred doubles (FP64 path), or null
+    ulonglong2 *d_consts_le3 = nullptr;   // [DCT_NCONST][k][n] Shoup pairs in the fused u64 kernels' order (dct_u64.hip), or null
     u32 k = 0, n = 0;
     bool has_quant = false;
 };
@@ -94,6 +95,10 @@ bool fhe_dct_f64_supported(const fhe_ctx *c);
 // which: bit 0 = row kernel, bit 1 = column kernel
 int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, double *mid, hipStream_t st, int which = 3);
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);
+// fused u64 (Shoup) DCT path for primes of 48..57 bits (dct_u64.hip)
+bool fhe_dct_u64_supported(const fhe_ctx *c);
+int fhe_dct_u64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st);
+int fhe_dct_u64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, u64 n_blocks, u64 *mid, hipStream_t st);
 bool fhe_rgb_f64_supported(const fhe_ctx *c);
 int fhe_poly_f64_launch(int mode, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_polys, const ulonglong2 *plain, hipStream_t st);
 int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **out, hipStream_t st);

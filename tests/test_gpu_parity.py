@@ -277,10 +277,11 @@ def test_digest_is_order_independent_and_matches_numpy(fhe, oracle_mod):
     assert ctx.digest(a.view(-1)[:5000].contiguous()) == ref
 
 
-@pytest.mark.parametrize("preset,n_blocks", [("P4096", 3), ("SEAL3_8192", 1), ("SEAL23_4096", 1)])
+@pytest.mark.parametrize("preset,n_blocks", [("P4096", 3), ("SEAL3_8192", 1), ("SEAL23_4096", 3), ("P8192", 2), ("SEAL23_2048", 2)])
 def test_dct_fp64_path_equals_u64_path(fhe, oracle_mod, preset, n_blocks, monkeypatch):
-    """The exact-FP64 fused kernels and the general u64 Shoup kernels produce identical bytes
-    (SEAL23_4096 has 55-bit primes and always takes the u64 path)."""
+    """The fused two-launch kernels -- exact-FP64 (dct_fused.hip, primes below 2^47) or u64 Shoup (dct_u64.hip,
+    the 54/55-bit primes of SEAL23_4096 / P8192 / SEAL23_2048) -- and the general three-launch u64 path produce
+    identical bytes, equal to the oracle's op-at-a-time evaluation."""
     ctx, orc = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
     blocks = ctx.random_ct(n_blocks, 64, seed=99)
@@ -301,6 +302,20 @@ def test_dct_extreme_residues(fhe, oracle_mod):
     for i, q in enumerate(ctx.q):
         blk[0, :, :, i, :] = q - 1
     blk[0, 5] = 0
+    out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))
+    assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
+
+
+@pytest.mark.parametrize("preset", ["SEAL23_4096", "P8192"])
+def test_dct_extreme_residues_u64_fused(fhe, oracle_mod, preset):
+    """all-(q-1) inputs through the lazy ranges of the fused u64 kernels (values up to 128 q before the scale product)"""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    blk = np.zeros((1, 64, 2, ctx.k, ctx.n), dtype=np.uint64)
+    for i, q in enumerate(ctx.q):
+        blk[0, :, :, i, :] = q - 1
+    blk[0, 5] = 0
+    blk[0, 9, :, :, ::2] = 1
     out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))
     assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
 
