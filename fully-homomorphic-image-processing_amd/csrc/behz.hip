@@ -35,7 +35,22 @@ struct BehzDev {   // lives in device memory; every access is wave-uniform (scal
     ulonglong2 punct_B_mod_msk[BK];
     ulonglong2 inv_B_mod_msk;
     ulonglong2 B_mod_q[BK];
+    // Lazy base conversions: every sum_i y_i * c_ij is accumulated as a 128-bit integer and reduced ONCE
+    // (four 32x32 multiply-adds per term + seven for the reduction, against ten per Shoup product), with the
+    // trailing constant factor of each step folded into the matrix entries:
+    u64 mu2_q[BK], mu2_b[BK + 1];          // floor(2^(bits+63) / m): wide Barrett constant, valid for z < 2^(bits+63)
+    u32 sh_q[BK], sh_b[BK + 1];            // bits - 1
+    u64 ext_q2b[BK][BK + 1];               // (q/q_i) * m~^-1 mod b_j               (step 0+1)
+    u64 ext_q_b[BK + 1];                   // q * m~^-1 mod b_j
+    ulonglong2 t_inv_punct[BK];            // t * (q/q_i)^-1 mod q_i                 (step 3)
+    u64 flo_q2b[BK][BK + 1];               // b_j - (q/q_i) * q^-1 mod b_j
+    u64 flo_t_b[BK + 1];                   // t * q^-1 mod b_j
+    u64 back_B2q[BK][BK];                  // (B/b_j) mod q_i                        (step 4)
+    u64 back_pos[BK], back_neg[BK];        // q_i - B mod q_i,  B mod q_i
+    u64 back_B2msk[BK];                    // (B/b_j) mod m_sk
 };
+
+typedef unsigned __int128 u128;
 
 struct BehzTables {
     BaseTables aux;     // NTT tables of Bsk (k+1 primes)
@@ -51,38 +66,85 @@ __device__ __forceinline__ u64 reduce64(u64 x, u64 q, u64 r64) {   // x mod q fo
     return csub(r, q);
 }
 
+// z mod m for z < 2^(bits(m)+63): x = floor(z / 2^(bits-1)) < 2^64, qhat = floor(x mu2 / 2^64) with
+// mu2 = floor(2^(bits+63) / m); z/m - qhat < 3, so the remainder estimate lies in [0, 3m)
+__device__ __forceinline__ u64 reduce128(u128 z, u64 m, u64 mu2, u32 sh) {
+    const u64 x = (u64)(z >> sh);
+    u64 r = (u64)z - __umul64hi(x, mu2) * m;
+    r = csub(r, 2 * m);
+    return csub(r, m);
+}
+
+// Terms of a 128-bit dot product between reductions.  Every term is below 2^122 (operands below 2^61), the reduced
+// carry below 2^61, and reduce128 takes z < 2^(bits(m)+63); three terms + carry stay below 2^124 for 61-bit moduli and,
+// for a smaller modulus q_i, the terms z_j c (c < q_i) are below 2^(61+bits(q_i)): again three fit.
+constexpr int DOT_CHUNK = 3;
+
 // x * c mod m for a context constant c = (value, Shoup companion); any x < 2^64; result in [0, m)
 __device__ __forceinline__ u64 mulc(u64 x, const ulonglong2 c, u64 m) { return mul_shoup(x, c.x, c.y, m); }
 // lazy variant, result in [0, 2m)
 __device__ __forceinline__ u64 mulc_lazy(u64 x, const ulonglong2 c, u64 m) { return mul_shoup_lazy(x, c.x, c.y, m); }
 
+// The base-conversion kernels are latency-bound, not multiply-bound, when their ~100 context constants come in
+// through dependent scalar loads inside loops of run-time length.  They are therefore templated on the number of
+// q-primes K (every loop unrolls, every table offset is a compile-time constant) and handle CPT coefficients per
+// thread, so that every constant fetched serves CPT coefficients and the independent chains overlap.
 // steps 0+1 for every coefficient of every input polynomial: in [polys][k][n] -> out [polys][k+1][n]
+// CPT coefficients per thread: every table constant fetched (scalar loads) serves CPT coefficients.
+constexpr int CPT = 4;          // floor/back kernel
+#ifndef TO_BSK_CPT
+#define TO_BSK_CPT 1
+#endif
+template <int K, int CPT>
 __global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in, u64 *__restrict__ out, const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
-    const BehzDev &T = *Tp;
-    const u32 k = T.k;
+    const BehzDev &T = *Tp;       // wave-uniform: scalar loads at compile-time offsets
+    const u32 stride = gridDim.x * blockDim.x;             // n == CPT * stride
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
     for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
-        for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-            u64 y[BK];
-            u64 xm = 0;
-            for (u32 i = 0; i < k; i++) {
-                y[i] = mulc(in[(p * k + i) * n + c], T.mt_inv_punct[i], T.q[i].q);      // canonical: used as an integer below
-                xm += (y[i] & 0xffffffffULL) * T.punct_q_mod_mt[i];
+        u64 y[CPT][K], r[CPT];
+#pragma unroll
+        for (int e = 0; e < CPT; e++) r[e] = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const ulonglong2 w = T.mt_inv_punct[i];
+            const u64 qi = T.q[i].q, pm = T.punct_q_mod_mt[i];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) {
+                y[e][i] = mul_shoup(in[(p * K + i) * n + c0 + e * stride], w.x, w.y, qi);      // canonical: used as an integer below
+                r[e] += (y[e][i] & 0xffffffffULL) * pm;
             }
-            const u64 r = ((xm & 0xffffffffULL) * T.neg_inv_q_mod_mt) & 0xffffffffULL;
-            for (u32 j = 0; j <= k; j++) {
-                const u64 bq = T.b[j].q, two = 2 * bq;
-                const u64 rb = r >= 0x80000000ULL ? r + bq - 0x100000000ULL : r;         // centred remainder
-                u64 acc = mulc_lazy(rb, T.q_mod_b[j], bq);
-                for (u32 i = 0; i < k; i++) acc = csub(acc + mulc_lazy(y[i], T.punct_q_mod_b[i][j], bq), two);
-                out[(p * (k + 1) + j) * n + c] = mulc(acc, T.inv_mt_mod_b[j], bq);
+        }
+        const u64 nq = T.neg_inv_q_mod_mt;
+#pragma unroll
+        for (int e = 0; e < CPT; e++) r[e] = ((r[e] & 0xffffffffULL) * nq) & 0xffffffffULL;
+#pragma unroll
+        for (int j = 0; j <= K; j++) {
+            const u64 bq = T.b[j].q, mu2 = T.mu2_b[j], eq = T.ext_q_b[j];
+            const u32 sh = T.sh_b[j];
+            u128 acc[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) {
+                const u64 rb = r[e] >= 0x80000000ULL ? r[e] + bq - 0x100000000ULL : r[e];    // centred remainder
+                acc[e] = (u128)rb * eq;
             }
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u64 cij = T.ext_q2b[i][j];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    if (i > 0 && i % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
+                    acc[e] += (u128)y[e][i] * cij;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CPT; e++) out[(p * (K + 1) + j) * n + c0 + e * stride] = reduce128(acc[e], bq, mu2, sh);
         }
     }
 }
 
 // tensor product in NTT form over one base: A [count][sa][nb][n], Bm [count][sb][nb][n] -> D [count][sa+sb-1][nb][n]
 __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
-                                                     const Modulus *__restrict__ mods, u32 nb, u32 n, u32 sa, u32 sb, u64 count) {
+                                                     const Modulus *__restrict__ mods, const u64 *__restrict__ mu2, u32 nb, u32 n, u32 sa, u32 sb, u64 count) {
     const u32 so = sa + sb - 1;
     for (u64 cp = blockIdx.y; cp < count * nb; cp += gridDim.y) {
         const u64 c = cp / nb;
@@ -90,13 +152,15 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
         const Modulus m = mods[j];
         for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
             for (u32 o = 0; o < so; o++) {
-                u64 acc = 0;
+                u128 acc = 0;
+                u32 terms = 0;
                 const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
                 for (u32 ja = lo; ja <= hi; ja++) {
                     const u64 x = A[((c * sa + ja) * nb + j) * n + s], y = Bm[((c * sb + (o - ja)) * nb + j) * n + s];
-                    acc = addmod(acc, mul_barrett(x, y, m), m.q);
+                    acc += (u128)x * y;                               // below 2^122 each; reduced every three terms
+                    if (++terms == 3) { acc = reduce128(acc, m.q, mu2[j], m.s1); terms = 0; }
                 }
-                D[((c * so + o) * nb + j) * n + s] = acc;
+                D[((c * so + o) * nb + j) * n + s] = reduce128(acc, m.q, mu2[j], m.s1);
             }
         }
     }
@@ -137,40 +201,87 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
 }
 
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
+template <int K>
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
                                                          const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
-    const BehzDev &T = *Tp;
-    const u32 k = T.k;
-    const u64 msk = T.b[k].q;
+    const BehzDev &T = *Tp;       // wave-uniform: scalar loads at compile-time offsets
+    const u64 msk = T.b[K].q;
+    const u32 stride = gridDim.x * blockDim.x;             // n == CPT * stride
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
     for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
-        for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-            u64 y[BK], f[BK + 1], z[BK];
-            for (u32 i = 0; i < k; i++) {
-                const u64 td = mulc_lazy(Dq[(p * k + i) * n + c], T.t_mod_q[i], T.q[i].q);
-                y[i] = mulc(td, T.inv_punct[i], T.q[i].q);                              // canonical integer in [0, q_i)
+        u64 y[CPT][K], f[CPT][K + 1], z[CPT][K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const ulonglong2 w = T.t_inv_punct[i];
+            const u64 qi = T.q[i].q;
+#pragma unroll
+            for (int e = 0; e < CPT; e++) y[e][i] = mul_shoup(Dq[(p * K + i) * n + c0 + e * stride], w.x, w.y, qi);   // [t D]_q (q/q_i)^-1, canonical
+        }
+#pragma unroll
+        for (int j = 0; j <= K; j++) {         // fast floor: (t D - FastBConv([t D]_q)) q^-1 in Bsk, one 128-bit sum per prime
+            const u64 bq = T.b[j].q, mu2 = T.mu2_b[j], ft = T.flo_t_b[j];
+            const u32 sh = T.sh_b[j];
+            u128 acc[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) acc[e] = (u128)Db[(p * (K + 1) + j) * n + c0 + e * stride] * ft;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u64 cij = T.flo_q2b[i][j];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    if (i > 0 && i % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
+                    acc[e] += (u128)y[e][i] * cij;
+                }
             }
-            for (u32 j = 0; j <= k; j++) {     // fast floor
-                const u64 bq = T.b[j].q, two = 2 * bq;
-                u64 conv = 0;
-                for (u32 i = 0; i < k; i++) conv = csub(conv + mulc_lazy(y[i], T.punct_q_mod_b[i][j], bq), two);
-                const u64 td = mulc_lazy(Db[(p * (k + 1) + j) * n + c], T.t_mod_b[j], bq);   // [0, 2b)
-                f[j] = mulc(td + two - conv, T.inv_q_mod_b[j], bq);                          // (td - conv) mod b, canonical
+#pragma unroll
+            for (int e = 0; e < CPT; e++) f[e][j] = reduce128(acc[e], bq, mu2, sh);
+        }
+        u64 a_abs[CPT];
+        bool neg[CPT];
+        {
+            const u64 mu2 = T.mu2_b[K];
+            const u32 sh = T.sh_b[K];
+            u128 acc[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) acc[e] = 0;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const ulonglong2 w = T.inv_punct_B[j];
+                const u64 bq = T.b[j].q, cj = T.back_B2msk[j];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    z[e][j] = mul_shoup(f[e][j], w.x, w.y, bq);                              // canonical integer in [0, b_j)
+                    if (j > 0 && j % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], msk, mu2, sh);
+                    acc[e] += (u128)z[e][j] * cj;
+                }
             }
-            u64 conv_sk = 0;
-            for (u32 j = 0; j < k; j++) {
-                z[j] = mulc(f[j], T.inv_punct_B[j], T.b[j].q);                               // canonical integer in [0, b_j)
-                conv_sk = csub(conv_sk + mulc_lazy(z[j], T.punct_B_mod_msk[j], msk), 2 * msk);
+            const ulonglong2 ib = T.inv_B_mod_msk;
+#pragma unroll
+            for (int e = 0; e < CPT; e++) {
+                const u64 conv_sk = reduce128(acc[e], msk, mu2, sh);
+                const u64 alpha = mul_shoup(conv_sk + msk - f[e][K], ib.x, ib.y, msk);
+                neg[e] = alpha > (msk >> 1);
+                a_abs[e] = neg[e] ? msk - alpha : alpha;                                     // |alpha_sk| <= k
             }
-            const u64 alpha = mulc(conv_sk + 2 * msk - f[k], T.inv_B_mod_msk, msk);
-            const bool neg = alpha > (msk >> 1);
-            for (u32 i = 0; i < k; i++) {
-                const u64 qi = T.q[i].q, two = 2 * qi;
-                u64 conv = 0;
-                for (u32 j = 0; j < k; j++) conv = csub(conv + mulc_lazy(z[j], T.punct_B_mod_q[j][i], qi), two);
-                const u64 corr = mulc_lazy(neg ? msk - alpha : alpha, T.B_mod_q[i], qi);    // [0, 2q)
-                const u64 r = neg ? conv + corr : conv + two - corr;                        // < 4q
-                out[(p * k + i) * n + c] = csub(csub(r, two), qi);
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const u64 qi = T.q[i].q, mu2 = T.mu2_q[i], bn = T.back_neg[i], bp = T.back_pos[i];
+            const u32 sh = T.sh_q[i];
+            u128 acc[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) acc[e] = (u128)a_abs[e] * (neg[e] ? bn : bp);
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const u64 cji = T.back_B2q[j][i];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    if (j > 0 && j % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], qi, mu2, sh);
+                    acc[e] += (u128)z[e][j] * cji;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < CPT; e++) out[(p * K + i) * n + c0 + e * stride] = reduce128(acc[e], qi, mu2, sh);
         }
     }
 }
@@ -289,6 +400,28 @@ int fhe_behz_build(fhe_ctx *c) {
         D.punct_B_mod_msk[j] = pair(prod_mod(bsk.data(), (int)k, (int)j, bsk[k]), bsk[k]);
     }
     D.inv_B_mod_msk = pair(invmod(prod_mod(bsk.data(), (int)k, -1, bsk[k]), bsk[k]), bsk[k]);
+    auto mu2_of = [](u64 m, u64 &mu2, u32 &sh) {
+        const int bits = bit_length(m);
+        sh = (u32)(bits - 1);
+        mu2 = (u64)((((u128)1) << (bits + 63)) / m);
+    };
+    for (u32 i = 0; i < k; ++i) {
+        mu2_of(q[i], D.mu2_q[i], D.sh_q[i]);
+        D.t_inv_punct[i] = pair(mulmod(c->t % q[i], D.inv_punct[i].x, q[i]), q[i]);
+        D.back_neg[i] = D.B_mod_q[i].x;
+        D.back_pos[i] = (q[i] - D.B_mod_q[i].x) % q[i];
+        for (u32 j = 0; j < k; ++j) D.back_B2q[j][i] = D.punct_B_mod_q[j][i].x;
+    }
+    for (u32 j = 0; j <= k; ++j) {
+        mu2_of(bsk[j], D.mu2_b[j], D.sh_b[j]);
+        D.ext_q_b[j] = mulmod(D.q_mod_b[j].x, D.inv_mt_mod_b[j].x, bsk[j]);
+        D.flo_t_b[j] = mulmod(c->t % bsk[j], D.inv_q_mod_b[j].x, bsk[j]);
+        for (u32 i = 0; i < k; ++i) {
+            D.ext_q2b[i][j] = mulmod(D.punct_q_mod_b[i][j].x, D.inv_mt_mod_b[j].x, bsk[j]);
+            D.flo_q2b[i][j] = (bsk[j] - mulmod(D.punct_q_mod_b[i][j].x, D.inv_q_mod_b[j].x, bsk[j])) % bsk[j];
+        }
+    }
+    for (u32 j = 0; j < k; ++j) D.back_B2msk[j] = D.punct_B_mod_msk[j].x;
     if (hipMalloc((void **)&T->dev, sizeof(BehzDev)) != hipSuccess ||
         hipMemcpy(T->dev, &D, sizeof(BehzDev), hipMemcpyHostToDevice) != hipSuccess) {
         fhe_free_base(T->aux);
@@ -332,7 +465,11 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
 // xb [count][s][k+1][n] (NTT)
 static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
     const u32 k = c->k, n = c->n;
-    k_behz_to_bsk<<<grid2(n, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s);
+    switch (k) {
+#define GO(KK) case KK: k_behz_to_bsk<KK, TO_BSK_CPT><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
+        GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+#undef GO
+    }
     int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
     if (r) return r;
     return qbase_ntt(false, c, src, xq, count * s, st);
@@ -345,7 +482,7 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
     if (count * so * (u64)(k + 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const bool q_f64 = fhe_rgb_f64_supported(c);      // FP64 inverse transforms beat the fused u64 kernel there
     if (q_f64) {
-        k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, k, n, sa, sb, count);
+        k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, c->behz->dev->mu2_q, k, n, sa, sb, count);
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
@@ -355,7 +492,11 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
         const RnsBase ab = c->behz->aux.dev();
         DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * (k + 1)), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb)));
     }
-    k_behz_floor_back<<<grid2(n, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so);
+    switch (k) {
+#define GO(KK) case KK: k_behz_floor_back<KK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
+        GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+#undef GO
+    }
     KERNEL_CHECK();
     return FHE_OK;
 }
