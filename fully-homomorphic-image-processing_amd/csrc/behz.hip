@@ -172,16 +172,21 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
 // -> D [count][sa+sb-1][nb][n] (coefficient form, canonical).
 template <int L>
 __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
-                                                                       RnsBase base, u32 sa, u32 sb) {
+                                                                       RnsBase base, u32 sa, u32 sb, u64 groups) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;
     const u32 nb = base.count, so = sa + sb - 1;
-    const u64 id = blockIdx.x;                         // (c * so + o) * nb + j
-    const u32 j = (u32)(id % nb);
-    const u64 co = id / nb;
-    const u32 o = (u32)(co % so);
-    const u64 c = co / so;
+    // Work order: the `so` output polynomials of one (pair c, prime j) read the same sa + sb operand polynomials
+    // (an operand enters up to min(sa, sb) outputs), so their workgroups are placed 8 apart in blockIdx -- same XCD,
+    // dispatched back to back -- and the repeated reads hit that XCD's L2 instead of going to memory again.
+    const u64 bid = blockIdx.x, chunk = bid / (8 * so), rem = bid % (8 * so);
+    const u32 o = (u32)(rem >> 3);
+    const u64 g = chunk * 8 + (rem & 7);               // c * nb + j
+    if (g >= groups) return;
+    const u32 j = (u32)(g % nb);
+    const u64 c = g / nb;
+    const u64 id = (c * so + o) * nb + j;              // output polynomial
     const Modulus m = base.mod[j];
     u64 acc[16];
 #pragma unroll
@@ -479,18 +484,18 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
                        u64 *Dq, u64 *Db, hipStream_t st) {
     const u32 k = c->k, n = c->n, so = sa + sb - 1;
     int rc;
-    if (count * so * (u64)(k + 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    if ((count * (u64)(k + 1) + 8) * so > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const bool q_f64 = fhe_rgb_f64_supported(c);      // FP64 inverse transforms beat the fused u64 kernel there
     if (q_f64) {
         k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, c->behz->dev->mu2_q, k, n, sa, sb, count);
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * k), NttShape<L>::TP, 0, st>>>(Aq, Bq, Dq, qb, sa, sb)));
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((count * k + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(Aq, Bq, Dq, qb, sa, sb, count * k)));
     }
     {
         const RnsBase ab = c->behz->aux.dev();
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(count * so * (k + 1)), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb)));
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((count * (k + 1) + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb, count * (k + 1))));
     }
     switch (k) {
 #define GO(KK) case KK: k_behz_floor_back<KK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
