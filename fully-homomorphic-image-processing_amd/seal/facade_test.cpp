@@ -80,6 +80,36 @@ int main(int argc, char **argv) {
       Encryptor e2(context, pk2); Decryptor d2(context, sk2); Ciphertext x; e2.encrypt(encoder.encode(5.0), x); Plaintext p; d2.decrypt(x, p);
       CHECK(encoder.decode(p) == 5.0, "key save/load"); }
     { bool threw = false; try { Ciphertext empty; evaluator.negate(empty); } catch (const std::invalid_argument &) { threw = true; } CHECK(threw, "empty ciphertext must throw"); }
+    // load() does not trust the stream: header fields are bounded, key records have a fixed polynomial count, and
+    // residues must be reduced modulo the moduli of a context of this process
+    {
+        std::stringstream ss; a.save(ss);
+        std::string rec = ss.str();
+        auto rejects = [](const std::string &bytes, int which) {
+            std::stringstream in(bytes);
+            try {
+                if (which == 0) { Ciphertext c; c.load(in); } else if (which == 1) { PublicKey k; k.load(in); } else { SecretKey k; k.load(in); }
+            } catch (const std::invalid_argument &) { return true; }
+            return false;
+        };
+        CHECK(!rejects(rec, 0), "a saved ciphertext loads");
+        std::string bad = rec; uint32_t huge = 0x7fffffffu; std::memcpy(&bad[8], &huge, 4);
+        CHECK(rejects(bad, 0), "polynomial count out of range must be rejected before allocating");
+        bad = rec; uint32_t n_bad = 12345; std::memcpy(&bad[16], &n_bad, 4);
+        CHECK(rejects(bad, 0), "non-power-of-two degree must be rejected");
+        bad = rec; uint64_t big = ~0ULL; std::memcpy(&bad[24 + 8 * 17], &big, 8);
+        CHECK(rejects(bad, 0), "a residue that is not reduced must be rejected");
+        CHECK(rejects(rec.substr(0, rec.size() - 8), 0), "a truncated record must be rejected");
+        CHECK(rejects(rec, 2), "a size-2 record is not a secret key");
+        std::stringstream ks; sk.save(ks);
+        CHECK(rejects(ks.str(), 1), "a secret-key record is not a public key");
+    }
+    // two encryptions of the same plaintext differ (fresh randomness from the OS-keyed generator every time)
+    {
+        Ciphertext c1, c2; encryptor.encrypt(encoder.encode(1.0), c1); encryptor.encrypt(encoder.encode(1.0), c2);
+        std::stringstream s1, s2; c1.save(s1); c2.save(s2);
+        CHECK(s1.str() != s2.str() && dec(c1) == 1.0 && dec(c2) == 1.0, "encryption is randomised");
+    }
 
     // fused block circuit on one encrypted 8x8 block
     const std::vector<double> yqt = {16,11,10,16,24,40,51,61,12,12,14,19,26,58,60,55,14,13,16,24,40,57,69,56,14,17,22,29,51,87,80,62,
