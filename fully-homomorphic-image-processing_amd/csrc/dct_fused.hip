@@ -615,6 +615,15 @@ static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves pe
     return le;
 }
 
+// coefficients per thread = 2^LE of the fused pair for this context: 8 (four waves per SIMD) at n = 4096 with primes
+// <= 40 bits and at n = 8192 (1024-thread workgroups, one per CU); 16 otherwise
+static u32 dct_shape_le(const fhe_ctx *c) {
+    if (dct_le() != 3) return 4;
+    if (c->logn == 12 && c->max_prime_bits <= 40) return 3;
+    if (c->logn == 13) return 3;
+    return 4;
+}
+
 bool fhe_dct_f64_supported(const fhe_ctx *c) {
     return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && (c->logn == 10 || c->logn == 12 || c->logn == 13);
 }
@@ -622,7 +631,7 @@ bool fhe_dct_f64_supported(const fhe_ctx *c) {
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
     const u32 total = DCT_NCONST * c->k * c->n;
     HIP_TRY(hipMalloc(&plan->d_consts_f64, sizeof(double) * total));
-    const u32 le = (dct_le() == 3 && c->logn == 12 && c->max_prime_bits <= 40) ? 3 : 4;
+    const u32 le = dct_shape_le(c);
     k_consts_to_f64<<<(total + 255) / 256, 256, 0, st>>>(plan->d_consts, plan->d_consts_f64, c->qb.d_mod, c->k, c->n, le, total);
     KERNEL_CHECK();
     return FHE_OK;
@@ -644,6 +653,11 @@ static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *i
         }
     }
     if constexpr (LE == 3) {
+        if (big) {
+            if (which & 1) k_dct_rows<L, LE, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 2) k_dct_cols<L, LE, true, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
+            return;
+        }
         if (c->max_prime_bits <= 37 && dct_pack_enabled()) {      // packed intermediate, 40 instead of 64 bytes
             if (which & 1) k_dct_rows<L, LE, false, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
             if (which & 2) k_dct_cols<L, LE, false, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
@@ -661,11 +675,10 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     const u64 grid = items * 2;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const bool big = c->max_prime_bits > 40;
-    const int le = dct_le();
     switch (c->logn) {   // LE = 3 is only built for the headline size
         case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
-        case 12: if (le == 3 && !big) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st, which); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
-        case 13: launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
+        case 12: if (dct_shape_le(c) == 3) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st, which); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
+        case 13: if (dct_shape_le(c) == 3) launch_pair<13, 3>(c, plan, in, out, mid, (unsigned)grid, big, st, which); else launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 4096, 8192}");
     }
     KERNEL_CHECK();

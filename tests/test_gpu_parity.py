@@ -294,9 +294,11 @@ def test_dct_fp64_path_equals_u64_path(fhe, oracle_mod, preset, n_blocks, monkey
     assert np.array_equal(fused[0], orc.dct_quant(fhe.to_host(blocks)[0], fhe.YQT))
 
 
-def test_dct_extreme_residues(fhe, oracle_mod):
-    """all-(q-1) and all-zero inputs: largest magnitudes through the lazy FP64 pipeline"""
-    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+@pytest.mark.parametrize("preset", ["P4096", "SEAL3_8192"])
+def test_dct_extreme_residues(fhe, oracle_mod, preset):
+    """all-(q-1) and all-zero inputs: largest magnitudes through the lazy FP64 pipeline (36-bit primes with the packed
+    intermediate; 43/44-bit primes with the reducing variant at 8 coefficients per thread, n = 8192)"""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
     blk = np.zeros((1, 64, 2, ctx.k, ctx.n), dtype=np.uint64)
     for i, q in enumerate(ctx.q):
