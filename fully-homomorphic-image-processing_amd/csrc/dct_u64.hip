@@ -10,11 +10,15 @@
 // instead of the general path's NTT -> 64-values-per-slot kernel -> inverse NTT (three launches, every
 // polynomial through HBM three times each way).
 //
-// Lazy ranges (q < 2^57 so that 128 q < 2^64): forward butterflies keep values in [0, 4q) (Harvey); a Shoup
-// product accepts ANY 64-bit operand and returns [0, 2q); sums inside the per-slot circuit are left
-// unreduced (bounds in the comments of line_half); the scale product brings column outputs to [0, 2q),
-// which is what the Gentleman-Sande inverse butterflies expect; one conditional subtraction at the store
-// gives canonical residues.  The ciphertexts are bit-identical to the op-at-a-time evaluation (exact ring
+// Lazy ranges (q < 2^57 so that 128 q < 2^64).  Every product is mul_shoup_lazy4 (modarith.h: v_mad_u64_u32 only,
+// approximate high word): ANY 64-bit operand in, [0, 4q) out.  Forward butterflies, primes <= 56 bits: no
+// conditional subtraction at all -- x0' = X + T, x1' = X - T + 4q grow by 4q per stage, (2 + 4 log2 n) q <= 54 q at the
+// end, and the per-slot circuit works on those (4 x 54 q < 2^64 / q holds up to 56 bits); 57-bit primes keep one
+// conditional subtraction per butterfly (Harvey with doubled ranges: values in [0, 8q)).  Sums inside the per-slot
+// circuit are left unreduced (bounds in the comments of line_half); row outputs 0 and 4, which meet no constant, are
+// brought below 4q by a product with 1 so that every row output is below 16 q; the scale product brings column
+// outputs to [0, 4q), the Gentleman-Sande inverse butterflies keep [0, 4q), two conditional subtractions at the store
+// give canonical residues.  The ciphertexts are bit-identical to the op-at-a-time evaluation (exact ring
 // arithmetic); tests/test_gpu_parity.py compares with the oracle.
 #include "internal.h"
 
@@ -63,11 +67,21 @@ __device__ __forceinline__ void load_stage(ulonglong2 (&w)[4], const ulonglong2 
     for (int i = 0; i < T::count(U); i++) w[i] = tw[(1 << (LE * P + U)) + ((th << (LE - 1 - T::rb(U))) | i)];
 }
 
-// Cooley-Tukey stage U of pass P on four polynomials; values in [0, 4q) in and out
-template <int L, int P, int U>
-__device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], u64 q) {
+// per-workgroup constants of one prime
+struct Prime { u64 q, nq, q4, one_p; u32 zero; };     // nq = 2^64 - q, q4 = 4q, one_p = floor(2^64 / q), zero: modarith.h
+__device__ __forceinline__ Prime prime_of(const Modulus &m) {
+    Prime o;
+    o.q = m.q; o.nq = 0 - m.q; o.q4 = 4 * m.q; o.zero = fhe_opaque_zero;
+    o.one_p = m.mu >> (2 * (m.s1 + 1) - 64);   // floor(floor(2^(2b) / q) / 2^(2b - 64)); b >= 48 here
+    return o;
+}
+// bound (in units of q) of the forward transform's outputs
+template <int L, bool LAZY> struct Bn { static constexpr u64 V = LAZY ? 2 + 4 * L : 8; };
+
+// Cooley-Tukey stage U of pass P on four polynomials.  LAZY: values grow by 4q per stage; otherwise [0, 8q) in and out
+template <int L, int P, int U, bool LAZY>
+__device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], const Prime &pr) {
     using T = Tw<L, P>;
-    const u64 twoq = 2 * q;
     constexpr int rb = T::rb(U);
 #pragma unroll
     for (int b = 0; b < E / 2; b++) {
@@ -75,29 +89,28 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
         const ulonglong2 wv = w[r0 >> (rb + 1)];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const u64 X = csub(x[m][r0], twoq);
-            const u64 Tm = mul_shoup_lazy(x[m][r1], wv.x, wv.y, q);
+            const u64 X = LAZY ? x[m][r0] : csub(x[m][r0], pr.q4);
+            const u64 Tm = mul_shoup_lazy4(x[m][r1], wv.x, wv.y, pr.nq, pr.zero);
             x[m][r0] = X + Tm;
-            x[m][r1] = X - Tm + twoq;
+            x[m][r1] = X - Tm + pr.q4;
         }
     }
 }
-template <int L, int P, int U = 0>
-__device__ __forceinline__ void fwd_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, u64 q, int tid) {
+template <int L, int P, bool LAZY, int U = 0>
+__device__ __forceinline__ void fwd_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, const Prime &pr, int tid) {
     if constexpr (U + 1 < Tw<L, P>::S) {
         ulonglong2 wn[4];
         load_stage<L, P, U + 1>(wn, tw, tid);
-        fwd_stage<L, P, U>(x, w, q);
-        fwd_pass<L, P, U + 1>(x, wn, tw, q, tid);
+        fwd_stage<L, P, U, LAZY>(x, w, pr);
+        fwd_pass<L, P, LAZY, U + 1>(x, wn, tw, pr, tid);
     } else {
-        fwd_stage<L, P, U>(x, w, q);
+        fwd_stage<L, P, U, LAZY>(x, w, pr);
     }
 }
-// Gentleman-Sande stage U of pass P; values in [0, 2q) in and out; n^-1 merged into the last stage of the transform
+// Gentleman-Sande stage U of pass P; values in [0, 4q) in and out; n^-1 merged into the last stage of the transform
 template <int L, int P, int U>
-__device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, u64 q) {
+__device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, const Prime &pr) {
     using T = Tw<L, P>;
-    const u64 twoq = 2 * q;
     constexpr int sigma = LE * P + U, rb = T::rb(U);
 #pragma unroll
     for (int b = 0; b < E / 2; b++) {
@@ -106,22 +119,22 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const u64 X = x[m][r0], Y = x[m][r1];
-            const u64 Tm = csub(X + Y, twoq);
-            const u64 D = X - Y + twoq;
-            x[m][r0] = (sigma == 0) ? mul_shoup_lazy(Tm, ninv.x, ninv.y, q) : Tm;
-            x[m][r1] = mul_shoup_lazy(D, wv.x, wv.y, q);
+            const u64 Tm = csub(X + Y, pr.q4);
+            const u64 D = X - Y + pr.q4;             // [0, 8q)
+            x[m][r0] = (sigma == 0) ? mul_shoup_lazy4(Tm, ninv.x, ninv.y, pr.nq, pr.zero) : Tm;
+            x[m][r1] = mul_shoup_lazy4(D, wv.x, wv.y, pr.nq, pr.zero);
         }
     }
 }
 template <int L, int P, int U = Tw<L, P>::S - 1>
-__device__ __forceinline__ void inv_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, u64 q, int tid) {
+__device__ __forceinline__ void inv_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, const Prime &pr, int tid) {
     if constexpr (U > 0) {
         ulonglong2 wn[4];
         load_stage<L, P, U - 1>(wn, itw, tid);
-        inv_stage<L, P, U>(x, w, ninv, q);
-        inv_pass<L, P, U - 1>(x, wn, itw, ninv, q, tid);
+        inv_stage<L, P, U>(x, w, ninv, pr);
+        inv_pass<L, P, U - 1>(x, wn, itw, ninv, pr, tid);
     } else {
-        inv_stage<L, P, U>(x, w, ninv, q);
+        inv_stage<L, P, U>(x, w, ninv, pr);
     }
 }
 
@@ -151,56 +164,58 @@ __device__ __forceinline__ void transpose(u64 (&x)[4][E], u64 *lds, int tid, int
 
 // `w` holds the twiddles of the first stage of pass P; the first stage of the next pass is fetched before the
 // LDS exchange so that its latency hides behind it
-template <int L, int P = 0>
-__device__ __forceinline__ void ntt_fwd(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, u64 q, u64 *lds, int tid, int &phase) {
-    fwd_pass<L, P>(x, w, tw, q, tid);
+template <int L, bool LAZY, int P = 0>
+__device__ __forceinline__ void ntt_fwd(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, const Prime &pr, u64 *lds, int tid, int &phase) {
+    fwd_pass<L, P, LAZY>(x, w, tw, pr, tid);
     if constexpr (P + 1 < Sh<L>::NP) {
         ulonglong2 wn[4];
         load_stage<L, P + 1, 0>(wn, tw, tid);
         transpose<L, p_lo(L, P), p_lo(L, P + 1)>(x, lds, tid, phase);
-        ntt_fwd<L, P + 1>(x, wn, tw, q, lds, tid, phase);
+        ntt_fwd<L, LAZY, P + 1>(x, wn, tw, pr, lds, tid, phase);
     }
 }
 template <int L, int P = Sh<L>::NP - 1>
-__device__ __forceinline__ void ntt_inv(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, u64 q, u64 *lds, int tid, int &phase) {
-    inv_pass<L, P>(x, w, itw, ninv, q, tid);
+__device__ __forceinline__ void ntt_inv(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, const Prime &pr, u64 *lds, int tid, int &phase) {
+    inv_pass<L, P>(x, w, itw, ninv, pr, tid);
     if constexpr (P > 0) {
         ulonglong2 wn[4];
         load_stage<L, P - 1, Tw<L, P - 1>::S - 1>(wn, itw, tid);
         transpose<L, p_lo(L, P), p_lo(L, P - 1)>(x, lds, tid, phase);
-        ntt_inv<L, P - 1>(x, wn, itw, ninv, q, lds, tid, phase);
+        ntt_inv<L, P - 1>(x, wn, itw, ninv, pr, lds, tid, phase);
     }
 }
 
-// Even / odd half of one LL&M line (homo/fhe_image.h:215-242) on one NTT slot.  In: x[m] < B q (B = 4 in the row
-// kernel, 32 in the column kernel).  Out: x[m] = line output 2m + HALF, below 4B q (even: outputs 0 and 4) or
-// below 8q.  `sub` = B q, the multiple of q added before a subtraction.  128 q < 2^64 covers B = 32.
-template <int HALF, typename CF>
-__device__ __forceinline__ void line_half(u64 &x0, u64 &x1, u64 &x2, u64 &x3, u64 q, u64 sub, CF C) {
-    auto MUL = [&](u64 v, int cid) { const ulonglong2 w = C(cid); return mul_shoup_lazy(v, w.x, w.y, q); };    // any v -> [0, 2q)
+// Even / odd half of one LL&M line (homo/fhe_image.h:215-242) on one NTT slot.  In: x[m] < B q (B = Bn in the row
+// kernel, 32 in the column kernel).  Out: x[m] = line output 2m + HALF: even outputs 0 and 4 below 4B q (RED04: brought
+// below 4q), outputs 2 and 6 below 8q, odd outputs below 16q.  `sub` = B q, the multiple of q added before a
+// subtraction.  4B q < 2^64 is the caller's condition (216 q for B = 54, 128 q for B = 32).
+template <int HALF, bool RED04, typename CF>
+__device__ __forceinline__ void line_half(u64 &x0, u64 &x1, u64 &x2, u64 &x3, const Prime &pr, u64 sub, CF C) {
+    auto MUL = [&](u64 v, int cid) { const ulonglong2 w = C(cid); return mul_shoup_lazy4(v, w.x, w.y, pr.nq, pr.zero); };    // any v -> [0, 4q)
     if constexpr (HALF == 0) {                       // x = tmp0..tmp3
         const u64 tmp10 = x0 + x3, tmp13 = x0 - x3 + sub, tmp11 = x1 + x2, tmp12 = x1 - x2 + sub;      // < 2B q
-        const u64 z1 = MUL(tmp12 + tmp13, 0);
+        const u64 z1 = MUL(tmp12 + tmp13, 0);        // operand < 4B q
         x0 = tmp10 + tmp11;                          // out 0, < 4B q
         x2 = tmp10 - tmp11 + 2 * sub;                // out 4, < 4B q
-        x1 = z1 + MUL(tmp13, 1);                     // out 2, < 4q
+        if constexpr (RED04) { x0 = reduce_lazy4(x0, pr.one_p, pr.nq, pr.zero); x2 = reduce_lazy4(x2, pr.one_p, pr.nq, pr.zero); }
+        x1 = z1 + MUL(tmp13, 1);                     // out 2, < 8q
         x3 = z1 + MUL(tmp12, 2);                     // out 6
     } else {                                         // x = tmp7, tmp6, tmp5, tmp4
         const u64 tmp7 = x0, tmp6 = x1, tmp5 = x2, tmp4 = x3;
         const u64 z1 = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;              // < 2B q
         const u64 z5 = MUL(z3 + z4, 3);              // operand < 4B q
         const u64 t4 = MUL(tmp4, 4), t5 = MUL(tmp5, 5), t6 = MUL(tmp6, 6), t7 = MUL(tmp7, 7);
-        const u64 m1 = MUL(z1, 8), m2 = MUL(z2, 9), m3 = MUL(z3, 10) + z5, m4 = MUL(z4, 11) + z5;      // m3, m4 < 4q
-        x0 = t7 + m1 + m4;                           // out 1, < 8q
+        const u64 m1 = MUL(z1, 8), m2 = MUL(z2, 9), m3 = MUL(z3, 10) + z5, m4 = MUL(z4, 11) + z5;      // m3, m4 < 8q
+        x0 = t7 + m1 + m4;                           // out 1, < 16q
         x1 = t6 + m2 + m3;                           // out 3
         x2 = t5 + m2 + m4;                           // out 5
         x3 = t4 + m1 + m3;                           // out 7
     }
 }
 
-template <int L, int HALF>
+template <int L, int HALF, bool LAZY>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__restrict__ mid, const ulonglong2 *__restrict__ consts,
-                                          const ulonglong2 *__restrict__ tw, const Work &wk, u64 q, u32 k, u64 *lds) {
+                                          const ulonglong2 *__restrict__ tw, const Work &wk, const Prime &pr, u32 k, u64 *lds) {
     constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
     const int tid = threadIdx.x;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
@@ -214,17 +229,17 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__res
 #pragma unroll
         for (int r = 0; r < E; r++) {                // pass-0 mapping: coefficient r*TP + tid; canonical inputs
             const u64 A = a[r * TP], B = b[r * TP];
-            x[m][r] = HALF ? A - B + q : A + B;      // [0, 2q)
+            x[m][r] = HALF ? A - B + pr.q : A + B;   // [0, 2q)
         }
     }
     int phase = 0;
-    ntt_fwd<L>(x, w0, tw, q, lds, tid, phase);       // [0, 4q), slot j = (tid << 3) + r at position r*TP + tid
+    ntt_fwd<L, LAZY>(x, w0, tw, pr, lds, tid, phase);    // below Bn q, slot j = (tid << 3) + r at position r*TP + tid
     const ulonglong2 *cp = consts + (size_t)wk.prime * N + tid;
     const size_t cstride = (size_t)k * N;
 #pragma unroll
     for (int r = 0; r < E; r++) {
         auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
-        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], q, 4 * q, C);
+        line_half<HALF, true>(x[0][r], x[1][r], x[2][r], x[3][r], pr, Bn<L, LAZY>::V * pr.q, C);
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {                    // row outputs below 16 q
@@ -236,13 +251,13 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__res
 
 template <int L, int HALF>
 __device__ __forceinline__ void cols_body(const u64 *__restrict__ mid, u64 *__restrict__ out, const ulonglong2 *__restrict__ consts,
-                                          const ulonglong2 *__restrict__ itw, const Work &wk, u64 q, u32 k, u64 *lds) {
+                                          const ulonglong2 *__restrict__ itw, const Work &wk, const Prime &pr, u32 k, u64 *lds) {
     constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
     const int tid = threadIdx.x;
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
     const size_t row_stride = 8 * ct_words, cstride = (size_t)k * N;
-    const u64 sub16 = 16 * q;
+    const u64 sub16 = 4 * pr.q4;
     u64 x[4][E];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -259,46 +274,47 @@ __device__ __forceinline__ void cols_body(const u64 *__restrict__ mid, u64 *__re
 #pragma unroll
     for (int r = 0; r < E; r++) {
         auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
-        line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], q, 32 * q, C);       // outputs below 128 q
+        line_half<HALF, false>(x[0][r], x[1][r], x[2][r], x[3][r], pr, 2 * sub16, C);     // outputs below 128 q
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const ulonglong2 s = sp[(size_t)(16 * m) * cstride + r * TP];
-            x[m][r] = mul_shoup_lazy(x[m][r], s.x, s.y, q);                      // [0, 2q)
+            x[m][r] = mul_shoup_lazy4(x[m][r], s.x, s.y, pr.nq, pr.zero);                 // [0, 4q)
         }
+        asm volatile("" ::: "memory");     // one slot's constants in flight at a time (four waves per SIMD hide the round trip)
     }
     int phase = 0;
     ulonglong2 wl[4];
     load_stage<L, Sh<L>::NP - 1, Tw<L, Sh<L>::NP - 1>::S - 1>(wl, itw, tid);
-    ntt_inv<L>(x, wl, itw, itw[0], q, lds, tid, phase);
+    ntt_inv<L>(x, wl, itw, itw[0], pr, lds, tid, phase);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         u64 *o = out + base + (size_t)(2 * m + HALF) * row_stride + tid;
 #pragma unroll
-        for (int r = 0; r < E; r++) o[r * TP] = csub(x[m][r], q);
+        for (int r = 0; r < E; r++) o[r * TP] = csub(csub(x[m][r], 2 * pr.q), pr.q);
     }
 }
 
 __host__ __device__ constexpr int occ_w(int tp, int lds_words) { return ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256 < 1 ? 1 : ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256; }
 
-template <int L>
+template <int L, bool LAZY>
 __global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_rows_u64(const u64 *__restrict__ in, u64 *__restrict__ mid,
                                                                                       const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
     __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);
-    const u64 q = base.mod[wk.prime].q;
+    const Prime pr = prime_of(base.mod[wk.prime]);
     const ulonglong2 *tw = base.tw + (size_t)wk.prime * Sh<L>::N;
-    if (wk.half) rows_body<L, 1>(in, mid, consts, tw, wk, q, k, lds);
-    else rows_body<L, 0>(in, mid, consts, tw, wk, q, k, lds);
+    if (wk.half) rows_body<L, 1, LAZY>(in, mid, consts, tw, wk, pr, k, lds);
+    else rows_body<L, 0, LAZY>(in, mid, consts, tw, wk, pr, k, lds);
 }
 template <int L>
 __global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_cols_u64(const u64 *__restrict__ mid, u64 *__restrict__ out,
                                                                                       const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
     __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);
-    const u64 q = base.mod[wk.prime].q;
+    const Prime pr = prime_of(base.mod[wk.prime]);
     const ulonglong2 *itw = base.itw + (size_t)wk.prime * Sh<L>::N;
-    if (wk.half) cols_body<L, 1>(mid, out, consts, itw, wk, q, k, lds);
-    else cols_body<L, 0>(mid, out, consts, itw, wk, q, k, lds);
+    if (wk.half) cols_body<L, 1>(mid, out, consts, itw, wk, pr, k, lds);
+    else cols_body<L, 0>(mid, out, consts, itw, wk, pr, k, lds);
 }
 
 // constants from the u64 kernels' slot order (16 slots per thread) to this file's (8 per thread):
@@ -330,8 +346,10 @@ int fhe_dct_u64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     const u64 grid = n_blocks * 8 * 2 * c->k * 2;      // (block, line, poly, prime) x two halves
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const RnsBase base = c->qb.dev();
+    const bool lazy = c->max_prime_bits <= 56;     // (2 + 4 log2 n) q x 4 must stay below 2^64
     switch (c->logn) {
-#define GO(LL) case LL: k_dct_rows_u64<LL><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
+#define GO(LL) case LL: if (lazy) k_dct_rows_u64<LL, true><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
+                        else k_dct_rows_u64<LL, false><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
                         k_dct_cols_u64<LL><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(mid, out, plan->d_consts_le3, base, c->k); break;
         GO(11) GO(12) GO(13)
 #undef GO

@@ -33,6 +33,31 @@ __device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wp, u64 q) {
     return csub(mul_shoup_lazy(x, w, wp, q), q);
 }
 
+// ---- the same product with cheaper multiplies ------------------------------------------------------------
+// Measured on gfx950 (tools/ubench.hip, tools/ubench4.hip): v_mad_u64_u32 issues at 52 lanes/clk/CU, v_mul_lo_u32 at
+// 29 and v_mul_hi_u32 at 33, yet hipcc lowers `x * w - umul64hi(x, wp) * q` to 5 v_mad_u64_u32 + 4 v_mul_lo_u32 +
+// 1 v_mul_hi_u32: wherever only the low word of a 32 x 32 product is demanded it narrows to v_mul_lo_u32.  Below
+//  * the high word of x * wp leaves out the low x low partial product and the carries of the cross terms: qhat in
+//    [exact - 2, exact], so the result is x * w mod q + {0, 1, 2} q, i.e. in [0, 4q) for ANY 64-bit x;
+//  * the subtraction of qhat * q is an addition of qhat * (2^64 - q), so the four cross terms whose low words make
+//    up the high word of the result form one v_mad_u64_u32 chain;
+//  * that chain's high word is kept demanded by and-ing it with a zero the compiler cannot see through
+//    (fhe_opaque_zero, a __device__ word nobody writes; one scalar load per kernel).
+// 2 v_mul_hi_u32 + 7 v_mad_u64_u32 against 10 multiplies of which 4 are the slow v_mul_lo_u32.  nq = 2^64 - q.
+inline __device__ u32 fhe_opaque_zero;
+__device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wp, u64 nq, u32 zero) {
+    const u32 xl = (u32)x, xh = (u32)(x >> 32), wl = (u32)w, wh = (u32)(w >> 32), pl = (u32)wp, ph = (u32)(wp >> 32);
+    u32 cy;
+    const u32 s = __builtin_addc(__umulhi(xh, pl), __umulhi(xl, ph), 0u, &cy);
+    const u64 A = (u64)xh * ph + (((u64)cy << 32) | s);
+    const u32 al = (u32)A, ah = (u32)(A >> 32), nl = (u32)nq, nh = (u32)(nq >> 32);
+    const u64 P = (u64)al * nl + (u64)xl * wl;
+    const u64 C = (u64)ah * nl + ((u64)al * nh + ((u64)xh * wl + (u64)xl * wh));
+    return P + ((u64)((u32)C + ((u32)(C >> 32) & zero)) << 32);
+}
+// any 64-bit v -> v mod q + {0, 1, 2} q, below 4q  (product with 1; one_p = floor(2^64 / q))
+__device__ __forceinline__ u64 reduce_lazy4(u64 v, u64 one_p, u64 nq, u32 zero) { return mul_shoup_lazy4(v, 1, one_p, nq, zero); }
+
 // a * b mod q for a, b in [0, q); Barrett with two multiplications, result in [0, q).
 // x = floor(z / 2^(b-1)) < 2^(b+1); qhat = floor(x mu / 2^(b+1)) in [Q-2, Q]  =>  z - qhat q in [0, 3q).
 __device__ __forceinline__ u64 mul_barrett(u64 a, u64 b, const Modulus &m) {

@@ -1,0 +1,149 @@
+// ubench4.hip -- 64-bit Shoup product formulations on gfx950: what hipcc emits for `x*w - umul64hi(x,wp)*q`
+// (5 v_mad_u64_u32 + 4 v_mul_lo_u32 + 1 v_mul_hi_u32) against the same product written only with
+// v_mad_u64_u32 (measured 1.8x the rate of v_mul_lo_u32, tools/ubench.hip), exact and with the approximate
+// high word (result in [0, 4q) instead of [0, 2q)).  Checks every variant against the exact value.  Not part
+// of the library.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef unsigned long long u64;
+typedef unsigned int u32;
+#define ITERS 2048
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c) {
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul0(u32 a, u32 b) {
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ u32 lo(u64 v) { return (u32)v; }
+__device__ __forceinline__ u32 hi(u64 v) { return (u32)(v >> 32); }
+
+// hipcc's own
+__device__ __forceinline__ u64 shoup_cc(u64 x, u64 w, u64 wp, u64 q, u64 nq) { return x * w - __umul64hi(x, wp) * q; }
+// exact, v_mad_u64_u32 only: [0, 2q)
+__device__ __forceinline__ u64 shoup_mad(u64 x, u64 w, u64 wp, u64 q, u64 nq) {
+    const u32 xl = lo(x), xh = hi(x);
+    const u64 t0 = mul0(xl, lo(wp));
+    const u64 t1 = mad(xh, lo(wp), (u64)hi(t0));
+    const u64 t2 = mad(xl, hi(wp), (u64)lo(t1));
+    const u64 A = mad(xh, hi(wp), (u64)hi(t1) + hi(t2));
+    u64 P = mul0(xl, lo(w));
+    P = mad(lo(A), lo(nq), P);
+    u64 C = mul0(xl, hi(w));
+    C = mad(xh, lo(w), C);
+    C = mad(lo(A), hi(nq), C);
+    C = mad(hi(A), lo(nq), C);
+    return P + ((u64)lo(C) << 32);
+}
+// approximate high word (A in [exact-2, exact]): [0, 4q)
+__device__ __forceinline__ u64 shoup_mad4(u64 x, u64 w, u64 wp, u64 q, u64 nq) {
+    const u32 xl = lo(x), xh = hi(x);
+    const u64 t1 = mul0(xh, lo(wp));
+    const u64 t2 = mul0(xl, hi(wp));
+    const u64 A = mad(xh, hi(wp), (u64)hi(t1) + hi(t2));
+    u64 P = mul0(xl, lo(w));
+    P = mad(lo(A), lo(nq), P);
+    u64 C = mul0(xl, hi(w));
+    C = mad(xh, lo(w), C);
+    C = mad(lo(A), hi(nq), C);
+    C = mad(hi(A), lo(nq), C);
+    return P + ((u64)lo(C) << 32);
+}
+
+template <int OP> __global__ __launch_bounds__(256) void k(u64 *out, const ulonglong2 *tw, u64 q, u64 seed) {
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 a[8];
+    for (int i = 0; i < 8; i++) a[i] = seed * (tid + i + 1);
+    const ulonglong2 t = tw[tid & 255];
+    const u64 nq = 0 - q;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (OP == 0) a[i] = shoup_cc(a[i], t.x, t.y, q, nq);
+            if (OP == 1) a[i] = shoup_mad(a[i], t.x, t.y, q, nq);
+            if (OP == 2) a[i] = shoup_mad4(a[i], t.x, t.y, q, nq);
+            if (OP == 3) { u64 X = a[i] >= 2 * q ? a[i] - 2 * q : a[i]; a[i] = X + shoup_cc(a[i ^ 1], t.x, t.y, q, nq); }
+            if (OP == 4) { u64 X = a[i] >= 2 * q ? a[i] - 2 * q : a[i]; a[i] = X + shoup_mad(a[i ^ 1], t.x, t.y, q, nq); }
+            if (OP == 5) { a[i] = (a[i] >> 3) + shoup_mad4(a[i ^ 1], t.x, t.y, q, nq); }
+        }
+    }
+    u64 acc = 0;
+    for (int i = 0; i < 8; i++) acc += a[i];
+    out[tid] = acc;
+}
+
+// correctness: r == x*w mod q up to the stated multiple of q, for random and extreme x
+__global__ void k_check(const ulonglong2 *tw, u64 q, u64 seed, u32 *bad) {
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const ulonglong2 t = tw[tid & 255];
+    const u64 nq = 0 - q;
+    u64 x = seed * (2 * tid + 1);
+    for (int it = 0; it < 64; it++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        u64 xs = x;
+        if (it == 0) xs = ~0ULL; if (it == 1) xs = 0; if (it == 2) xs = 0xffffffffULL; if (it == 3) xs = 0xffffffff00000000ULL; if (it == 4) xs = q - 1; if (it == 5) xs = 4 * q - 1;
+        const u64 r0 = shoup_cc(xs, t.x, t.y, q, nq);
+        const u64 r1 = shoup_mad(xs, t.x, t.y, q, nq);
+        const u64 r2 = shoup_mad4(xs, t.x, t.y, q, nq);
+        if (r0 >= 2 * q) atomicAdd(bad + 0, 1);
+        if (r1 != r0) atomicAdd(bad + 1, 1);
+        const u64 d = r2 - r0;
+        if (!(d == 0 || d == q || d == 2 * q)) atomicAdd(bad + 2, 1);
+        if (d == 2 * q) atomicAdd(bad + 3, 1);   // statistics: how often the approximation loses two
+    }
+}
+
+template <int OP> int run(const char *name, u64 *out, const ulonglong2 *tw, u64 q) {
+    const int blocks = 256 * 8, threads = 256;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    k<OP><<<blocks, threads>>>(out, tw, q, 0x9E3779B97F4A7C15ULL);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    for (int r = 0; r < 5; r++) k<OP><<<blocks, threads>>>(out, tw, q, 0x9E3779B97F4A7C15ULL + r);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double n = 5.0 * blocks * threads * (double)ITERS * 8, rate = n / (ms * 1e-3);
+    printf("%-40s %8.3f ms  %9.2f Gop/s  => %6.2f lane-ops/clk/CU @2.4GHz\n", name, ms / 5, rate / 1e9, rate / 256 / 2.4e9);
+    return 0;
+}
+
+int main() {
+    const u64 qs[3] = {0x7fffffffe90001ULL, 0xffffee001ULL, 0x1fffffffffe00001ULL};   // 55-, 36-, 61-bit
+    u64 *out; CHK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 256));
+    ulonglong2 *tw; CHK(hipMalloc(&tw, sizeof(ulonglong2) * 256));
+    u32 *bad; CHK(hipMalloc(&bad, 16));
+    for (int qi = 0; qi < 3; qi++) {
+        const u64 q = qs[qi];
+        ulonglong2 h[256];
+        u64 s = 88172645463325252ULL;
+        for (int i = 0; i < 256; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            u64 w = s % q;
+            if (i == 0) w = q - 1; if (i == 1) w = 1; if (i == 2) w = 0;
+            h[i].x = w; h[i].y = (u64)(((unsigned __int128)w << 64) / q);
+        }
+        CHK(hipMemcpy(tw, h, sizeof(h), hipMemcpyHostToDevice));
+        CHK(hipMemset(bad, 0, 16));
+        k_check<<<4096, 256>>>(tw, q, 0x2545F4914F6CDD1DULL, bad);
+        u32 hb[4]; CHK(hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost));
+        printf("q = %#llx: hipcc out of range %u, all-mad exact mismatches %u, approximate outside {0,q,2q} %u (lost two: %u of %u)\n",
+               q, hb[0], hb[1], hb[2], hb[3], 4096u * 256u * 64u);
+        if (qi == 0) {
+            run<0>("shoup product, hipcc", out, tw, q);
+            run<1>("shoup product, v_mad_u64_u32 only", out, tw, q);
+            run<2>("shoup product, approximate high word", out, tw, q);
+            run<3>("half butterfly, hipcc", out, tw, q);
+            run<4>("half butterfly, v_mad_u64_u32 only", out, tw, q);
+            run<5>("half butterfly, approximate, no csub", out, tw, q);
+        }
+    }
+    return 0;
+}
