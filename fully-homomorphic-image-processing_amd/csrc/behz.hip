@@ -7,8 +7,8 @@
 //   2. NTT in q and Bsk, tensor product sum_{a+b=o} c'1_a c'2_b, inverse NTT, times t
 //   3. fast floor: (t D - FastBConv([t D]_q -> Bsk)) q^-1 in Bsk
 //   4. Shenoy-Kumaresan conversion Bsk -> q with m_sk
-// The result is a function of (inputs, q, t, m~) only; the auxiliary primes (k 61-bit NTT primes
-// + m_sk, the first primes = 1 mod 2^17 below 2^61) just have to be large enough.
+// The result is a function of (inputs, q, t, m~) only; the auxiliary primes (k NTT primes + m_sk, the first primes
+// = 1 mod 2^17 below 2^58, or below 2^61 when those are too small: fhe_behz_build) just have to be large enough.
 // Reference call sites: homo/fhe_resize.h:174-179,197-198; homo/fhe_decode.h:67-97,235,239.
 #include "internal.h"
 
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
     }
-    ntt_inv_regs<L>(acc, base.itw + (size_t)j * N, m.q, lds, tid);
+    ntt_inv_regs4<L>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);               // [0, q) in, [0, 4q) out
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = csub(acc[r], m.q);
+    for (int r = 0; r < 16; r++) acc[r] = csub(csub(acc[r], 2 * m.q), m.q);
     store_coeff<L>(acc, D + id * N, tid);
 }
 
@@ -359,9 +359,17 @@ int fhe_behz_build(fhe_ctx *c) {
     memset(&D, 0, sizeof(D));
     D.k = k;
     const std::vector<u64> &q = c->qb.primes;
-    // auxiliary primes: 61-bit, = 1 (mod 2^17), descending; first one is m_sk, the next k form B
+    // auxiliary primes: = 1 (mod 2^17), descending from 2^58 (or 2^61); first one is m_sk, the next k form B.
+    // The result of a product does not depend on them (header comment) as long as the value the fast floor leaves in
+    // Bsk -- at most min(sa, sb) n t q / 4 in magnitude, sizes up to 2^8 here -- stays below B m_sk / 2.  58-bit primes
+    // let the forward transforms run without conditional subtractions (ntt_core.h LAZY); 61-bit ones (what SEAL 2.3
+    // takes) remain the fallback when k + 1 of the smaller ones are not enough.
+    int q_bits = 0;
+    for (u64 qi : q) q_bits += bit_length(qi);
+    const int need = q_bits + bit_length(c->t) + (int)c->logn + 8 + 4;
+    const int aux_bits = (57 * (int)(k + 1) >= need && !getenv("FHE_BEHZ_AUX61")) ? 58 : 61;
     std::vector<u64> found;
-    for (u64 cand = (1ULL << 61) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
+    for (u64 cand = (1ULL << aux_bits) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
         if (!is_prime(cand)) continue;
         bool clash = false;
         for (u64 qi : q) clash |= (qi == cand);

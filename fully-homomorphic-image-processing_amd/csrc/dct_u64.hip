@@ -72,7 +72,7 @@ struct Prime { u64 q, nq, q4, one_p; u32 zero; };     // nq = 2^64 - q, q4 = 4q,
 __device__ __forceinline__ Prime prime_of(const Modulus &m) {
     Prime o;
     o.q = m.q; o.nq = 0 - m.q; o.q4 = 4 * m.q; o.zero = fhe_opaque_zero;
-    o.one_p = m.mu >> (2 * (m.s1 + 1) - 64);   // floor(floor(2^(2b) / q) / 2^(2b - 64)); b >= 48 here
+    o.one_p = one_companion(m);
     return o;
 }
 // bound (in units of q) of the forward transform's outputs

@@ -430,39 +430,50 @@ extern "C" int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, ui
 // ------------------------------------------------------------------------------------------------
 // NTT kernels: one workgroup per residue polynomial
 // ------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(NttShape<L>::TP) void k_ntt_fwd(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
+template <int L, bool LAZY>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     const int tid = threadIdx.x;
     const u64 rp = blockIdx.x;
     const u32 prime = (u32)(rp % base.count);
     const u64 q = base.mod[prime].q;
+    const NttMod m = ntt_mod(q);
     u64 x[16];
     load_coeff<L>(x, in + rp * NttShape<L>::N, tid);
-    ntt_fwd_regs<L>(x, base.tw + (size_t)prime * NttShape<L>::N, q, lds, tid);
+    ntt_fwd_regs4<L, LAZY>(x, base.tw + (size_t)prime * NttShape<L>::N, m, lds, tid);
+    if constexpr (LAZY) {       // every prime <= 58 bits: no conditional subtraction in the butterflies, one product with 1 at the end
+        const u64 one_p = one_companion(base.mod[prime]);
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
+        for (int r = 0; r < 16; r++) {
+            x[r] = csub(csub(reduce_lazy4(x[r], one_p, m.nq, m.zero), 2 * q), q);
+            if ((r & 3) == 3) asm volatile("" ::: "memory");      // four products in flight, not sixteen
+        }
+    } else {                    // below 8q
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = csub(csub(csub(x[r], m.q4), 2 * q), q);
+    }
     store_slots<L>(x, out + rp * NttShape<L>::N, tid);
 }
 
 template <int L>
-__global__ __launch_bounds__(NttShape<L>::TP) void k_ntt_inv(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     const int tid = threadIdx.x;
     const u64 rp = blockIdx.x;
     const u32 prime = (u32)(rp % base.count);
     const u64 q = base.mod[prime].q;
+    const NttMod m = ntt_mod(q);
     u64 x[16];
     load_slots<L>(x, in + rp * NttShape<L>::N, tid);
-    ntt_inv_regs<L>(x, base.itw + (size_t)prime * NttShape<L>::N, q, lds, tid);
+    ntt_inv_regs4<L>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);             // [0, 4q)
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = csub(x[r], q);
+    for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
     store_coeff<L>(x, out + rp * NttShape<L>::N, tid);
 }
 
 // multiply_plain: NTT -> dyadic product with a prepared plaintext (Shoup pairs) -> inverse NTT
-template <int L>
-__global__ __launch_bounds__(NttShape<L>::TP) void k_mulplain(const u64 *__restrict__ in, u64 *__restrict__ out,
+template <int L, bool LAZY>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain(const u64 *__restrict__ in, u64 *__restrict__ out,
                                                                const ulonglong2 *__restrict__ plain, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
@@ -470,18 +481,20 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_mulplain(const u64 *__restr
     const u64 rp = blockIdx.x;
     const u32 prime = (u32)(rp % base.count);
     const u64 q = base.mod[prime].q;
+    const NttMod m = ntt_mod(q);
     u64 x[16];
     load_coeff<L>(x, in + rp * N, tid);
-    ntt_fwd_regs<L>(x, base.tw + (size_t)prime * N, q, lds, tid);
+    ntt_fwd_regs4<L, LAZY>(x, base.tw + (size_t)prime * N, m, lds, tid);     // LAZY: every prime <= 58 bits; the product takes any operand
+    asm volatile("" ::: "memory");       // keep the 16 plaintext pairs (64 VGPRs) from being fetched before the transform
     const ulonglong2 *pl = plain + (size_t)prime * N;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const ulonglong2 w = pl[r * TP + tid];
-        x[r] = mul_shoup_lazy(x[r], w.x, w.y, q);
+        x[r] = mul_shoup_lazy4(x[r], w.x, w.y, m.nq, m.zero);
     }
-    ntt_inv_regs<L>(x, base.itw + (size_t)prime * N, q, lds, tid);
+    ntt_inv_regs4<L>(x, base.itw + (size_t)prime * N, m, lds, tid);
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = csub(x[r], q);
+    for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
     store_coeff<L>(x, out + rp * N, tid);
 }
 
@@ -489,9 +502,12 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     if (n_res_polys == 0) return FHE_OK;
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const RnsBase base = B.dev();
+    bool lazy = true;        // forward transform without conditional subtractions: every prime of the base <= 58 bits
+    for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0;
     DISPATCH_L(c->logn, {
         if (inverse) k_ntt_inv<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
-        else k_ntt_fwd<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        else if (lazy) k_ntt_fwd<L, true><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        else k_ntt_fwd<L, false><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
     });
     KERNEL_CHECK();
     return FHE_OK;
@@ -518,7 +534,11 @@ extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t
         return fhe_poly_f64_launch(2, c, (const u64 *)in, (u64 *)out, n_polys, (const ulonglong2 *)d_plain_ntt, (hipStream_t)s);
     const RnsBase base = c->qb.dev();
     hipStream_t st = (hipStream_t)s;
-    DISPATCH_L(c->logn, (k_mulplain<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));
+    if (c->max_prime_bits <= 58) {
+        DISPATCH_L(c->logn, (k_mulplain<L, true><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));
+    } else {
+        DISPATCH_L(c->logn, (k_mulplain<L, false><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));
+    }
     KERNEL_CHECK();
     return FHE_OK;
 }

@@ -33,18 +33,20 @@ __device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wp, u64 q) {
     return csub(mul_shoup_lazy(x, w, wp, q), q);
 }
 
-// ---- the same product with cheaper multiplies ------------------------------------------------------------
-// Measured on gfx950 (tools/ubench.hip, tools/ubench4.hip): v_mad_u64_u32 issues at 52 lanes/clk/CU, v_mul_lo_u32 at
-// 29 and v_mul_hi_u32 at 33, yet hipcc lowers `x * w - umul64hi(x, wp) * q` to 5 v_mad_u64_u32 + 4 v_mul_lo_u32 +
-// 1 v_mul_hi_u32: wherever only the low word of a 32 x 32 product is demanded it narrows to v_mul_lo_u32.  Below
-//  * the high word of x * wp leaves out the low x low partial product and the carries of the cross terms: qhat in
-//    [exact - 2, exact], so the result is x * w mod q + {0, 1, 2} q, i.e. in [0, 4q) for ANY 64-bit x;
+// Multiplier rates measured on gfx950 (tools/ubench.hip): v_mad_u64_u32 52 lanes/clk/CU, v_mul_hi_u32 33,
+// v_mul_lo_u32 29.  hipcc narrows every 32 x 32 product of which only the low word is demanded to the slow
+// v_mul_lo_u32 (four of the ten multiplies of the product above).  mul_shoup_lazy4 keeps them on v_mad_u64_u32:
 //  * the subtraction of qhat * q is an addition of qhat * (2^64 - q), so the four cross terms whose low words make
-//    up the high word of the result form one v_mad_u64_u32 chain;
+//    up the high word of the result form ONE multiply-add chain;
 //  * that chain's high word is kept demanded by and-ing it with a zero the compiler cannot see through
-//    (fhe_opaque_zero, a __device__ word nobody writes; one scalar load per kernel).
-// 2 v_mul_hi_u32 + 7 v_mad_u64_u32 against 10 multiplies of which 4 are the slow v_mul_lo_u32.  nq = 2^64 - q.
+//    (fhe_opaque_zero: a __device__ word that nobody writes; one scalar load per kernel);
+//  * the high word of x * wp leaves out the low x low partial product and the carries of the cross terms: qhat in
+//    [exact - 2, exact], so the result is x * w mod q + {0, 1, 2} q, i.e. in [0, 4q) for ANY 64-bit x.
+// 2 v_mul_hi_u32 + 7 v_mad_u64_u32: 4.5 against 3.5 products/clk/CU, 4.2 against 3.3 as a butterfly without the
+// conditional subtraction the wider range makes unnecessary (tools/ubench4.hip, profiles/r02_ubench4_shoup_products.txt;
+// the exact product written the same way measured no faster inside the transforms).
 inline __device__ u32 fhe_opaque_zero;
+// nq = 2^64 - q; `zero` = fhe_opaque_zero, read once per kernel
 __device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wp, u64 nq, u32 zero) {
     const u32 xl = (u32)x, xh = (u32)(x >> 32), wl = (u32)w, wh = (u32)(w >> 32), pl = (u32)wp, ph = (u32)(wp >> 32);
     u32 cy;

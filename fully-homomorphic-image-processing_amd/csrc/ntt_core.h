@@ -93,6 +93,65 @@ __device__ __forceinline__ void ntt_inv_pass(u64 (&x)[16], const ulonglong2 *__r
     }
 }
 
+// ---- the same passes on mul_shoup_lazy4 (modarith.h: cheaper multiplies, result in [0, 4q)) -------------------------
+// Forward: Harvey butterflies with doubled ranges, values in [0, 8q) in and out (8q < 2^64 for every q < 2^61); with
+// LAZY (primes <= 58 bits, (2 + 4L) q < 2^64) no conditional subtraction at all, values grow by 4q per stage.
+// Inverse: Gentleman-Sande, values in [0, 4q) in and out.
+struct NttMod { u64 q, nq, q4; u32 zero; };      // nq = 2^64 - q, q4 = 4q, zero = fhe_opaque_zero
+__device__ __forceinline__ NttMod ntt_mod(u64 q) { NttMod o; o.q = q; o.nq = 0 - q; o.q4 = 4 * q; o.zero = fhe_opaque_zero; return o; }
+// LAZY is valid when (2 + 4 log2 n) q < 2^64 for n <= 2^14: primes of at most 58 bits
+__device__ __forceinline__ bool lazy_ok(const Modulus &m) { return m.s1 + 1 <= 58; }
+// floor(2^64 / q) from the Barrett constant mu = floor(2^(2b) / q) (q is odd, so floor((2^64 - 1) / q) is the same)
+__device__ __forceinline__ u64 one_companion(const Modulus &m) {
+    const u32 b2 = 2 * (m.s1 + 1);
+    return b2 >= 64 ? m.mu >> (b2 - 64) : ~0ULL / m.q;
+}
+
+template <int L, int P, bool LAZY>
+__device__ __forceinline__ void ntt_fwd_pass4(u64 (&x)[16], const ulonglong2 *__restrict__ tw, const NttMod &m, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const u64 X = LAZY ? x[r0] : csub(x[r0], m.q4);
+            const u64 T = mul_shoup_lazy4(x[r1], w.x, w.y, m.nq, m.zero);
+            x[r0] = X + T;
+            x[r1] = X - T + m.q4;
+        }
+    }
+}
+template <int L, int P>
+__device__ __forceinline__ void ntt_inv_pass4(u64 (&x)[16], const ulonglong2 *__restrict__ itw, const NttMod &m, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = S - 1; u >= 0; u--) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = itw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const u64 X = x[r0], Y = x[r1];            // both in [0, 4q)
+            const u64 T = csub(X + Y, m.q4);
+            const u64 D = X - Y + m.q4;                // [0, 8q)
+            if (sigma == 0) {
+                const ulonglong2 ni = itw[0];
+                x[r0] = mul_shoup_lazy4(T, ni.x, ni.y, m.nq, m.zero);
+            } else {
+                x[r0] = T;
+            }
+            x[r1] = mul_shoup_lazy4(D, w.x, w.y, m.nq, m.zero);    // [0, 4q)
+        }
+    }
+}
+
 template <int LO_FROM, int LO_TO>
 __device__ __forceinline__ void ntt_transpose(u64 (&x)[16], u64 *lds, int tid) {
     constexpr int PL = imin(LO_FROM, LO_TO);
@@ -120,6 +179,24 @@ __device__ __forceinline__ void ntt_inv_regs(u64 (&x)[16], const ulonglong2 *__r
     if constexpr (P > 0) {
         ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x, lds, tid);
         ntt_inv_regs<L, P - 1>(x, itw, q, lds, tid);
+    }
+}
+
+// the same drivers on the lazy4 passes: forward out below 8q (LAZY: below (2 + 4L) q), inverse [0, 4q) -> [0, 4q)
+template <int L, bool LAZY, int P = 0>
+__device__ __forceinline__ void ntt_fwd_regs4(u64 (&x)[16], const ulonglong2 *__restrict__ tw, const NttMod &m, u64 *lds, int tid) {
+    ntt_fwd_pass4<L, P, LAZY>(x, tw, m, tid);
+    if constexpr (P + 1 < NttShape<L>::NP) {
+        ntt_transpose<pass_lo(L, P), pass_lo(L, P + 1)>(x, lds, tid);
+        ntt_fwd_regs4<L, LAZY, P + 1>(x, tw, m, lds, tid);
+    }
+}
+template <int L, int P = NttShape<L>::NP - 1>
+__device__ __forceinline__ void ntt_inv_regs4(u64 (&x)[16], const ulonglong2 *__restrict__ itw, const NttMod &m, u64 *lds, int tid) {
+    ntt_inv_pass4<L, P>(x, itw, m, tid);
+    if constexpr (P > 0) {
+        ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x, lds, tid);
+        ntt_inv_regs4<L, P - 1>(x, itw, m, lds, tid);
     }
 }
 

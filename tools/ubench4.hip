@@ -1,60 +1,21 @@
 // ubench4.hip -- 64-bit Shoup product formulations on gfx950: what hipcc emits for `x*w - umul64hi(x,wp)*q`
-// (5 v_mad_u64_u32 + 4 v_mul_lo_u32 + 1 v_mul_hi_u32) against the same product written only with
-// v_mad_u64_u32 (measured 1.8x the rate of v_mul_lo_u32, tools/ubench.hip), exact and with the approximate
-// high word (result in [0, 4q) instead of [0, 2q)).  Checks every variant against the exact value.  Not part
-// of the library.
+// (5 v_mad_u64_u32 + 4 v_mul_lo_u32 + 1 v_mul_hi_u32) against the library's products (csrc/modarith.h), which keep
+// every multiply on v_mad_u64_u32 (measured 1.8x the rate of v_mul_lo_u32, tools/ubench.hip): exact, and with the
+// approximate high word (result in [0, 4q) instead of [0, 2q)).  Checks every variant against the exact value.
+// Not part of the library.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-typedef unsigned long long u64;
-typedef unsigned int u32;
 #define ITERS 2048
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c) {
-    u64 d, cy;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ u64 mul0(u32 a, u32 b) {
-    u64 d, cy;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ u32 lo(u64 v) { return (u32)v; }
-__device__ __forceinline__ u32 hi(u64 v) { return (u32)(v >> 32); }
-
-// hipcc's own
+#include "../fully-homomorphic-image-processing_amd/csrc/modarith.h"
+// hipcc's own lowering of the textbook formula (5 v_mad_u64_u32 + 4 v_mul_lo_u32 + 1 v_mul_hi_u32)
 __device__ __forceinline__ u64 shoup_cc(u64 x, u64 w, u64 wp, u64 q, u64 nq) { return x * w - __umul64hi(x, wp) * q; }
-// exact, v_mad_u64_u32 only: [0, 2q)
-__device__ __forceinline__ u64 shoup_mad(u64 x, u64 w, u64 wp, u64 q, u64 nq) {
-    const u32 xl = lo(x), xh = hi(x);
-    const u64 t0 = mul0(xl, lo(wp));
-    const u64 t1 = mad(xh, lo(wp), (u64)hi(t0));
-    const u64 t2 = mad(xl, hi(wp), (u64)lo(t1));
-    const u64 A = mad(xh, hi(wp), (u64)hi(t1) + hi(t2));
-    u64 P = mul0(xl, lo(w));
-    P = mad(lo(A), lo(nq), P);
-    u64 C = mul0(xl, hi(w));
-    C = mad(xh, lo(w), C);
-    C = mad(lo(A), hi(nq), C);
-    C = mad(hi(A), lo(nq), C);
-    return P + ((u64)lo(C) << 32);
-}
-// approximate high word (A in [exact-2, exact]): [0, 4q)
-__device__ __forceinline__ u64 shoup_mad4(u64 x, u64 w, u64 wp, u64 q, u64 nq) {
-    const u32 xl = lo(x), xh = hi(x);
-    const u64 t1 = mul0(xh, lo(wp));
-    const u64 t2 = mul0(xl, hi(wp));
-    const u64 A = mad(xh, hi(wp), (u64)hi(t1) + hi(t2));
-    u64 P = mul0(xl, lo(w));
-    P = mad(lo(A), lo(nq), P);
-    u64 C = mul0(xl, hi(w));
-    C = mad(xh, lo(w), C);
-    C = mad(lo(A), hi(nq), C);
-    C = mad(hi(A), lo(nq), C);
-    return P + ((u64)lo(C) << 32);
-}
+// the library's exact product (modarith.h mul_shoup_lazy: v_mad_u64_u32 only), [0, 2q)
+__device__ __forceinline__ u64 shoup_mad(u64 x, u64 w, u64 wp, u64 q, u64 nq) { return mul_shoup_lazy(x, w, wp, q); }
+// the library's product with the approximate high word (modarith.h mul_shoup_lazy4), [0, 4q)
+__device__ __forceinline__ u64 shoup_mad4(u64 x, u64 w, u64 wp, u64 q, u64 nq) { return mul_shoup_lazy4(x, w, wp, nq, fhe_opaque_zero); }
 
 template <int OP> __global__ __launch_bounds__(256) void k(u64 *out, const ulonglong2 *tw, u64 q, u64 seed) {
     const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,10 +99,10 @@ int main() {
                q, hb[0], hb[1], hb[2], hb[3], 4096u * 256u * 64u);
         if (qi == 0) {
             run<0>("shoup product, hipcc", out, tw, q);
-            run<1>("shoup product, v_mad_u64_u32 only", out, tw, q);
+            run<1>("shoup product, library exact", out, tw, q);
             run<2>("shoup product, approximate high word", out, tw, q);
             run<3>("half butterfly, hipcc", out, tw, q);
-            run<4>("half butterfly, v_mad_u64_u32 only", out, tw, q);
+            run<4>("half butterfly, library exact", out, tw, q);
             run<5>("half butterfly, approximate, no csub", out, tw, q);
         }
     }
