@@ -619,6 +619,77 @@ def test_other_degrees(fhe, oracle_mod, n, q):
     assert np.array_equal(out, ref)
 
 
+def _is_prime(m):
+    if m < 2:
+        return False
+    for sp in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if m % sp == 0:
+            return m == sp
+    d, r = m - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):      # deterministic below 3.3e24
+        x = pow(a, d, m)
+        if x in (1, m - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % m
+            if x == m - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _largest_ntt_prime_below(bits, n):
+    c = (1 << bits) - 2 * n + 1
+    while not _is_prime(c):
+        c -= 2 * n
+    assert c >> (bits - 1) == 1
+    return c
+
+
+@pytest.mark.parametrize("bits,n", [(56, 4096), (57, 4096), (58, 8192), (58, 16384), (59, 4096), (61, 8192)])
+def test_u64_lazy_ranges_at_boundary_prime_sizes(fhe, oracle_mod, bits, n):
+    """The u64 kernels choose their lazy ranges by prime size (csrc/ntt_core.h, csrc/dct_u64.hip): no conditional
+    subtraction in the forward butterflies up to 58 bits (values grow to (2 + 4 log2 n) q, which must stay below 2^64),
+    doubled Harvey ranges [0, 8q) above; the fused u64 DCT is lazy up to 56 bits and keeps one subtraction per
+    butterfly at 57.  The LARGEST prime of each size with all-(q-1) inputs is the worst case of every bound."""
+    q = [_largest_ntt_prime_below(bits, n), _largest_ntt_prime_below(bits - 1, n)]
+    ctx, orc = fhe.SEALContext(n, q, 1 << 14), oracle_mod.Oracle(n, q, 1 << 14)
+    ev = fhe.Evaluator(ctx)
+    a = np.zeros((2, 2, ctx.k, ctx.n), dtype=np.uint64)
+    for i, qi in enumerate(q):
+        a[0, :, i, :] = qi - 1
+    a[1] = fhe.to_host(ctx.random_ct(1, seed=91))[0]
+    a[1, 0, :, ::3] = 0
+    da = fhe.to_device(a)
+    f = ev.ntt_forward(da)
+    hf = fhe.to_host(f)
+    for c in range(2):
+        for i in range(ctx.k):
+            assert np.array_equal(np.sort(hf[c, 1, i]), np.sort(orc.ntt_fwd(a[c, 1, i], i)))
+    assert np.array_equal(fhe.to_host(ev.ntt_inverse(f)), a)
+    rng = np.random.default_rng(17)
+    plain = rng.integers(0, ctx.t, size=ctx.n, dtype=np.uint64)
+    plain[:4] = ctx.t - 1
+    got = fhe.to_host(ev.multiply_plain(da, plain))
+    for c in range(2):
+        assert np.array_equal(got[c], orc.multiply_plain(a[c], plain))
+    prod = fhe.to_host(ev.multiply(da, da))
+    for c in range(2):
+        assert np.array_equal(prod[c], orc.multiply(a[c], a[c]))
+    if n <= 8192:
+        blk = np.zeros((1, 64, 2, ctx.k, ctx.n), dtype=np.uint64)
+        for i, qi in enumerate(q):
+            blk[0, :, :, i, :] = qi - 1
+        blk[0, 7] = 0
+        blk[0, 11, :, :, 1::2] = 1
+        out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), fhe.to_device(blk)))
+        assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
+
+
 @pytest.mark.parametrize("n_ct", [3, 4])
 def test_fp64_transforms_and_multiply_plain_equal_u64_kernels(fhe, oracle_mod, monkeypatch, n_ct):
     """P4096: fhe_ntt_forward / fhe_ntt_inverse / fhe_multiply_plain on the FP64 kernels write the same
