@@ -241,7 +241,32 @@ __device__ __forceinline__ void store_packed(u64 *__restrict__ o, const double (
     }
     o[4 * TP] = (u64)h[0] | ((u64)h[1] << 32);
 }
-template <int L, int LE, bool BIG, int HALF, bool PACK>
+// Circuit constants through LDS (gfx950 `global_load_lds_dwordx4`): the per-slot constants of a wave -- NT tables x 64
+// doubles -- are brought straight from L2 into that wave's own LDS region without passing through VGPRs, one slot
+// ahead (two regions per wave, used alternately): the request for slot r+1 is issued before slot r is evaluated, so
+// the L2 round trip that each of the eight per-slot rounds used to expose runs behind the products of the current
+// slot, and no prefetch registers are needed (the 128-VGPR budget is what defeated every register prefetch,
+// DESIGN.md 5c).  Requests of one wave complete in order, so `s_waitcnt vmcnt(<requests of slot r+1>)` means slot r
+// has landed; the waits are written by hand (hipcc does not order a ds_read behind an LDS-DMA request).
+// One instruction moves 1 KiB: lanes 0..31 fetch the wave's 64 values (two per lane) of table i, lanes 32..63 those of
+// table i+1; LDS destination = M0 base + 16 * lane, i.e. table i at doubles [0, 64), table i+1 at [64, 128).
+// (A divergent `if (lane < 32)` for an odd last table would split the basic block, and hipcc then sinks the slots'
+// arithmetic below all eight fetches: 351 spilled VGPRs.)
+typedef __attribute__((address_space(1))) const void lc_gptr;
+typedef __attribute__((address_space(3))) void lc_lptr;
+// `ubase` is wave-uniform (table FIRST of this prime, slot r), `voff` the lane's byte offset: scalar base + 32-bit
+// vector offset keeps the eight slots' addresses out of the VGPRs.
+template <int NT>
+__device__ __forceinline__ void stage_consts(const char *ubase, u32 voff, size_t cstride_bytes, double *stg, int lane) {
+#pragma unroll
+    for (int i0 = 0; i0 < NT; i0 += 2) {
+        const int i = (i0 + 1 < NT) ? i0 : NT - 2;      // odd count: the last instruction fetches tables NT-2 (again) and NT-1 --
+        const char *b = ubase + (size_t)i * cstride_bytes;      // no divergent branch, no spare table, no extra LDS
+        __builtin_amdgcn_global_load_lds((lc_gptr *)(b + voff), (lc_lptr *)(stg + i * 64), 16, 0, 0);
+    }
+}
+
+template <int L, int LE, bool BIG, int HALF, bool PACK, bool LDSC>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__restrict__ mid, const double *__restrict__ consts,
                                           const double *__restrict__ tw, const Work &wk, double p, double pinv, u32 k, double *lds) {
     using SH = Shape<L, LE>;
@@ -300,13 +325,33 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
     };
     int phase = 0;
     ntt_fwd<L, LE, 4>(x, w0, tw, p, pinv, lds, tid, phase, [&] { if (LE >= 4) fetch(0); });
+    // LDSC: two staging buffers of NC x 64 doubles per wave (9 x 512 B x 2 x 8 waves = the two exchange buffers exactly)
+    const int lane = tid & 63;
+    double *stg = lds + (tid >> 6) * (2 * NC * 64);
+    const char *sbase = (const char *)(consts + (size_t)FIRST * cstride + (size_t)wk.prime * N);
+    const u32 svoff = (u32)(((size_t)(lane >> 5) * cstride + (tid & ~63) + 2 * (lane & 31)) * sizeof(double));
+    constexpr int NDMA = (NC + 1) / 2;      // instructions per slot
+    if constexpr (LDSC) {
+        __syncthreads();                    // every wave is done with the exchange buffers
+        stage_consts<NC>(sbase, svoff, cstride * sizeof(double), stg, lane);
+    }
 #pragma unroll
     for (int r = 0; r < E; r++) {
         double c[9];
+        if constexpr (LDSC) {
+            // slot r+1 on its way into the other buffer (last read in slot r-1) while slot r is evaluated
+            if (r + 1 < E) stage_consts<NC>(sbase + (size_t)(r + 1) * TP * sizeof(double), svoff, cstride * sizeof(double), stg + ((r + 1) & 1) * NC * 64, lane);
+            if (r + 1 < E) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double *sr = stg + (r & 1) * NC * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NC; i++) c[i] = sr[i * 64];
+        } else {
         if (LE < 4) fetch(r);               // four waves per SIMD: no software prefetch, fewer registers
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = cn[i];
         if (LE >= 4 && r + 1 < E) fetch(r + 1);
+        }
         line_half<HALF>(x[0][r], x[1][r], x[2][r], x[3][r], c, p, pinv);
         if (BIG) {
 #pragma unroll
@@ -315,6 +360,9 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, double *__
             x[0][r] = red(x[0][r], p, pinv);
             x[2][r] = red(x[2][r], p, pinv);
         }
+        // pin the slot's arithmetic between its own constant reads and the next slot's fetch: without a consumer here
+        // hipcc orders all eight fetch / wait / read groups first and the arithmetic after them (constants spilled)
+        if constexpr (LDSC) asm volatile("" ::"v"(x[0][r]), "v"(x[1][r]), "v"(x[2][r]), "v"(x[3][r]) : "memory");
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -334,7 +382,7 @@ __host__ __device__ constexpr int occ_waves(int tp, int lds_words) {
 }
 template <int L, int LE> struct Occ { static constexpr int W = occ_waves(Shape<L, LE>::TP, Shape<L, LE>::LDS_WORDS); };
 
-template <int L, int LE, bool BIG, bool PACK>
+template <int L, int LE, bool BIG, bool PACK, bool LDSC>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_rows(const u64 *__restrict__ in, double *__restrict__ mid,
                                                                   const double *__restrict__ consts, const double *__restrict__ tw_all,
                                                                   const Modulus *__restrict__ mods, u32 k) {
@@ -342,8 +390,8 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_row
     const Work wk = decode(blockIdx.x, k);
     const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
     const double *tw = tw_all + (size_t)wk.prime * Shape<L, LE>::N;
-    if (wk.half) rows_body<L, LE, BIG, 1, PACK>(in, mid, consts, tw, wk, p, pinv, k, lds);
-    else rows_body<L, LE, BIG, 0, PACK>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    if (wk.half) rows_body<L, LE, BIG, 1, PACK, LDSC>(in, mid, consts, tw, wk, p, pinv, k, lds);
+    else rows_body<L, LE, BIG, 0, PACK, LDSC>(in, mid, consts, tw, wk, p, pinv, k, lds);
 }
 
 template <int L, int LE, bool BIG, int HALF, bool PACK>
@@ -642,30 +690,41 @@ static bool dct_pack_enabled() {
     return on;
 }
 
+// row kernel: circuit constants through LDS (stage_consts); FHE_DCT_LDSC=0 reads them into registers as before.
+// (The column kernel has four more constants per slot and no register to spare: the same staging spills 36-56 VGPRs
+// there and measured 68 k blocks/s against 80 k, so it keeps its loads.)
+static bool dct_ldsc_enabled() {
+    static const bool on = [] { const char *e = getenv("FHE_DCT_LDSC"); return !(e && e[0] == '0' && !e[1]); }();
+    return on;
+}
+
 template <int L, int LE>
 static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st, int which) {
     constexpr int TP = Shape<L, LE>::TP;
     if constexpr (LE == 4) {
         if (big) {
-            if (which & 1) k_dct_rows<L, LE, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 1) k_dct_rows<L, LE, true, false, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
             if (which & 2) k_dct_cols<L, LE, true, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
     }
     if constexpr (LE == 3) {
         if (big) {
-            if (which & 1) k_dct_rows<L, LE, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 1) k_dct_rows<L, LE, true, false, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
             if (which & 2) k_dct_cols<L, LE, true, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
         if (c->max_prime_bits <= 37 && dct_pack_enabled()) {      // packed intermediate, 40 instead of 64 bytes
-            if (which & 1) k_dct_rows<L, LE, false, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            if (which & 1) {
+                if (dct_ldsc_enabled()) k_dct_rows<L, LE, false, true, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+                else k_dct_rows<L, LE, false, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+            }
             if (which & 2) k_dct_cols<L, LE, false, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
     }
     {
-        if (which & 1) k_dct_rows<L, LE, false, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+        if (which & 1) k_dct_rows<L, LE, false, false, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
         if (which & 2) k_dct_cols<L, LE, false, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
     }
 }
