@@ -668,12 +668,12 @@ static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves pe
 static u32 dct_shape_le(const fhe_ctx *c) {
     if (dct_le() != 3) return 4;
     if (c->logn == 12 && c->max_prime_bits <= 40) return 3;
-    if (c->logn == 13) return 3;
+    if (c->logn == 13 || c->logn == 11) return 3;
     return 4;
 }
 
 bool fhe_dct_f64_supported(const fhe_ctx *c) {
-    return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && (c->logn == 10 || c->logn == 12 || c->logn == 13);
+    return c && c->qb.d_tw_f64 && c->max_prime_bits <= 47 && (c->logn >= 10 && c->logn <= 13);
 }
 
 int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {
@@ -736,9 +736,10 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     const bool big = c->max_prime_bits > 40;
     switch (c->logn) {   // LE = 3 is only built for the headline size
         case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
+        case 11: launch_pair<11, 3>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         case 12: if (dct_shape_le(c) == 3) launch_pair<12, 3>(c, plan, in, out, mid, (unsigned)grid, false, st, which); else launch_pair<12, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         case 13: if (dct_shape_le(c) == 3) launch_pair<13, 3>(c, plan, in, out, mid, (unsigned)grid, big, st, which); else launch_pair<13, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
-        default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 4096, 8192}");
+        default: return fail(FHE_ERR_PARAM, "fused FP64 path supports n in {1024, 2048, 4096, 8192}");
     }
     KERNEL_CHECK();
     return FHE_OK;

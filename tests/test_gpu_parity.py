@@ -308,6 +308,26 @@ def test_dct_extreme_residues(fhe, oracle_mod, preset):
     assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
 
 
+def test_dct_fp64_fused_at_n2048(fhe, oracle_mod, monkeypatch):
+    """n = 2048 with primes below 2^47 (the P4096 primes are = 1 mod 8192, so they serve n = 2048 too): the fused FP64 pair
+    with 8 coefficients per thread and a last register pass of two stages; random and all-(q-1) blocks against the oracle
+    and against the general three-launch path"""
+    q = [0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001]
+    ctx, orc = fhe.SEALContext(2048, q, 1 << 14), oracle_mod.Oracle(2048, q, 1 << 14)
+    ev = fhe.Evaluator(ctx)
+    blk = fhe.to_host(ctx.random_ct(3, 64, seed=77))
+    for i, qi in enumerate(q):
+        blk[1, :, :, i, :] = qi - 1
+    blk[1, 3] = 0
+    d = fhe.to_device(blk)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    out = fhe.to_host(ev.dct8x8_quant(plan, d))
+    for b in range(3):
+        assert np.array_equal(out[b], orc.dct_quant(blk[b], fhe.YQT)), b
+    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
+    assert np.array_equal(fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), d)), out)
+
+
 @pytest.mark.parametrize("preset", ["SEAL23_4096", "P8192"])
 def test_dct_extreme_residues_u64_fused(fhe, oracle_mod, preset):
     """all-(q-1) inputs through the lazy ranges of the fused u64 kernels (values up to 128 q before the scale product)"""
