@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak test: repeat the fused kernels on the same inputs and compare output digests every time
 (would expose a rare ordering hazard in the barrier-free in-wave LDS exchanges or the packed
-intermediate).  usage: python tools/soak.py [iterations]"""
+intermediate, the hand-written LDS-DMA waits of the row kernel, or the lazy ranges of the u64 kernels).
+usage: python tools/soak.py [iterations] [preset]     (preset P4096 by default; SEAL23_4096 / P8192 run the u64 kernels,
+and every preset also repeats a ct x ct product)"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +11,11 @@ sys.path.insert(0, ROOT)
 import fhip_amd as fhe
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-ctx = fhe.SEALContext.preset("P4096")
+preset = sys.argv[2] if len(sys.argv) > 2 else "P4096"
+ctx = fhe.SEALContext.preset(preset)
 ev = fhe.Evaluator(ctx)
 plan = fhe.DctPlan(ctx, fhe.YQT)
-blocks = ctx.random_ct(1024, 64, seed=fhe.SEED)
+blocks = ctx.random_ct(1024 if ctx.n <= 4096 else 256, 64, seed=fhe.SEED)
 out = torch.empty_like(blocks)
 ev.dct8x8_quant(plan, blocks, out=out)
 ref = ctx.digest(out.view(-1))
@@ -23,6 +26,8 @@ ref_rgb = ctx.digest(torch.cat([r, g, b]).view(-1))
 a = ctx.random_ct(4096, seed=5)
 ref_ntt = ctx.digest(ev.ntt_inverse(ev.ntt_forward(a)).view(-1))
 assert ref_ntt == ctx.digest(a.view(-1))
+ma, mb = ctx.random_ct(256, seed=21), ctx.random_ct(256, seed=22)
+ref_mul = ctx.digest(ev.multiply(ma, mb).view(-1))
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -40,5 +45,8 @@ for i in range(iters):
         if ctx.digest(ev.ntt_inverse(ev.ntt_forward(a)).view(-1)) != ref_ntt:
             bad += 1
             print("ntt digest mismatch at iteration", i, flush=True)
-print("soak: %d iterations, %d mismatches, %.1f s" % (iters, bad, time.time() - t0))
+        if ctx.digest(ev.multiply(ma, mb).view(-1)) != ref_mul:
+            bad += 1
+            print("multiply digest mismatch at iteration", i, flush=True)
+print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
