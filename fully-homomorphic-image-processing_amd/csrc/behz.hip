@@ -205,6 +205,50 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
     store_coeff<L>(acc, D + id * N, tid);
 }
 
+// The same for TWO ciphertext pairs (2 cc, 2 cc + 1) per workgroup at n >= 8192: the two output polynomials share the
+// prime, so every twiddle pair of the inverse transform is fetched once for both (ntt_inv_regs4m).  groups = (count / 2) * nb.
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
+                                                                           RnsBase base, u32 sa, u32 sb, u64 groups) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u32 nb = base.count, so = sa + sb - 1;
+    const u64 bid = blockIdx.x, chunk = bid / (8 * so), rem = bid % (8 * so);      // same XCD-aware order as k_behz_tensor_intt
+    const u32 o = (u32)(rem >> 3);
+    const u64 g = chunk * 8 + (rem & 7);               // cc * nb + j
+    if (g >= groups) return;
+    const u32 j = (u32)(g % nb);
+    const u64 cc = g / nb;
+    const Modulus m = base.mod[j];
+    u64 acc[2][16];
+    const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const u64 c = 2 * cc + h;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][r] = 0;
+        for (u32 ja = lo; ja <= hi; ja++) {
+            const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((c * sb + (o - ja)) * nb + j) * N + tid;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {       // eight slots at a time: 64 accumulator + 32 operand VGPRs
+                u64 xa[8], xb[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) acc[h][r0 + r] = addmod(acc[h][r0 + r], mul_barrett(xa[r], xb[r], m), m.q);
+            }
+        }
+    }
+    ntt_inv_regs4m<L, 2>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][r] = csub(csub(acc[h][r], 2 * m.q), m.q);
+        store_coeff<L>(acc[h], D + (((2 * cc + h) * so + o) * nb + j) * N, tid);
+    }
+}
+
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
 template <int K>
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
@@ -487,6 +531,31 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
     if (r) return r;
     return qbase_ntt(false, c, src, xq, count * s, st);
 }
+// tensor product fused into the inverse transforms over one base: pairs of ciphertext pairs per workgroup at n >= 8192
+// (P8192 inverse transform +19 % with shared twiddles), the odd one out and the smaller degrees one per workgroup
+static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st) {
+    const u32 nb = base.count, so = sa + sb - 1;
+    static const bool single = [] { const char *e = getenv("FHE_NTT_SINGLE"); return e && *e && !(e[0] == '0' && !e[1]); }();
+    u64 done = 0;
+    if (c->logn >= 13 && !single && count >= 2) {
+        const u64 pairs = count / 2;
+        switch (c->logn) {
+            case 13: k_behz_tensor_intt2<13><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<13>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb); break;
+            default: k_behz_tensor_intt2<14><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<14>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb); break;
+        }
+        done = 2 * pairs;
+    }
+    if (done < count) {
+        const u64 rest = count - done;
+        const size_t n = c->n;
+        const u64 *A2 = A + done * sa * nb * n, *B2 = Bm + done * sb * nb * n;
+        u64 *D2 = D + done * so * nb * n;
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb)));
+    }
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
 // tensor product + inverse transforms + floor/back-conversion from prepared operands; D = scratch for so polynomials
 static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, const u64 *Bq, const u64 *Bb, u32 sb, u64 *out, u64 count,
                        u64 *Dq, u64 *Db, hipStream_t st) {
@@ -499,12 +568,9 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((count * k + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(Aq, Bq, Dq, qb, sa, sb, count * k)));
+        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st))) return rc;
     }
-    {
-        const RnsBase ab = c->behz->aux.dev();
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((count * (k + 1) + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(Ab, Bb, Db, ab, sa, sb, count * (k + 1))));
-    }
+    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st))) return rc;
     switch (k) {
 #define GO(KK) case KK: k_behz_floor_back<KK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)

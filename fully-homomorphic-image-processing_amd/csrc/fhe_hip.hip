@@ -455,6 +455,36 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd(const u64 *__res
     store_slots<L>(x, out + rp * NttShape<L>::N, tid);
 }
 
+// two polynomials of one prime per workgroup (rp and rp + pair_stride): every twiddle serves both
+template <int L, bool LAZY>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd2(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base, u32 pair_stride) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    // blockIdx -> (pair g, prime): residue polynomials (2g) * pair_stride + prime and (2g + 1) * pair_stride + prime
+    const u32 prime = blockIdx.x % base.count;
+    const u64 g = blockIdx.x / base.count;
+    const u64 rp0 = (2 * g) * pair_stride + prime, rp1 = rp0 + pair_stride;
+    const u64 q = base.mod[prime].q;
+    const NttMod m = ntt_mod(q);
+    u64 x[2][16];
+    load_coeff<L>(x[0], in + rp0 * NttShape<L>::N, tid);
+    load_coeff<L>(x[1], in + rp1 * NttShape<L>::N, tid);
+    ntt_fwd_regs4m<L, LAZY, 2>(x, base.tw + (size_t)prime * NttShape<L>::N, m, lds, tid);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if constexpr (LAZY) {
+            const u64 one_p = one_companion(base.mod[prime]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[j][r] = csub(csub(reduce_lazy4(x[j][r], one_p, m.nq, m.zero), 2 * q), q);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[j][r] = csub(csub(csub(x[j][r], m.q4), 2 * q), q);
+        }
+    }
+    store_slots<L>(x[0], out + rp0 * NttShape<L>::N, tid);
+    store_slots<L>(x[1], out + rp1 * NttShape<L>::N, tid);
+}
+
 template <int L>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
@@ -469,6 +499,28 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv(const u64 *__res
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
     store_coeff<L>(x, out + rp * NttShape<L>::N, tid);
+}
+
+template <int L>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv2(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base, u32 pair_stride) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const u64 g = blockIdx.x / base.count;
+    const u64 rp0 = (2 * g) * pair_stride + prime, rp1 = rp0 + pair_stride;
+    const u64 q = base.mod[prime].q;
+    const NttMod m = ntt_mod(q);
+    u64 x[2][16];
+    load_slots<L>(x[0], in + rp0 * NttShape<L>::N, tid);
+    load_slots<L>(x[1], in + rp1 * NttShape<L>::N, tid);
+    ntt_inv_regs4m<L, 2>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[j][r] = csub(csub(x[j][r], 2 * q), q);
+    }
+    store_coeff<L>(x[0], out + rp0 * NttShape<L>::N, tid);
+    store_coeff<L>(x[1], out + rp1 * NttShape<L>::N, tid);
 }
 
 // multiply_plain: NTT -> dyadic product with a prepared plaintext (Shoup pairs) -> inverse NTT
@@ -503,9 +555,14 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const RnsBase base = B.dev();
     bool lazy = true;        // forward transform without conditional subtractions: every prime of the base <= 58 bits
+    // n >= 8192: two polynomials of one prime per workgroup, every twiddle pair fetched once for both (P8192 forward +7 %,
+    // inverse +19 %; at n = 4096 the pair kernels spill and are slower, so single polynomials stay there)
+    const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !env_on("FHE_NTT_SINGLE");
     for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0;
     DISPATCH_L(c->logn, {
-        if (inverse) k_ntt_inv<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        if (inverse && pair) k_ntt_inv2<L><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
+        else if (inverse) k_ntt_inv<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        else if (lazy && pair) k_ntt_fwd2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
         else if (lazy) k_ntt_fwd<L, true><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
         else k_ntt_fwd<L, false><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
     });

@@ -200,6 +200,54 @@ __device__ __forceinline__ void ntt_inv_regs4(u64 (&x)[16], const ulonglong2 *__
     }
 }
 
+// ---- M polynomials of one prime per workgroup: every twiddle pair is fetched once for the M butterflies that use it ----
+template <int L, int P, bool LAZY, int M>
+__device__ __forceinline__ void ntt_fwd_pass4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ tw, const NttMod &m, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const u64 X = LAZY ? x[j][r0] : csub(x[j][r0], m.q4);
+                const u64 T = mul_shoup_lazy4(x[j][r1], w.x, w.y, m.nq, m.zero);
+                x[j][r0] = X + T;
+                x[j][r1] = X - T + m.q4;
+            }
+        }
+    }
+}
+template <int L, bool LAZY, int M, int P = 0>
+__device__ __forceinline__ void ntt_fwd_regs4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ tw, const NttMod &m, u64 *lds, int tid) {
+    ntt_fwd_pass4m<L, P, LAZY, M>(x, tw, m, tid);
+    if constexpr (P + 1 < NttShape<L>::NP) {
+#pragma unroll
+        for (int j = 0; j < M; j++) ntt_transpose<pass_lo(L, P), pass_lo(L, P + 1)>(x[j], lds, tid);
+        ntt_fwd_regs4m<L, LAZY, M, P + 1>(x, tw, m, lds, tid);
+    }
+}
+
+template <int L, int P, int M>
+__device__ __forceinline__ void ntt_inv_pass4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ itw, const NttMod &m, int tid) {
+#pragma unroll
+    for (int j = 0; j < M; j++) ntt_inv_pass4<L, P>(x[j], itw, m, tid);      // the twiddle loads of the M copies are merged by the compiler
+}
+template <int L, int M, int P = NttShape<L>::NP - 1>
+__device__ __forceinline__ void ntt_inv_regs4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ itw, const NttMod &m, u64 *lds, int tid) {
+    ntt_inv_pass4m<L, P, M>(x, itw, m, tid);
+    if constexpr (P > 0) {
+#pragma unroll
+        for (int j = 0; j < M; j++) ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x[j], lds, tid);
+        ntt_inv_regs4m<L, M, P - 1>(x, itw, m, lds, tid);
+    }
+}
+
 // global <-> register helpers
 template <int L> __device__ __forceinline__ void load_coeff(u64 (&x)[16], const u64 *__restrict__ p, int tid) {
 #pragma unroll
