@@ -552,6 +552,7 @@ private:
 #ifdef FHE_FACADE_TEST_HOOKS
 namespace detail {
 inline std::function<bool(const Plaintext &, Ciphertext &)> &encrypt_hook() { static std::function<bool(const Plaintext &, Ciphertext &)> h; return h; }
+inline std::function<void(double)> &decode_hook() { static std::function<void(double)> h; return h; }
 }
 #endif
 
@@ -678,7 +679,13 @@ public:
     double decode(const Plaintext &p) const {
         std::vector<uint64_t> c(p.data());
         c.resize(n_, 0);
-        return fhe_frac_decode(n_, t_, c.data(), ic_, fc_);
+        const double v = fhe_frac_decode(n_, t_, c.data(), ic_, fc_);
+#ifdef FHE_FACADE_TEST_HOOKS
+        // TEST BUILDS ONLY: the parity harness records the decoded values BEFORE the caller converts them
+        // (homo/client_resize.cpp:207-209 clamps, the client that produced benchmark/results.txt did not).
+        if (detail::decode_hook()) detail::decode_hook()(v);
+#endif
+        return v;
     }
 private:
     uint64_t t_;

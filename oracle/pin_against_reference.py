@@ -21,8 +21,12 @@ are.  (benchmark.py never passes --bicubic to the receiving client, so both mode
 INTER_LINEAR.)  OpenCV is absent from this image; the compare step uses the validated stand-in
 tests/stubs/opencv2/opencv.hpp.  Only the deterministic entries of the reference's table are listed:
   17.9597  bilinear, noise budget intact            19.8048  bicubic (t3 = t*t quirk included), budget intact
-  34.4     bicubic at t = 11: the plaintext wraps mod t, deterministically.  NOT reproduced here: oracle, GPU
-           and the exact plaintext-ring model tools/plain_ring_model.py all give 29.715
+  34.4     bicubic at t = 11: the plaintext wraps mod t, deterministically, and 23 of the 867 decoded samples leave
+           [0, 255].  The committed client clamps them (CLAMP, homo/client_resize.cpp:208) and prints 29.715; the same
+           decoded samples cast to uint8_t without the clamp (modulo 256) give exactly 34.4 -- the published table
+           comes from a client without that line (no other published entry has a sample outside [0, 255], so no
+           other entry can tell the two apart).  Reproduced from the decoded samples (run_resize_set(decoded=...),
+           tests/test_reference_published_resize.py) and by the exact plaintext-ring model tools/plain_ring_model.py
   113.692  budget exhausted: every pixel decodes to garbage, `int pixel = decode()` saturates and
            CLAMP gives 0 -- the RMS of the INTER_LINEAR image against black; pins the stand-in alone
 The reference also recorded 67.2706 (bilinear 2048/307) and 20.004 / 30.8092 / 113.438 (bicubic 4096 at
@@ -56,9 +60,12 @@ for _n in (2048, 4096, 8192, 16384):
             PUBLISHED_RESIZE[("bicubic", _n, _t)] = "113.692"
 
 
-def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17):
+def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17, decoded=None):
     """client_resize --send / server_resize / client_resize --recieve exactly as benchmark/benchmark.py:18-29
-    runs them; returns (RMSError string, seconds, the reference's own per-call timer values of the server)."""
+    runs them; returns (RMSError string, seconds, the reference's own per-call timer values of the server).
+    `decoded`: a list that receives the doubles FractionalEncoder::decode returned to the receiving client, in
+    call order (oracle/ref_hook.cpp, FHE_DECODE_LOG_FILE): the samples before the client's int / clamp / uint8_t
+    conversion."""
     sfx = "" if gpu else "_cpu"
     cl = os.path.join(ROOT, "oracle", "_ref", "ref_client_resize" + sfx)
     sv = os.path.join(ROOT, "oracle", "_ref", "ref_server_resize" + sfx)
@@ -72,12 +79,19 @@ def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17):
         for argv in ([cl, "--send", "-f", "image/in.jpg", "-o", "image/ct_in.txt"] + par,
                      [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt"] + par + (["--bicubic"] if inter == "bicubic" else []),
                      [cl, "--recieve", "-f", "image/in.jpg", "-c", "image/ct_out.txt", "-o", "image/out.png"] + par):
-            r = subprocess.run(argv, cwd=d, capture_output=True, text=True)
+            env = dict(os.environ)
+            if decoded is not None and "--recieve" in argv:
+                env["FHE_DECODE_LOG_FILE"] = d + "/decoded.f64"
+            r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=env)
             if r.returncode:
                 raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-1000:])
             if argv[0] == sv:
                 timers = [float(x) for ln in r.stdout.splitlines() if ln.startswith(("Linear,", "Cubic,")) for x in ln.split(",")[1:] if x.strip()]
         rms = [ln.split(",")[1] for ln in r.stdout.splitlines() if ln.startswith("RMSError,")]
+        if decoded is not None:
+            import struct
+            raw = open(d + "/decoded.f64", "rb").read()
+            decoded.extend(struct.unpack("<%dd" % (len(raw) // 8), raw))
     return rms[0] if rms else None, time.time() - t0, timers
 
 

@@ -33,4 +33,19 @@ struct HookInstaller {
         };
     }
 } installer;
+
+// FHE_DECODE_LOG_FILE: every value FractionalEncoder::decode returns is appended to this file as a raw double, in call
+// order -- what the reference's client sees before its `int pixel = ...; CLAMP(...); (uint8_t) pixel` conversion.
+struct DecodeLogInstaller {
+    DecodeLogInstaller() {
+        const char *path = std::getenv("FHE_DECODE_LOG_FILE");
+        if (!path || !*path) return;
+        FILE *f = std::fopen(path, "ab");
+        if (!f) { std::fprintf(stderr, "ref_hook: cannot open %s\n", path); std::exit(2); }
+        seal::detail::decode_hook() = [f](double v) {
+            std::fwrite(&v, sizeof v, 1, f);
+            std::fflush(f);
+        };
+    }
+} decode_log_installer;
 }  // namespace

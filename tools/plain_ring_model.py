@@ -13,9 +13,14 @@ of this image).  Reference image for the RMS: tests/stubs/opencv2/opencv.hpp's i
 in as an array.
 
   bilinear, any t >= 11 -> 17.9597 (published)      bicubic, t >= 31 -> 19.8048 (published)
-  bicubic, t = 11       -> 29.715; the reference's table says 34.4 for this one deterministic entry.
-      Oracle, GPU and this model agree on 29.715; the cause of SEAL 2.3's 34.4 is not known
-      (DESIGN.md section 4)."""
+  bicubic, t = 11       -> 29.715 with the committed client's CLAMP(pixel, 0, 255) (homo/client_resize.cpp:208),
+                           34.4 (published) when the decoded int is cast to uint8_t WITHOUT the clamp (modulo 256):
+      at t = 11 plaintext coefficients wrap and 23 of the 867 decoded samples leave [0, 255] (-142 ... 397); at every
+      t >= 31, and for bilinear at every t, all samples stay inside [17, 239], so the clamp changes nothing there.
+      The table in benchmark/results.txt was therefore produced by a client without the clamp line; every
+      deterministic entry of it is reproduced.
+
+  usage: plain_ring_model.py T [bicubic] [wrap]"""
 import math
 import os
 import sys
@@ -61,7 +66,16 @@ def decode(p, t):
     return val
 
 
-def model(src_rgb, w, h, t, bicubic):
+def to_pixel(r, conversion):
+    """`int pixel = encoder.decode(p); CLAMP(pixel, 0, 255) (uint8_t) pixel` (homo/client_resize.cpp:207-209):
+    'clamp' is the committed code, 'wrap' the same cast without the CLAMP line."""
+    pv = -2 ** 31 if abs(r) >= 2 ** 31 else int(r)       # cvttsd2si: out of range -> INT_MIN
+    if conversion == "wrap":
+        return pv % 256
+    return max(0, min(255, pv))
+
+
+def model(src_rgb, w, h, t, bicubic, conversion="clamp"):
     H, W = src_rgb.shape[:2]
     f32 = np.float32
     E = lambda v: encode(v, t)
@@ -95,8 +109,7 @@ def model(src_rgb, w, h, t, bicubic):
                     r = decode(cubic(cols[0], cols[1], cols[2], cols[3], yf), t)
                 else:
                     r = decode(linear(linear(P(0, 0), P(1, 0), xf), linear(P(0, 1), P(1, 1), xf), yf), t)
-                pv = -2 ** 31 if abs(r) >= 2 ** 31 else int(r)       # `int pixel = decode()`: cvttsd2si saturates to INT_MIN
-                out[y, x, ch] = cl(pv, 0, 255)
+                out[y, x, ch] = to_pixel(r, conversion)
     return out
 
 
@@ -105,17 +118,25 @@ def rms_string(out_rgb, ref_rgb):
     return "%.6g" % math.sqrt(float((d * d).sum()) / d.size)       # std::cout << double, homo/fhe_resize.h:65-67
 
 
-if __name__ == "__main__":
+def reference_image(width=17, height=17):
+    """cv::imread + cv::resize(INTER_LINEAR) of the benchmark image through the validated stand-in
+    (tests/stubs/opencv2/opencv.hpp), as RGB [h, w, 3]: what compare_resize_opencv (homo/fhe_resize.h:40-68)
+    measures the decrypted image against."""
     import subprocess
     import tempfile
-    t = int(sys.argv[1]) if len(sys.argv) > 1 else 101
-    bicubic = len(sys.argv) > 2 and sys.argv[2] == "bicubic"
-    src = np.load(os.path.join(ROOT, "tests", "golden", "boazbarak_stb_rgb.npy"))
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "standin_check")
         subprocess.check_call(["g++", "-O2", "-std=c++11", "-I" + os.path.join(ROOT, "tests", "stubs"),
                                os.path.join(ROOT, "tests", "stubs", "standin_check.cpp"), "-o", exe])
-        subprocess.check_call([exe, os.path.join(ROOT, "tests", "golden", "boazbarak.jpg"), os.path.join(d, "r.raw"), "17", "17", "1"])
+        subprocess.check_call([exe, os.path.join(ROOT, "tests", "golden", "boazbarak.jpg"), os.path.join(d, "r.raw"), str(width), str(height), "1"])
         raw = open(os.path.join(d, "r.raw"), "rb").read()
-    ref = np.frombuffer(raw[8:], dtype=np.uint8).reshape(17, 17, 3)[:, :, ::-1]
-    print("t=%d %s: RMSError %s" % (t, "bicubic" if bicubic else "bilinear", rms_string(model(src, 17, 17, t, bicubic), ref)))
+    return np.frombuffer(raw[8:], dtype=np.uint8).reshape(height, width, 3)[:, :, ::-1]
+
+
+if __name__ == "__main__":
+    t = int(sys.argv[1]) if len(sys.argv) > 1 else 101
+    bicubic = "bicubic" in sys.argv[2:]
+    conversion = "wrap" if "wrap" in sys.argv[2:] else "clamp"
+    src = np.load(os.path.join(ROOT, "tests", "golden", "boazbarak_stb_rgb.npy"))
+    print("t=%d %s %s: RMSError %s" % (t, "bicubic" if bicubic else "bilinear", conversion,
+                                       rms_string(model(src, 17, 17, t, bicubic, conversion), reference_image())))
