@@ -126,13 +126,24 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.resize:
         sets = [t for t in a.pmod if (a.resize, a.n, t) in PUBLISHED_RESIZE]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import numpy as np
+        import plain_ring_model as prm          # to_pixel / rms_string / reference_image only (no FHE in them)
+
+        def one(t):
+            decoded = []
+            rms, dt, timers = run_resize_set(a.resize, a.n, t, a.gpu, decoded=decoded)
+            # the published table's conversion: the decoded int cast to uint8_t without the committed client's CLAMP
+            img = np.array([prm.to_pixel(v, "wrap") for v in decoded], dtype=np.int64).reshape(17, 17, 3)
+            return t, rms, prm.rms_string(img, prm.reference_image()), dt, timers
         with ThreadPoolExecutor(a.jobs) as ex:
-            res = list(ex.map(lambda t: (t,) + run_resize_set(a.resize, a.n, t, a.gpu), sets))
+            res = list(ex.map(one, sets))
         rows, ok = [], True
-        for t, rms, dt, timers in res:
+        for t, rms_clamped, rms, dt, timers in res:
             want = PUBLISHED_RESIZE[(a.resize, a.n, t)]
             ok &= rms == want
-            rows.append({"inter": a.resize, "n": a.n, "plain_modulus": t, "rms": rms, "published": want, "match": rms == want,
+            rows.append({"inter": a.resize, "n": a.n, "plain_modulus": t, "rms": rms, "rms_printed_by_committed_client": rms_clamped,
+                         "published": want, "match": rms == want,
                          "seconds": round(dt, 1), "ms_per_call": round(sum(timers) / max(1, len(timers)), 3), "calls": len(timers)})
             print(rows[-1], flush=True)
         if a.out:
