@@ -52,6 +52,23 @@ def resize(args):
     res = {"workload": "bicubic resize %dx%d -> %dx%d, one channel, %s (n=%d, k=%d)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
            "output_pixels": done, "seconds": dt, "pixels_per_s": done / dt, "cubic_calls_per_s": 5 * done / dt,
            "out_size": int(out.shape[-3]), "batch_pixels": P}
+    if args.shared:
+        # SURVEY.md 8(d) config 3 input convention: one offset ciphertext per distinct fractional value, i.e. per output
+        # column / row; every repeated ring element (row Cubics of overlapping windows, squares, prepared operands) is
+        # then formed once -- bit-identical to the per-pixel evaluation with those ciphertexts (tests/test_gpu_configs.py)
+        xc, yc = ctx.random_ct(w, size=2, seed=11), ctx.random_ct(h, size=2, seed=12)
+        fhe.circuits.resize_bicubic_shared(ev, pc, pixels[: 16 * W], W, 16, w, 4, xc, yc[:4].contiguous(), batch=P)       # warm-up
+        torch.cuda.synchronize()
+        for _ in range(2):            # the first full-size pass sizes the allocator's pools; the second is the steady state
+            sink = []
+            t0 = time.perf_counter()
+            fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=lambda first, t: sink.append(int(t.shape[0])))
+            torch.cuda.synchronize()
+            sdt = time.perf_counter() - t0
+            assert sum(sink) == n_out
+        rows_touched = len({taps[y * w][4 * j] // W for y in range(h) for j in range(4)})
+        res["shared_offsets"] = {"seconds": sdt, "pixels_per_s": n_out / sdt, "row_cubics": rows_touched * w, "column_cubics": n_out,
+                                 "note": "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"}
     if args.cpu_pixels:
         from oracle import oracle as om
         orc = om.Oracle.preset(args.preset)
@@ -102,6 +119,7 @@ if __name__ == "__main__":
     ap.add_argument("--pixels", type=int, default=256)
     ap.add_argument("--max-pixels", type=int, default=0)
     ap.add_argument("--cpu-pixels", type=int, default=0)
+    ap.add_argument("--shared", action="store_true", help="resize: also time the shared-offset form (one offset ciphertext per output column / row)")
     ap.add_argument("--degree", type=int, default=12)
     ap.add_argument("--positions", type=int, default=16)
     a = ap.parse_args()

@@ -163,6 +163,76 @@ def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
     return cubic(ev, pc, cols[0], cols[1], cols[2], cols[3], yfract)
 
 
+def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None):
+    """ResizeImage with SampleBicubic (homo/fhe_resize.h:254-392) for one colour channel when the fractional
+    offsets arrive as ONE ciphertext per output column (xfract [dst_w, 2, k, n]) and ONE per output row
+    (yfract [dst_h, 2, k, n]) -- SURVEY.md section 8(d), config 3: "xfract/yfract ciphertexts are inputs generated
+    per distinct fractional value".  frac(u) depends on x only and frac(v) on y only (:351,382), so with shared
+    ciphertexts the reference's per-pixel work repeats itself and this function forms every repeated ring element
+    once; each output equals sample_bicubic(..., xfract[x], yfract[y]) bit for bit:
+
+      * a row Cubic (:296-299) is a function of (output column x, source row r) only; consecutive output rows'
+        4-row windows overlap, so the 4 * dst_h row Cubics of a column collapse to one per source row touched
+        (128 instead of 256 for 128 -> 64);
+      * xfract^2 and the prepared (extended + transformed) forms of xfract, xfract^2 are formed once per column,
+        yfract^2 and its prepared forms once per row, and gathered into the batches.
+
+    The reference's server encrypts fresh offsets for every sample (:262,266); its results are therefore
+    randomised per pixel and only sample_bicubic with per-pixel ciphertexts reproduces that run bit for bit
+    (server.server_resize does).  Source rows are visited as a sliding window (`band_rows` output rows at a
+    time; row Cubics no output row needs any more are dropped), like the reference's loader (:352-379).
+
+    Returns [dst_h * dst_w, 6, k, n] (row-major), or None when `consume(first_pixel, tensor)` takes the bands."""
+    taps, _, _ = resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic=True)
+    colx = [[t % src_w for t in taps[x][0:4]] for x in range(dst_w)]                       # clamped xi-1 .. xi+2
+    rows_of = [[taps[y * dst_w][4 * j] // src_w for j in range(4)] for y in range(dst_h)]  # clamped yi-1 .. yi+2
+    xfract, yfract = xfract.contiguous(), yfract.contiguous()
+    x2, y2 = ev.square(xfract), ev.square(yfract)                                          # t2 (= t3, :174-175) per column / row
+    px2, px1 = ev.prepare_operand(x2), ev.prepare_operand(xfract)
+    py2, py1 = ev.prepare_operand(y2), ev.prepare_operand(yfract)
+    dev = pixels.device
+    cache = {}                                                                             # source row -> [dst_w, 4, k, n]
+
+    def row_cubics(new_rows):
+        if not new_rows:
+            return
+        pairs = [(r, x) for r in new_rows for x in range(dst_w)]
+        res = []
+        for s0 in range(0, len(pairs), batch):
+            part = pairs[s0:s0 + batch]
+            xs = [x for _, x in part]
+            tap = [torch.as_tensor([r * src_w + colx[x][i] for r, x in part], dtype=torch.long, device=dev) for i in range(4)]
+            A, B, C, D = (pixels.index_select(0, t) for t in tap)
+            g2 = px2.gather(xs)
+            xi = torch.as_tensor(xs, dtype=torch.long, device=dev)
+            t2 = x2.index_select(0, xi)
+            res.append(cubic(ev, pc, A, B, C, D, None, powers=(t2, t2), prepared=(g2, g2, px1.gather(xs))))
+        allr = torch.cat(res, dim=0) if len(res) > 1 else res[0]
+        for i, r in enumerate(new_rows):
+            cache[r] = allr[i * dst_w:(i + 1) * dst_w]
+
+    outs = []
+    for y0 in range(0, dst_h, band_rows):
+        ys = list(range(y0, min(y0 + band_rows, dst_h)))
+        need = sorted({r for y in ys for r in rows_of[y]})
+        row_cubics([r for r in need if r not in cache])
+        for r in [r for r in cache if r < need[0]]:                                        # the window only moves down
+            del cache[r]
+        rows_per_call = max(1, batch // dst_w)
+        for s0 in range(0, len(ys), rows_per_call):
+            yy = ys[s0:s0 + rows_per_call]
+            part = [y for y in yy for _ in range(dst_w)]
+            A, B, C, D = (torch.cat([cache[rows_of[y][j]] for y in yy], dim=0) for j in range(4))
+            g2 = py2.gather(part)
+            t2 = y2.index_select(0, torch.as_tensor(part, dtype=torch.long, device=dev))
+            o = cubic(ev, pc, A, B, C, D, None, powers=(t2, t2), prepared=(g2, g2, py1.gather(part)))
+            if consume is not None:
+                consume(yy[0] * dst_w, o)
+            else:
+                outs.append(o)
+    return None if consume is not None else torch.cat(outs, dim=0)
+
+
 def sample_linear(ev, pc, pixels, taps, xfract, yfract):
     """SampleLinear for one channel (homo/fhe_resize.h:222-252).  Returns [B, 4, k, n]."""
     idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 4]

@@ -140,6 +140,26 @@ class PreparedCt:
     def __init__(self, buf, size, lead):
         self.buf, self.size, self.lead = buf, size, lead
 
+    def gather(self, index):
+        """The prepared operands `index` (a sequence of positions in the flattened batch, repeats allowed) as a new
+        prepared batch -- a copy of words, no arithmetic.  Layout (include/fhe_hip.h, fhe_multiply_prepare):
+        [count][size][k][n] over the coefficient base followed by [count][size][k+1][n] over the auxiliary base."""
+        count = 1
+        for d in self.lead:
+            count *= d
+        per = self.buf.numel() // count                       # size * (2k + 1) * n
+        k = getattr(self, "_k", None)
+        if k is None:
+            raise ValueError("gather needs a PreparedCt made by Evaluator.prepare_operand")
+        qw = per // (2 * k + 1) * k                           # size * k * n
+        bw = per - qw                                         # size * (k + 1) * n
+        idx = torch.as_tensor(index, dtype=torch.long, device=self.buf.device)
+        q = self.buf[:count * qw].view(count, qw).index_select(0, idx)
+        b = self.buf[count * qw:].view(count, bw).index_select(0, idx)
+        out = PreparedCt(torch.cat([q.reshape(-1), b.reshape(-1)]), self.size, (int(idx.numel()),))
+        out._k = self._k
+        return out
+
 
 class DctPlan:
     def __init__(self, ctx, quant=YQT, int_coeffs=100, frac_coeffs=100):
@@ -256,7 +276,9 @@ class Evaluator:
         words = _lib.load().fhe_multiply_operand_words(self.ctx.h, size, count)
         buf = torch.empty(words, dtype=torch.int64, device=self.ctx.device)
         _lib.call("fhe_multiply_prepare", self.ctx.h, _ptr(a), size, count, _ptr(buf), _stream())
-        return PreparedCt(buf, size, lead)
+        out = PreparedCt(buf, size, lead)
+        out._k = self.ctx.k
+        return out
 
     def multiply(self, a, b):
         pa = a if isinstance(a, PreparedCt) else None

@@ -64,6 +64,68 @@ def test_config2_bicubic_128_to_64_at_n8192(fhe, oracle_mod):
         assert np.array_equal(got, ref), o
 
 
+def test_config2_shared_offsets_full_size_equals_per_pixel_sampling(fhe):
+    """configs[2] at its stated size and parameters with one offset ciphertext per output column / row:
+    the shared-row evaluation (12,288 Cubics) and the per-pixel evaluation (20,480 Cubics) give the same 4096 size-6
+    ciphertexts -- compared through the position-dependent digest of all 6 GiB and on sampled pixels."""
+    import torch
+    ctx = fhe.SEALContext.preset("P8192")
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    W = H = 128
+    w = h = 64
+    pixels = ctx.random_ct(W * H, size=2, seed=fhe.SEED)
+    xf, yf = ctx.random_ct(w, size=2, seed=11), ctx.random_ct(h, size=2, seed=12)
+    words = 6 * ctx.k * ctx.n
+    keep, acc = {}, [0]
+
+    def consume(first, t):
+        acc[0] = (acc[0] + ctx.digest(t, index0=first * words)) % (1 << 64)
+        for o in (0, 63, 64 * 31 + 17, w * h - 1):
+            if first <= o < first + t.shape[0]:
+                keep[o] = t[o - first].clone()
+    assert fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xf, yf, consume=consume) is None
+    taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+    xs = torch.as_tensor([x for y in range(h) for x in range(w)], device=pixels.device)
+    ys = torch.as_tensor([y for y in range(h) for x in range(w)], device=pixels.device)
+    total = 0
+    for s in range(0, w * h, 256):
+        e = s + 256
+        out = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf[xs[s:e]].contiguous(), yf[ys[s:e]].contiguous())
+        total = (total + ctx.digest(out, index0=s * words)) % (1 << 64)
+        for o, t in keep.items():
+            if s <= o < e:
+                assert torch.equal(out[o - s], t), o
+    assert len(keep) == 4 and total == acc[0]
+
+
+@pytest.mark.parametrize("preset,W,H,w,h,band,batch", [("SMALL", 16, 12, 8, 7, 3, 16), ("SMALL", 9, 9, 17, 17, 4, 64), ("P8192", 24, 24, 12, 12, 4, 48)])
+def test_shared_row_cubics_equal_per_pixel_sampling(fhe, preset, W, H, w, h, band, batch):
+    """circuits.resize_bicubic_shared (one offset ciphertext per output column / row: every row Cubic, square and
+    prepared operand formed once) == circuits.sample_bicubic pixel by pixel with those ciphertexts, bit for bit:
+    down- and up-scaling, ragged last band, windows that skip and that repeat source rows, clamped borders."""
+    import torch
+    ctx = fhe.SEALContext(1024, [0xFFFFEE001, 0xFFFFC4001, 0x1FFFFE0001], 1 << 14, 0) if preset == "SMALL" else fhe.SEALContext.preset(preset)
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    pixels = ctx.random_ct(W * H, size=2, seed=5)
+    xf, yf = ctx.random_ct(w, size=2, seed=11), ctx.random_ct(h, size=2, seed=12)
+    got = fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xf, yf, batch=batch, band_rows=band)
+    assert got.shape == (w * h, 6, ctx.k, ctx.n)
+    taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+    xs = torch.as_tensor([x for y in range(h) for x in range(w)], device=pixels.device)
+    ys = torch.as_tensor([y for y in range(h) for x in range(w)], device=pixels.device)
+    step = 64
+    for s in range(0, w * h, step):
+        e = min(s + step, w * h)
+        want = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf[xs[s:e]].contiguous(), yf[ys[s:e]].contiguous())
+        assert torch.equal(got[s:e], want), s
+    # streamed form: the bands handed to a consumer are the same tensor in pieces
+    seen = []
+    assert fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xf, yf, batch=batch, band_rows=band,
+                                              consume=lambda first, t: seen.append((first, t))) is None
+    assert [f for f, _ in seen] == sorted(f for f, _ in seen) and sum(t.shape[0] for _, t in seen) == w * h
+    assert all(torch.equal(t, got[f:f + t.shape[0]]) for f, t in seen)
+
+
 def test_config3_approximated_step_16_positions_degree_12_at_n8192(fhe, oracle_mod, tmp_path):
     ctx = fhe.SEALContext.preset("P8192")
     orc = oracle_mod.Oracle.preset("P8192")
