@@ -62,6 +62,7 @@ SIGNATURES = {
     "fhe_multiply_operand_words": (C.c_size_t, [_vp, _u32, _u64]),
     "fhe_multiply_prepare": (_i, [_vp, _vp, _u32, _u64, _vp, _vp]),
     "fhe_multiply_prepared": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
+    "fhe_multiply_prepared_shared": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _u64, _u64, _u64, _vp, _u64, _vp, C.c_size_t, _vp]),
     "fhe_evk_digits": (_u32, [_vp, _u32]),
     "fhe_relinearize": (_i, [_vp, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_relinearize_scratch_bytes": (_sz, [_vp, _u32, _u64]),

@@ -175,7 +175,8 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
         4-row windows overlap, so the 4 * dst_h row Cubics of a column collapse to one per source row touched
         (128 instead of 256 for 128 -> 64);
       * xfract^2 and the prepared (extended + transformed) forms of xfract, xfract^2 are formed once per column,
-        yfract^2 and its prepared forms once per row, and gathered into the batches.
+        yfract^2 and its prepared forms once per row; the products index them in place (entry c % dst_w resp.
+        first_row + c // dst_w of the prepared batch: fhe_multiply_prepared_shared), nothing is copied.
 
     The reference's server encrypts fresh offsets for every sample (:262,266); its results are therefore
     randomised per pixel and only sample_bicubic with per-pixel ciphertexts reproduces that run bit for bit
@@ -190,23 +191,22 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
     x2, y2 = ev.square(xfract), ev.square(yfract)                                          # t2 (= t3, :174-175) per column / row
     px2, px1 = ev.prepare_operand(x2), ev.prepare_operand(xfract)
     py2, py1 = ev.prepare_operand(y2), ev.prepare_operand(yfract)
+    sx2, sx1 = px2.shared(1), px1.shared(1)
     dev = pixels.device
     cache = {}                                                                             # source row -> [dst_w, 4, k, n]
 
     def row_cubics(new_rows):
         if not new_rows:
             return
-        pairs = [(r, x) for r in new_rows for x in range(dst_w)]
         res = []
-        for s0 in range(0, len(pairs), batch):
-            part = pairs[s0:s0 + batch]
-            xs = [x for _, x in part]
+        rows_per_call = max(1, batch // dst_w)
+        for s0 in range(0, len(new_rows), rows_per_call):
+            part = [(r, x) for r in new_rows[s0:s0 + rows_per_call] for x in range(dst_w)]
             tap = [torch.as_tensor([r * src_w + colx[x][i] for r, x in part], dtype=torch.long, device=dev) for i in range(4)]
             A, B, C, D = (pixels.index_select(0, t) for t in tap)
-            g2 = px2.gather(xs)
-            xi = torch.as_tensor(xs, dtype=torch.long, device=dev)
-            t2 = x2.index_select(0, xi)
-            res.append(cubic(ev, pc, A, B, C, D, None, powers=(t2, t2), prepared=(g2, g2, px1.gather(xs))))
+            # pairs are ordered (row, column) with the column fastest and whole rows per call: pair c multiplies the
+            # column's xfract / xfract^2, entry c % dst_w of the prepared batches -- no copy (fhe_multiply_prepared_shared)
+            res.append(cubic(ev, pc, A, B, C, D, None, powers=(None, None), prepared=(sx2, sx2, sx1)))
         allr = torch.cat(res, dim=0) if len(res) > 1 else res[0]
         for i, r in enumerate(new_rows):
             cache[r] = allr[i * dst_w:(i + 1) * dst_w]
@@ -221,11 +221,10 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
         rows_per_call = max(1, batch // dst_w)
         for s0 in range(0, len(ys), rows_per_call):
             yy = ys[s0:s0 + rows_per_call]
-            part = [y for y in yy for _ in range(dst_w)]
             A, B, C, D = (torch.cat([cache[rows_of[y][j]] for y in yy], dim=0) for j in range(4))
-            g2 = py2.gather(part)
-            t2 = y2.index_select(0, torch.as_tensor(part, dtype=torch.long, device=dev))
-            o = cubic(ev, pc, A, B, C, D, None, powers=(t2, t2), prepared=(g2, g2, py1.gather(part)))
+            # pixel c of the call sits in output row yy[c // dst_w]: entry yy[0] + c // dst_w of the prepared yfract batches
+            sy2, sy1 = py2.shared(dst_w, yy[0]), py1.shared(dst_w, yy[0])
+            o = cubic(ev, pc, A, B, C, D, None, powers=(None, None), prepared=(sy2, sy2, sy1))
             if consume is not None:
                 consume(yy[0] * dst_w, o)
             else:

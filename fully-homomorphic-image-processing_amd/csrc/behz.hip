@@ -142,12 +142,19 @@ __global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in,
     }
 }
 
+// Which entry of the B operand batch pair c multiplies: c itself, or -- for an operand batch shared between pairs
+// (fhe_multiply_prepared_shared: one xfract per output column, one yfract per output row) -- (c / div) % cnt.
+struct BMap {
+    u64 div, cnt, off;      // cnt == 0: identity; off: absolute number of the launch's first pair
+    __device__ __forceinline__ u64 operator()(u64 c) const { return cnt ? ((c + off) / div) % cnt : c; }
+};
 // tensor product in NTT form over one base: A [count][sa][nb][n], Bm [count][sb][nb][n] -> D [count][sa+sb-1][nb][n]
 __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
-                                                     const Modulus *__restrict__ mods, const u64 *__restrict__ mu2, u32 nb, u32 n, u32 sa, u32 sb, u64 count) {
+                                                     const Modulus *__restrict__ mods, const u64 *__restrict__ mu2, u32 nb, u32 n, u32 sa, u32 sb, u64 count,
+                                                     BMap bm) {
     const u32 so = sa + sb - 1;
     for (u64 cp = blockIdx.y; cp < count * nb; cp += gridDim.y) {
-        const u64 c = cp / nb;
+        const u64 c = cp / nb, cb = bm(c);
         const u32 j = (u32)(cp % nb);
         const Modulus m = mods[j];
         for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
                 u32 terms = 0;
                 const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
                 for (u32 ja = lo; ja <= hi; ja++) {
-                    const u64 x = A[((c * sa + ja) * nb + j) * n + s], y = Bm[((c * sb + (o - ja)) * nb + j) * n + s];
+                    const u64 x = A[((c * sa + ja) * nb + j) * n + s], y = Bm[((cb * sb + (o - ja)) * nb + j) * n + s];
                     acc += (u128)x * y;                               // below 2^122 each; reduced every three terms
                     if (++terms == 3) { acc = reduce128(acc, m.q, mu2[j], m.s1); terms = 0; }
                 }
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
 // -> D [count][sa+sb-1][nb][n] (coefficient form, canonical).
 template <int L>
 __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
-                                                                       RnsBase base, u32 sa, u32 sb, u64 groups) {
+                                                                       RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
     for (u32 ja = lo; ja <= hi; ja++) {
         u64 xa[16], xb[16];
         load_slots<L>(xa, A + ((c * sa + ja) * nb + j) * N, tid);
-        load_slots<L>(xb, Bm + ((c * sb + (o - ja)) * nb + j) * N, tid);
+        load_slots<L>(xb, Bm + ((bm(c) * sb + (o - ja)) * nb + j) * N, tid);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
     }
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
 // prime, so every twiddle pair of the inverse transform is fetched once for both (ntt_inv_regs4m).  groups = (count / 2) * nb.
 template <int L>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
-                                                                           RnsBase base, u32 sa, u32 sb, u64 groups) {
+                                                                           RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
     const int tid = threadIdx.x;
@@ -225,11 +232,11 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
     const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const u64 c = 2 * cc + h;
+        const u64 c = 2 * cc + h, cb = bm(c);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[h][r] = 0;
         for (u32 ja = lo; ja <= hi; ja++) {
-            const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((c * sb + (o - ja)) * nb + j) * N + tid;
+            const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {       // eight slots at a time: 64 accumulator + 32 operand VGPRs
                 u64 xa[8], xb[8];
@@ -533,24 +540,26 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
 }
 // tensor product fused into the inverse transforms over one base: pairs of ciphertext pairs per workgroup at n >= 8192
 // (P8192 inverse transform +19 % with shared twiddles), the odd one out and the smaller degrees one per workgroup
-static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st) {
+static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm) {
     const u32 nb = base.count, so = sa + sb - 1;
     static const bool single = [] { const char *e = getenv("FHE_NTT_SINGLE"); return e && *e && !(e[0] == '0' && !e[1]); }();
     u64 done = 0;
     if (c->logn >= 13 && !single && count >= 2) {
         const u64 pairs = count / 2;
         switch (c->logn) {
-            case 13: k_behz_tensor_intt2<13><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<13>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb); break;
-            default: k_behz_tensor_intt2<14><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<14>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb); break;
+            case 13: k_behz_tensor_intt2<13><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<13>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm); break;
+            default: k_behz_tensor_intt2<14><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<14>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm); break;
         }
         done = 2 * pairs;
     }
     if (done < count) {
         const u64 rest = count - done;
         const size_t n = c->n;
-        const u64 *A2 = A + done * sa * nb * n, *B2 = Bm + done * sb * nb * n;
+        // a shared B batch is indexed by the absolute pair number: its pointer stays, the map carries the offset
+        const u64 *A2 = A + done * sa * nb * n, *B2 = bm.cnt ? Bm : Bm + done * sb * nb * n;
         u64 *D2 = D + done * so * nb * n;
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb)));
+        if (bm.cnt) bm.off += done;
+        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm)));
     }
     KERNEL_CHECK();
     return FHE_OK;
@@ -558,19 +567,19 @@ static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, co
 
 // tensor product + inverse transforms + floor/back-conversion from prepared operands; D = scratch for so polynomials
 static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, const u64 *Bq, const u64 *Bb, u32 sb, u64 *out, u64 count,
-                       u64 *Dq, u64 *Db, hipStream_t st) {
+                       u64 *Dq, u64 *Db, hipStream_t st, BMap bm = BMap{1, 0, 0}) {
     const u32 k = c->k, n = c->n, so = sa + sb - 1;
     int rc;
     if ((count * (u64)(k + 1) + 8) * so > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const bool q_f64 = fhe_rgb_f64_supported(c);      // FP64 inverse transforms beat the fused u64 kernel there
     if (q_f64) {
-        k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, c->behz->dev->mu2_q, k, n, sa, sb, count);
+        k_behz_tensor<<<grid2(n, count * k), 256, 0, st>>>(Aq, Bq, Dq, c->qb.d_mod, c->behz->dev->mu2_q, k, n, sa, sb, count, bm);
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
-        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st))) return rc;
+        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm))) return rc;
     }
-    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st))) return rc;
+    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm))) return rc;
     switch (k) {
 #define GO(KK) case KK: k_behz_floor_back<KK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
@@ -632,6 +641,37 @@ extern "C" int fhe_multiply_prepared(const fhe_ctx *c, const uint64_t *a, const 
                                      uint32_t sb, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream s) {
     return behz_multiply(c, (const u64 *)a, (const u64 *)ap, sa, (const u64 *)b, (const u64 *)bp, sb, (u64 *)out, count, scratch, scratch_bytes,
                          (hipStream_t)s);
+}
+
+// a (plain or prepared) x a prepared operand batch of b_count entries shared between the pairs:
+// pair c takes entry (b_first + c / b_div) % b_count
+extern "C" int fhe_multiply_prepared_shared(const fhe_ctx *cc, const uint64_t *a, const uint64_t *ap, uint32_t sa, const uint64_t *bp, uint32_t sb,
+                                            uint64_t b_count, uint64_t b_div, uint64_t b_first, uint64_t *out, uint64_t count, void *scratch,
+                                            size_t scratch_bytes, fhe_stream s) {
+    if (!cc || (!a && !ap) || !bp || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (sa < 1 || sb < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
+    if (!b_count || !b_div) return fail(FHE_ERR_PARAM, "shared operand: b_count and b_div must be positive");
+    if (!count) return FHE_OK;
+    const fhe_ctx *c = cc;
+    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, false) * sizeof(u64))
+        return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
+    hipStream_t st = (hipStream_t)s;
+    const u32 k = c->k, n = c->n, so = sa + sb - 1;
+    const size_t kn = (size_t)k * n, bn = (size_t)(k + 1) * n;
+    u64 *p = (u64 *)scratch;
+    const u64 *Aq, *Ab;
+    int rc;
+    if (ap) { Aq = (const u64 *)ap; Ab = Aq + count * sa * kn; }
+    else {
+        u64 *xq = p, *xb = xq + count * sa * kn;
+        p = xb + count * sa * bn;
+        if ((rc = behz_prepare(c, (const u64 *)a, sa, count, xq, xb, st))) return rc;
+        Aq = xq; Ab = xb;
+    }
+    const u64 *Bq = (const u64 *)bp, *Bb = Bq + b_count * sb * kn;
+    u64 *Dq = p, *Db = Dq + count * so * kn;
+    return behz_finish(c, Aq, Ab, sa, Bq, Bb, sb, (u64 *)out, count, Dq, Db, st, BMap{b_div, b_count, (b_first % b_count) * b_div});
 }
 
 extern "C" int fhe_multiply(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out,

@@ -140,6 +140,9 @@ class PreparedCt:
     def __init__(self, buf, size, lead):
         self.buf, self.size, self.lead = buf, size, lead
 
+    def shared(self, div=1, first=0):
+        return SharedPrepared(self, div, first)
+
     def gather(self, index):
         """The prepared operands `index` (a sequence of positions in the flattened batch, repeats allowed) as a new
         prepared batch -- a copy of words, no arithmetic.  Layout (include/fhe_hip.h, fhe_multiply_prepare):
@@ -154,11 +157,25 @@ class PreparedCt:
         qw = per // (2 * k + 1) * k                           # size * k * n
         bw = per - qw                                         # size * (k + 1) * n
         idx = torch.as_tensor(index, dtype=torch.long, device=self.buf.device)
-        q = self.buf[:count * qw].view(count, qw).index_select(0, idx)
-        b = self.buf[count * qw:].view(count, bw).index_select(0, idx)
-        out = PreparedCt(torch.cat([q.reshape(-1), b.reshape(-1)]), self.size, (int(idx.numel()),))
+        m = int(idx.numel())
+        buf = torch.empty(m * per, dtype=self.buf.dtype, device=self.buf.device)
+        torch.index_select(self.buf[:count * qw].view(count, qw), 0, idx, out=buf[:m * qw].view(m, qw))
+        torch.index_select(self.buf[count * qw:].view(count, bw), 0, idx, out=buf[m * qw:].view(m, bw))
+        out = PreparedCt(buf, self.size, (m,))
         out._k = self._k
         return out
+
+
+class SharedPrepared:
+    """A prepared operand batch shared between the pairs of one multiply(): pair c takes entry
+    (first + c // div) % count (fhe_multiply_prepared_shared); PreparedCt.shared(div, first) makes one.
+    Right-hand side of multiply() only."""
+
+    def __init__(self, prep, div, first=0):
+        count = 1
+        for d in prep.lead:
+            count *= d
+        self.prep, self.div, self.first, self.count, self.size = prep, int(div), int(first), count, prep.size
 
 
 class DctPlan:
@@ -281,6 +298,20 @@ class Evaluator:
         return out
 
     def multiply(self, a, b):
+        if isinstance(b, SharedPrepared):
+            pa = a if isinstance(a, PreparedCt) else None
+            sa = pa.size if pa else a.shape[-3]
+            lead = pa.lead if pa else tuple(a.shape[:-3])
+            count = 1
+            for d in lead:
+                count *= d
+            out = self.ctx.empty(*lead, size=sa + b.size - 1)
+            nbytes = _lib.load().fhe_multiply_scratch_bytes(self.ctx.h, sa, b.size, count)
+            scr = self._scratch_buf(nbytes)
+            null = C.c_void_p(None)
+            _lib.call("fhe_multiply_prepared_shared", self.ctx.h, null if pa else _ptr(a), _ptr(pa.buf) if pa else null, sa,
+                      _ptr(b.prep.buf), b.size, b.count, b.div, b.first, _ptr(out), count, _ptr(scr), nbytes, _stream())
+            return out
         pa = a if isinstance(a, PreparedCt) else None
         pb = b if isinstance(b, PreparedCt) else None
         sa = pa.size if pa else a.shape[-3]

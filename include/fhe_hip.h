@@ -173,6 +173,15 @@ int fhe_multiply_prepare(const fhe_ctx *ctx, const uint64_t *a, uint32_t size, u
 int fhe_multiply_prepared(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *a_prepared, uint32_t size_a,
                           const uint64_t *b, const uint64_t *b_prepared, uint32_t size_b, uint64_t *out, uint64_t count,
                           void *scratch, size_t scratch_bytes, fhe_stream stream);
+/* The same with a prepared operand batch SHARED between the pairs: b_prepared holds b_count entries and pair c
+ * multiplies entry (b_first + c / b_div) % b_count -- ResizeImage's offsets (homo/fhe_resize.h:351,382): frac(u) depends
+ * on the output column only and frac(v) on the output row only, so a batch of whole pixel rows in row-major order
+ * multiplies xfract[c % width] (b_div = 1, b_count = width) and yfract[first_row + c / width] (b_div = width).
+ * Bit-identical to fhe_multiply_prepared on the gathered operand; no copy of the prepared words is made. */
+int fhe_multiply_prepared_shared(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *a_prepared, uint32_t size_a,
+                                 const uint64_t *b_prepared, uint32_t size_b, uint64_t b_count, uint64_t b_div,
+                                 uint64_t b_first, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes,
+                                 fhe_stream stream);
 
 /* ---- seal::Evaluator::relinearize (north_star API surface; the reference never calls it, only
  * tests/parameters.cpp:112 touches evaluation keys).  Key-switch inner product for `count`

@@ -804,6 +804,24 @@ def test_multiply_with_prepared_operands(fhe, oracle_mod, preset):
         assert torch.equal(ev.multiply(a2, pb), ev.multiply(a2, b))
 
 
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192"])
+def test_multiply_with_shared_prepared_operand(fhe, oracle_mod, preset):
+    """fhe_multiply_prepared_shared: pair c multiplies entry (first + c // div) % count of a prepared batch; equal to
+    fhe_multiply on the gathered operand bit for bit -- odd and even pair counts (the two-pair kernels at n = 8192
+    and their one-pair remainder), both operand-side forms, wrap-around of the index."""
+    import torch
+    ctx, _ = _pair(fhe, oracle_mod, preset)
+    ev = fhe.Evaluator(ctx)
+    for sa, sb, count, nb, div, first in ((2, 3, 7, 3, 1, 0), (4, 3, 6, 4, 2, 1), (2, 2, 5, 2, 3, 5), (3, 2, 1, 4, 1, 2)):
+        a, b = ctx.random_ct(count, size=sa, seed=510 + sa), ctx.random_ct(nb, size=sb, seed=610 + sb)
+        idx = [(first + c // div) % nb for c in range(count)]
+        ref = ev.multiply(a, b[torch.as_tensor(idx, device=b.device)].contiguous())
+        pb = ev.prepare_operand(b)
+        assert torch.equal(ev.multiply(a, pb.shared(div, first)), ref), (sa, sb, count)
+        assert torch.equal(ev.multiply(ev.prepare_operand(a), pb.shared(div, first)), ref), (sa, sb, count)
+        assert torch.equal(ev.multiply(a, pb.gather(idx)), ref), (sa, sb, count)
+
+
 @pytest.mark.parametrize("preset", ["SMALL", "P4096", "SEAL23_4096"])
 def test_randomised_op_sequences_vs_oracle(fhe, oracle_mod, preset):
     """seeded random sequences of Evaluator calls on small batches (odd and even counts, sparse and
