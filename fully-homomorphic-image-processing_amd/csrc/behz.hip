@@ -56,6 +56,7 @@ struct BehzTables {
     BaseTables aux;     // NTT tables of Bsk (k+1 primes)
     BehzDev host;       // host copy (k, moduli)
     BehzDev *dev = nullptr;
+    bool wide_dot = false;   // 58-bit auxiliary primes and q-primes <= 58 bits: dot products of <= 8 terms need no inner reduction
 };
 
 namespace {
@@ -79,6 +80,12 @@ __device__ __forceinline__ u64 reduce128(u128 z, u64 m, u64 mu2, u32 sh) {
 // carry below 2^61, and reduce128 takes z < 2^(bits(m)+63); three terms + carry stay below 2^124 for 61-bit moduli and,
 // for a smaller modulus q_i, the terms z_j c (c < q_i) are below 2^(61+bits(q_i)): again three fit.
 constexpr int DOT_CHUNK = 3;
+// With auxiliary primes of 58 bits and q-primes of at most 58 bits no intermediate reduction is needed at all for up to
+// 8 terms: a term is below 2^116, the start value below 2^116, and reduce128 takes z < 2^(bits(m)+63) -- 2^(58+63) for
+// the auxiliary moduli (9 x 2^116 < 2^120), and for a q-prime of b bits the terms z_j c (c < q_i) are below 2^(58+b)
+// against 2^(b+63): 32 of them fit.  BehzTables::wide_dot says when this holds; the kernels take the chunk as a
+// template parameter (WIDE_CHUNK = no reduction inside a dot product of <= 8 terms).
+constexpr int WIDE_CHUNK = 9;
 
 // x * c mod m for a context constant c = (value, Shoup companion); any x < 2^64; result in [0, m)
 __device__ __forceinline__ u64 mulc(u64 x, const ulonglong2 c, u64 m) { return mul_shoup(x, c.x, c.y, m); }
@@ -95,7 +102,7 @@ constexpr int CPT = 4;          // floor/back kernel
 #ifndef TO_BSK_CPT
 #define TO_BSK_CPT 1
 #endif
-template <int K, int CPT>
+template <int K, int CPT, int CH>
 __global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in, u64 *__restrict__ out, const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
     const BehzDev &T = *Tp;       // wave-uniform: scalar loads at compile-time offsets
     const u32 stride = gridDim.x * blockDim.x;             // n == CPT * stride
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in,
                 const u64 cij = T.ext_q2b[i][j];
 #pragma unroll
                 for (int e = 0; e < CPT; e++) {
-                    if (i > 0 && i % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
+                    if (i > 0 && i % CH == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
                     acc[e] += (u128)y[e][i] * cij;
                 }
             }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
 }
 
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
-template <int K>
+template <int K, int CH>
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
                                                          const BehzDev *__restrict__ Tp, u32 n, u64 n_polys) {
     const BehzDev &T = *Tp;       // wave-uniform: scalar loads at compile-time offsets
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__
                 const u64 cij = T.flo_q2b[i][j];
 #pragma unroll
                 for (int e = 0; e < CPT; e++) {
-                    if (i > 0 && i % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
+                    if (i > 0 && i % CH == 0) acc[e] = reduce128(acc[e], bq, mu2, sh);
                     acc[e] += (u128)y[e][i] * cij;
                 }
             }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__
 #pragma unroll
                 for (int e = 0; e < CPT; e++) {
                     z[e][j] = mul_shoup(f[e][j], w.x, w.y, bq);                              // canonical integer in [0, b_j)
-                    if (j > 0 && j % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], msk, mu2, sh);
+                    if (j > 0 && j % CH == 0) acc[e] = reduce128(acc[e], msk, mu2, sh);
                     acc[e] += (u128)z[e][j] * cj;
                 }
             }
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__
                 const u64 cji = T.back_B2q[j][i];
 #pragma unroll
                 for (int e = 0; e < CPT; e++) {
-                    if (j > 0 && j % DOT_CHUNK == 0) acc[e] = reduce128(acc[e], qi, mu2, sh);
+                    if (j > 0 && j % CH == 0) acc[e] = reduce128(acc[e], qi, mu2, sh);
                     acc[e] += (u128)z[e][j] * cji;
                 }
             }
@@ -419,6 +426,7 @@ int fhe_behz_build(fhe_ctx *c) {
     for (u64 qi : q) q_bits += bit_length(qi);
     const int need = q_bits + bit_length(c->t) + (int)c->logn + 8 + 4;
     const int aux_bits = (57 * (int)(k + 1) >= need && !getenv("FHE_BEHZ_AUX61")) ? 58 : 61;
+    T->wide_dot = aux_bits == 58 && c->max_prime_bits <= 58 && k <= 8 && !getenv("FHE_BEHZ_CHUNK3");
     std::vector<u64> found;
     for (u64 cand = (1ULL << aux_bits) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
         if (!is_prime(cand)) continue;
@@ -530,7 +538,8 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
 static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
     const u32 k = c->k, n = c->n;
     switch (k) {
-#define GO(KK) case KK: k_behz_to_bsk<KK, TO_BSK_CPT><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
+#define GO(KK) case KK: if (c->behz->wide_dot) k_behz_to_bsk<KK, TO_BSK_CPT, WIDE_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); \
+                        else k_behz_to_bsk<KK, TO_BSK_CPT, DOT_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
     }
@@ -581,7 +590,8 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
     }
     if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm))) return rc;
     switch (k) {
-#define GO(KK) case KK: k_behz_floor_back<KK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
+#define GO(KK) case KK: if (c->behz->wide_dot) k_behz_floor_back<KK, WIDE_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); \
+                        else k_behz_floor_back<KK, DOT_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
     }
