@@ -56,6 +56,7 @@ struct BehzTables {
     BaseTables aux;     // NTT tables of Bsk (k+1 primes)
     BehzDev host;       // host copy (k, moduli)
     BehzDev *dev = nullptr;
+    int aux_bits = 61;
     bool wide_dot = false;   // 58-bit auxiliary primes and q-primes <= 58 bits: dot products of <= 8 terms need no inner reduction
 };
 
@@ -184,7 +185,16 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
 // ciphertext pair c at base prime j from the NTT-form operands and transforms it back, so the
 // NTT-form product never goes to memory.  A [count][sa][nb][n], Bm [count][sb][nb][n] (NTT order)
 // -> D [count][sa+sb-1][nb][n] (coefficient form, canonical).
-template <int L>
+// WIDE (every modulus of the base <= 58 bits, at most 21 terms): the products stay in [0, 3q) and are summed as plain
+// integers (21 x 3q < 2^64); the sum is brought below 4q -- the range the inverse transform takes -- by at most four
+// conditional subtractions per output instead of three per term.
+__device__ __forceinline__ u64 fold_below_4q(u64 acc, u32 terms, u64 q4) {     // acc < 3 terms q, terms <= 21
+#pragma unroll
+    for (int s = 3; s >= 0; s--)
+        if (3 * terms > (4u << s)) acc = csub(acc, q4 << s);
+    return acc;
+}
+template <int L, bool WIDE>
 __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
                                                                        RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
@@ -211,17 +221,25 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
         load_slots<L>(xa, A + ((c * sa + ja) * nb + j) * N, tid);
         load_slots<L>(xb, Bm + ((bm(c) * sb + (o - ja)) * nb + j) * N, tid);
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
+        for (int r = 0; r < 16; r++) acc[r] = WIDE ? acc[r] + mul_barrett_lazy3(xa[r], xb[r], m) : addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
     }
-    ntt_inv_regs4<L>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);               // [0, q) in, [0, 4q) out
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = csub(csub(acc[r], 2 * m.q), m.q);
+        for (int r = 0; r < 16; r++) acc[r] = fold_below_4q(acc[r], hi - lo + 1, 4 * m.q);
+    }
+    ntt_inv_regs4<L>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);               // [0, 4q) in, [0, 4q) out
+    // WIDE: the only reader is k_behz_floor_back<.., WIDE_CHUNK>, whose Shoup products take any 64-bit value and whose
+    // 128-bit sums have room for a start value below 4 b_j (2^118 + 8 x 2^116 < 2^121): no canonical form needed
+    if constexpr (!WIDE) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = csub(csub(acc[r], 2 * m.q), m.q);
+    }
     store_coeff<L>(acc, D + id * N, tid);
 }
 
 // The same for TWO ciphertext pairs (2 cc, 2 cc + 1) per workgroup at n >= 8192: the two output polynomials share the
 // prime, so every twiddle pair of the inverse transform is fetched once for both (ntt_inv_regs4m).  groups = (count / 2) * nb.
-template <int L>
+template <int L, bool WIDE>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
                                                                            RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
@@ -250,15 +268,22 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
 #pragma unroll
                 for (int r = 0; r < 8; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
 #pragma unroll
-                for (int r = 0; r < 8; r++) acc[h][r0 + r] = addmod(acc[h][r0 + r], mul_barrett(xa[r], xb[r], m), m.q);
+                for (int r = 0; r < 8; r++)
+                    acc[h][r0 + r] = WIDE ? acc[h][r0 + r] + mul_barrett_lazy3(xa[r], xb[r], m) : addmod(acc[h][r0 + r], mul_barrett(xa[r], xb[r], m), m.q);
             }
+        }
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[h][r] = fold_below_4q(acc[h][r], hi - lo + 1, 4 * m.q);
         }
     }
     ntt_inv_regs4m<L, 2>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[h][r] = csub(csub(acc[h][r], 2 * m.q), m.q);
+            for (int r = 0; r < 16; r++) acc[h][r] = csub(csub(acc[h][r], 2 * m.q), m.q);
+        }
         store_coeff<L>(acc[h], D + (((2 * cc + h) * so + o) * nb + j) * N, tid);
     }
 }
@@ -426,6 +451,7 @@ int fhe_behz_build(fhe_ctx *c) {
     for (u64 qi : q) q_bits += bit_length(qi);
     const int need = q_bits + bit_length(c->t) + (int)c->logn + 8 + 4;
     const int aux_bits = (57 * (int)(k + 1) >= need && !getenv("FHE_BEHZ_AUX61")) ? 58 : 61;
+    T->aux_bits = aux_bits;
     T->wide_dot = aux_bits == 58 && c->max_prime_bits <= 58 && k <= 8 && !getenv("FHE_BEHZ_CHUNK3");
     std::vector<u64> found;
     for (u64 cand = (1ULL << aux_bits) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
@@ -549,15 +575,19 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
 }
 // tensor product fused into the inverse transforms over one base: pairs of ciphertext pairs per workgroup at n >= 8192
 // (P8192 inverse transform +19 % with shared twiddles), the odd one out and the smaller degrees one per workgroup
-static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm) {
+static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm,
+                       bool wide_base) {
     const u32 nb = base.count, so = sa + sb - 1;
+    const bool wide = wide_base && (sa < sb ? sa : sb) <= 21 && !getenv("FHE_BEHZ_TENSOR_CANON");     // terms per output <= min(sa, sb)
     static const bool single = [] { const char *e = getenv("FHE_NTT_SINGLE"); return e && *e && !(e[0] == '0' && !e[1]); }();
     u64 done = 0;
     if (c->logn >= 13 && !single && count >= 2) {
         const u64 pairs = count / 2;
         switch (c->logn) {
-            case 13: k_behz_tensor_intt2<13><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<13>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm); break;
-            default: k_behz_tensor_intt2<14><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<14>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm); break;
+#define GO2(LL, WW) k_behz_tensor_intt2<LL, WW><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<LL>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm)
+            case 13: if (wide) GO2(13, true); else GO2(13, false); break;
+            default: if (wide) GO2(14, true); else GO2(14, false); break;
+#undef GO2
         }
         done = 2 * pairs;
     }
@@ -568,7 +598,8 @@ static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, co
         const u64 *A2 = A + done * sa * nb * n, *B2 = bm.cnt ? Bm : Bm + done * sb * nb * n;
         u64 *D2 = D + done * so * nb * n;
         if (bm.cnt) bm.off += done;
-        DISPATCH_L(c->logn, (k_behz_tensor_intt<L><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm)));
+        if (wide) { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, true><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
+        else { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, false><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
     }
     KERNEL_CHECK();
     return FHE_OK;
@@ -586,9 +617,9 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
-        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm))) return rc;
+        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm, c->max_prime_bits <= 58))) return rc;
     }
-    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm))) return rc;
+    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm, c->behz->aux_bits <= 58))) return rc;
     switch (k) {
 #define GO(KK) case KK: if (c->behz->wide_dot) k_behz_floor_back<KK, WIDE_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); \
                         else k_behz_floor_back<KK, DOT_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;

@@ -72,6 +72,15 @@ __device__ __forceinline__ u64 mul_barrett(u64 a, u64 b, const Modulus &m) {
     return csub(r, m.q);
 }
 
+// the same without the two conditional subtractions: a * b mod q + {0, 1, 2} q, in [0, 3q)
+__device__ __forceinline__ u64 mul_barrett_lazy3(u64 a, u64 b, const Modulus &m) {
+    u64 lo = a * b, hi = __umul64hi(a, b);
+    u64 x = (hi << (64 - m.s1)) | (lo >> m.s1);
+    u64 plo = x * m.mu, phi = __umul64hi(x, m.mu);
+    u64 qhat = (phi << (64 - m.s2)) | (plo >> m.s2);
+    return lo - qhat * m.q;
+}
+
 // floor(w * 2^64 / q) for w < q, by restoring division (setup kernels only)
 __device__ inline u64 shoup_companion(u64 w, u64 q) {
     u64 rem = w, quo = 0;
