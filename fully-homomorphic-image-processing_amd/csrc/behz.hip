@@ -87,6 +87,32 @@ constexpr int DOT_CHUNK = 3;
 // against 2^(b+63): 32 of them fit.  BehzTables::wide_dot says when this holds; the kernels take the chunk as a
 // template parameter (WIDE_CHUNK = no reduction inside a dot product of <= 8 terms).
 constexpr int WIDE_CHUNK = 9;
+// k_behz_to_bsk in WIDE mode writes its sums for the multiplier this chip has: every operand is below 2^58, so it
+// splits into two 29-bit halves, and a dot product of <= 9 terms becomes three 64-bit columns
+//   value = ll + mid 2^29 + hh 2^58,   ll = sum xl cl,  mid = sum (xl ch + xh cl),  hh = sum xh ch      (each < 2^63)
+// that v_mad_u64_u32 accumulates directly: four multiply-adds per term and NO carry chain, where the 128-bit
+// accumulator costs four multiply-adds plus a four-word add with carries through VCC per term.  The columns are joined
+// once per sum; the integer is the same.  (In k_behz_floor_back the same form needs 148 VGPRs -- three waves per SIMD
+// instead of four -- and measured 287 against 269 us per 256 products: it keeps its 128-bit accumulators.)
+constexpr u64 M29 = (1ULL << 29) - 1;
+struct Dot58 {
+    u64 ll, mid, hh;
+    __device__ __forceinline__ void init(u64 x, u64 c) {          // x, c < 2^58
+        const u32 xl = (u32)(x & M29), xh = (u32)(x >> 29), cl = (u32)(c & M29), ch = (u32)(c >> 29);
+        ll = (u64)xl * cl;
+        mid = (u64)xl * ch + (u64)xh * cl;
+        hh = (u64)xh * ch;
+    }
+    __device__ __forceinline__ void mac(u32 xl, u32 xh, u32 cl, u32 ch) {
+        ll = (u64)xl * cl + ll;
+        mid = (u64)xl * ch + mid;
+        mid = (u64)xh * cl + mid;
+        hh = (u64)xh * ch + hh;
+    }
+    __device__ __forceinline__ unsigned __int128 value() const {
+        return (unsigned __int128)ll + ((unsigned __int128)mid << 29) + ((unsigned __int128)hh << 58);
+    }
+};
 
 // x * c mod m for a context constant c = (value, Shoup companion); any x < 2^64; result in [0, m)
 __device__ __forceinline__ u64 mulc(u64 x, const ulonglong2 c, u64 m) { return mul_shoup(x, c.x, c.y, m); }
@@ -125,6 +151,35 @@ __global__ __launch_bounds__(256) void k_behz_to_bsk(const u64 *__restrict__ in,
         const u64 nq = T.neg_inv_q_mod_mt;
 #pragma unroll
         for (int e = 0; e < CPT; e++) r[e] = ((r[e] & 0xffffffffULL) * nq) & 0xffffffffULL;
+        if constexpr (CH == WIDE_CHUNK) {
+            u32 yl[CPT][K], yh[CPT][K];
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+#pragma unroll
+                for (int e = 0; e < CPT; e++) { yl[e][i] = (u32)(y[e][i] & M29); yh[e][i] = (u32)(y[e][i] >> 29); }
+            }
+#pragma unroll
+            for (int j = 0; j <= K; j++) {
+                const u64 bq = T.b[j].q, mu2 = T.mu2_b[j], eq = T.ext_q_b[j];
+                const u32 sh = T.sh_b[j];
+                Dot58 d[CPT];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    const u64 rb = r[e] >= 0x80000000ULL ? r[e] + bq - 0x100000000ULL : r[e];    // centred remainder
+                    d[e].init(rb, eq);
+                }
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const u64 cij = T.ext_q2b[i][j];
+                    const u32 cl = (u32)(cij & M29), ch = (u32)(cij >> 29);
+#pragma unroll
+                    for (int e = 0; e < CPT; e++) d[e].mac(yl[e][i], yh[e][i], cl, ch);
+                }
+#pragma unroll
+                for (int e = 0; e < CPT; e++) out[(p * (K + 1) + j) * n + c0 + e * stride] = reduce128(d[e].value(), bq, mu2, sh);
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j <= K; j++) {
             const u64 bq = T.b[j].q, mu2 = T.mu2_b[j], eq = T.ext_q_b[j];
