@@ -27,14 +27,17 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def kernel_source_hash():
-    """identifies the kernel sources a PMC record belongs to (git is not available on the GPU box)"""
+    """identifies the sources a PMC record belongs to (git is not available on the GPU box): the translation unit of the
+    two measured kernels (dct_fused.hip and every header it includes) plus fhe_hip.hip, which holds their launch plan
+    and wave size -- a change to another kernel file (behz.hip, dct_u64.hip) does not invalidate the record"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    files = [os.path.join(d, n) for n in ("dct_fused.hip", "fhe_hip.hip", "fp64_core.h", "internal.h", "modarith.h", "ntt_core.h", "host_math.h")]
+    files.append(os.path.join(ROOT, "include", "fhe_hip.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 
