@@ -90,9 +90,9 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const u64 X = LAZY ? x[m][r0] : csub(x[m][r0], pr.q4);
-            const u64 Tm = mul_shoup_lazy4(x[m][r1], wv.x, wv.y, pr.nq, pr.zero);
-            x[m][r0] = X + Tm;
-            x[m][r1] = X - Tm + pr.q4;
+            const u64 S = mul_shoup_lazy4_acc(x[m][r1], wv.x, wv.y, pr.nq, pr.zero, X);      // X + T
+            x[m][r0] = S;
+            x[m][r1] = (X << 1) + pr.q4 - S;                                                // X - T + 4q
         }
     }
 }

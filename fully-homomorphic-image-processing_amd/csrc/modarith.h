@@ -55,7 +55,23 @@ __device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wp, u64 nq, u32
     const u32 al = (u32)A, ah = (u32)(A >> 32), nl = (u32)nq, nh = (u32)(nq >> 32);
     const u64 P = (u64)al * nl + (u64)xl * wl;
     const u64 C = (u64)ah * nl + ((u64)al * nh + ((u64)xh * wl + (u64)xl * wh));
-    return P + ((u64)((u32)C + ((u32)(C >> 32) & zero)) << 32);
+    const u32 hi = (u32)(P >> 32) + (u32)C + ((u32)(C >> 32) & zero);      // one v_add3_u32; no 64-bit add of a shifted word
+    return ((u64)hi << 32) | (u32)P;
+}
+// acc + x * w mod q (same product; the accumulator enters the multiply-add chain as its first addend, and the high
+// word is finished with one three-operand add instead of a 64-bit add of a shifted word): a Harvey butterfly gets
+// X + T from the product itself and X - T + 4q as 2X + 4q - (X + T).  All arithmetic is mod 2^64, so the values are
+// the ones mul_shoup_lazy4 followed by a 64-bit addition gives.
+__device__ __forceinline__ u64 mul_shoup_lazy4_acc(u64 x, u64 w, u64 wp, u64 nq, u32 zero, u64 acc) {
+    const u32 xl = (u32)x, xh = (u32)(x >> 32), wl = (u32)w, wh = (u32)(w >> 32), pl = (u32)wp, ph = (u32)(wp >> 32);
+    u32 cy;
+    const u32 s = __builtin_addc(__umulhi(xh, pl), __umulhi(xl, ph), 0u, &cy);
+    const u64 A = (u64)xh * ph + (((u64)cy << 32) | s);
+    const u32 al = (u32)A, ah = (u32)(A >> 32), nl = (u32)nq, nh = (u32)(nq >> 32);
+    const u64 P = (u64)al * nl + ((u64)xl * wl + acc);
+    const u64 C = (u64)ah * nl + ((u64)al * nh + ((u64)xh * wl + (u64)xl * wh));
+    const u32 hi = (u32)(P >> 32) + (u32)C + ((u32)(C >> 32) & zero);
+    return ((u64)hi << 32) | (u32)P;
 }
 // any 64-bit v -> v mod q + {0, 1, 2} q, below 4q  (product with 1; one_p = floor(2^64 / q))
 __device__ __forceinline__ u64 reduce_lazy4(u64 v, u64 one_p, u64 nq, u32 zero) { return mul_shoup_lazy4(v, 1, one_p, nq, zero); }

@@ -120,9 +120,9 @@ __device__ __forceinline__ void ntt_fwd_pass4(u64 (&x)[16], const ulonglong2 *__
             const int r1 = r0 | (1 << rb);
             const ulonglong2 w = tw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
             const u64 X = LAZY ? x[r0] : csub(x[r0], m.q4);
-            const u64 T = mul_shoup_lazy4(x[r1], w.x, w.y, m.nq, m.zero);
-            x[r0] = X + T;
-            x[r1] = X - T + m.q4;
+            const u64 S = mul_shoup_lazy4_acc(x[r1], w.x, w.y, m.nq, m.zero, X);     // X + T
+            x[r0] = S;
+            x[r1] = (X << 1) + m.q4 - S;                                              // X - T + 4q
         }
     }
 }
@@ -216,9 +216,9 @@ __device__ __forceinline__ void ntt_fwd_pass4m(u64 (&x)[M][16], const ulonglong2
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 const u64 X = LAZY ? x[j][r0] : csub(x[j][r0], m.q4);
-                const u64 T = mul_shoup_lazy4(x[j][r1], w.x, w.y, m.nq, m.zero);
-                x[j][r0] = X + T;
-                x[j][r1] = X - T + m.q4;
+                const u64 S = mul_shoup_lazy4_acc(x[j][r1], w.x, w.y, m.nq, m.zero, X);     // X + T
+                x[j][r0] = S;
+                x[j][r1] = (X << 1) + m.q4 - S;                                              // X - T + 4q
             }
         }
     }
