@@ -240,13 +240,13 @@ __global__ __launch_bounds__(256) void k_behz_tensor(const u64 *__restrict__ A, 
 // ciphertext pair c at base prime j from the NTT-form operands and transforms it back, so the
 // NTT-form product never goes to memory.  A [count][sa][nb][n], Bm [count][sb][nb][n] (NTT order)
 // -> D [count][sa+sb-1][nb][n] (coefficient form, canonical).
-// WIDE (every modulus of the base <= 58 bits, at most 21 terms): the products stay in [0, 3q) and are summed as plain
-// integers (21 x 3q < 2^64); the sum is brought below 4q -- the range the inverse transform takes -- by at most four
-// conditional subtractions per output instead of three per term.
-__device__ __forceinline__ u64 fold_below_4q(u64 acc, u32 terms, u64 q4) {     // acc < 3 terms q, terms <= 21
+// WIDE (every modulus of the base <= 58 bits, at most 12 terms): the products stay in [0, 5q) (mul_barrett_lazy5) and are
+// summed as plain integers (12 x 5q < 2^64); the sum is brought below 4q -- the range the inverse transform takes -- by
+// at most four conditional subtractions per output instead of three per term.
+__device__ __forceinline__ u64 fold_below_4q(u64 acc, u32 terms, u64 q4) {     // acc < 5 terms q, terms <= 12
 #pragma unroll
     for (int s = 3; s >= 0; s--)
-        if (3 * terms > (4u << s)) acc = csub(acc, q4 << s);
+        if (5 * terms > (4u << s)) acc = csub(acc, q4 << s);
     return acc;
 }
 template <int L, bool WIDE>
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
     const u64 c = g / nb;
     const u64 id = (c * so + o) * nb + j;              // output polynomial
     const Modulus m = base.mod[j];
+    const BarrettLazy bl = barrett_lazy(m);
     u64 acc[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0;
@@ -276,13 +277,13 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_behz_tensor_intt(const u64 
         load_slots<L>(xa, A + ((c * sa + ja) * nb + j) * N, tid);
         load_slots<L>(xb, Bm + ((bm(c) * sb + (o - ja)) * nb + j) * N, tid);
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = WIDE ? acc[r] + mul_barrett_lazy3(xa[r], xb[r], m) : addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
+        for (int r = 0; r < 16; r++) acc[r] = WIDE ? acc[r] + mul_barrett_lazy5(xa[r], xb[r], bl) : addmod(acc[r], mul_barrett(xa[r], xb[r], m), m.q);
     }
     if constexpr (WIDE) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = fold_below_4q(acc[r], hi - lo + 1, 4 * m.q);
     }
-    ntt_inv_regs4<L>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);               // [0, 4q) in, [0, 4q) out
+    ntt_inv_regs4<L, WIDE>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);               // [0, 4q) in, [0, 4q) out
     // WIDE: the only reader is k_behz_floor_back<.., WIDE_CHUNK>, whose Shoup products take any 64-bit value and whose
     // 128-bit sums have room for a start value below 4 b_j (2^118 + 8 x 2^116 < 2^121): no canonical form needed
     if constexpr (!WIDE) {
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
     const u32 j = (u32)(g % nb);
     const u64 cc = g / nb;
     const Modulus m = base.mod[j];
+    const BarrettLazy bl = barrett_lazy(m);
     u64 acc[2][16];
     const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
 #pragma unroll
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
                 for (int r = 0; r < 8; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
 #pragma unroll
                 for (int r = 0; r < 8; r++)
-                    acc[h][r0 + r] = WIDE ? acc[h][r0 + r] + mul_barrett_lazy3(xa[r], xb[r], m) : addmod(acc[h][r0 + r], mul_barrett(xa[r], xb[r], m), m.q);
+                    acc[h][r0 + r] = WIDE ? acc[h][r0 + r] + mul_barrett_lazy5(xa[r], xb[r], bl) : addmod(acc[h][r0 + r], mul_barrett(xa[r], xb[r], m), m.q);
             }
         }
         if constexpr (WIDE) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
             for (int r = 0; r < 16; r++) acc[h][r] = fold_below_4q(acc[h][r], hi - lo + 1, 4 * m.q);
         }
     }
-    ntt_inv_regs4m<L, 2>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);
+    ntt_inv_regs4m<L, 2, WIDE>(acc, base.itw + (size_t)j * N, ntt_mod(m.q), lds, tid);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if constexpr (!WIDE) {
@@ -633,7 +635,7 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
 static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm,
                        bool wide_base) {
     const u32 nb = base.count, so = sa + sb - 1;
-    const bool wide = wide_base && (sa < sb ? sa : sb) <= 21 && !getenv("FHE_BEHZ_TENSOR_CANON");     // terms per output <= min(sa, sb)
+    const bool wide = wide_base && (sa < sb ? sa : sb) <= 12 && !getenv("FHE_BEHZ_TENSOR_CANON");     // terms per output <= min(sa, sb); 12 x 5q < 2^64
     static const bool single = [] { const char *e = getenv("FHE_NTT_SINGLE"); return e && *e && !(e[0] == '0' && !e[1]); }();
     u64 done = 0;
     if (c->logn >= 13 && !single && count >= 2) {

@@ -17,7 +17,7 @@
 // conditional subtraction per butterfly (Harvey with doubled ranges: values in [0, 8q)).  Sums inside the per-slot
 // circuit are left unreduced (bounds in the comments of line_half); row outputs 0 and 4, which meet no constant, are
 // brought below 4q by a product with 1 so that every row output is below 16 q; the scale product brings column
-// outputs to [0, 4q), the Gentleman-Sande inverse butterflies keep [0, 4q), two conditional subtractions at the store
+// outputs to [0, 4q), the Gentleman-Sande inverse butterflies track their ranges statically (inv_stage), two conditional subtractions at the store
 // give canonical residues.  The ciphertexts are bit-identical to the op-at-a-time evaluation (exact ring
 // arithmetic); tests/test_gpu_parity.py compares with the oracle.
 #include "internal.h"
@@ -107,7 +107,20 @@ __device__ __forceinline__ void fwd_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4
         fwd_stage<L, P, U, LAZY>(x, w, pr);
     }
 }
-// Gentleman-Sande stage U of pass P; values in [0, 4q) in and out; n^-1 merged into the last stage of the transform
+// Bound (in units of q) of register r after the stages S-1 ... U of inverse pass P have run (U = S: at entry).  A sum
+// X + Y is left unreduced and doubles the bound (both sides of a butterfly share their history, hence their bound); a
+// product resets its register to [0, 4q).  Entry: 4 for the first pass executed (the scale products), 8 after an exchange.
+template <int L, int P>
+__host__ __device__ constexpr int inv_bd(int r, int U) {
+    int bd = (P == Sh<L>::NP - 1) ? 4 : 8;
+    for (int u = Tw<L, P>::S - 1; u >= U; u--) bd = ((r >> Tw<L, P>::rb(u)) & 1) ? 4 : 2 * bd;
+    return bd;
+}
+// Gentleman-Sande stage U of pass P with static range tracking (q < 2^57: 128q < 2^64): sums stay unreduced inside a
+// pass (at most 8 x 2^3 = 64q), differences get the partner's bound added, products take any 64-bit operand; after the
+// last stage of a pass every register is brought below 8q again (7 conditional subtractions per 8 coefficients and
+// three stages instead of 12).  The last pass ends with both sides through a product: [0, 4q) out.
+// n^-1 is merged into the last stage of the transform.
 template <int L, int P, int U>
 __device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, const Prime &pr) {
     using T = Tw<L, P>;
@@ -116,13 +129,27 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
     for (int b = 0; b < E / 2; b++) {
         const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
         const ulonglong2 wv = w[r0 >> (rb + 1)];
+        const int bd = inv_bd<L, P>(r1, U + 1);                        // bound of Y (and of X) before this stage: 4 ... 32
+        const u64 off = pr.q4 << (bd == 4 ? 0 : bd == 8 ? 1 : bd == 16 ? 2 : 3);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const u64 X = x[m][r0], Y = x[m][r1];
-            const u64 Tm = csub(X + Y, pr.q4);
-            const u64 D = X - Y + pr.q4;             // [0, 8q)
+            const u64 Tm = X + Y;                    // < 2 bd q <= 64q
+            const u64 D = X - Y + off;               // (0, 2 bd q)
             x[m][r0] = (sigma == 0) ? mul_shoup_lazy4(Tm, ninv.x, ninv.y, pr.nq, pr.zero) : Tm;
             x[m][r1] = mul_shoup_lazy4(D, wv.x, wv.y, pr.nq, pr.zero);
+        }
+    }
+    if constexpr (U == 0 && P > 0) {
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const int bd = inv_bd<L, P>(r, 0);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (bd > 32) x[m][r] = csub(x[m][r], pr.q4 << 3);
+                if (bd > 16) x[m][r] = csub(x[m][r], pr.q4 << 2);
+                if (bd > 8) x[m][r] = csub(x[m][r], pr.q4 << 1);
+            }
         }
     }
 }

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd2(const u64 *__re
     store_slots<L>(x[1], out + rp1 * NttShape<L>::N, tid);
 }
 
-template <int L>
+template <int L, bool LAZY>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     const int tid = threadIdx.x;
@@ -495,13 +495,13 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv(const u64 *__res
     const NttMod m = ntt_mod(q);
     u64 x[16];
     load_slots<L>(x, in + rp * NttShape<L>::N, tid);
-    ntt_inv_regs4<L>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);             // [0, 4q)
+    ntt_inv_regs4<L, LAZY>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);       // [0, 4q)
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
     store_coeff<L>(x, out + rp * NttShape<L>::N, tid);
 }
 
-template <int L>
+template <int L, bool LAZY>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv2(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base, u32 pair_stride) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     const int tid = threadIdx.x;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv2(const u64 *__re
     u64 x[2][16];
     load_slots<L>(x[0], in + rp0 * NttShape<L>::N, tid);
     load_slots<L>(x[1], in + rp1 * NttShape<L>::N, tid);
-    ntt_inv_regs4m<L, 2>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);
+    ntt_inv_regs4m<L, 2, LAZY>(x, base.itw + (size_t)prime * NttShape<L>::N, m, lds, tid);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain(const u64 *__re
         const ulonglong2 w = pl[r * TP + tid];
         x[r] = mul_shoup_lazy4(x[r], w.x, w.y, m.nq, m.zero);
     }
-    ntt_inv_regs4<L>(x, base.itw + (size_t)prime * N, m, lds, tid);
+    ntt_inv_regs4<L, LAZY>(x, base.itw + (size_t)prime * N, m, lds, tid);
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = csub(csub(x[r], 2 * q), q);
     store_coeff<L>(x, out + rp * N, tid);
@@ -554,14 +554,16 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     if (n_res_polys == 0) return FHE_OK;
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const RnsBase base = B.dev();
-    bool lazy = true;        // forward transform without conditional subtractions: every prime of the base <= 58 bits
+    bool lazy = !env_on("FHE_NTT_NOLAZY");        // forward transform without conditional subtractions, inverse with static range tracking: every prime of the base <= 58 bits
     // n >= 8192: two polynomials of one prime per workgroup, every twiddle pair fetched once for both (P8192 forward +7 %,
     // inverse +19 %; at n = 4096 the pair kernels spill and are slower, so single polynomials stay there)
     const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !env_on("FHE_NTT_SINGLE");
     for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0;
     DISPATCH_L(c->logn, {
-        if (inverse && pair) k_ntt_inv2<L><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
-        else if (inverse) k_ntt_inv<L><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        if (inverse && pair && lazy) k_ntt_inv2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
+        else if (inverse && pair) k_ntt_inv2<L, false><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
+        else if (inverse && lazy) k_ntt_inv<L, true><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
+        else if (inverse) k_ntt_inv<L, false><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
         else if (lazy && pair) k_ntt_fwd2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
         else if (lazy) k_ntt_fwd<L, true><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);
         else k_ntt_fwd<L, false><<<(unsigned)n_res_polys, NttShape<L>::TP, 0, st>>>(in, out, base);

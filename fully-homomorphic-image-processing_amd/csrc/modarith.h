@@ -97,6 +97,28 @@ __device__ __forceinline__ u64 mul_barrett_lazy3(u64 a, u64 b, const Modulus &m)
     return lo - qhat * m.q;
 }
 
+// a * b mod q + {0..4} q for a, b in [0, q), q <= 58 bits, on the multiply-add chain of mul_shoup_lazy4: with
+// mu' = mu << (63 - b) the Barrett quotient floor(x mu / 2^(b+1)) IS the high word of x * mu', which is taken with the
+// same approximation (exact - 2 ... exact), and z - qhat q becomes lo(z) + qhat (2^64 - q) with lo(z) as the chain's
+// first addend.  qhat in [Q - 4, Q]: result in [0, 5q).  8 v_mad_u64_u32 + 2 v_mul_hi_u32 against 9 + 6 v_mul_lo_u32.
+struct BarrettLazy { u64 mup, nq; u32 s1, zero; };      // mup = mu << (63 - b), nq = 2^64 - q, s1 = b - 1
+__device__ __forceinline__ BarrettLazy barrett_lazy(const Modulus &m) {
+    BarrettLazy o; o.mup = m.mu << (62 - m.s1); o.nq = 0 - m.q; o.s1 = m.s1; o.zero = fhe_opaque_zero; return o;
+}
+__device__ __forceinline__ u64 mul_barrett_lazy5(u64 a, u64 b, const BarrettLazy &k) {
+    const u64 lo = a * b, hi = __umul64hi(a, b);
+    const u64 x = (hi << (64 - k.s1)) | (lo >> k.s1);
+    const u32 xl = (u32)x, xh = (u32)(x >> 32), pl = (u32)k.mup, ph = (u32)(k.mup >> 32);
+    u32 cy;
+    const u32 s = __builtin_addc(__umulhi(xh, pl), __umulhi(xl, ph), 0u, &cy);
+    const u64 A = (u64)xh * ph + (((u64)cy << 32) | s);
+    const u32 al = (u32)A, ah = (u32)(A >> 32), nl = (u32)k.nq, nh = (u32)(k.nq >> 32);
+    const u64 P = (u64)al * nl + lo;
+    const u64 C = (u64)ah * nl + (u64)al * nh;
+    const u32 h = (u32)(P >> 32) + (u32)C + ((u32)(C >> 32) & k.zero);
+    return ((u64)h << 32) | (u32)P;
+}
+
 // floor(w * 2^64 / q) for w < q, by restoring division (setup kernels only)
 __device__ inline u64 shoup_companion(u64 w, u64 q) {
     u64 rem = w, quo = 0;

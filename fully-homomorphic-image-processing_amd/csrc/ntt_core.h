@@ -152,6 +152,55 @@ __device__ __forceinline__ void ntt_inv_pass4(u64 (&x)[16], const ulonglong2 *__
     }
 }
 
+// Inverse pass for primes of at most 58 bits (32q < 2^64) with STATIC range tracking: which register is the sum side and
+// which the product side of a butterfly is known at compile time, so the bound of every register (in units of q) is a
+// compile-time value after unrolling.  A sum X + Y is left unreduced while its bound stays <= 16q (its difference
+// X - Y + bound(Y) q then stays below 32q, and the product takes any 64-bit operand); a product resets its register to
+// [0, 4q).  Entry: every register below EB q (4 for the first pass executed, 8 after a transpose, where the bounds of the
+// previous pass sit in the lane index and must be uniform); exit: below 8q (one subtraction for the registers that
+// reached 16q), and below 4q after the last pass, whose final stage sends both sides through a product.  For L = 13 that
+// is 36 conditional subtractions per 16 coefficients instead of 104.
+template <int L, int P>
+__device__ __forceinline__ void ntt_inv_pass4t(u64 (&x)[16], const ulonglong2 *__restrict__ itw, const NttMod &m, int tid) {
+    constexpr int LO = pass_lo(L, P), S = pass_stages(L, P);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+    const u64 q8 = m.q4 << 1, q16 = m.q4 << 2;
+    int bd[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bd[r] = (P == NttShape<L>::NP - 1) ? 4 : 8;
+#pragma unroll
+    for (int u = S - 1; u >= 0; u--) {
+        const int sigma = 4 * P + u, b = L - 1 - sigma, rb = b - LO;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            const ulonglong2 w = itw[(1 << sigma) + ((th << (3 - rb)) | (r0 >> (rb + 1)))];
+            const u64 X = x[r0], Y = x[r1];
+            const u64 off = bd[r1] == 4 ? m.q4 : bd[r1] == 8 ? q8 : q16;
+            u64 T = X + Y;                             // < (bd[r0] + bd[r1]) q <= 32q
+            const u64 D = X - Y + off;                 // in (0, 32q)
+            if (sigma == 0) {
+                const ulonglong2 ni = itw[0];
+                x[r0] = mul_shoup_lazy4(T, ni.x, ni.y, m.nq, m.zero);
+                bd[r0] = 4;
+            } else {
+                int bs = bd[r0] + bd[r1];
+                if (bs > 16) { T = csub(T, q16); bs = 16; }
+                x[r0] = T;
+                bd[r0] = bs;
+            }
+            x[r1] = mul_shoup_lazy4(D, w.x, w.y, m.nq, m.zero);    // [0, 4q)
+            bd[r1] = 4;
+        }
+    }
+    if (P > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (bd[r] > 8) x[r] = csub(x[r], q8);
+    }
+}
+
 template <int LO_FROM, int LO_TO>
 __device__ __forceinline__ void ntt_transpose(u64 (&x)[16], u64 *lds, int tid) {
     constexpr int PL = imin(LO_FROM, LO_TO);
@@ -191,12 +240,14 @@ __device__ __forceinline__ void ntt_fwd_regs4(u64 (&x)[16], const ulonglong2 *__
         ntt_fwd_regs4<L, LAZY, P + 1>(x, tw, m, lds, tid);
     }
 }
-template <int L, int P = NttShape<L>::NP - 1>
+// LAZY: every prime of the base has at most 58 bits (the range-tracking passes above)
+template <int L, bool LAZY = false, int P = NttShape<L>::NP - 1>
 __device__ __forceinline__ void ntt_inv_regs4(u64 (&x)[16], const ulonglong2 *__restrict__ itw, const NttMod &m, u64 *lds, int tid) {
-    ntt_inv_pass4<L, P>(x, itw, m, tid);
+    if constexpr (LAZY) ntt_inv_pass4t<L, P>(x, itw, m, tid);
+    else ntt_inv_pass4<L, P>(x, itw, m, tid);
     if constexpr (P > 0) {
         ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x, lds, tid);
-        ntt_inv_regs4<L, P - 1>(x, itw, m, lds, tid);
+        ntt_inv_regs4<L, LAZY, P - 1>(x, itw, m, lds, tid);
     }
 }
 
@@ -233,18 +284,21 @@ __device__ __forceinline__ void ntt_fwd_regs4m(u64 (&x)[M][16], const ulonglong2
     }
 }
 
-template <int L, int P, int M>
+// M polynomials of one prime.  The range-tracking pass is NOT used here: with two polynomials in flight it spills
+// (k_ntt_inv2<13>: 80 B of scratch per lane against 20, -14 % measured; with the polynomial index innermost 272 B), so
+// the pair kernels keep one conditional subtraction per butterfly whatever LAZY says.
+template <int L, int P, int M, bool LAZY>
 __device__ __forceinline__ void ntt_inv_pass4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ itw, const NttMod &m, int tid) {
 #pragma unroll
     for (int j = 0; j < M; j++) ntt_inv_pass4<L, P>(x[j], itw, m, tid);      // the twiddle loads of the M copies are merged by the compiler
 }
-template <int L, int M, int P = NttShape<L>::NP - 1>
+template <int L, int M, bool LAZY = false, int P = NttShape<L>::NP - 1>
 __device__ __forceinline__ void ntt_inv_regs4m(u64 (&x)[M][16], const ulonglong2 *__restrict__ itw, const NttMod &m, u64 *lds, int tid) {
-    ntt_inv_pass4m<L, P, M>(x, itw, m, tid);
+    ntt_inv_pass4m<L, P, M, LAZY>(x, itw, m, tid);
     if constexpr (P > 0) {
 #pragma unroll
         for (int j = 0; j < M; j++) ntt_transpose<pass_lo(L, P), pass_lo(L, P - 1)>(x[j], lds, tid);
-        ntt_inv_regs4m<L, M, P - 1>(x, itw, m, lds, tid);
+        ntt_inv_regs4m<L, M, LAZY, P - 1>(x, itw, m, lds, tid);
     }
 }
 

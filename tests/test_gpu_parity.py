@@ -422,6 +422,22 @@ def test_multiply_large_sizes_decode_shapes(fhe, oracle_mod):
     assert np.array_equal(fhe.to_host(u)[0], orc.multiply(fhe.to_host(t)[0], fhe.to_host(c)[0]))
 
 
+@pytest.mark.parametrize("size", [12, 13])
+def test_multiply_term_limit_of_the_lazy_tensor_sum(fhe, oracle_mod, size):
+    """12 x 12 is the largest product whose tensor sums stay unreduced (12 terms of [0, 5q) below 2^64 on a base of 58-bit
+    primes), 13 x 13 takes the reduced schedule; operands at q - 1 everywhere put every residue product at its extreme"""
+    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ev = fhe.Evaluator(ctx)
+    a = fhe.to_host(ctx.random_ct(1, size=size, seed=311))
+    b = np.zeros_like(a)
+    for i, q in enumerate(ctx.q):
+        b[0, :, i, :] = q - 1
+    for x, y in ((a, a[:, ::-1].copy()), (a, b), (b, b)):
+        t = ev.multiply(fhe.to_device(x), fhe.to_device(y))
+        assert t.shape[-3] == 2 * size - 1
+        assert np.array_equal(fhe.to_host(t)[0], orc.multiply(x[0], y[0]))
+
+
 def test_multiply_edge_inputs(fhe, oracle_mod):
     """zero, q-1 everywhere: extremes of the base conversions"""
     ctx, orc = _pair(fhe, oracle_mod, "SMALL")
