@@ -636,7 +636,10 @@ static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, co
                        bool wide_base) {
     const u32 nb = base.count, so = sa + sb - 1;
     const bool wide = wide_base && (sa < sb ? sa : sb) <= 12 && !getenv("FHE_BEHZ_TENSOR_CANON");     // terms per output <= min(sa, sb); 12 x 5q < 2^64
-    static const bool single = [] { const char *e = getenv("FHE_NTT_SINGLE"); return e && *e && !(e[0] == '0' && !e[1]); }();
+    static const bool single = [] {      // FHE_BEHZ_TENSOR_SINGLE: only this step on the one-polynomial kernel (which has the range-tracking inverse)
+        auto on = [](const char *n) { const char *e = getenv(n); return e && *e && !(e[0] == '0' && !e[1]); };
+        return on("FHE_NTT_SINGLE") || on("FHE_BEHZ_TENSOR_SINGLE");
+    }();
     u64 done = 0;
     if (c->logn >= 13 && !single && count >= 2) {
         const u64 pairs = count / 2;
