@@ -442,12 +442,9 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd(const u64 *__res
     load_coeff<L>(x, in + rp * NttShape<L>::N, tid);
     ntt_fwd_regs4<L, LAZY>(x, base.tw + (size_t)prime * NttShape<L>::N, m, lds, tid);
     if constexpr (LAZY) {       // every prime <= 58 bits: no conditional subtraction in the butterflies, one product with 1 at the end
-        const u64 one_p = one_companion(base.mod[prime]);
+        const float cs = canon_scale(q);                          // outputs below (2 + 4 log2 n) q <= 58q: canon_below_64q
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            x[r] = csub(csub(reduce_lazy4(x[r], one_p, m.nq, m.zero), 2 * q), q);
-            if ((r & 3) == 3) asm volatile("" ::: "memory");      // four products in flight, not sixteen
-        }
+        for (int r = 0; r < 16; r++) x[r] = canon_below_64q(x[r], q, cs);
     } else {                    // below 8q
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r] = csub(csub(csub(x[r], m.q4), 2 * q), q);
@@ -473,9 +470,9 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd2(const u64 *__re
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         if constexpr (LAZY) {
-            const u64 one_p = one_companion(base.mod[prime]);
+            const float cs = canon_scale(q);
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[j][r] = csub(csub(reduce_lazy4(x[j][r], one_p, m.nq, m.zero), 2 * q), q);
+            for (int r = 0; r < 16; r++) x[j][r] = canon_below_64q(x[j][r], q, cs);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) x[j][r] = csub(csub(csub(x[j][r], m.q4), 2 * q), q);
@@ -558,7 +555,7 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     // n >= 8192: two polynomials of one prime per workgroup, every twiddle pair fetched once for both (P8192 forward +7 %,
     // inverse +19 %; at n = 4096 the pair kernels spill and are slower, so single polynomials stay there)
     const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !env_on("FHE_NTT_SINGLE");
-    for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0;
+    for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0 && (p >> 33) != 0;      // canon_below_64q needs q >= 2^33
     DISPATCH_L(c->logn, {
         if (inverse && pair && lazy) k_ntt_inv2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
         else if (inverse && pair) k_ntt_inv2<L, false><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);

@@ -726,6 +726,28 @@ def test_u64_lazy_ranges_at_boundary_prime_sizes(fhe, oracle_mod, bits, n):
         assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
 
 
+@pytest.mark.parametrize("bits,n", [(35, 8192), (34, 4096), (35, 16384)])
+def test_u64_forward_canonicalisation_at_the_smallest_lazy_primes(fhe, oracle_mod, monkeypatch, bits, n):
+    """canon_below_64q (csrc/ntt_core.h) estimates the quotient of the lazy forward transform's outputs from their high
+    word in single precision; its error bound 2^32 / q is largest at the smallest primes the lazy kernels take (2^33):
+    the u64 kernels forced onto 34- / 35-bit primes (the FP64 kernels would take them otherwise), all-(q-1) inputs"""
+    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
+    q = [_largest_ntt_prime_below(bits, n), _largest_ntt_prime_below(bits - 1, n)]
+    ctx, orc = fhe.SEALContext(n, q, 1 << 10), oracle_mod.Oracle(n, q, 1 << 10)
+    ev = fhe.Evaluator(ctx)
+    a = np.zeros((2, 2, ctx.k, ctx.n), dtype=np.uint64)
+    for i, qi in enumerate(q):
+        a[0, :, i, :] = qi - 1
+    a[1] = fhe.to_host(ctx.random_ct(1, seed=92))[0]
+    f = ev.ntt_forward(fhe.to_device(a))
+    hf = fhe.to_host(f)
+    for c in range(2):
+        for i in range(ctx.k):
+            assert hf[c, 1, i].max() < q[i]
+            assert np.array_equal(np.sort(hf[c, 1, i]), np.sort(orc.ntt_fwd(a[c, 1, i], i)))
+    assert np.array_equal(fhe.to_host(ev.ntt_inverse(f)), a)
+
+
 @pytest.mark.parametrize("n_ct", [3, 4])
 def test_fp64_transforms_and_multiply_plain_equal_u64_kernels(fhe, oracle_mod, monkeypatch, n_ct):
     """P4096: fhe_ntt_forward / fhe_ntt_inverse / fhe_multiply_plain on the FP64 kernels write the same
