@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfhe_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
+HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h")]
 
 FHE_OK = 0
 
@@ -73,6 +74,27 @@ SIGNATURES = {
     "fhe_rgb_to_ycc": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _i, _vp]),
     "fhe_fill_random": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "fhe_digest": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    # include/fhe_circuits.h
+    "fhe_circuits_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "fhe_circuits_destroy": (_i, [_vp]),
+    "fhe_resize_sample_plan": (_i, [_u32, _u32, _u32, _u32, _i, _vp, _vp, _vp]),
+    "fhe_cubic_scratch_bytes": (_sz, [_vp, _u32, _u64]),
+    "fhe_cubic": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp, _sz, _vp]),
+    "fhe_linear_scratch_bytes": (_sz, [_vp, _u32, _u64]),
+    "fhe_linear": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp, _sz, _vp]),
+    "fhe_sample_bicubic_scratch_bytes": (_sz, [_vp, _u64]),
+    "fhe_sample_bicubic": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
+    "fhe_sample_linear_scratch_bytes": (_sz, [_vp, _u64]),
+    "fhe_sample_linear": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
+    "fhe_resize_bicubic_shared_scratch_bytes": (_sz, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _i]),
+    "fhe_resize_bicubic_shared": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "fhe_homomorphic_sincos_scratch_bytes": (_sz, [_vp, _u64]),
+    "fhe_homomorphic_sincos": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
+    "fhe_approximated_step_out_size": (_u32, [_i]),
+    "fhe_approximated_step_scratch_bytes": (_sz, [_vp, _i, _u32]),
+    "fhe_approximated_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "fhe_decode_channel_scratch_bytes": (_sz, [_vp, _i, _u32, _u32]),
+    "fhe_decode_channel": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _sz, _vp]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
 _COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode"}

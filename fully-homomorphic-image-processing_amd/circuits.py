@@ -1,8 +1,10 @@
-"""The reference's homomorphic circuits, re-expressed over the batched Evaluator.
+"""The reference's homomorphic circuits on whole batches: ctypes callers of include/fhe_circuits.h.
 
-Each function follows the Evaluator call sequence of the cited reference lines, but on whole
-batches: the leading dimension of every ciphertext tensor ([B, size, k, n]) runs over independent
-pixels / output positions, which the reference visits in serial loops
+The circuits themselves -- tap gathers, the t^2 reuse of Cubic, prepared operands, the growth of ciphertext
+sizes, every temporary -- live inside libfhe_hip.so (csrc/circuits.hip); this module only allocates the
+output and scratch tensors and passes pointers, so a C++ host gets exactly the same batched path
+(seal/hip_circuits.h).  The leading dimension of every ciphertext tensor ([B, size, k, n]) runs over
+independent pixels / output positions, which the reference visits in serial loops
 (homo/server_jpeg.cpp:113, homo/fhe_resize.h:350,381, homo/server_decode.cpp:120-137).
 
 Server-side fresh encryptions inside the reference's circuits (the fractional offsets in
@@ -10,11 +12,14 @@ SampleLinear/SampleBicubic, homo/fhe_resize.h:230-266, and the Enc(0) accumulato
 homomorphic_sin/cos, homo/fhe_decode.h:54,134) are randomised; here they are explicit inputs so that
 results are reproducible.
 """
+import ctypes as C
 import math
 
+import numpy as np
 import torch
 
-from .evaluator import FractionalEncoder, PreparedPlain
+from . import _lib
+from .evaluator import FractionalEncoder, PreparedPlain, _ptr, _stream
 
 
 class PlainCache:
@@ -52,281 +57,298 @@ def rgb_to_ycc(ev, pc, r, g, b):
 
 
 # ------------------------------------------------------------------------------------------------
+# the circuits handle and scratch
+# ------------------------------------------------------------------------------------------------
+class Circuits:
+    """fhe_circuits: the constants of the resize / decode circuits for one context and encoder."""
+
+    def __init__(self, ctx, int_coeffs=100, frac_coeffs=100):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _lib.call("fhe_circuits_create", ctx.h, int_coeffs, frac_coeffs, C.byref(h))
+        self.h = h
+        self._scratch = None
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                _lib.load().fhe_circuits_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def scratch(self, nbytes):
+        if not nbytes:
+            raise _lib.FheError(-1, _lib.load().fhe_last_error().decode("utf-8", "replace") or "scratch query failed")
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = None
+            self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.ctx.device)
+        return self._scratch
+
+
+def circuits_of(pc):
+    """the fhe_circuits handle that goes with a PlainCache (same context and encoder), created on first use"""
+    h = getattr(pc, "_circuits", None)
+    if h is None:
+        h = pc._circuits = Circuits(pc.ctx, pc.enc.int_coeffs, pc.enc.frac_coeffs)
+    return h
+
+
+def _count(t, size):
+    assert t.dtype == torch.int64 and t.is_contiguous() and t.shape[-3] == size, (t.shape, size)
+    c = 1
+    for d in t.shape[:-3]:
+        c *= d
+    return c
+
+
+def _taps_array(taps, width):
+    a = np.ascontiguousarray(taps, dtype=np.uint32)
+    assert a.ndim == 2 and a.shape[1] == width, a.shape
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
 # resize path
 # ------------------------------------------------------------------------------------------------
 def _base2_cubic_constants(pc):
     """True if the encoder writes Cubic's constants the way the fused passes assume (base 2):
     encode(3) = x+1, encode(2) = x, encode(5) = x^2+1, encode(4) = x^2, encode(0.5) = -x^(n-1)."""
-    if getattr(pc, "_cubic_ok", None) is None:
-        import numpy as np
-        t, n = pc.ctx.t, pc.ctx.n
+    t, n = pc.ctx.t, pc.ctx.n
 
-        def nz(v):
-            p = np.asarray(pc.plain(v), dtype=np.uint64)
-            return {int(i): int(p[i]) for i in np.nonzero(p)[0]}
+    def nz(v):
+        p = np.asarray(pc.plain(v), dtype=np.uint64)
+        return {int(i): int(p[i]) for i in np.nonzero(p)[0]}
 
-        pc._cubic_ok = (nz(3) == {0: 1, 1: 1} and nz(2) == {1: 1} and nz(5) == {0: 1, 2: 1} and nz(4) == {2: 1}
-                        and nz(0.5) == {n - 1: t - 1})
-    return pc._cubic_ok
+    return (nz(3) == {0: 1, 1: 1} and nz(2) == {1: 1} and nz(5) == {0: 1, 2: 1} and nz(4) == {2: 1}
+            and nz(0.5) == {n - 1: t - 1})
 
 
-def cubic_powers(ev, t, relin=None):
-    """t2 = square(t) and t3 = multiply(t, t) of Cubic (homo/fhe_resize.h:174-175).  Both are the same
-    ring tensor (the library's square IS multiply(t, t)), so one product serves both, and a caller
-    that evaluates several Cubics at the same t (SampleBicubic: four rows share xfract) passes the
-    pair in instead of recomputing it -- the ciphertext bits are the same either way."""
-    t2 = ev.square(t)
-    if relin is not None and t2.shape[-3] == 3:
-        t2 = ev.relinearize(t2, relin[0], relin[1])
-    return t2, t2
-
-
-def cubic(ev, pc, A, B, C, D, t, relin=None, powers=None, prepared=None):
-    """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189.  Note t3 = t*t exactly as the reference
-    computes it (:175).  powers = cubic_powers(ev, t) may be shared between calls with the same t, and
-    prepared = (prepare_operand(t3), prepare_operand(t2), prepare_operand(t)) for the same batch shape
-    saves their base extension and transforms in every call.
-
-    relin=(evk_ntt, dbc) switches on the relinearised mode (NOT what the
-    reference does): every product is brought back to size 2, so the result has size 2 instead of
-    s+2 and memory stays flat; ciphertext bits then differ from the reference path by construction
-    (key-switching noise), the decrypted value does not."""
+def cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin=None):
+    """Cubic(result, A,B,C,D,t) as the reference's Evaluator call sequence, one (batched) call per line of
+    homo/fhe_resize.h:149-188 -- the op-by-op form the fused circuit (cubic below) is tested against, and the
+    carrier of the relinearised mode: relin=(evk_ntt, dbc) brings every product back to size 2 (SURVEY.md
+    section 8(f) #4, NOT what the reference does), so the result has size 2 instead of s+2; ciphertext bits
+    then differ from the reference path by construction (key-switching noise), the decrypted value does not."""
     M, P = ev.multiply_plain, pc.prepared
 
     def mul(x, y):
         z = ev.multiply(x, y)
         return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
 
-    fused = _base2_cubic_constants(pc) and A.shape == B.shape == C.shape == D.shape
-    if fused:       # the linear parts in one pass each (same ring elements as the calls below)
-        a, b, c = ev.cubic_coeffs(A.contiguous(), B.contiguous(), C.contiguous(), D.contiguous())
-    else:
-        a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
-        b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
-        c = ev.sub(C, A)
-    t2, t3 = powers if powers is not None else cubic_powers(ev, t, relin)
-    if prepared is not None:
-        a, b, c = mul(a, prepared[0]), mul(b, prepared[1]), mul(c, prepared[2])
-    else:
-        a, b, c = mul(a, t3), mul(b, t2), mul(c, t)
-    if fused and a.shape == b.shape and c.shape[-3] <= a.shape[-3] and B.shape[-3] <= a.shape[-3]:
-        if c.shape[-3] < a.shape[-3]:                # c * t is one polynomial shorter than a * t3: pad with zeros
-            c = torch.cat([c, torch.zeros_like(a[..., c.shape[-3]:, :, :])], dim=-3)
-        return ev.cubic_combine(a.contiguous(), b.contiguous(), c.contiguous(), B.contiguous())
+    a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
+    b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
+    c = ev.sub(C, A)
+    t2 = ev.square(t)
+    if relin is not None and t2.shape[-3] == 3:
+        t2 = ev.relinearize(t2, relin[0], relin[1])
+    t3 = t2 if relin is not None else ev.multiply(t, t)          # t3 = t * t exactly as the reference computes it (:175)
+    a, b, c = mul(a, t3), mul(b, t2), mul(c, t)
     a = ev.add(ev.add(a, b), c)
     a = M(a, P(0.5))
     return ev.add(a, B)
 
 
+def cubic(ev, pc, A, B, C, D, t, relin=None):
+    """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189 for a batch (fhe_cubic).  Note t3 = t*t exactly as the
+    reference computes it (:175).  relin=(evk_ntt, dbc) selects the relinearised mode (cubic_evaluator_calls)."""
+    if relin is not None:
+        return cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin)
+    cc = circuits_of(pc)
+    size = A.shape[-3]
+    count = _count(A, size)
+    assert A.shape == B.shape == C.shape == D.shape and _count(t, 2) == count
+    out = ev.ctx.empty(*A.shape[:-3], size=size + 2)
+    nbytes = _lib.load().fhe_cubic_scratch_bytes(cc.h, size, count)
+    scr = cc.scratch(nbytes)
+    _lib.call("fhe_cubic", cc.h, _ptr(A), _ptr(B), _ptr(C), _ptr(D), size, _ptr(t), _ptr(out), count, _ptr(scr), nbytes, _stream())
+    return out
+
+
 def linear(ev, pc, A, B, t):
-    """Linear(result, A,B,t): homo/fhe_resize.h:191-204: (1 - t) A + t B."""
-    omt = ev.add_plain(ev.negate(t), pc.plain(1.0))
-    return ev.add(ev.multiply(omt, A), ev.multiply(B, t))
-
-
-def _clamp(v, lo, hi):
-    return lo if v < lo else hi if v > hi else v
+    """Linear(result, A,B,t): homo/fhe_resize.h:191-204: (1 - t) A + t B (fhe_linear)."""
+    cc = circuits_of(pc)
+    size = A.shape[-3]
+    count = _count(A, size)
+    assert A.shape == B.shape and _count(t, 2) == count
+    out = ev.ctx.empty(*A.shape[:-3], size=size + 1)
+    nbytes = _lib.load().fhe_linear_scratch_bytes(cc.h, size, count)
+    scr = cc.scratch(nbytes)
+    _lib.call("fhe_linear", cc.h, _ptr(A), _ptr(B), size, _ptr(t), _ptr(out), count, _ptr(scr), nbytes, _stream())
+    return out
 
 
 def resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic=True):
     """The index arithmetic of ResizeImage / SampleBicubic / SampleLinear / GetPixelClamped
-    (homo/fhe_resize.h:350-351, 381-382, 260-290, 215-220), in float32 like the reference.
-    Returns per output pixel: the clamped source pixel indices (16 for bicubic, row-major 4x4;
-    4 for bilinear) and the fractional offsets (xfract, yfract)."""
-    import numpy as np
-    f32 = np.float32
-    taps, fx, fy = [], [], []
-    for y in range(dst_h):
-        v = f32(f32(y) / f32(dst_h - 1) * f32(src_h)) - f32(0.5)
-        for x in range(dst_w):
-            u = f32(f32(x) / f32(dst_w - 1) * f32(src_w)) - f32(0.5)
-            xi, yi = int(u), int(v)
-            fx.append(float(u - f32(math.floor(u))))
-            fy.append(float(v - f32(math.floor(v))))
-            offs = [(-1, -1), (0, -1), (1, -1), (2, -1), (-1, 0), (0, 0), (1, 0), (2, 0),
-                    (-1, 1), (0, 1), (1, 1), (2, 1), (-1, 2), (0, 2), (1, 2), (2, 2)] if bicubic else \
-                   [(0, 0), (1, 0), (0, 1), (1, 1)]
-            taps.append([_clamp(yi + dy, 0, src_h - 1) * src_w + _clamp(xi + dx, 0, src_w - 1) for dx, dy in offs])
-    return taps, fx, fy
+    (homo/fhe_resize.h:350-351, 381-382, 260-290, 215-220), in float32 like the reference
+    (fhe_resize_sample_plan).  Returns per output pixel: the clamped source pixel indices (uint32 array
+    [dst_w * dst_h, 16] for bicubic, row-major 4x4; [.., 4] for bilinear) and the fractional offsets
+    (xfract, yfract) as lists of floats."""
+    npx = dst_w * dst_h
+    taps = np.zeros((npx, 16 if bicubic else 4), dtype=np.uint32)
+    fx, fy = np.zeros(npx), np.zeros(npx)
+    _lib.call("fhe_resize_sample_plan", src_w, src_h, dst_w, dst_h, int(bool(bicubic)), taps.ctypes.data_as(C.c_void_p),
+              fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p))
+    return taps, [float(v) for v in fx], [float(v) for v in fy]
+
+
+def _sample(name, width, out_size, ev, pc, pixels, taps, xfract, yfract):
+    cc = circuits_of(pc)
+    taps = _taps_array(taps, width)
+    count = taps.shape[0]
+    n_pixels = _count(pixels, 2)
+    assert _count(xfract, 2) == count and _count(yfract, 2) == count
+    out = ev.ctx.empty(count, size=out_size)
+    L = _lib.load()
+    nbytes = getattr(L, name + "_scratch_bytes")(cc.h, count)
+    scr = cc.scratch(nbytes)
+    _lib.call(name, cc.h, _ptr(pixels), n_pixels, taps.ctypes.data_as(C.c_void_p), _ptr(xfract), _ptr(yfract), _ptr(out), count,
+              _ptr(scr), nbytes, _stream())
+    return out
 
 
 def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
-    """SampleBicubic for a batch of output pixels and one colour channel (homo/fhe_resize.h:254-305).
-    pixels: [src_pixels, 2, k, n]; taps: [B][16] source indices; xfract/yfract: [B, 2, k, n]
+    """SampleBicubic for a batch of output pixels and one colour channel (homo/fhe_resize.h:254-305;
+    fhe_sample_bicubic).  pixels: [src_pixels, 2, k, n]; taps: [B][16] source indices; xfract/yfract: [B, 2, k, n]
     ciphertexts of the fractional offsets.  Returns [B, 6, k, n]."""
-    idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 16]
-    p = [pixels[idx[:, i]].contiguous() for i in range(16)]
-    px = cubic_powers(ev, xfract)                       # shared by the four row Cubics, prepared once
-    p2 = ev.prepare_operand(px[0])
-    prep = (p2, p2, ev.prepare_operand(xfract.contiguous()))
-    cols = [cubic(ev, pc, p[4 * r + 0], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract, powers=px, prepared=prep) for r in range(4)]
-    return cubic(ev, pc, cols[0], cols[1], cols[2], cols[3], yfract)
+    return _sample("fhe_sample_bicubic", 16, 6, ev, pc, pixels, taps, xfract, yfract)
+
+
+def sample_linear(ev, pc, pixels, taps, xfract, yfract):
+    """SampleLinear for one channel (homo/fhe_resize.h:222-252; fhe_sample_linear).  Returns [B, 4, k, n]."""
+    return _sample("fhe_sample_linear", 4, 4, ev, pc, pixels, taps, xfract, yfract)
+
+
+BAND_CONSUMER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None):
     """ResizeImage with SampleBicubic (homo/fhe_resize.h:254-392) for one colour channel when the fractional
     offsets arrive as ONE ciphertext per output column (xfract [dst_w, 2, k, n]) and ONE per output row
     (yfract [dst_h, 2, k, n]) -- SURVEY.md section 8(d), config 3: "xfract/yfract ciphertexts are inputs generated
-    per distinct fractional value".  frac(u) depends on x only and frac(v) on y only (:351,382), so with shared
-    ciphertexts the reference's per-pixel work repeats itself and this function forms every repeated ring element
-    once; each output equals sample_bicubic(..., xfract[x], yfract[y]) bit for bit:
+    per distinct fractional value" (fhe_resize_bicubic_shared).  frac(u) depends on x only and frac(v) on y only
+    (:351,382), so with shared ciphertexts the reference's per-pixel work repeats itself and the library forms every
+    repeated ring element once; each output equals sample_bicubic(..., xfract[x], yfract[y]) bit for bit:
 
       * a row Cubic (:296-299) is a function of (output column x, source row r) only; consecutive output rows'
         4-row windows overlap, so the 4 * dst_h row Cubics of a column collapse to one per source row touched
         (128 instead of 256 for 128 -> 64);
       * xfract^2 and the prepared (extended + transformed) forms of xfract, xfract^2 are formed once per column,
-        yfract^2 and its prepared forms once per row; the products index them in place (entry c % dst_w resp.
-        first_row + c // dst_w of the prepared batch: fhe_multiply_prepared_shared), nothing is copied.
+        yfract^2 and its prepared forms once per row; the products index them in place.
 
     The reference's server encrypts fresh offsets for every sample (:262,266); its results are therefore
     randomised per pixel and only sample_bicubic with per-pixel ciphertexts reproduces that run bit for bit
     (server.server_resize does).  Source rows are visited as a sliding window (`band_rows` output rows at a
-    time; row Cubics no output row needs any more are dropped), like the reference's loader (:352-379).
+    time), like the reference's loader (:352-379).
 
-    Returns [dst_h * dst_w, 6, k, n] (row-major), or None when `consume(first_pixel, tensor)` takes the bands."""
-    taps, _, _ = resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic=True)
-    colx = [[t % src_w for t in taps[x][0:4]] for x in range(dst_w)]                       # clamped xi-1 .. xi+2
-    rows_of = [[taps[y * dst_w][4 * j] // src_w for j in range(4)] for y in range(dst_h)]  # clamped yi-1 .. yi+2
-    xfract, yfract = xfract.contiguous(), yfract.contiguous()
-    x2, y2 = ev.square(xfract), ev.square(yfract)                                          # t2 (= t3, :174-175) per column / row
-    px2, px1 = ev.prepare_operand(x2), ev.prepare_operand(xfract)
-    py2, py1 = ev.prepare_operand(y2), ev.prepare_operand(yfract)
-    sx2, sx1 = px2.shared(1), px1.shared(1)
-    dev = pixels.device
-    cache = {}                                                                             # source row -> [dst_w, 4, k, n]
+    Returns [dst_h * dst_w, 6, k, n] (row-major), or None when `consume(first_pixel, tensor)` takes the bands
+    (the tensor is a view of a buffer the library reuses: clone what must outlive the callback)."""
+    cc = circuits_of(pc)
+    ctx = ev.ctx
+    assert _count(pixels, 2) == src_w * src_h and _count(xfract, 2) == dst_w and _count(yfract, 2) == dst_h
+    L = _lib.load()
+    out = None if consume is not None else ctx.empty(dst_w * dst_h, size=6)
+    nbytes = L.fhe_resize_bicubic_shared_scratch_bytes(cc.h, src_w, src_h, dst_w, dst_h, batch, band_rows, int(out is not None))
+    scr = cc.scratch(nbytes)
+    words = 6 * ctx.k * ctx.n
+    err = []
 
-    def row_cubics(new_rows):
-        if not new_rows:
-            return
-        res = []
-        rows_per_call = max(1, batch // dst_w)
-        for s0 in range(0, len(new_rows), rows_per_call):
-            part = [(r, x) for r in new_rows[s0:s0 + rows_per_call] for x in range(dst_w)]
-            tap = [torch.as_tensor([r * src_w + colx[x][i] for r, x in part], dtype=torch.long, device=dev) for i in range(4)]
-            A, B, C, D = (pixels.index_select(0, t) for t in tap)
-            # pairs are ordered (row, column) with the column fastest and whole rows per call: pair c multiplies the
-            # column's xfract / xfract^2, entry c % dst_w of the prepared batches -- no copy (fhe_multiply_prepared_shared)
-            res.append(cubic(ev, pc, A, B, C, D, None, powers=(None, None), prepared=(sx2, sx2, sx1)))
-        allr = torch.cat(res, dim=0) if len(res) > 1 else res[0]
-        for i, r in enumerate(new_rows):
-            cache[r] = allr[i * dst_w:(i + 1) * dst_w]
+    def on_band(_user, first, d_band, npx, _stream_):
+        try:
+            off = d_band - scr.data_ptr()                              # the band buffer lies inside the scratch tensor
+            assert 0 <= off and off + npx * words * 8 <= scr.numel() and off % 8 == 0
+            consume(int(first), scr[off:off + npx * words * 8].view(torch.int64).view(npx, 6, ctx.k, ctx.n))
+            return 0
+        except BaseException as e:                                     # must not propagate through the C frame
+            err.append(e)
+            return -1
 
-    outs = []
-    for y0 in range(0, dst_h, band_rows):
-        ys = list(range(y0, min(y0 + band_rows, dst_h)))
-        need = sorted({r for y in ys for r in rows_of[y]})
-        row_cubics([r for r in need if r not in cache])
-        for r in [r for r in cache if r < need[0]]:                                        # the window only moves down
-            del cache[r]
-        rows_per_call = max(1, batch // dst_w)
-        for s0 in range(0, len(ys), rows_per_call):
-            yy = ys[s0:s0 + rows_per_call]
-            A, B, C, D = (torch.cat([cache[rows_of[y][j]] for y in yy], dim=0) for j in range(4))
-            # pixel c of the call sits in output row yy[c // dst_w]: entry yy[0] + c // dst_w of the prepared yfract batches
-            sy2, sy1 = py2.shared(dst_w, yy[0]), py1.shared(dst_w, yy[0])
-            o = cubic(ev, pc, A, B, C, D, None, powers=(None, None), prepared=(sy2, sy2, sy1))
-            if consume is not None:
-                consume(yy[0] * dst_w, o)
-            else:
-                outs.append(o)
-    return None if consume is not None else torch.cat(outs, dim=0)
-
-
-def sample_linear(ev, pc, pixels, taps, xfract, yfract):
-    """SampleLinear for one channel (homo/fhe_resize.h:222-252).  Returns [B, 4, k, n]."""
-    idx = torch.as_tensor(taps, dtype=torch.long, device=pixels.device)        # [B, 4]
-    p00, p10, p01, p11 = (pixels[idx[:, i]].contiguous() for i in range(4))
-    col0 = linear(ev, pc, p00, p10, xfract)
-    col1 = linear(ev, pc, p01, p11, xfract)
-    return linear(ev, pc, col0, col1, yfract)
+    cb = BAND_CONSUMER(on_band) if consume is not None else None
+    try:
+        _lib.call("fhe_resize_bicubic_shared", cc.h, _ptr(pixels), src_w, src_h, dst_w, dst_h, _ptr(xfract), _ptr(yfract),
+                  _ptr(out) if out is not None else C.c_void_p(None), batch, band_rows, cb, None, _ptr(scr), nbytes, _stream())
+    except _lib.FheError:
+        if err:
+            raise err[0]
+        raise
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
 # decode path
 # ------------------------------------------------------------------------------------------------
-def _taylor_terms(ev, pc, x, coeffs):
-    """the five power terms of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:56-113 / :136-193):
-    even Taylor polynomial of degree 10 in (x - 3 pi / 2); only the coefficients differ."""
-    M, P = ev.multiply_plain, pc.prepared
-    sx = ev.add_plain(x, pc.plain(-3 * math.pi / 2.0))
-    # The reference rebuilds every power from a fresh copy of sx (11 squares, 4 multiplies); the
-    # repeated squares are the same ring elements bit for bit, so each is formed once here.
-    s2 = ev.square(sx)
-    s4 = ev.square(s2)
-    s8 = ev.square(s4)
-    p2 = M(s2, P(coeffs[0]))
-    p4 = M(s4, P(coeffs[1]))
-    psx = ev.prepare_operand(sx.contiguous())            # the four products below share this operand
-    p6 = M(ev.multiply(ev.multiply(s4, psx), psx), P(coeffs[2]))
-    p8 = M(s8, P(coeffs[3]))
-    p10 = M(ev.multiply(ev.multiply(s8, psx), psx), P(coeffs[4]))
-    return (p2, p4, p6, p8, p10)
-
-
-def _taylor_sum(ev, pc, zero, constant, terms):
-    """res = Enc(0) + constant, then the terms in the reference's order (homo/fhe_decode.h:114-119)."""
-    res = ev.add_plain(zero, pc.plain(constant))
-    for term in terms:
-        res = ev.add(res, term)
-    return res
-
-
-SIN_COEFFS = (0.5, -1.0 / 24.0, 1.0 / 720.0, -1.0 / 40320.0, 1.0 / 3628800.0)
-COS_COEFFS = (-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0)
+def _sincos(cosine, ev, pc, x, zero):
+    cc = circuits_of(pc)
+    count = _count(x, 2)
+    assert _count(zero, 2) == count
+    out = ev.ctx.empty(*x.shape[:-3], size=11)
+    nbytes = _lib.load().fhe_homomorphic_sincos_scratch_bytes(cc.h, count)
+    scr = cc.scratch(nbytes)
+    _lib.call("fhe_homomorphic_sincos", cc.h, cosine, _ptr(x), _ptr(zero), _ptr(out), count, _ptr(scr), nbytes, _stream())
+    return out
 
 
 def homomorphic_sin(ev, pc, x, zero):
     """homo/fhe_decode.h:48-120; `zero` plays the role of encrypt(encode(0.0)) (:54)."""
-    return _taylor_sum(ev, pc, zero, -1.0, _taylor_terms(ev, pc, x, SIN_COEFFS))
+    return _sincos(0, ev, pc, x, zero)
 
 
 def homomorphic_cos(ev, pc, x, zero):
     """homo/fhe_decode.h:128-200 (the reference shifts by -3pi/2 here too, :137, and falls off the end
     without a return statement, :200; the value it leaves in `res` is what is returned here)."""
-    return _taylor_sum(ev, pc, zero, 1.0, _taylor_terms(ev, pc, x, COS_COEFFS))
+    return _sincos(1, ev, pc, x, zero)
+
+
+def stack_zeros(zeros, npos, degree):
+    """zeros: callable (i, j, which) -> [1, 2, k, n] -> one tensor [npos, degree, 2, 2, k, n] in the reference's
+    call order (position i, harmonic j = 1..degree, homomorphic_sin's Enc(0) then homomorphic_cos's)."""
+    return torch.cat([zeros(i, j, w) for i in range(npos) for j in range(1, degree + 1) for w in ("sin", "cos")]).contiguous()
 
 
 def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros):
-    """The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run.
-    amplitude/index/count: [1, 2, k, n].  zeros: callable (i, j, which) -> [1, 2, k, n] encryption of
-    zero for position i, harmonic j, which in {"sin", "cos"}.  Returns a list of width*height
-    ciphertexts [1, 22, k, n].
+    """The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run
+    (fhe_approximated_step).  amplitude/index/count: [1, 2, k, n].  zeros: a tensor [npos, degree, 2, 2, k, n]
+    (stack_zeros order) or a callable (i, j, which) -> [1, 2, k, n] encryption of zero for position i, harmonic j,
+    which in {"sin", "cos"}.  Returns a list of width*height ciphertexts [1, 22, k, n].
 
     Faithful to the reference's quirk: `offset` is advanced by add_plain(offset, encode(i)) INSIDE
     the harmonic loop (:229), after cos_arg was copied from it.
 
-    The reference walks positions x harmonics serially with one ciphertext per call; here only the
+    The reference walks positions x harmonics serially with one ciphertext per call; in the library only the
     (cheap) offset chain is serial.  All width*height*degree cosine polynomials are evaluated as ONE
     batch, the sine polynomial once per harmonic (its argument b * f_j does not depend on the
     position) -- the same ring operations on the same operands, so the same bits, but launches that
     fill the GPU."""
-    import numpy as np
-    M, P = ev.multiply_plain, pc.prepared
+    cc = circuits_of(pc)
     npos = width * height
-    b = M(count, P(0.5))
-    offset = ev.negate(ev.add_plain(ev.add(index, b), pc.plain(-0.5)))
-    b = ev.add_plain(b, pc.plain(delta - 0.5))
-    factors = [float(np.float32(j)) * math.pi / float(order) for j in range(1, degree + 1)]
-    pre = []                                    # pre[i][j-1] = offset as copied into cos_arg (:226)
-    for i in range(npos):
-        row = []
-        for _ in range(degree):
-            row.append(offset)
-            offset = ev.add_plain(offset, pc.plain(float(i)))
-        pre.append(row)
-    # batch index = (j-1) * npos + i
-    cos_arg = torch.cat([M(torch.cat([pre[i][j] for i in range(npos)]), P(factors[j])) for j in range(degree)])
-    zc = torch.cat([zeros(i, j + 1, "cos") for j in range(degree) for i in range(npos)])
-    zs = torch.cat([zeros(i, j + 1, "sin") for j in range(degree) for i in range(npos)])
-    co = _taylor_sum(ev, pc, zc, 1.0, _taylor_terms(ev, pc, cos_arg, COS_COEFFS))
-    sin_arg = torch.cat([M(b, P(factors[j])) for j in range(degree)])                  # [degree, 2, k, n]
-    sin_terms = [t.repeat_interleave(npos, dim=0) for t in _taylor_terms(ev, pc, sin_arg, SIN_COEFFS)]
-    s = _taylor_sum(ev, pc, zs, -1.0, sin_terms)
-    del sin_terms
-    prod = ev.multiply(s, co)                                                           # [degree * npos, 21, k, n]
-    c = M(b, P(1.0 / float(order))).repeat(npos, 1, 1, 1)
-    for j in range(degree):
-        term = M(prod[j * npos:(j + 1) * npos], P(2.0 / (math.pi * float(np.float32(j + 1)))))
-        c = ev.add(c, term)
-    out = ev.multiply(c, amplitude.repeat(npos, 1, 1, 1))
+    if callable(zeros):
+        zeros = stack_zeros(zeros, npos, degree) if degree > 0 else None
+    L = _lib.load()
+    so = L.fhe_approximated_step_out_size(degree)
+    out = ev.ctx.empty(npos, size=so)
+    nbytes = L.fhe_approximated_step_scratch_bytes(cc.h, degree, npos)
+    scr = cc.scratch(nbytes)
+    _lib.call("fhe_approximated_step", cc.h, _ptr(amplitude), _ptr(index), _ptr(count), order, degree, float(delta), width, height,
+              _ptr(zeros) if zeros is not None else C.c_void_p(None), _ptr(out), _ptr(scr), nbytes, _stream())
     return [out[i:i + 1] for i in range(npos)]
+
+
+def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height):
+    """One colour channel of the server_decode driver loop (homo/server_decode.cpp:120-137; fhe_decode_channel).
+    runs: [pairs, 2, 2, k, n] (elem, count per run); index: [1, 2, k, n] or [2, k, n], UPDATED IN PLACE (index += count
+    per run, :137); acc0: [npos, 2, k, n], the channel's Enc(0) accumulators (:126); zeros: [pairs, npos, degree, 2, 2, k, n].
+    Returns [npos, S, k, n], S = 22 for degree >= 1 and pairs > 0."""
+    cc = circuits_of(pc)
+    npos = width * height
+    pairs = int(runs.shape[0]) if runs is not None else 0
+    assert _count(acc0, 2) == npos and index.is_contiguous()
+    L = _lib.load()
+    so = L.fhe_approximated_step_out_size(degree) if pairs else 2
+    out = ev.ctx.empty(npos, size=so)
+    nbytes = L.fhe_decode_channel_scratch_bytes(cc.h, degree, npos, pairs)
+    scr = cc.scratch(nbytes)
+    null = C.c_void_p(None)
+    _lib.call("fhe_decode_channel", cc.h, _ptr(runs) if pairs else null, pairs, _ptr(index), _ptr(acc0),
+              _ptr(zeros) if (pairs and degree > 0) else null, order, degree, float(delta), width, height, _ptr(out), _ptr(scr), nbytes, _stream())
+    return out

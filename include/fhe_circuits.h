@@ -1,0 +1,127 @@
+/*
+ * fhe_circuits.h -- C ABI of libfhe_hip.so, part 2: the reference's ciphertext x ciphertext CIRCUITS on whole
+ * batches (the resize path of homo/fhe_resize.h and the decode path of homo/fhe_decode.h, plus the driver
+ * loop of homo/server_decode.cpp), so that a C / C++ host gets the batched evaluation without any tensor
+ * library in between.  Part 1 (include/fhe_hip.h) holds the context, the Evaluator primitives and the
+ * fused JPEG circuit; everything here composes those primitives inside the library:
+ * tap gathers, the t^2 reuse of Cubic, prepared (extended + transformed) operands, the growth of
+ * ciphertext sizes, unequal-size additions and all temporaries live in caller-supplied scratch.
+ *
+ * Conventions: as in fhe_hip.h (plain pointers and sizes, `stream` = hipStream_t as void*, status codes,
+ * fhe_last_error()).  Ciphertext batches are device memory, u64 [count][size][k][n], residues fully
+ * reduced.  Index arrays (`taps`) and scalars are HOST memory; they are consumed before the call returns.
+ * Every circuit has a `*_scratch_bytes` query that runs the same host logic without launching anything, so
+ * the figure is exact for the arguments given; scratch may be reused by the next call on the same stream.
+ * Results are bit-identical to the reference's op-by-op evaluation through seal::Evaluator with the same
+ * server-side encryptions (which the reference draws inside the circuits and which are INPUTS here:
+ * the fractional offsets of SampleLinear / SampleBicubic, the Enc(0) accumulators of homomorphic_sin/cos).
+ */
+#ifndef FHE_CIRCUITS_H
+#define FHE_CIRCUITS_H
+
+#include "fhe_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Constants of the circuits for one context and one seal::FractionalEncoder(t, poly, int_coeffs,
+ * frac_coeffs, 2) (homo/server_resize.cpp:110, homo/server_decode.cpp:117): each distinct plaintext is encoded,
+ * lifted and transformed once and kept on the device (the reference re-encodes on every call).  Thread-safe;
+ * must outlive every call that uses it; the context must outlive it. */
+typedef struct fhe_circuits fhe_circuits;
+int fhe_circuits_create(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, fhe_circuits **out);
+int fhe_circuits_destroy(fhe_circuits *circ);
+
+/* ---- resize path ---------------------------------------------------------------------------------------
+ * Index arithmetic of ResizeImage / SampleBicubic / SampleLinear / GetPixelClamped in the reference's float
+ * arithmetic (homo/fhe_resize.h:350-351,381-382,260-290,215-220): per output pixel (row-major) the clamped
+ * source pixel indices y * src_w + x -- 16 for bicubic (row-major 4 x 4: x-1..x+2 fastest, y-1..y+2), 4 for
+ * bilinear (p00, p10, p01, p11) -- and the fractional offsets frac(u), frac(v).  Host only.  Any output
+ * pointer may be NULL. */
+int fhe_resize_sample_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, int bicubic,
+                           uint32_t *taps, double *xfract, double *yfract);
+
+/* Cubic(result, A, B, C, D, t) (homo/fhe_resize.h:143-189) for `count` independent 5-tuples: A..D of `size`
+ * polynomials, t of size 2, out of size + 2.  t2 = square(t) and t3 = multiply(t, t) (:174-175, the
+ * reference's t^3 IS t^2) are one ring element, formed once. */
+size_t fhe_cubic_scratch_bytes(const fhe_circuits *circ, uint32_t size, uint64_t count);
+int fhe_cubic(const fhe_circuits *circ, const uint64_t *A, const uint64_t *B, const uint64_t *C, const uint64_t *D,
+              uint32_t size, const uint64_t *t, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes,
+              fhe_stream stream);
+/* Linear(result, A, B, t) = (1 - t) A + t B (homo/fhe_resize.h:191-204); out has size + 1 polynomials. */
+size_t fhe_linear_scratch_bytes(const fhe_circuits *circ, uint32_t size, uint64_t count);
+int fhe_linear(const fhe_circuits *circ, const uint64_t *A, const uint64_t *B, uint32_t size, const uint64_t *t,
+               uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream stream);
+
+/* SampleBicubic (homo/fhe_resize.h:254-305) for `count` output pixels of one colour channel.
+ * pixels: [n_pixels][2][k][n] (the resident source window); taps: host, [count][16] indices into `pixels`
+ * (fhe_resize_sample_plan order); xfract, yfract: [count][2][k][n] encryptions of the offsets (:262,266);
+ * out: [count][6][k][n].  Five Cubic evaluations per pixel; xfract^2 and the prepared forms of xfract,
+ * xfract^2 are shared by the four row Cubics. */
+size_t fhe_sample_bicubic_scratch_bytes(const fhe_circuits *circ, uint64_t count);
+int fhe_sample_bicubic(const fhe_circuits *circ, const uint64_t *pixels, uint64_t n_pixels, const uint32_t *taps,
+                       const uint64_t *xfract, const uint64_t *yfract, uint64_t *out, uint64_t count, void *scratch,
+                       size_t scratch_bytes, fhe_stream stream);
+/* SampleLinear (homo/fhe_resize.h:222-252): taps [count][4]; out [count][4][k][n]. */
+size_t fhe_sample_linear_scratch_bytes(const fhe_circuits *circ, uint64_t count);
+int fhe_sample_linear(const fhe_circuits *circ, const uint64_t *pixels, uint64_t n_pixels, const uint32_t *taps,
+                      const uint64_t *xfract, const uint64_t *yfract, uint64_t *out, uint64_t count, void *scratch,
+                      size_t scratch_bytes, fhe_stream stream);
+
+/* ResizeImage with SampleBicubic (homo/fhe_resize.h:308-392) for one colour channel of a resident source
+ * image when the offsets arrive as ONE ciphertext per output column (xfract [dst_w][2][k][n]) and ONE per
+ * output row (yfract [dst_h][2][k][n]) -- SURVEY.md section 8(d), configs[2]: frac(u) depends on the column
+ * only and frac(v) on the row only (:351,382).  Every repeated ring element is formed once (row Cubics of
+ * overlapping 4-row windows, squares and prepared operands per column / row); each output equals
+ * fhe_sample_bicubic with xfract[x], yfract[y] bit for bit.  Output pixels are produced in bands of
+ * `band_rows` destination rows, row-major: written to out ([dst_w * dst_h][6][k][n]) when out != NULL, and /
+ * or handed to `consume` (may be NULL) as consume(user, first_pixel, d_band, n_pixels, stream), which must
+ * enqueue its reads of d_band on `stream` (the band buffer is reused).  `batch` bounds the Cubics per launch
+ * sequence (rounded to whole rows of dst_w). */
+typedef int (*fhe_band_consumer)(void *user, uint64_t first_pixel, const uint64_t *d_band, uint64_t n_pixels,
+                                 fhe_stream stream);
+size_t fhe_resize_bicubic_shared_scratch_bytes(const fhe_circuits *circ, uint32_t src_w, uint32_t src_h,
+                                               uint32_t dst_w, uint32_t dst_h, uint32_t batch, uint32_t band_rows,
+                                               int has_out);
+int fhe_resize_bicubic_shared(const fhe_circuits *circ, const uint64_t *pixels, uint32_t src_w, uint32_t src_h,
+                              uint32_t dst_w, uint32_t dst_h, const uint64_t *xfract, const uint64_t *yfract,
+                              uint64_t *out, uint32_t batch, uint32_t band_rows, fhe_band_consumer consume,
+                              void *user, void *scratch, size_t scratch_bytes, fhe_stream stream);
+
+/* ---- decode path ---------------------------------------------------------------------------------------
+ * homomorphic_sin (cosine = 0, homo/fhe_decode.h:48-120) / homomorphic_cos (cosine = 1, :128-200; the value
+ * the reference leaves in `res` before falling off the end without a return statement) for `count`
+ * arguments: x, zero (the Enc(0) of :54 / :134): [count][2][k][n]; out: [count][11][k][n]. */
+size_t fhe_homomorphic_sincos_scratch_bytes(const fhe_circuits *circ, uint64_t count);
+int fhe_homomorphic_sincos(const fhe_circuits *circ, int cosine, const uint64_t *x, const uint64_t *zero,
+                           uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream stream);
+
+/* The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run (amplitude, index,
+ * count_ct: [2][k][n]) over npos = width * height positions.  zeros: [npos][degree][2][2][k][n], the Enc(0)
+ * accumulators in the reference's call order (position i, harmonic j = 1..degree, sin then cos).
+ * out: [npos][fhe_approximated_step_out_size(degree)][k][n] (22 polynomials for degree >= 1).
+ * `offset` advances by add_plain(offset, encode(i)) inside the harmonic loop (:229), as the reference does. */
+uint32_t fhe_approximated_step_out_size(int degree);
+size_t fhe_approximated_step_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos);
+int fhe_approximated_step(const fhe_circuits *circ, const uint64_t *amplitude, const uint64_t *index,
+                          const uint64_t *count_ct, int order, int degree, double delta, uint32_t width,
+                          uint32_t height, const uint64_t *zeros, uint64_t *out, void *scratch,
+                          size_t scratch_bytes, fhe_stream stream);
+
+/* One colour channel of the server_decode driver loop (homo/server_decode.cpp:120-137): the channel's
+ * accumulators start as acc0 ([npos][2][k][n], the Enc(0) of :126); for each of `pairs` runs
+ * (runs: [pairs][2][2][k][n] = elem, count as loaded at :131-132) approximated_step is evaluated with the
+ * running `index` ([2][k][n], in/out: :121 and :137 `index += count`), and its npos results are added to the
+ * accumulators (:134-136).  zeros: [pairs][npos][degree][2][2][k][n].
+ * out: [npos][S][k][n] with S = fhe_approximated_step_out_size(degree) if pairs > 0, else 2. */
+size_t fhe_decode_channel_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos, uint32_t pairs);
+int fhe_decode_channel(const fhe_circuits *circ, const uint64_t *runs, uint32_t pairs, uint64_t *index,
+                       const uint64_t *acc0, const uint64_t *zeros, int order, int degree, double delta,
+                       uint32_t width, uint32_t height, uint64_t *out, void *scratch, size_t scratch_bytes,
+                       fhe_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

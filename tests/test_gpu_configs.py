@@ -121,7 +121,7 @@ def test_shared_row_cubics_equal_per_pixel_sampling(fhe, preset, W, H, w, h, ban
     # streamed form: the bands handed to a consumer are the same tensor in pieces
     seen = []
     assert fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xf, yf, batch=batch, band_rows=band,
-                                              consume=lambda first, t: seen.append((first, t))) is None
+                                              consume=lambda first, t: seen.append((first, t.clone()))) is None      # the band buffer is reused
     assert [f for f, _ in seen] == sorted(f for f, _ in seen) and sum(t.shape[0] for _, t in seen) == w * h
     assert all(torch.equal(t, got[f:f + t.shape[0]]) for f, t in seen)
 

@@ -807,8 +807,9 @@ def test_sparse_multiply_plain_equals_transform_path_and_oracle(fhe, oracle_mod,
 
 @pytest.mark.parametrize("preset,size", [("SMALL", 2), ("P8192", 4)])
 def test_fused_cubic_linear_parts_equal_evaluator_calls(fhe, oracle_mod, preset, size):
-    """fhe_cubic_coeffs / fhe_cubic_combine against the same Cubic evaluated call by call (level 1:
-    size-2 inputs; level 2: size-4 inputs, where c*t is one polynomial shorter than a*t3)."""
+    """fhe_cubic (linear parts as single passes through index maps, t^2 formed once, prepared operands) against the
+    same Cubic evaluated Evaluator call by Evaluator call (level 1: size-2 inputs; level 2: size-4 inputs, where
+    c*t is one polynomial shorter than a*t3)."""
     import torch
     ctx, _ = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
@@ -818,8 +819,7 @@ def test_fused_cubic_linear_parts_equal_evaluator_calls(fhe, oracle_mod, preset,
     A[0, 0] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=A.device).view(ctx.k, 1)
     assert fhe.circuits._base2_cubic_constants(pc)
     fused = fhe.circuits.cubic(ev, pc, A, B, C, D, t)
-    pc._cubic_ok = False
-    plain = fhe.circuits.cubic(ev, pc, A, B, C, D, t)
+    plain = fhe.circuits.cubic_evaluator_calls(ev, pc, A, B, C, D, t)
     assert fused.shape == plain.shape and fused.shape[-3] == size + 2
     assert torch.equal(fused, plain)
 
