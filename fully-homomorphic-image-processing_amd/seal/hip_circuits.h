@@ -1,0 +1,244 @@
+// seal/hip_circuits.h -- the batched resize / decode circuits of include/fhe_circuits.h behind SEAL-typed arguments,
+// for C++ hosts (the reference's server mains are C++): what `circuits.py` is to the Python harness.
+//
+//   seal::hip::CiphertextBatch   `count` ciphertexts of one size in ONE device allocation ([count][size][k][n]); loads and
+//                                saves the same stream records as seal::Ciphertext (a saved batch is a concatenation of
+//                                Ciphertext::save records), converts to / from std::vector<seal::Ciphertext>
+//   seal::hip::Circuits          one fhe_circuits handle + scratch: cubic, linear, sample_bicubic, sample_linear,
+//                                resize_bicubic (shared offsets), homomorphic_sin / _cos, approximated_step, decode_channel
+//
+// Each method is one library call: the taps are index arrays, every temporary lives in the handle's scratch buffer, no
+// per-ciphertext work happens on the host.  Results are bit-identical to the reference's functions of the same names
+// (homo/fhe_resize.h:143-392, homo/fhe_decode.h:48-242, homo/server_decode.cpp:120-137) called one ciphertext at a
+// time through seal::Evaluator with the same server-side encryptions (seal/circuits_test.cpp checks exactly that).
+#ifndef FHE_SEAL_HIP_CIRCUITS_H
+#define FHE_SEAL_HIP_CIRCUITS_H
+
+#include "fhe_circuits.h"
+#include "seal/seal.h"
+
+namespace seal {
+namespace hip {
+
+class CiphertextBatch {
+public:
+    CiphertextBatch() : count_(0), size_(0), k_(0), n_(0) {}
+    CiphertextBatch(const SEALContext &ctx, size_t count, uint32_t size) { shape(ctx, count, size); }
+    void shape(const SEALContext &ctx, size_t count, uint32_t size) {
+        const detail::CtxState &s = *ctx.state();
+        count_ = count; size_ = size; k_ = s.k; n_ = s.n;
+        buf_.resize(count * ct_words());
+    }
+    size_t count() const { return count_; }
+    uint32_t size() const { return size_; }
+    size_t ct_words() const { return (size_t)size_ * k_ * n_; }
+    uint64_t *ptr() { return buf_.ptr(); }
+    const uint64_t *ptr() const { return buf_.ptr(); }
+    uint64_t *at(size_t i) { return buf_.ptr() + i * ct_words(); }
+    const uint64_t *at(size_t i) const { return buf_.ptr() + i * ct_words(); }
+
+    // gather / scatter between one-allocation-per-ciphertext objects and the batch (device copies)
+    static CiphertextBatch from(const SEALContext &ctx, const std::vector<Ciphertext> &v) {
+        CiphertextBatch b;
+        if (v.empty()) return b;
+        b.shape(ctx, v.size(), (uint32_t)v[0].size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            if ((uint32_t)v[i].size() != b.size_ || v[i].k() != b.k_ || v[i].n() != b.n_) throw std::invalid_argument("CiphertextBatch: ciphertexts of one size and context only");
+            detail::check(fhe_copy(b.at(i), v[i].ptr(), b.ct_words() * 8, nullptr), "copy");
+        }
+        return b;
+    }
+    Ciphertext get(size_t i) const {
+        if (i >= count_) throw std::out_of_range("CiphertextBatch::get");
+        Ciphertext c;
+        c.shape(size_, k_, n_);
+        detail::check(fhe_copy(c.ptr(), at(i), ct_words() * 8, nullptr), "copy");
+        return c;
+    }
+    void set(size_t i, const Ciphertext &c) {
+        if (i >= count_ || (uint32_t)c.size() != size_ || c.k() != k_ || c.n() != n_) throw std::invalid_argument("CiphertextBatch::set");
+        detail::check(fhe_copy(at(i), c.ptr(), ct_words() * 8, nullptr), "copy");
+    }
+    // `count` stream records (Ciphertext::save format) -> the batch, through one host staging buffer
+    void load(const SEALContext &ctx, std::istream &is, size_t count, uint32_t size = 2) {
+        shape(ctx, count, size);
+        std::vector<uint64_t> h(count * ct_words());
+        const detail::CtxState &s = *ctx.state();
+        for (size_t i = 0; i < count; ++i) {
+            char magic[8];
+            uint32_t hdr[4];
+            is.read(magic, 8);
+            is.read((char *)hdr, sizeof hdr);
+            if (!is || std::memcmp(magic, "FHEHIP1", 7) != 0) throw std::invalid_argument("stream does not hold a ciphertext");
+            if (hdr[0] != size || hdr[1] != k_ || hdr[2] != n_) throw std::invalid_argument("ciphertext record does not match the batch");
+            uint64_t *dst = h.data() + i * ct_words();
+            is.read((char *)dst, (std::streamsize)(ct_words() * 8));
+            if (!is) throw std::invalid_argument("truncated ciphertext stream");
+            for (size_t p = 0; p < (size_t)size * k_; ++p) {            // canonical residues only (every kernel assumes them)
+                const uint64_t q = s.q[p % k_], *v = dst + p * n_;
+                uint64_t bad = 0;
+                for (uint32_t c = 0; c < n_; ++c) bad |= (uint64_t)(v[c] >= q);
+                if (bad) throw std::invalid_argument("ciphertext holds residues that are not reduced modulo the coefficient moduli");
+            }
+        }
+        if (!h.empty()) buf_.upload(h.data(), h.size());
+    }
+    void save(std::ostream &os) const {
+        std::vector<uint64_t> h(count_ * ct_words());
+        if (!h.empty()) { buf_.download(h.data(), h.size()); detail::check(fhe_stream_sync(nullptr), "sync"); }
+        const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
+        const uint32_t hdr[4] = {size_, k_, n_, 0};
+        for (size_t i = 0; i < count_; ++i) {
+            os.write(magic, 8);
+            os.write((const char *)hdr, sizeof hdr);
+            os.write((const char *)(h.data() + i * ct_words()), (std::streamsize)(ct_words() * 8));
+        }
+    }
+    std::vector<uint64_t> to_host() const {
+        std::vector<uint64_t> h(count_ * ct_words());
+        if (!h.empty()) { buf_.download(h.data(), h.size()); detail::check(fhe_stream_sync(nullptr), "sync"); }
+        return h;
+    }
+private:
+    detail::DevBuf buf_;
+    size_t count_;
+    uint32_t size_, k_, n_;
+};
+
+// sample plan of ResizeImage (homo/fhe_resize.h:350-351,381-382 and the tap order of SampleBicubic / SampleLinear)
+struct SamplePlan {
+    std::vector<uint32_t> taps;         // [dst_w * dst_h][16 or 4]
+    std::vector<double> xfract, yfract; // frac(u), frac(v) per output pixel
+    uint32_t taps_per_pixel;
+};
+inline SamplePlan resize_sample_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, bool bicubic) {
+    SamplePlan p;
+    p.taps_per_pixel = bicubic ? 16 : 4;
+    const size_t npx = (size_t)dst_w * dst_h;
+    p.taps.resize(npx * p.taps_per_pixel);
+    p.xfract.resize(npx);
+    p.yfract.resize(npx);
+    detail::check(fhe_resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic ? 1 : 0, p.taps.data(), p.xfract.data(), p.yfract.data()), "resize_sample_plan");
+    return p;
+}
+
+class Circuits {
+public:
+    // the encoder arguments of seal::FractionalEncoder(t, poly, int_coeffs, frac_coeffs, 2) (homo/server_resize.cpp:110)
+    explicit Circuits(const SEALContext &ctx, int int_coeffs = 100, int frac_coeffs = 100) : ctx_(ctx), h_(nullptr) {
+        detail::check(fhe_circuits_create(ctx.state()->h, int_coeffs, frac_coeffs, &h_), "circuits");
+    }
+    ~Circuits() { if (h_) fhe_circuits_destroy(h_); }
+    Circuits(const Circuits &) = delete;
+    Circuits &operator=(const Circuits &) = delete;
+
+    // Cubic (homo/fhe_resize.h:143-189) for A.count() independent tuples; t has size 2; result size A.size() + 2
+    CiphertextBatch cubic(const CiphertextBatch &A, const CiphertextBatch &B, const CiphertextBatch &C, const CiphertextBatch &D, const CiphertextBatch &t) {
+        same(A, B); same(A, C); same(A, D); need(t, A.count(), 2);
+        CiphertextBatch out(ctx_, A.count(), A.size() + 2);
+        const size_t bytes = scratch(fhe_cubic_scratch_bytes(h_, A.size(), A.count()));
+        detail::check(fhe_cubic(h_, A.ptr(), B.ptr(), C.ptr(), D.ptr(), A.size(), t.ptr(), out.ptr(), A.count(), scratch_.ptr(), bytes, nullptr), "cubic");
+        return out;
+    }
+    // Linear (homo/fhe_resize.h:191-204); result size A.size() + 1
+    CiphertextBatch linear(const CiphertextBatch &A, const CiphertextBatch &B, const CiphertextBatch &t) {
+        same(A, B); need(t, A.count(), 2);
+        CiphertextBatch out(ctx_, A.count(), A.size() + 1);
+        const size_t bytes = scratch(fhe_linear_scratch_bytes(h_, A.size(), A.count()));
+        detail::check(fhe_linear(h_, A.ptr(), B.ptr(), A.size(), t.ptr(), out.ptr(), A.count(), scratch_.ptr(), bytes, nullptr), "linear");
+        return out;
+    }
+    // SampleBicubic / SampleLinear (homo/fhe_resize.h:222-305) for `count` output pixels of one channel: taps = count x 16 (x 4)
+    // indices into `pixels`; xfract / yfract = the offsets' encryptions (:230,234 / :262,266), one pair per output pixel
+    CiphertextBatch sample_bicubic(const CiphertextBatch &pixels, const uint32_t *taps, const CiphertextBatch &xfract, const CiphertextBatch &yfract) {
+        need(pixels, pixels.count(), 2); need(xfract, xfract.count(), 2); need(yfract, xfract.count(), 2);
+        CiphertextBatch out(ctx_, xfract.count(), 6);
+        const size_t bytes = scratch(fhe_sample_bicubic_scratch_bytes(h_, xfract.count()));
+        detail::check(fhe_sample_bicubic(h_, pixels.ptr(), pixels.count(), taps, xfract.ptr(), yfract.ptr(), out.ptr(), xfract.count(), scratch_.ptr(), bytes, nullptr), "sample_bicubic");
+        return out;
+    }
+    CiphertextBatch sample_linear(const CiphertextBatch &pixels, const uint32_t *taps, const CiphertextBatch &xfract, const CiphertextBatch &yfract) {
+        need(pixels, pixels.count(), 2); need(xfract, xfract.count(), 2); need(yfract, xfract.count(), 2);
+        CiphertextBatch out(ctx_, xfract.count(), 4);
+        const size_t bytes = scratch(fhe_sample_linear_scratch_bytes(h_, xfract.count()));
+        detail::check(fhe_sample_linear(h_, pixels.ptr(), pixels.count(), taps, xfract.ptr(), yfract.ptr(), out.ptr(), xfract.count(), scratch_.ptr(), bytes, nullptr), "sample_linear");
+        return out;
+    }
+    // ResizeImage with SampleBicubic for one channel of a resident image, one offset ciphertext per output column / row
+    // (fhe_resize_bicubic_shared).  Returns dst_w * dst_h size-6 ciphertexts, row-major.
+    CiphertextBatch resize_bicubic(const CiphertextBatch &pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h,
+                                   const CiphertextBatch &xfract, const CiphertextBatch &yfract, uint32_t batch = 256, uint32_t band_rows = 4) {
+        need(pixels, (size_t)src_w * src_h, 2); need(xfract, dst_w, 2); need(yfract, dst_h, 2);
+        CiphertextBatch out(ctx_, (size_t)dst_w * dst_h, 6);
+        const size_t bytes = scratch(fhe_resize_bicubic_shared_scratch_bytes(h_, src_w, src_h, dst_w, dst_h, batch, band_rows, 1));
+        detail::check(fhe_resize_bicubic_shared(h_, pixels.ptr(), src_w, src_h, dst_w, dst_h, xfract.ptr(), yfract.ptr(), out.ptr(), batch, band_rows, nullptr, nullptr,
+                                                scratch_.ptr(), bytes, nullptr), "resize_bicubic");
+        return out;
+    }
+    // the same with the output bands handed to `consume` (e.g. a stream writer) instead of being kept resident
+    void resize_bicubic(const CiphertextBatch &pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, const CiphertextBatch &xfract,
+                        const CiphertextBatch &yfract, fhe_band_consumer consume, void *user, uint32_t batch = 256, uint32_t band_rows = 4) {
+        need(pixels, (size_t)src_w * src_h, 2); need(xfract, dst_w, 2); need(yfract, dst_h, 2);
+        const size_t bytes = scratch(fhe_resize_bicubic_shared_scratch_bytes(h_, src_w, src_h, dst_w, dst_h, batch, band_rows, 0));
+        detail::check(fhe_resize_bicubic_shared(h_, pixels.ptr(), src_w, src_h, dst_w, dst_h, xfract.ptr(), yfract.ptr(), nullptr, batch, band_rows, consume, user,
+                                                scratch_.ptr(), bytes, nullptr), "resize_bicubic");
+    }
+    // homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:48-120 / :128-200); zero = the Enc(0) of :54 / :134
+    CiphertextBatch homomorphic_sin(const CiphertextBatch &x, const CiphertextBatch &zero) { return sincos(0, x, zero); }
+    CiphertextBatch homomorphic_cos(const CiphertextBatch &x, const CiphertextBatch &zero) { return sincos(1, x, zero); }
+    // approximated_step, homomorphic overload (homo/fhe_decode.h:202-242), one run; zeros: width * height * degree * 2
+    // Enc(0)s in the reference's call order
+    CiphertextBatch approximated_step(const Ciphertext &amplitude, const Ciphertext &index, const Ciphertext &count, int order, int degree, double delta,
+                                      uint32_t width, uint32_t height, const CiphertextBatch &zeros) {
+        const size_t npos = (size_t)width * height;
+        if (degree > 0) need(zeros, npos * degree * 2, 2);
+        CiphertextBatch out(ctx_, npos, fhe_approximated_step_out_size(degree));
+        const size_t bytes = scratch(fhe_approximated_step_scratch_bytes(h_, degree, (uint32_t)npos));
+        detail::check(fhe_approximated_step(h_, amplitude.ptr(), index.ptr(), count.ptr(), order, degree, delta, width, height, zeros.ptr(), out.ptr(), scratch_.ptr(), bytes,
+                                            nullptr), "approximated_step");
+        return out;
+    }
+    // one channel of the server_decode driver loop (homo/server_decode.cpp:120-137).  runs: (elem, count) per run;
+    // index: the channel's Enc(0) index, advanced in place; acc0: width * height Enc(0) accumulators;
+    // zeros: runs x width * height x degree x 2 Enc(0)s in call order
+    CiphertextBatch decode_channel(const CiphertextBatch &runs, Ciphertext &index, const CiphertextBatch &acc0, const CiphertextBatch &zeros, int order, int degree,
+                                   double delta, uint32_t width, uint32_t height) {
+        const size_t npos = (size_t)width * height;
+        const uint32_t pairs = (uint32_t)(runs.count() / 2);
+        need(acc0, npos, 2);
+        if (pairs) { need(runs, (size_t)pairs * 2, 2); if (degree > 0) need(zeros, (size_t)pairs * npos * degree * 2, 2); }
+        CiphertextBatch out(ctx_, npos, pairs ? fhe_approximated_step_out_size(degree) : 2);
+        const size_t bytes = scratch(fhe_decode_channel_scratch_bytes(h_, degree, (uint32_t)npos, pairs));
+        detail::check(fhe_decode_channel(h_, runs.ptr(), pairs, index.ptr(), acc0.ptr(), zeros.ptr(), order, degree, delta, width, height, out.ptr(), scratch_.ptr(), bytes,
+                                         nullptr), "decode_channel");
+        return out;
+    }
+    fhe_circuits *handle() { return h_; }
+
+private:
+    CiphertextBatch sincos(int cosine, const CiphertextBatch &x, const CiphertextBatch &zero) {
+        need(x, x.count(), 2); need(zero, x.count(), 2);
+        CiphertextBatch out(ctx_, x.count(), 11);
+        const size_t bytes = scratch(fhe_homomorphic_sincos_scratch_bytes(h_, x.count()));
+        detail::check(fhe_homomorphic_sincos(h_, cosine, x.ptr(), zero.ptr(), out.ptr(), x.count(), scratch_.ptr(), bytes, nullptr), "homomorphic_sincos");
+        return out;
+    }
+    static void same(const CiphertextBatch &a, const CiphertextBatch &b) {
+        if (a.count() != b.count() || a.size() != b.size()) throw std::invalid_argument("circuit operands differ in count or size");
+    }
+    static void need(const CiphertextBatch &a, size_t count, uint32_t size) {
+        if (a.count() != count || a.size() != size) throw std::invalid_argument("circuit operand has the wrong count or size");
+    }
+    size_t scratch(size_t bytes) {
+        if (!bytes) throw std::runtime_error(std::string("circuit scratch query: ") + fhe_last_error());
+        if (scratch_.words() * 8 < bytes) scratch_.resize((bytes + 7) / 8);
+        return bytes;
+    }
+    SEALContext ctx_;
+    fhe_circuits *h_;
+    detail::DevBuf scratch_;
+};
+
+}  // namespace hip
+}  // namespace seal
+#endif

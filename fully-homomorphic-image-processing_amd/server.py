@@ -322,3 +322,83 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         os.close(fin)
         os.close(fout)
     return dst_w * dst_h
+
+
+# ------------------------------------------------------------------------------------------------
+# server_decode: the run-length decoder's driver loop (homo/server_decode.cpp:113-148) over a ciphertext stream
+# ------------------------------------------------------------------------------------------------
+def make_zero_encryptor(ctx, public_key, encoder=None, seed=None):
+    """The decode path's server-side encryptions (homo/server_decode.cpp:121,126; homo/fhe_decode.h:54,134): a
+    callable count -> [count, 2, k, n] of fresh encryptions of encode(0.0) under `public_key` ([2, k, n] device
+    tensor).  seed=None draws from the OS CSPRNG."""
+    from .evaluator import FractionalEncoder
+    from .keys import Encryptor
+    enc = encoder or FractionalEncoder(ctx)
+    er = Encryptor(ctx, public_key, seed=seed)
+    zero = enc.encode(0.0)
+
+    def encrypt(count):
+        return torch.stack([er.encrypt(zero) for _ in range(count)]) if count else ctx.empty(0)
+    return encrypt
+
+
+def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, order=64, degree=12, delta=0.5):
+    """homo/server_decode.cpp:113-148 on the GPU, with the HOMOMORPHIC overload of approximated_step
+    (homo/fhe_decode.h:202-242; the reference's main passes its debugging Decryptor and thereby selects the
+    decrypting overload, :244-282, which needs the secret key on the server -- out of scope).
+
+    Input stream: for each of the three colour channels, pairs[ch] runs of two ciphertext records
+    (elem = the run's amplitude, count = its length; :131-132).  Output stream: for every position i < width * height
+    the three channels' accumulators, interleaved (:139-143); a record has 22 polynomials (2 for a channel without
+    runs).  width, height, pairs are the five integers of keys/params.txt (:15-24).
+
+    Per channel the library evaluates the whole driver loop (fhe_decode_channel): the running `index`
+    ciphertext (:121,137), one approximated_step per run over all positions and harmonics as batches, and the
+    accumulation of its results into the channel (:134-136).
+
+    encrypt_zeros(count) -> [count, 2, k, n] supplies the server-side encryptions of encode(0.0) in the reference's
+    call order: per channel `index` (:121), the width * height accumulators (:126), then for every run the
+    Enc(0) of homomorphic_sin and homomorphic_cos per (position, harmonic) (homo/fhe_decode.h:231-232)."""
+    from . import circuits
+    ev = Evaluator(ctx)
+    pc = circuits.PlainCache(ctx)
+    npos = width * height
+    pairs = [int(p) for p in pairs]
+    if len(pairs) != 3 or min(pairs) < 0 or npos < 1:
+        raise ValueError("pairs must hold three non-negative run counts and the image must not be empty")
+    total = sum(pairs)
+    rec_in = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+    if os.path.getsize(in_path) < 2 * total * rec_in:
+        raise EOFError("ciphertext stream ended")
+    expect = (2, ctx.k, ctx.n)
+    dev = None
+    if total:
+        host = _pinned(("dec_in",), (total, 2, 2, ctx.k, ctx.n))
+        arr = host.numpy().view(np.uint64)
+        fin = os.open(in_path, os.O_RDONLY)
+        try:
+            _pread_records(fin, [arr[r, j] for r in range(total) for j in range(2)], 0, rec_in, expect)
+        finally:
+            os.close(fin)
+        dev = host.to(ctx.device, non_blocking=True)
+    res, first = [], 0
+    for ch in range(3):
+        p = pairs[ch]
+        z = encrypt_zeros(1 + npos + p * npos * degree * 2)
+        index = z[0:1].clone()
+        acc0 = z[1:1 + npos].contiguous()
+        zeros = z[1 + npos:].reshape(p, npos, degree, 2, 2, ctx.k, ctx.n).contiguous() if p and degree else None
+        runs = dev[first:first + p].contiguous() if p else None
+        res.append(circuits.decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height))
+        first += p
+    torch.cuda.synchronize()
+    host_res = [to_host_array(r) for r in res]
+    with open(out_path, "wb") as f:
+        for i in range(npos):
+            for ch in range(3):
+                write_ciphertext(f, host_res[ch][i])
+    return npos
+
+
+def to_host_array(t):
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)

@@ -1,0 +1,205 @@
+// ref_vs_batched_main.cpp -- TEST INFRASTRUCTURE (built into oracle/_ref/, never committed as binary).
+//
+// One C++ process, two evaluations of the same circuits on the same ciphertexts, compared bit for bit:
+//   (1) the REFERENCE's own functions -- Cubic, Linear, SampleBicubic, SampleLinear (/root/reference/homo/fhe_resize.h:143-305),
+//       homomorphic_sin, homomorphic_cos, approximated_step (homo/fhe_decode.h:48-242) and the per-channel loop of
+//       homo/server_decode.cpp:120-137 -- included unchanged from where they lie and run one ciphertext at a time through
+//       the SEAL-shaped facade;
+//   (2) the batched C++ host API of this repository, seal::hip::Circuits (seal/hip_circuits.h over include/fhe_circuits.h):
+//       one library call per circuit and batch.
+// The circuits' server-side encryptions (fractional offsets, Enc(0) accumulators) are supplied to (1) through the
+// facade's test hook and to (2) as arguments, from the same ciphertexts.
+//
+// usage: ref_vs_batched <n> <t>          (FHE_SEAL23_MODULI=1 selects SEAL 2.3's own moduli, as in the other harnesses)
+// Built at -O0 with the stack scrubbed before the decode circuits: homomorphic_cos has no return statement
+// (homo/fhe_decode.h:200), see ref_decode_circuit_main.cpp.
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "fhe_resize.h"   // the reference's headers, unchanged
+#include "fhe_decode.h"
+#include "seal/hip_circuits.h"
+
+using seal::hip::CiphertextBatch;
+
+static void __attribute__((noinline)) scrub_stack() {
+    volatile char z[1 << 20];
+    for (size_t i = 0; i < sizeof z; i++) z[i] = 0;
+}
+
+static std::deque<Ciphertext> g_hook;        // what the reference's encryptor.encrypt calls return, in order
+static int g_fail = 0;
+
+static std::vector<uint64_t> host(const Ciphertext &c) {
+    std::vector<uint64_t> h((size_t)c.size() * c.k() * c.n());
+    c.buffer().download(h.data(), h.size());
+    fhe_stream_sync(nullptr);
+    return h;
+}
+static void expect_equal(const char *what, size_t i, const Ciphertext &ref, const CiphertextBatch &got, size_t gi) {
+    const std::vector<uint64_t> a = host(ref), b = host(got.get(gi));
+    if ((uint32_t)ref.size() != got.size() || a != b) {
+        std::printf("MISMATCH %s[%zu]: reference size %d, batched size %u\n", what, i, ref.size(), got.size());
+        ++g_fail;
+    }
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: %s n t\n", argv[0]); return 2; }
+    const int n = std::atoi(argv[1]);
+    const uint64_t t = std::strtoull(argv[2], nullptr, 0);
+    EncryptionParameters params;
+    char poly_mod[32];
+    std::snprintf(poly_mod, sizeof poly_mod, "1x^%i + 1", n);
+    params.set_poly_modulus(poly_mod);
+    params.set_coeff_modulus(coeff_modulus_128(n));
+    params.set_plain_modulus(t);
+    SEALContext context(params);
+    KeyGenerator keygen(context);
+    PublicKey public_key = keygen.public_key();
+    Encryptor encryptor(context, public_key);
+    Evaluator evaluator(context);
+    FractionalEncoder encoder(context.plain_modulus(), context.poly_modulus(), 100, 100, 2);       // homo/server_resize.cpp:110
+    seal::detail::encrypt_hook() = [](const seal::Plaintext &, seal::Ciphertext &out) -> bool {
+        if (g_hook.empty()) { std::fprintf(stderr, "encrypt hook exhausted\n"); std::exit(2); }
+        out = g_hook.front();
+        g_hook.pop_front();
+        return true;
+    };
+    const seal::detail::CtxState &st = *context.state();
+    uint64_t seed = 1;
+    auto random_batch = [&](size_t count, uint32_t size) {           // random-residue ciphertexts (every op is defined on them)
+        CiphertextBatch b(context, count, size);
+        seal::detail::check(fhe_fill_random(st.h, b.ptr(), count * size, 0x5EA12026ULL + 977 * seed++, 0, nullptr), "fill");
+        return b;
+    };
+    seal::hip::Circuits circ(context, 100, 100);
+
+    // ---- Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 and 3 -> 4 ----------------------------
+    for (uint32_t size : {2u, 4u}) {
+        const size_t cnt = 3;
+        CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), C = random_batch(cnt, size), D = random_batch(cnt, size), T = random_batch(cnt, 2);
+        CiphertextBatch got = circ.cubic(A, B, C, D, T);
+        for (size_t i = 0; i < cnt; ++i) {
+            Ciphertext a = A.get(i), b = B.get(i), c = C.get(i), d = D.get(i), tt = T.get(i), res;
+            Cubic(res, a, b, c, d, tt, evaluator, encoder, encryptor);                              // homo/fhe_resize.h:143
+            expect_equal(size == 2 ? "Cubic(2)" : "Cubic(4)", i, res, got, i);
+        }
+    }
+    for (uint32_t size : {2u, 3u}) {
+        const size_t cnt = 3;
+        CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), T = random_batch(cnt, 2);
+        CiphertextBatch got = circ.linear(A, B, T);
+        for (size_t i = 0; i < cnt; ++i) {
+            Ciphertext a = A.get(i), b = B.get(i), tt = T.get(i), res;
+            Linear(res, a, b, tt, evaluator, encoder, encryptor);                                   // homo/fhe_resize.h:191
+            expect_equal(size == 2 ? "Linear(2)" : "Linear(3)", i, res, got, i);
+        }
+    }
+    std::printf("\n");
+
+    // ---- SampleBicubic / SampleLinear over an image (the sampling loop of ResizeImage, :350-388) -------------------------
+    const int W = 7, H = 6, w = 5, h = 4;
+    CiphertextBatch chan[3] = {random_batch(W * H, 2), random_batch(W * H, 2), random_batch(W * H, 2)};
+    SImageData image;
+    image.width = W; image.height = H; image.start = 0;
+    for (int p = 0; p < W * H; ++p) image.pixels.push_back({chan[0].get(p), chan[1].get(p), chan[2].get(p)});
+    for (int bicubic = 0; bicubic < 2; ++bicubic) {
+        seal::hip::SamplePlan plan = seal::hip::resize_sample_plan(W, H, w, h, bicubic);
+        CiphertextBatch xf = random_batch(w * h, 2), yf = random_batch(w * h, 2);
+        CiphertextBatch got[3];
+        for (int ch = 0; ch < 3; ++ch)
+            got[ch] = bicubic ? circ.sample_bicubic(chan[ch], plan.taps.data(), xf, yf) : circ.sample_linear(chan[ch], plan.taps.data(), xf, yf);
+        for (int y = 0; y < h; ++y) {
+            float v = float(y) / float(h - 1) * float(H) - 0.5;                                     // :351
+            for (int x = 0; x < w; ++x) {
+                float u = float(x) / float(w - 1) * float(W) - 0.5;                                 // :382
+                g_hook.push_back(xf.get(y * w + x));
+                g_hook.push_back(yf.get(y * w + x));
+                std::vector<Ciphertext> sample(3);
+                if (bicubic) SampleBicubic(sample, image, u, v, evaluator, encoder, encryptor);     // :386
+                else SampleLinear(sample, image, u, v, evaluator, encoder, encryptor);              // :384
+                for (int ch = 0; ch < 3; ++ch) expect_equal(bicubic ? "SampleBicubic" : "SampleLinear", (size_t)(y * w + x) * 3 + ch, sample[ch], got[ch], y * w + x);
+            }
+        }
+    }
+    {   // shared offsets: one ciphertext per output column / row; every pixel must equal SampleBicubic with (xf[x], yf[y])
+        CiphertextBatch xf = random_batch(w, 2), yf = random_batch(h, 2);
+        CiphertextBatch got = circ.resize_bicubic(chan[1], W, H, w, h, xf, yf, 8, 3);
+        SImageData one;
+        one.width = W; one.height = H; one.start = 0;
+        for (int p = 0; p < W * H; ++p) one.pixels.push_back({chan[1].get(p), chan[1].get(p), chan[1].get(p)});
+        for (int y = 0; y < h; ++y) {
+            float v = float(y) / float(h - 1) * float(H) - 0.5;
+            for (int x = 0; x < w; ++x) {
+                float u = float(x) / float(w - 1) * float(W) - 0.5;
+                g_hook.push_back(xf.get(x));
+                g_hook.push_back(yf.get(y));
+                std::vector<Ciphertext> sample(3);
+                SampleBicubic(sample, one, u, v, evaluator, encoder, encryptor);
+                expect_equal("resize_bicubic(shared)", (size_t)y * w + x, sample[0], got, (size_t)y * w + x);
+            }
+        }
+    }
+    std::printf("\n");
+
+    // ---- decode path ----------------------------------------------------------------------------------------------------
+    {
+        const size_t cnt = 2;
+        CiphertextBatch X = random_batch(cnt, 2), Z = random_batch(cnt, 2);
+        CiphertextBatch s = circ.homomorphic_sin(X, Z), c = circ.homomorphic_cos(X, Z);
+        for (size_t i = 0; i < cnt; ++i) {
+            Ciphertext x = X.get(i), res;
+            g_hook.push_back(Z.get(i));
+            scrub_stack();
+            homomorphic_sin(x, res, evaluator, encoder, encryptor);                                 // homo/fhe_decode.h:48
+            expect_equal("homomorphic_sin", i, res, s, i);
+            Ciphertext x2 = X.get(i), res2;
+            g_hook.push_back(Z.get(i));
+            scrub_stack();
+            homomorphic_cos(x2, res2, evaluator, encoder, encryptor);                               // :128
+            expect_equal("homomorphic_cos", i, res2, c, i);
+        }
+    }
+    {
+        const int width = 3, height = 1, degree = 2, order = 64, pairs = 2;
+        const double delta = 0.5;
+        const size_t npos = (size_t)width * height;
+        CiphertextBatch runs = random_batch(2 * pairs, 2), acc0 = random_batch(npos, 2), zeros = random_batch((size_t)pairs * npos * degree * 2, 2), idx0 = random_batch(1, 2);
+        // one run through approximated_step alone
+        {
+            CiphertextBatch z1(context, npos * degree * 2, 2);
+            for (size_t i = 0; i < z1.count(); ++i) z1.set(i, zeros.get(i));
+            Ciphertext amp = runs.get(0), index = idx0.get(0), cnt = runs.get(1);
+            CiphertextBatch got = circ.approximated_step(amp, index, cnt, order, degree, delta, width, height, z1);
+            for (size_t i = 0; i < z1.count(); ++i) g_hook.push_back(z1.get(i));
+            std::vector<Ciphertext> run;
+            scrub_stack();
+            approximated_step(amp, index, cnt, order, degree, delta, width, height, run, evaluator, encoder, encryptor);      // :202
+            for (size_t i = 0; i < npos; ++i) expect_equal("approximated_step", i, run[i], got, i);
+        }
+        // the per-channel driver loop, homo/server_decode.cpp:120-137, with the homomorphic overload
+        Ciphertext index_b = idx0.get(0);
+        CiphertextBatch got = circ.decode_channel(runs, index_b, acc0, zeros, order, degree, delta, width, height);
+        Ciphertext index = idx0.get(0);                                                             // :121
+        std::vector<Ciphertext> channel;
+        for (size_t j = 0; j < npos; ++j) channel.push_back(acc0.get(j));                           // :124-128
+        for (size_t i = 0; i < zeros.count(); ++i) g_hook.push_back(zeros.get(i));
+        for (int j = 0; j < pairs; ++j) {
+            std::vector<Ciphertext> run;
+            Ciphertext elem = runs.get(2 * j), count = runs.get(2 * j + 1);                         // :131-132
+            scrub_stack();
+            approximated_step(elem, index, count, order, degree, delta, width, height, run, evaluator, encoder, encryptor);   // :133 (homomorphic overload)
+            for (size_t k = 0; k < npos; ++k) evaluator.add(channel[k], run[k]);                    // :134-136
+            evaluator.add(index, count);                                                            // :137
+        }
+        for (size_t k = 0; k < npos; ++k) expect_equal("decode_channel", k, channel[k], got, k);
+        if (host(index) != host(index_b)) { std::printf("MISMATCH decode_channel index\n"); ++g_fail; }
+    }
+    std::printf("\n");
+    if (!g_hook.empty()) { std::printf("MISMATCH: %zu hook ciphertexts unused\n", g_hook.size()); ++g_fail; }
+    std::printf(g_fail ? "FAILED: %d mismatches\n" : "OK: reference circuits == batched C++ API, bit for bit\n", g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -110,3 +110,69 @@ def run_decode_circuit(workdir, orc, mode, inputs, hook_cts, gpu, n_arg, extra=(
         pos += s * orc.k * orc.n
     assert pos == raw.size
     return out
+
+
+def run_server_decode(workdir, orc, runs, pairs, width, height, hook_cts, gpu, n_arg, order, degree, delta, env_extra=None):
+    """homo/server_decode.cpp's main (unchanged; its approximated_step call sent to the homomorphic overload by
+    oracle/ref_server_decode_main.cpp) on a ciphertext stream.  runs: [sum(pairs), 2, 2, k, n] (elem, count per
+    run, channel after channel); hook_cts: the server-side Enc(0)s in call order.  Returns the raw output file."""
+    exe = ref_bin("ref_server_decode", gpu)
+    os.makedirs(os.path.join(workdir, "keys"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "image"), exist_ok=True)
+    with open(os.path.join(workdir, "keys", "params.txt"), "w") as f:
+        f.write("%d %d %d %d %d\n" % (width, height, pairs[0], pairs[1], pairs[2]))
+    sk, pk = orc.keygen(3)
+    with open(os.path.join(workdir, "keys", "pubkey.txt"), "wb") as f:
+        write_record(f, pk)
+    with open(os.path.join(workdir, "keys", "seckey.txt"), "wb") as f:
+        write_record(f, sk[None])
+    with open(os.path.join(workdir, "image", "in.ct"), "wb") as f:
+        for r in range(runs.shape[0]):
+            write_record(f, runs[r, 0])
+            write_record(f, runs[r, 1])
+    hook = os.path.join(workdir, "hook.bin")
+    np.ascontiguousarray(hook_cts, dtype=np.uint64).tofile(hook)
+    env = dict(os.environ, FHE_ENCRYPT_HOOK_FILE=hook)
+    env.update(env_extra or {})
+    argv = [exe, "--cmod", str(n_arg), "--pmod", str(orc.t), "--order", str(order), "--degree", str(degree), "--delta", repr(float(delta)),
+            "-f", "image/in.ct", "-o", "image/out.ct"]
+    r = subprocess.run(argv, cwd=workdir, env=env, capture_output=True, text=True, timeout=3600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return open(os.path.join(workdir, "image", "out.ct"), "rb").read()
+
+
+def parse_stream(raw, k, n):
+    """a ciphertext stream of records of any sizes -> list of arrays [size, k, n]"""
+    out, pos = [], 0
+    while pos < len(raw):
+        magic, s, kk, nn, _ = HDR.unpack(raw[pos:pos + HDR.size])
+        assert magic[:7] == b"FHEHIP1" and (kk, nn) == (k, n)
+        pos += HDR.size
+        out.append(np.frombuffer(raw[pos:pos + s * k * n * 8], dtype=np.uint64).reshape(s, k, n))
+        pos += s * k * n * 8
+    return out
+
+
+def oracle_server_decode(orc, om, runs, pairs, width, height, hook_cts, order, degree, delta):
+    """The driver loop of homo/server_decode.cpp:120-143 composed from the ORACLE's single operations (restated here,
+    independently of the product's server.py / csrc/circuits.hip).  Returns res[channel][position]."""
+    npos = width * height
+    it = iter(range(hook_cts.shape[0]))
+    nxt = lambda: hook_cts[next(it)]
+    res, r = [], 0
+    for ch in range(3):
+        index = nxt()                                                  # :121
+        channel = [nxt() for _ in range(npos)]                        # :124-128
+        for _ in range(pairs[ch]):
+            elem, count = runs[r, 0], runs[r, 1]                      # :131-132
+            r += 1
+            bank = {}
+            for i in range(npos):                                      # the Enc(0)s of :231-232 in call order
+                for j in range(1, degree + 1):
+                    bank[(i, j, "sin")] = nxt()
+                    bank[(i, j, "cos")] = nxt()
+            run = om.oracle_approximated_step(orc, elem, index, count, order, degree, delta, width, height, lambda i, j, w: bank[(i, j, w)])   # :133
+            channel = [orc.add(channel[k], run[k]) for k in range(npos)]   # :134-136
+            index = orc.add(index, count)                             # :137
+        res.append(channel)
+    return res

@@ -1,0 +1,22 @@
+"""GPU: the batched C++ host API (seal::hip::Circuits over include/fhe_circuits.h) against the REFERENCE's own circuit
+functions run one ciphertext at a time through the facade, in ONE C++ process (oracle/ref_vs_batched_main.cpp):
+Cubic (sizes 2, 4), Linear (2, 3), SampleBicubic / SampleLinear over an image, the shared-offset resize,
+homomorphic_sin / cos, approximated_step and the per-channel loop of homo/server_decode.cpp:120-137 -- bit for bit."""
+import os
+import subprocess
+
+import pytest
+
+from refrun import ref_bin
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,env", [(4096, {}), (8192, {"FHE_SEAL23_MODULI": "1"})])
+def test_reference_functions_equal_batched_cpp_api(n, env):
+    exe = ref_bin("ref_vs_batched", True)
+    if not exe:
+        pytest.skip("oracle/_ref/ref_vs_batched not built (needs /root/reference at build time)")
+    r = subprocess.run([exe, str(n), str(1 << 14)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1800)
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "OK: reference circuits == batched C++ API" in r.stdout and "MISMATCH" not in r.stdout, tail
