@@ -94,9 +94,11 @@ def main():
     ap.add_argument("--cpu-blocks", type=int, default=16, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--preset", default="P4096", help="parameter set (default: the BASELINE.json configuration)")
-    ap.add_argument("--gather", choices=["none", "wave"], default="none",
+    ap.add_argument("--gather", choices=["none", "wave", "local"], default="none",
                     help="wave: every wave of output ciphertexts is sent to rank 0 (RCCL send/recv over xGMI, overlapped with the "
-                         "next wave's compute) and drained there by digest; none (default): outputs stay sharded (SURVEY.md 8e)")
+                         "next wave's compute) and drained there by digest; local: every rank drains ITS OWN waves to pinned host "
+                         "memory over its own PCIe link (parallel.LocalDrain; the consumer that scales with the GPU count); "
+                         "none (default): outputs stay sharded in HBM (SURVEY.md 8e)")
     ap.add_argument("--gather-wave-blocks", type=int, default=64)
     args = ap.parse_args()
 
@@ -140,8 +142,26 @@ def main():
                             index0=(src * B + w * wave) * words_per_block)
         if world > 1:
             gather = fhe.parallel.WaveGather((wave,) + tuple(blocks.shape[1:]), blocks.dtype, blocks.device, n_waves, consume=consume)
+    local = None
+    if args.gather == "local":
+        if B % args.gather_wave_blocks:
+            raise SystemExit("--blocks must be a multiple of --gather-wave-blocks")
+        wave, n_waves = args.gather_wave_blocks, B // args.gather_wave_blocks
+        drained = [0]
+
+        def on_host(w, host_tensor):                            # where a per-GPU stream writer would take over
+            drained[0] += host_tensor.numel() * 8
+        local = fhe.parallel.LocalDrain((wave,) + tuple(blocks.shape[1:]), blocks.dtype, blocks.device, consume=on_host)
 
     def step():
+        if args.gather == "local":
+            for w in range(n_waves):
+                buf = local.acquire()
+                ev.dct8x8_quant(plan, blocks[w * wave:(w + 1) * wave], out=buf)
+                local.commit(w)
+            local.finish()
+            local.reset()
+            return
         if args.gather != "wave":
             ev.dct8x8_quant(plan, blocks, out=out)
             return
@@ -178,13 +198,26 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    rank_ms, rccl_ranks = [wall / args.steps * 1e3], 1
     if dist is not None:
         tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # self-check of the multi-GPU run: every rank contributes 1 to a SUM all-reduce (= ranks RCCL really connected)
+        # and its own per-step time to an all-gather, so the one JSON line shows the whole job
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
+        mine = torch.tensor([wall / args.steps * 1e3], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) for t in every]
         wall = float(tt.item())
 
     # ---- verification: sampled blocks against the CPU oracle, digest over everything -----------------
-    if args.gather == "wave":       # the root holds the digest of every rank's last step; the ciphertexts were not kept
+    if args.gather == "local":      # the last step's waves went to the host; digest a fresh in-HBM evaluation of the same inputs
+        ev.dct8x8_quant(plan, blocks, out=out)
+        digest_all = fhe.parallel.combine_digests(ctx.digest(out.view(-1), index0=first_index))
+    elif args.gather == "wave":     # the root holds the digest of every rank's last step; the ciphertexts were not kept
         digest_all = int(wave_digests.cpu().numpy().view(np.uint64).sum(dtype=np.uint64)) if rank == 0 else 0
         if gather is not None:
             out = None
@@ -223,30 +256,44 @@ def main():
                 traffic_src = tj.get("source")
             else:
                 traffic_src = "profiles/pmc_traffic.json was measured on other kernel sources (%s); re-run tools/collect_traffic.py" % tj.get("kernel_source_hash")
+        path = fhe._lib.load().fhe_dct_path(ctx.h)             # 1 fused FP64 pair, 2 fused u64 pair, 0 general three-launch path
+        kernels = {1: "k_dct_rows + k_dct_cols", 2: "k_dct_rows_u64 + k_dct_cols_u64", 0: "k_ntt_fwd + k_dct_slots + k_ntt_inv"}[path]
         res = {
             "metric": "encrypted 8x8 blocks/sec (homomorphic DCT+quant)",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if path == 1 else "u64", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": rank_ms,
             "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=%d, %d coeff moduli, t=2^14" % (B, ctx.n, ctx.k),
                        "blocks_per_gpu": B, "poly_modulus_degree": ctx.n, "coeff_moduli": [hex(x) for x in ctx.q],
                        "sharding": ("blocks x%d, no data-path collective" % world) if args.gather == "none" else
+                                   ("blocks x%d, every rank drains its own %d-block waves to pinned host memory over its own PCIe link" % (world, args.gather_wave_blocks))
+                                   if args.gather == "local" else
                                    ("blocks x%d, every %d-block wave of outputs sent to rank 0 (RCCL send/recv) and drained by digest" % (world, args.gather_wave_blocks)),
                        "gather": args.gather,
-                       "arithmetic": ("exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out"
-                                      if max(ctx.q) < (1 << 47) else "u64 Shoup/Barrett modular arithmetic (general path)")},
+                       "arithmetic": {1: "exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out",
+                                      2: "u64 Shoup modular arithmetic, fused row / column kernels",
+                                      0: "u64 Shoup modular arithmetic, general three-launch path"}[path]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_dct_rows + k_dct_cols (the two launches of fhe_dct8x8_quant, all waves of one step; "
-                                   "HIP events on the launch stream)",
+                         "kernel": kernels + " (the launches of fhe_dct8x8_quant, all waves of one step; HIP events on the launch stream)",
                          "algorithmic_bytes_per_launch": B * bytes_per_block, "algorithmic_bytes_per_block": bytes_per_block,
                          "ms_per_launch": dev_ms_per_step},
             # secondary view: the fused circuit needs ~213e6 FP64 lane-operations per block;
             # 29.3e12/s is the densest v_fma_f64 rate measured on this chip (profiles/r01_ubench2_fp64_latency.txt)
-            "fp64_alu": {"ops_per_block": 213e6, "achieved_tops": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 1e12,
-                         "measured_peak_tops": 29.3, "frac": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 29.3e12},
             "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
         }
+        if path == 1 and ctx.n == 4096 and ctx.k == 3:
+            res["fp64_alu"] = {"ops_per_block": 213e6, "achieved_tops": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 1e12,
+                               "measured_peak_tops": 29.3, "frac": 213e6 * (B / (dev_ms_per_step * 1e-3)) / 29.3e12}
+        elif path != 1:
+            # issue-side view for the u64 kernels: 64-bit modular products per block (512 transforms of (n/2) log2 n butterflies
+            # + the per-slot circuit's 4.3 per coefficient) against the measured v_mad_u64_u32-bound product rate
+            # (tools/ubench4.hip, profiles/r02_ubench4_shoup_products.txt: 4.5 products/clk/CU = 2.76 T/s at 2.4 GHz x 256 CUs)
+            logn = ctx.n.bit_length() - 1
+            per_block = 2 * ctx.k * (2 * 64 * (ctx.n // 2) * logn + 64 * ctx.n * 4.3) if path == 2 else 2 * ctx.k * (2 * 64 * (ctx.n // 2) * logn + 64 * ctx.n * 5.0)
+            res["issue_roofline"] = {"modular_products_per_block": per_block, "achieved_tproducts": per_block * (B / (dev_ms_per_step * 1e-3)) / 1e12,
+                                     "measured_peak_tproducts": 2.76, "frac": per_block * (B / (dev_ms_per_step * 1e-3)) / 2.76e12}
         if world == 1 and args.cpu_blocks > 0 and args.preset == "P4096":
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
             try:

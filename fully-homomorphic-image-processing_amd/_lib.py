@@ -70,6 +70,7 @@ SIGNATURES = {
     "fhe_dct_plan_create": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(_vp)]),
     "fhe_dct_plan_destroy": (_i, [_vp]),
     "fhe_dct8x8_scratch_bytes": (_sz, [_vp, _u64]),
+    "fhe_dct_path": (_i, [_vp]),
     "fhe_dct8x8_quant": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
     "fhe_rgb_to_ycc": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _i, _vp]),
     "fhe_fill_random": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
@@ -97,7 +98,7 @@ SIGNATURES = {
     "fhe_decode_channel": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _sz, _vp]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
-_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode"}
+_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path"}
 
 
 def load():

@@ -507,9 +507,9 @@ int fhe_behz_build(fhe_ctx *c) {
     int q_bits = 0;
     for (u64 qi : q) q_bits += bit_length(qi);
     const int need = q_bits + bit_length(c->t) + (int)c->logn + 8 + 4;
-    const int aux_bits = (57 * (int)(k + 1) >= need && !getenv("FHE_BEHZ_AUX61")) ? 58 : 61;
+    const int aux_bits = (57 * (int)(k + 1) >= need && !c->opt.behz_aux61) ? 58 : 61;
     T->aux_bits = aux_bits;
-    T->wide_dot = aux_bits == 58 && c->max_prime_bits <= 58 && k <= 8 && !getenv("FHE_BEHZ_CHUNK3");
+    T->wide_dot = aux_bits == 58 && c->max_prime_bits <= 58 && k <= 8 && !c->opt.behz_chunk3;
     std::vector<u64> found;
     for (u64 cand = (1ULL << aux_bits) + 1 - (1ULL << 17); found.size() < k + 1; cand -= (1ULL << 17)) {
         if (!is_prime(cand)) continue;
@@ -611,8 +611,7 @@ extern "C" size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint
 // q-base transforms of `n_rns` RNS polynomials: the FP64 kernels where the context supports them (same
 // NTT-form order and canonical residues as the u64 kernels), the u64 kernels otherwise
 static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_rns, hipStream_t st) {
-    static const bool force_u64 = [] { const char *e = getenv("FHE_DCT_FORCE_U64"); return e && *e && !(e[0] == '0' && !e[1]); }();
-    if (n_rns && fhe_rgb_f64_supported(c) && !force_u64) return fhe_poly_f64_launch(inverse ? 1 : 0, c, in, out, n_rns, nullptr, st);
+    if (n_rns && fhe_rgb_f64_supported(c) && !c->opt.force_u64) return fhe_poly_f64_launch(inverse ? 1 : 0, c, in, out, n_rns, nullptr, st);
     return fhe_ntt_launch(inverse, c, c->qb, in, out, n_rns * c->k, st);
 }
 
@@ -625,6 +624,7 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
                         else k_behz_to_bsk<KK, TO_BSK_CPT, DOT_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
+        default: return fail(FHE_ERR_PARAM, "base extension is built for up to 8 coefficient moduli, not %u", k);
     }
     int r = fhe_ntt_launch(false, c, c->behz->aux, xb, xb, count * s * (k + 1), st);
     if (r) return r;
@@ -635,11 +635,8 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
 static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm,
                        bool wide_base) {
     const u32 nb = base.count, so = sa + sb - 1;
-    const bool wide = wide_base && (sa < sb ? sa : sb) <= 12 && !getenv("FHE_BEHZ_TENSOR_CANON");     // terms per output <= min(sa, sb); 12 x 5q < 2^64
-    static const bool single = [] {      // FHE_BEHZ_TENSOR_SINGLE: only this step on the one-polynomial kernel (which has the range-tracking inverse)
-        auto on = [](const char *n) { const char *e = getenv(n); return e && *e && !(e[0] == '0' && !e[1]); };
-        return on("FHE_NTT_SINGLE") || on("FHE_BEHZ_TENSOR_SINGLE");
-    }();
+    const bool wide = wide_base && (sa < sb ? sa : sb) <= 12 && !c->opt.behz_tensor_canon;     // terms per output <= min(sa, sb); 12 x 5q < 2^64
+    const bool single = c->opt.ntt_single || c->opt.behz_tensor_single;      // behz_tensor_single: only this step on the one-polynomial kernel (which has the range-tracking inverse)
     u64 done = 0;
     if (c->logn >= 13 && !single && count >= 2) {
         const u64 pairs = count / 2;
@@ -685,6 +682,7 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
                         else k_behz_floor_back<KK, DOT_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
+        default: return fail(FHE_ERR_PARAM, "floor / back conversion is built for up to 8 coefficient moduli, not %u", k);
     }
     KERNEL_CHECK();
     return FHE_OK;

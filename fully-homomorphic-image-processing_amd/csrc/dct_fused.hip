@@ -658,15 +658,11 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_poly_f6
 
 }  // namespace
 
-static int dct_le() {   // coefficients per thread = 2^LE; 3 keeps four waves per SIMD resident
-    static int le = [] { const char *e = getenv("FHE_DCT_LE"); int v = e ? atoi(e) : 3; return (v == 4) ? 4 : 3; }();
-    return le;
-}
 
 // coefficients per thread = 2^LE of the fused pair for this context: 8 (four waves per SIMD) at n = 4096 with primes
 // <= 40 bits and at n = 8192 (1024-thread workgroups, one per CU); 16 otherwise
 static u32 dct_shape_le(const fhe_ctx *c) {
-    if (dct_le() != 3) return 4;
+    if (c->opt.dct_le != 3) return 4;      // coefficients per thread = 2^LE; 3 keeps four waves per SIMD resident
     if (c->logn == 12 && c->max_prime_bits <= 40) return 3;
     if (c->logn == 13 || c->logn == 11) return 3;
     return 4;
@@ -685,18 +681,10 @@ int fhe_dct_f64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st
     return FHE_OK;
 }
 
-static bool dct_pack_enabled() {
-    static const bool on = [] { const char *e = getenv("FHE_DCT_PACK"); return !(e && e[0] == '0' && !e[1]); }();
-    return on;
-}
 
-// row kernel: circuit constants through LDS (stage_consts); FHE_DCT_LDSC=0 reads them into registers as before.
+// row kernel: circuit constants through LDS (stage_consts); FheOptions::dct_ldsc = false reads them into registers as before.
 // (The column kernel has four more constants per slot and no register to spare: the same staging spills 36-56 VGPRs
 // there and measured 68 k blocks/s against 80 k, so it keeps its loads.)
-static bool dct_ldsc_enabled() {
-    static const bool on = [] { const char *e = getenv("FHE_DCT_LDSC"); return !(e && e[0] == '0' && !e[1]); }();
-    return on;
-}
 
 template <int L, int LE>
 static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in, u64 *out, double *mid, unsigned grid, bool big, hipStream_t st, int which) {
@@ -714,9 +702,9 @@ static void launch_pair(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *i
             if (which & 2) k_dct_cols<L, LE, true, false><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);
             return;
         }
-        if (c->max_prime_bits <= 37 && dct_pack_enabled()) {      // packed intermediate, 40 instead of 64 bytes
+        if (c->max_prime_bits <= 37 && c->opt.dct_pack) {      // packed intermediate, 40 instead of 64 bytes
             if (which & 1) {
-                if (dct_ldsc_enabled()) k_dct_rows<L, LE, false, true, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
+                if (c->opt.dct_ldsc) k_dct_rows<L, LE, false, true, true><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
                 else k_dct_rows<L, LE, false, true, false><<<grid, TP, 0, st>>>(in, mid, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_mod, c->k);
             }
             if (which & 2) k_dct_cols<L, LE, false, true><<<grid, TP, 0, st>>>(mid, out, plan->d_consts_f64, c->qb.d_itw_f64, c->qb.d_mod, c->k);

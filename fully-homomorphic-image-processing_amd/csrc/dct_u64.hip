@@ -357,8 +357,7 @@ __global__ void k_consts_to_le3(const ulonglong2 *__restrict__ in, ulonglong2 *_
 }  // namespace
 
 bool fhe_dct_u64_supported(const fhe_ctx *c) {
-    static const bool off = [] { const char *e = getenv("FHE_DCT_U64_FUSED"); return e && e[0] == '0' && !e[1]; }();
-    return c && !off && c->max_prime_bits <= 57 && (c->logn == 11 || c->logn == 12 || c->logn == 13);
+    return c && c->opt.dct_u64_fused && c->max_prime_bits <= 57 && (c->logn == 11 || c->logn == 12 || c->logn == 13);
 }
 
 int fhe_dct_u64_make_consts(const fhe_ctx *c, fhe_dct_plan *plan, hipStream_t st) {

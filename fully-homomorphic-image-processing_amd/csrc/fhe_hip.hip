@@ -152,6 +152,23 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
             if (primes[j] == primes[i]) return fail(FHE_ERR_PARAM, "duplicate modulus");
     }
     fhe_ctx *c = new fhe_ctx();
+    {   // the experiment switches, once (internal.h: FheOptions)
+        FheOptions &o = c->opt;
+        auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0' && !e[1]; };
+        o.force_u64 = env_on("FHE_DCT_FORCE_U64");
+        o.dct_pipeline = env_on("FHE_DCT_PIPELINE");
+        if (const char *e = getenv("FHE_DCT_WAVE_BLOCKS")) { const u64 v = strtoull(e, nullptr, 10); if (v) o.dct_wave_blocks = v; }
+        if (const char *e = getenv("FHE_DCT_LE")) o.dct_le = atoi(e) == 4 ? 4 : 3;
+        o.dct_pack = !off("FHE_DCT_PACK");
+        o.dct_ldsc = !off("FHE_DCT_LDSC");
+        o.dct_u64_fused = !off("FHE_DCT_U64_FUSED");
+        o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
+        o.ntt_single = env_on("FHE_NTT_SINGLE");
+        o.behz_aux61 = env_on("FHE_BEHZ_AUX61");
+        o.behz_chunk3 = env_on("FHE_BEHZ_CHUNK3");
+        o.behz_tensor_canon = env_on("FHE_BEHZ_TENSOR_CANON");
+        o.behz_tensor_single = env_on("FHE_BEHZ_TENSOR_SINGLE");
+    }
     c->n = n;
     c->k = k;
     c->t = t;
@@ -551,10 +568,10 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     if (n_res_polys == 0) return FHE_OK;
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     const RnsBase base = B.dev();
-    bool lazy = !env_on("FHE_NTT_NOLAZY");        // forward transform without conditional subtractions, inverse with static range tracking: every prime of the base <= 58 bits
+    bool lazy = !c->opt.ntt_nolazy;        // forward transform without conditional subtractions, inverse with static range tracking: every prime of the base <= 58 bits
     // n >= 8192: two polynomials of one prime per workgroup, every twiddle pair fetched once for both (P8192 forward +7 %,
     // inverse +19 %; at n = 4096 the pair kernels spill and are slower, so single polynomials stay there)
-    const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !env_on("FHE_NTT_SINGLE");
+    const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !c->opt.ntt_single;
     for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0 && (p >> 33) != 0;      // canon_below_64q needs q >= 2^33
     DISPATCH_L(c->logn, {
         if (inverse && pair && lazy) k_ntt_inv2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
@@ -571,12 +588,12 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
 
 extern "C" int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
-    if (n_polys && fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) return fhe_poly_f64_launch(0, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
+    if (n_polys && fhe_rgb_f64_supported(c) && !c->opt.force_u64) return fhe_poly_f64_launch(0, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
     return fhe_ntt_launch(false, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 extern "C" int fhe_ntt_inverse(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n_polys, fhe_stream s) {
     if (!c || !in || !out) return fail(FHE_ERR_PARAM, "null argument");
-    if (n_polys && fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) return fhe_poly_f64_launch(1, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
+    if (n_polys && fhe_rgb_f64_supported(c) && !c->opt.force_u64) return fhe_poly_f64_launch(1, c, (const u64 *)in, (u64 *)out, n_polys, nullptr, (hipStream_t)s);
     return fhe_ntt_launch(true, c, c->qb, (const u64 *)in, (u64 *)out, n_polys * c->k, (hipStream_t)s);
 }
 
@@ -586,7 +603,7 @@ extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t
     const u64 nrp = n_polys * c->k;
     if (nrp == 0) return FHE_OK;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
-    if (fhe_rgb_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64"))
+    if (fhe_rgb_f64_supported(c) && !c->opt.force_u64)
         return fhe_poly_f64_launch(2, c, (const u64 *)in, (u64 *)out, n_polys, (const ulonglong2 *)d_plain_ntt, (hipStream_t)s);
     const RnsBase base = c->qb.dev();
     hipStream_t st = (hipStream_t)s;
@@ -960,14 +977,18 @@ extern "C" int fhe_dct_plan_destroy(fhe_dct_plan *p) {
 // The fused path keeps one row-transformed copy of a wave of blocks between its two kernels
 // (12 MiB per block at n=4096, k=3).  Measured: 32 blocks 74.4 k blocks/s, 64: 76.7 k, 128: 78.3 k,
 // 256: 79.1 k, 512: 79.0 k (launch tails amortise; Infinity Cache residency of the copy does not pay).
-static u64 dct_wave_blocks() {
-    if (const char *e = getenv("FHE_DCT_WAVE_BLOCKS")) { u64 v = strtoull(e, nullptr, 10); if (v) return v; }
-    return 256;
-}
+static u64 dct_wave_blocks(const fhe_ctx *c) { return c->opt.dct_wave_blocks; }
 extern "C" size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *c, uint64_t n_blocks) {
     if (!c || !(fhe_dct_f64_supported(c) || fhe_dct_u64_supported(c))) return 0;
-    const u64 wave = dct_wave_blocks() < n_blocks ? dct_wave_blocks() : n_blocks;
+    const u64 wave = dct_wave_blocks(c) < n_blocks ? dct_wave_blocks(c) : n_blocks;
     return (size_t)wave * 64 * 2 * c->k * c->n * sizeof(double);
+}
+
+extern "C" int fhe_dct_path(const fhe_ctx *c) {
+    if (!c) return fail(FHE_ERR_PARAM, "null argument");
+    if (fhe_dct_f64_supported(c) && !c->opt.force_u64) return 1;
+    if (fhe_dct_u64_supported(c) && !c->opt.force_u64) return 2;
+    return 0;
 }
 
 extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out, uint64_t n_blocks,
@@ -976,13 +997,13 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
     if (plan->k != c->k || plan->n != c->n) return fail(FHE_ERR_PARAM, "plan was built for another context");
     if (n_blocks == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)s;
-    if (plan->d_consts_f64 && fhe_dct_f64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) {
+    if (plan->d_consts_f64 && fhe_dct_f64_supported(c) && !c->opt.force_u64) {
         const size_t per_block = (size_t)64 * 2 * c->k * c->n;
         const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(double)) : 0;
         if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
-        u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
+        u64 wave = fit < dct_wave_blocks(c) ? fit : dct_wave_blocks(c);
         // measured: 68.1k blocks/s pipelined vs 71.8k plain at 64-block waves, so this is opt-in
-        const bool pipelined = env_on("FHE_DCT_PIPELINE") && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
+        const bool pipelined = c->opt.dct_pipeline && fit >= 2 && n_blocks > wave / 2 && wave >= 2;
         if (!pipelined) {
             for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
                 const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
@@ -1014,11 +1035,11 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
         return FHE_OK;
     }
     // primes of 48..57 bits (SEAL 2.3's own coeff_modulus_128 tables): the same two-launch structure in u64 Shoup arithmetic
-    if (plan->d_consts_le3 && fhe_dct_u64_supported(c) && !env_on("FHE_DCT_FORCE_U64")) {
+    if (plan->d_consts_le3 && fhe_dct_u64_supported(c) && !c->opt.force_u64) {
         const size_t per_block = (size_t)64 * 2 * c->k * c->n;
         const u64 fit = scratch ? scratch_bytes / (per_block * sizeof(u64)) : 0;
         if (fit == 0) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_dct8x8_scratch_bytes()");
-        const u64 wave = fit < dct_wave_blocks() ? fit : dct_wave_blocks();
+        const u64 wave = fit < dct_wave_blocks(c) ? fit : dct_wave_blocks(c);
         for (u64 b0 = 0; b0 < n_blocks; b0 += wave) {
             const u64 nb = (n_blocks - b0) < wave ? (n_blocks - b0) : wave;
             int rc = fhe_dct_u64_launch(c, plan, (const u64 *)in + b0 * per_block, (u64 *)out + b0 * per_block, nb, (u64 *)scratch, st);
@@ -1143,7 +1164,7 @@ extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64
     const fhe_ctx::RgbConsts *k9 = nullptr;
     int rc = rgb_consts(c, int_coeffs, frac_coeffs, st, &k9);
     if (rc) return rc;
-    if (k9->d_c_f64 && !env_on("FHE_DCT_FORCE_U64"))
+    if (k9->d_c_f64 && !c->opt.force_u64)
         return fhe_rgb_f64_launch(c, (u64 *)r, (u64 *)g, (u64 *)b, count, k9->d_c_f64, k9->d_off, k9->off_len, st);
     const u64 nrp = count * 2 * c->k;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");

@@ -34,8 +34,29 @@ struct BaseTables {
     RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size()}; }
 };
 
+// Experiment switches.  Read from the environment ONCE, in fhe_ctx_create, and fixed for the life of the context: no
+// launch path calls getenv, two contexts of one process may differ, and a concurrent setenv cannot race a launch.
+// Every default is the measured-best path; the alternatives stay for A/B measurements and for the parity tests that
+// run the fallback kernels (tests/test_gpu_parity.py creates a second context with the variable set).
+struct FheOptions {
+    bool force_u64 = false;          // FHE_DCT_FORCE_U64=1: the u64 kernels where the exact-FP64 ones would run (NTT, multiply_plain, DCT, rgb_to_ycc)
+    bool dct_pipeline = false;       // FHE_DCT_PIPELINE=1: column kernel of wave w on a second stream beside the row kernel of wave w + 1
+    u64 dct_wave_blocks = 256;       // FHE_DCT_WAVE_BLOCKS: blocks per wave of the fused DCT pair (size of the intermediate)
+    int dct_le = 3;                  // FHE_DCT_LE=4: 16 coefficients per thread in the fused FP64 pair where 8 is the default
+    bool dct_pack = true;            // FHE_DCT_PACK=0: FP64 intermediate instead of the packed one (primes <= 37 bits)
+    bool dct_ldsc = true;            // FHE_DCT_LDSC=0: row-kernel constants through registers instead of LDS
+    bool dct_u64_fused = true;       // FHE_DCT_U64_FUSED=0: three-launch general path instead of the fused u64 pair
+    bool ntt_nolazy = false;         // FHE_NTT_NOLAZY=1: Harvey butterflies with conditional subtractions everywhere
+    bool ntt_single = false;         // FHE_NTT_SINGLE=1: one polynomial per workgroup at n >= 8192 as well
+    bool behz_aux61 = false;         // FHE_BEHZ_AUX61=1: 61-bit auxiliary base (SEAL 2.3's size) where 58 bits suffice
+    bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
+    bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions
+    bool behz_tensor_single = false; // FHE_BEHZ_TENSOR_SINGLE=1: tensor + inverse transform one polynomial per workgroup
+};
+
 struct fhe_ctx {
     u32 n = 0, logn = 0, k = 0;
+    FheOptions opt;
     u64 t = 0;
     int device = 0;
     int max_prime_bits = 0;

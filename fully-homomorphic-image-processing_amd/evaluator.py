@@ -49,20 +49,33 @@ def to_host(t):
 class SEALContext:
     """EncryptionParameters + SEALContext: poly_modulus_degree n, coeff_modulus q[], plain_modulus t."""
 
-    def __init__(self, n, q, t, device=0):
+    def __init__(self, n, q, t, device=0, switches=None):
+        """switches: {"FHE_DCT_FORCE_U64": "1", ...} -- experiment switches for THIS context (the library reads them
+        from the environment once, in fhe_ctx_create; they are set around that call only).  Tests and A/B runs."""
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device: this framework has no CPU path")
         self.n, self.q, self.t, self.k = int(n), [int(x) for x in q], int(t), len(q)
         self.device = torch.device("cuda", device)
         arr = (C.c_uint64 * self.k)(*self.q)
         h = C.c_void_p()
-        _lib.call("fhe_ctx_create", self.n, arr, self.k, self.t, device, C.byref(h))
+        import os
+        saved = {name: os.environ.get(name) for name in (switches or {})}
+        try:
+            for name, value in (switches or {}).items():
+                os.environ[name] = str(value)
+            _lib.call("fhe_ctx_create", self.n, arr, self.k, self.t, device, C.byref(h))
+        finally:
+            for name, value in saved.items():
+                if value is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = value
         self.h = h
 
     @classmethod
-    def preset(cls, name, device=0):
+    def preset(cls, name, device=0, switches=None):
         p = PRESETS[name]
-        return cls(p["n"], p["q"], p["t"], device)
+        return cls(p["n"], p["q"], p["t"], device, switches)
 
     def __del__(self):
         h = getattr(self, "h", None)

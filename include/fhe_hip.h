@@ -25,6 +25,13 @@
  *    pipelined DCT mode (FHE_DCT_PIPELINE=1) uses one second stream owned by the context, so at most
  *    one fhe_dct8x8_quant call per context may be in flight in that mode; (2) fhe_ctx_destroy must not
  *    race with any other call on the same context.  Plans and scratch buffers belong to their caller.
+ *  - experiment switches (FHE_DCT_*, FHE_NTT_*, FHE_BEHZ_* environment variables; csrc/internal.h lists
+ *    them) are read ONCE, by fhe_ctx_create, and are fixed for the life of that context: no launch path
+ *    reads the environment.  The defaults are the measured-best kernels; every alternative gives the same
+ *    bits (the parity tests create a second context with the variable set).  Creating a context costs a few
+ *    milliseconds and a few MB of device tables (twiddles for the coefficient base and for the k+1 auxiliary
+ *    primes of the ct x ct path, base-conversion constants, one stream, four events), whether or not the
+ *    caller ever multiplies ciphertexts.
  *  - "NTT form" buffers use a library-internal slot order; they are only meaningful to this
  *    library (produced by fhe_plain_prepare / fhe_ntt_forward, consumed by the matching calls).
  */
@@ -203,6 +210,10 @@ int fhe_dct_plan_create(const fhe_ctx *ctx, const double *quant64, int int_coeff
                         fhe_stream stream, fhe_dct_plan **out);
 int fhe_dct_plan_destroy(fhe_dct_plan *plan);
 size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *ctx, uint64_t n_blocks);
+/* which kernels fhe_dct8x8_quant launches for this context (for labels in measurements): 1 = the fused exact-FP64
+ * pair k_dct_rows + k_dct_cols (primes < 2^47, n <= 8192), 2 = the fused u64 pair k_dct_rows_u64 + k_dct_cols_u64
+ * (primes <= 57 bits, n in 2048..8192), 0 = the general path k_ntt_fwd + k_dct_slots + k_ntt_inv. */
+int fhe_dct_path(const fhe_ctx *ctx);
 int fhe_dct8x8_quant(const fhe_ctx *ctx, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out,
                      uint64_t n_blocks, void *scratch, size_t scratch_bytes, fhe_stream stream);
 

@@ -18,6 +18,12 @@ def _pair(fhe, om, name):
     return fhe.SEALContext(p["n"], p["q"], p["t"]), om.Oracle(p["n"], p["q"], p["t"])
 
 
+def _variant(fhe, ctx, **switches):
+    """a second context on the same parameters with experiment switches set: the library reads them once, in
+    fhe_ctx_create (csrc/internal.h FheOptions); device tensors, plans and prepared plaintexts are interchangeable"""
+    return fhe.SEALContext(ctx.n, ctx.q, ctx.t, switches=switches)
+
+
 @pytest.fixture(scope="module", params=["SMALL", "P4096", "P8192"])
 def pair(request, fhe, oracle_mod):
     return _pair(fhe, oracle_mod, request.param)
@@ -230,10 +236,8 @@ def test_rgb_to_ycc_fp64_path_equals_u64_path_and_extremes(fhe, oracle_mod, monk
     ev.rgb_to_ycc(*fast)
     again = [t.clone() for t in base]
     ev.rgb_to_ycc(*again)
-    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
     slow = [t.clone() for t in base]
-    ev.rgb_to_ycc(*slow)
-    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    fhe.Evaluator(_variant(fhe, ctx, FHE_DCT_FORCE_U64=1)).rgb_to_ycc(*slow)
     for a, b, c in zip(fast, slow, again):
         assert torch.equal(a, b) and torch.equal(a, c)
     for i in (0, 1, 2):
@@ -287,9 +291,7 @@ def test_dct_fp64_path_equals_u64_path(fhe, oracle_mod, preset, n_blocks, monkey
     blocks = ctx.random_ct(n_blocks, 64, seed=99)
     plan = fhe.DctPlan(ctx, fhe.YQT)
     fused = fhe.to_host(ev.dct8x8_quant(plan, blocks))
-    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
-    general = fhe.to_host(ev.dct8x8_quant(plan, blocks))
-    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    general = fhe.to_host(fhe.Evaluator(_variant(fhe, ctx, FHE_DCT_FORCE_U64=1)).dct8x8_quant(plan, blocks))
     assert np.array_equal(fused, general)
     assert np.array_equal(fused[0], orc.dct_quant(fhe.to_host(blocks)[0], fhe.YQT))
 
@@ -324,8 +326,8 @@ def test_dct_fp64_fused_at_n2048(fhe, oracle_mod, monkeypatch):
     out = fhe.to_host(ev.dct8x8_quant(plan, d))
     for b in range(3):
         assert np.array_equal(out[b], orc.dct_quant(blk[b], fhe.YQT)), b
-    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
-    assert np.array_equal(fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), d)), out)
+    ctx_u64 = _variant(fhe, ctx, FHE_DCT_FORCE_U64=1)
+    assert np.array_equal(fhe.to_host(fhe.Evaluator(ctx_u64).dct8x8_quant(fhe.DctPlan(ctx_u64, fhe.YQT), d)), out)
 
 
 @pytest.mark.parametrize("preset", ["SEAL23_4096", "P8192"])
@@ -597,8 +599,8 @@ def test_empty_inputs_are_no_ops(fhe, oracle_mod):
 def test_ragged_block_counts(fhe, oracle_mod, monkeypatch):
     """block counts that do not divide the launch wave (7 blocks in waves of 3)"""
     ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+    ctx = _variant(fhe, ctx, FHE_DCT_WAVE_BLOCKS=3)
     ev = fhe.Evaluator(ctx)
-    monkeypatch.setenv("FHE_DCT_WAVE_BLOCKS", "3")
     blocks = ctx.random_ct(7, 64, seed=77)
     out = fhe.to_host(ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
     for b in (0, 3, 6):
@@ -731,9 +733,8 @@ def test_u64_forward_canonicalisation_at_the_smallest_lazy_primes(fhe, oracle_mo
     """canon_below_64q (csrc/ntt_core.h) estimates the quotient of the lazy forward transform's outputs from their high
     word in single precision; its error bound 2^32 / q is largest at the smallest primes the lazy kernels take (2^33):
     the u64 kernels forced onto 34- / 35-bit primes (the FP64 kernels would take them otherwise), all-(q-1) inputs"""
-    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
     q = [_largest_ntt_prime_below(bits, n), _largest_ntt_prime_below(bits - 1, n)]
-    ctx, orc = fhe.SEALContext(n, q, 1 << 10), oracle_mod.Oracle(n, q, 1 << 10)
+    ctx, orc = fhe.SEALContext(n, q, 1 << 10, switches={"FHE_DCT_FORCE_U64": 1}), oracle_mod.Oracle(n, q, 1 << 10)
     ev = fhe.Evaluator(ctx)
     a = np.zeros((2, 2, ctx.k, ctx.n), dtype=np.uint64)
     for i, qi in enumerate(q):
@@ -764,14 +765,12 @@ def test_fp64_transforms_and_multiply_plain_equal_u64_kernels(fhe, oracle_mod, m
     plain = enc.encode(-0.168736)
     pp = fhe.PreparedPlain(ctx, plain)
 
-    def run():
-        f = ev.ntt_forward(a)
-        return f, ev.ntt_inverse(f), (ev.multiply_plain(a, pp) if n_ct == 4 else None)
+    def run(e):
+        f = e.ntt_forward(a)
+        return f, e.ntt_inverse(f), (e.multiply_plain(a, pp) if n_ct == 4 else None)
 
-    fast = run()
-    monkeypatch.setenv("FHE_DCT_FORCE_U64", "1")
-    slow = run()
-    monkeypatch.delenv("FHE_DCT_FORCE_U64")
+    fast = run(ev)
+    slow = run(fhe.Evaluator(_variant(fhe, ctx, FHE_DCT_FORCE_U64=1)))
     assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1]) and torch.equal(fast[1], a)
     if n_ct == 4:
         assert torch.equal(fast[2], slow[2])
@@ -898,3 +897,53 @@ def test_randomised_op_sequences_vs_oracle(fhe, oracle_mod, preset):
                 dev[i] = ev.multiply(dev[i], dev[j])
                 host[i] = np.stack([orc.multiply(host[i][c], host[j][c]) for c in range(count)])
             assert np.array_equal(fhe.to_host(dev[i]), host[i]), (preset, trial, step, op)
+
+
+# ---------------------------------------------------------------------------------------------
+# the kernels behind the experiment switches (former defaults, fallbacks): same bits as the default path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("switch", ["FHE_BEHZ_AUX61", "FHE_BEHZ_CHUNK3", "FHE_NTT_NOLAZY", "FHE_NTT_SINGLE", "FHE_BEHZ_TENSOR_CANON",
+                                    "FHE_BEHZ_TENSOR_SINGLE"])
+def test_fallback_kernels_give_the_same_bits(fhe, oracle_mod, switch):
+    """61-bit auxiliary base, three-term dot-product schedule, Harvey butterflies with conditional subtractions, one
+    polynomial per workgroup, canonical tensor sum: each selected for a second context (the switches are read in
+    fhe_ctx_create), each bit-equal to the default kernels and to the oracle on transforms, multiply_plain and ct x ct
+    products of sizes 2x2, 3x2 and a square, at n = 8192 with 54/55-bit primes (where all of them differ from the default)."""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, "P8192")
+    alt = _variant(fhe, ctx, **{switch: 1})
+    ev, ev2 = fhe.Evaluator(ctx), fhe.Evaluator(alt)
+    a, b, c3 = ctx.random_ct(4, size=2, seed=41), ctx.random_ct(4, size=2, seed=42), ctx.random_ct(4, size=3, seed=43)
+    a[0] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=a.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
+    pp, pp2 = (fhe.PreparedPlain(x, fhe.FractionalEncoder(x).encode(0.299)) for x in (ctx, alt))
+    f = ev.ntt_forward(a)
+    assert torch.equal(f, ev2.ntt_forward(a)) and torch.equal(ev2.ntt_inverse(f), a)
+    assert torch.equal(ev.multiply_plain(a, pp), ev2.multiply_plain(a, pp2))
+    m22, m32, sq = ev2.multiply(a, b), ev2.multiply(c3, b), ev2.square(c3)
+    assert torch.equal(m22, ev.multiply(a, b)) and torch.equal(m32, ev.multiply(c3, b)) and torch.equal(sq, ev.square(c3))
+    ha, hb = fhe.to_host(a), fhe.to_host(b)
+    assert np.array_equal(fhe.to_host(m22)[0], orc.multiply(ha[0], hb[0]))
+    assert np.array_equal(fhe.to_host(m22)[3], orc.multiply(ha[3], hb[3]))
+
+
+@pytest.mark.parametrize("switches", [{"FHE_DCT_PIPELINE": 1, "FHE_DCT_WAVE_BLOCKS": 4}, {"FHE_DCT_PACK": 0}, {"FHE_DCT_LDSC": 0}, {"FHE_DCT_LE": 4}])
+def test_dct_variants_give_the_same_bits(fhe, oracle_mod, switches):
+    """the two-stream pipelined mode (include/fhe_hip.h threading note), the FP64 intermediate, register-path constants
+    and the 16-coefficient shape of the fused FP64 pair against the default launch and the oracle (P4096, 10 blocks:
+    ragged against the 2-block half waves of the pipelined mode)"""
+    ctx, orc = _pair(fhe, oracle_mod, "P4096")
+    alt = _variant(fhe, ctx, **switches)
+    blocks = ctx.random_ct(10, 64, seed=123)
+    want = fhe.to_host(fhe.Evaluator(ctx).dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
+    got = fhe.to_host(fhe.Evaluator(alt).dct8x8_quant(fhe.DctPlan(alt, fhe.YQT), blocks))
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[9], orc.dct_quant(fhe.to_host(blocks)[9], fhe.YQT))
+
+
+def test_u64_fused_switch_selects_the_general_path(fhe, oracle_mod):
+    ctx, orc = _pair(fhe, oracle_mod, "SEAL23_4096")
+    alt = _variant(fhe, ctx, FHE_DCT_U64_FUSED=0)
+    blocks = ctx.random_ct(3, 64, seed=5)
+    want = fhe.to_host(fhe.Evaluator(ctx).dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
+    assert np.array_equal(fhe.to_host(fhe.Evaluator(alt).dct8x8_quant(fhe.DctPlan(alt, fhe.YQT), blocks)), want)
+    assert np.array_equal(want[1], orc.dct_quant(fhe.to_host(blocks)[1], fhe.YQT))
