@@ -311,7 +311,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
                 sampler = circuits.sample_bicubic if bicubic else circuits.sample_linear
                 wait(pending_w[si & 1])
                 for ch in range(3):
-                    pix = window[:, :, ch].reshape(-1, 2, ctx.k, ctx.n)
+                    pix = window[:, :, ch].reshape(-1, 2, ctx.k, ctx.n).contiguous()
                     res = sampler(ev, pc, pix, taps, xf, yf)                         # [npx, out_size, k, n]
                     host_out[si & 1][:npx, ch].copy_(res, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
