@@ -74,7 +74,7 @@ def cpu_baseline(n_blocks_sample):
 def cpu_baseline_all_cores(blocks_per_thread=1):
     """Same oracle, OpenMP over independent blocks (extra field, not the `cpu_baseline` object)."""
     from oracle import oracle as om
-    orc = om.Oracle.preset("P4096")
+    orc = om.Oracle.preset("P4096", omp=True)          # the optional OpenMP build (oracle/libfhe_oracle_omp.so)
     nb = max(1, (os.cpu_count() or 1) * blocks_per_thread)
     nb = min(nb, 256)                                              # 12 MiB per block
     blocks = orc.random_ct(nb * 64, seed=om.SEED).reshape(nb, 64, 2, orc.k, orc.n)

@@ -6,6 +6,11 @@
  * a hardware remainder, one operation at a time, plaintexts re-lifted and
  * re-transformed on every multiply_plain exactly as the reference's call
  * pattern makes SEAL do (homo/fhe_image.h:221 `multiply_plain(x, encoder.encode(c))`).
+ * One concession to speed, because this file is also bench.py's cpu_baseline ("port"): the
+ * butterflies of the two transforms multiply by their table constants the way SEAL's own
+ * transforms do (a precomputed quotient per twiddle, "Shoup"/Harvey style, App. A.3 of SURVEY.md)
+ * instead of a 128-by-64-bit hardware division per butterfly; the value is the same canonical
+ * residue (mulmod_const below is checked against mulmod in tests/test_oracle_properties.py).
  */
 #include "fhe_oracle.h"
 
@@ -30,6 +35,14 @@ static inline u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s
 static inline u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 static inline u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
 static inline u64 mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+/* a * w mod q for a constant w with wq = floor(w 2^64 / q): q < 2^63, any a < 2^64 */
+static inline u64 const_quotient(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+static inline u64 mulmod_const(u64 a, u64 w, u64 wq, u64 q) {
+    const u64 hi = (u64)(((u128)a * wq) >> 64);
+    const u64 r = a * w - hi * q;              /* exact value in [0, 2q), taken modulo 2^64 */
+    return r >= q ? r - q : r;
+}
+uint64_t fo_mulmod_const_check(uint64_t a, uint64_t w, uint64_t q) { return mulmod_const(a, w, const_quotient(w, q), q); }
 static u64 powmod(u64 a, u64 e, u64 q) {
     u64 r = 1 % q;
     a %= q;
@@ -85,7 +98,8 @@ typedef struct {
     u64 q;
     u64 *psi_br;  /* psi^bitrev(i) */
     u64 *ipsi_br; /* psi^-bitrev(i) */
-    u64 ninv;
+    u64 *psi_brq, *ipsi_brq; /* floor(w 2^64 / q) of the two tables */
+    u64 ninv, ninvq;
 } ntt_tab;
 
 static int ntt_tab_init(ntt_tab *T, u64 q, u32 n, u32 logn) {
@@ -100,6 +114,8 @@ static int ntt_tab_init(ntt_tab *T, u64 q, u32 n, u32 logn) {
     u64 ipsi = invmod_prime(psi, q);
     T->psi_br = (u64 *)malloc(sizeof(u64) * n);
     T->ipsi_br = (u64 *)malloc(sizeof(u64) * n);
+    T->psi_brq = (u64 *)malloc(sizeof(u64) * n);
+    T->ipsi_brq = (u64 *)malloc(sizeof(u64) * n);
     u64 p = 1, ip = 1;
     for (u32 i = 0; i < n; i++) {
         u32 r = bitrev(i, logn);
@@ -108,10 +124,15 @@ static int ntt_tab_init(ntt_tab *T, u64 q, u32 n, u32 logn) {
         p = mulmod(p, psi, q);
         ip = mulmod(ip, ipsi, q);
     }
+    for (u32 i = 0; i < n; i++) {
+        T->psi_brq[i] = const_quotient(T->psi_br[i], q);
+        T->ipsi_brq[i] = const_quotient(T->ipsi_br[i], q);
+    }
     T->ninv = invmod_prime(n, q);
+    T->ninvq = const_quotient(T->ninv, q);
     return 0;
 }
-static void ntt_tab_free(ntt_tab *T) { free(T->psi_br); free(T->ipsi_br); }
+static void ntt_tab_free(ntt_tab *T) { free(T->psi_br); free(T->ipsi_br); free(T->psi_brq); free(T->ipsi_brq); }
 
 /* Cooley-Tukey, natural in -> bit-reversed out (merged psi twiddles) */
 static void ntt_fwd(const ntt_tab *T, u32 n, u64 *a) {
@@ -120,10 +141,10 @@ static void ntt_fwd(const ntt_tab *T, u32 n, u64 *a) {
     for (u32 m = 1; m < n; m <<= 1) {
         t >>= 1;
         for (u32 i = 0; i < m; i++) {
-            u64 W = T->psi_br[m + i];
+            u64 W = T->psi_br[m + i], Wq = T->psi_brq[m + i];
             u32 j1 = 2 * i * t;
             for (u32 j = j1; j < j1 + t; j++) {
-                u64 U = a[j], V = mulmod(a[j + t], W, q);
+                u64 U = a[j], V = mulmod_const(a[j + t], W, Wq, q);
                 a[j] = addmod(U, V, q);
                 a[j + t] = submod(U, V, q);
             }
@@ -137,17 +158,17 @@ static void ntt_inv(const ntt_tab *T, u32 n, u64 *a) {
     for (u32 m = n; m > 1; m >>= 1) {
         u32 h = m >> 1, j1 = 0;
         for (u32 i = 0; i < h; i++) {
-            u64 W = T->ipsi_br[h + i];
+            u64 W = T->ipsi_br[h + i], Wq = T->ipsi_brq[h + i];
             for (u32 j = j1; j < j1 + t; j++) {
                 u64 U = a[j], V = a[j + t];
                 a[j] = addmod(U, V, q);
-                a[j + t] = mulmod(submod(U, V, q), W, q);
+                a[j + t] = mulmod_const(submod(U, V, q), W, Wq, q);
             }
             j1 += 2 * t;
         }
         t <<= 1;
     }
-    for (u32 j = 0; j < n; j++) a[j] = mulmod(a[j], T->ninv, q);
+    for (u32 j = 0; j < n; j++) a[j] = mulmod_const(a[j], T->ninv, T->ninvq, q);
 }
 
 /* ------------------------------------------------------------------------- */

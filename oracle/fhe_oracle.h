@@ -68,6 +68,8 @@ uint64_t fo_ctx_aux(const fo_ctx *c, uint32_t i);
 /* deterministic synthetic input generator shared with the HIP side:
  * value = splitmix64(seed ^ linear_index) mod q_i   */
 uint64_t fo_splitmix64(uint64_t x);
+/* the transforms' constant product (a * w mod q through a precomputed quotient) exposed for its property test */
+uint64_t fo_mulmod_const_check(uint64_t a, uint64_t w, uint64_t q);
 void fo_fill_random_ct(const fo_ctx *c, uint64_t *ct, uint64_t n_polys, uint64_t seed,
                        uint64_t first_linear_index);
 

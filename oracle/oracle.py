@@ -40,15 +40,22 @@ def build(force=False):
 
 
 _lib = None
+_libs = {}
+_OMP_LIB_PATH = os.path.join(_HERE, "libfhe_oracle_omp.so")
 u64p = C.POINTER(C.c_uint64)
 
 
-def lib():
+def lib(omp=False):
+    """the oracle library: the portable single-threaded build, or (omp=True) the optional OpenMP / AVX2 build that only
+    parallelises fo_dct_quant_blocks; same source file, same results"""
     global _lib
-    if _lib is None:
+    if omp:
+        if not os.path.exists(_OMP_LIB_PATH):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libfhe_oracle_omp.so"])
+    if _libs.get(bool(omp)) is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_OMP_LIB_PATH if omp else _LIB_PATH)
         L.fo_ctx_create.restype = C.c_void_p
         L.fo_ctx_create.argtypes = [C.c_uint32, u64p, C.c_uint32, C.c_uint64]
         L.fo_ctx_destroy.argtypes = [C.c_void_p]
@@ -56,6 +63,8 @@ def lib():
         L.fo_ctx_aux.argtypes = [C.c_void_p, C.c_uint32]
         L.fo_splitmix64.restype = C.c_uint64
         L.fo_splitmix64.argtypes = [C.c_uint64]
+        L.fo_mulmod_const_check.restype = C.c_uint64
+        L.fo_mulmod_const_check.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.fo_fill_random_ct.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         for name in ("fo_ntt_fwd", "fo_ntt_inv"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
@@ -95,8 +104,10 @@ def lib():
         L.fo_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.fo_digest.restype = C.c_uint64
         L.fo_digest.argtypes = [C.c_void_p, C.c_uint64]
-        _lib = L
-    return _lib
+        _libs[bool(omp)] = L
+        if not omp:
+            _lib = L
+    return _libs[bool(omp)]
 
 
 def _p(a):
@@ -110,23 +121,26 @@ class Oracle:
     INT_COEFFS = 100   # FractionalEncoder(t, poly, 100, 100, 2): homo/server_jpeg.cpp:100
     FRAC_COEFFS = 100
 
-    def __init__(self, n, q, t):
+    def __init__(self, n, q, t, omp=False):
+        """omp=True: the OpenMP / AVX2 build (oracle/libfhe_oracle_omp.so) -- only bench.py's all-cores CPU baseline
+        asks for it; every parity test runs on the portable single-threaded build."""
         self.n, self.q, self.t, self.k = int(n), [int(x) for x in q], int(t), len(q)
+        self.L = lib(omp)
         arr = (C.c_uint64 * self.k)(*self.q)
-        self.h = lib().fo_ctx_create(self.n, arr, self.k, self.t)
+        self.h = self.L.fo_ctx_create(self.n, arr, self.k, self.t)
         if not self.h:
             raise ValueError("invalid encryption parameters")
-        self.aux = [int(lib().fo_ctx_aux(self.h, i)) for i in range(self.k + 1)]
+        self.aux = [int(self.L.fo_ctx_aux(self.h, i)) for i in range(self.k + 1)]
 
     @classmethod
-    def preset(cls, name):
+    def preset(cls, name, omp=False):
         p = PRESETS[name]
-        return cls(p["n"], p["q"], p["t"])
+        return cls(p["n"], p["q"], p["t"], omp)
 
     def __del__(self):
         try:
             if getattr(self, "h", None):
-                lib().fo_ctx_destroy(self.h)
+                self.L.fo_ctx_destroy(self.h)
                 self.h = None
         except Exception:
             pass
@@ -137,18 +151,18 @@ class Oracle:
 
     def random_ct(self, n_cts, size=2, seed=SEED, first_index=0):
         out = np.empty((n_cts, size, self.k, self.n), dtype=np.uint64)
-        lib().fo_fill_random_ct(self.h, _p(out), n_cts * size, seed, first_index)
+        self.L.fo_fill_random_ct(self.h, _p(out), n_cts * size, seed, first_index)
         return out
 
     # -- ntt ------------------------------------------------------------
     def ntt_fwd(self, a, prime, base=0):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
-        lib().fo_ntt_fwd(self.h, base, prime, _p(a))
+        self.L.fo_ntt_fwd(self.h, base, prime, _p(a))
         return a
 
     def ntt_inv(self, a, prime, base=0):
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
-        lib().fo_ntt_inv(self.h, base, prime, _p(a))
+        self.L.fo_ntt_inv(self.h, base, prime, _p(a))
         return a
 
     # -- evaluator --------------------------------------------------------
@@ -162,18 +176,18 @@ class Oracle:
     def add(self, a, b):
         s = max(a.shape[0], b.shape[0])
         out = self._grow(a, s)
-        lib().fo_add(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
+        self.L.fo_add(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
         return out
 
     def sub(self, a, b):
         s = max(a.shape[0], b.shape[0])
         out = self._grow(a, s)
-        lib().fo_sub(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
+        self.L.fo_sub(self.h, _p(out), a.shape[0], _p(np.ascontiguousarray(b)), b.shape[0])
         return out
 
     def negate(self, a):
         out = np.ascontiguousarray(a).copy()
-        lib().fo_negate(self.h, _p(out), a.shape[0])
+        self.L.fo_negate(self.h, _p(out), a.shape[0])
         return out
 
     def _plain(self, plain):
@@ -183,98 +197,98 @@ class Oracle:
     def add_plain(self, a, plain):
         out = np.ascontiguousarray(a).copy()
         p, ln = self._plain(plain)
-        lib().fo_add_plain(self.h, _p(out), _p(p), ln)
+        self.L.fo_add_plain(self.h, _p(out), _p(p), ln)
         return out
 
     def sub_plain(self, a, plain):
         out = np.ascontiguousarray(a).copy()
         p, ln = self._plain(plain)
-        lib().fo_sub_plain(self.h, _p(out), _p(p), ln)
+        self.L.fo_sub_plain(self.h, _p(out), _p(p), ln)
         return out
 
     def multiply_plain(self, a, plain):
         out = np.ascontiguousarray(a).copy()
         p, ln = self._plain(plain)
-        lib().fo_multiply_plain(self.h, _p(out), a.shape[0], _p(p), ln)
+        self.L.fo_multiply_plain(self.h, _p(out), a.shape[0], _p(p), ln)
         return out
 
     def plain_lift(self, plain):
         p, ln = self._plain(plain)
         out = np.zeros((self.k, self.n), dtype=np.uint64)
-        lib().fo_plain_lift(self.h, _p(p), ln, _p(out))
+        self.L.fo_plain_lift(self.h, _p(p), ln, _p(out))
         return out
 
     def multiply(self, a, b):
         a = np.ascontiguousarray(a)
         b = np.ascontiguousarray(b)
         out = np.zeros((a.shape[0] + b.shape[0] - 1, self.k, self.n), dtype=np.uint64)
-        lib().fo_multiply(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+        self.L.fo_multiply(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(out))
         return out
 
     def square(self, a):
         a = np.ascontiguousarray(a)
         out = np.zeros((2 * a.shape[0] - 1, self.k, self.n), dtype=np.uint64)
-        lib().fo_square(self.h, _p(a), a.shape[0], _p(out))
+        self.L.fo_square(self.h, _p(a), a.shape[0], _p(out))
         return out
 
     # -- encoder ----------------------------------------------------------
     def encode(self, v):
         out = np.zeros(self.n, dtype=np.uint64)
-        lib().fo_frac_encode(self.h, float(v), self.INT_COEFFS, self.FRAC_COEFFS, _p(out))
+        self.L.fo_frac_encode(self.h, float(v), self.INT_COEFFS, self.FRAC_COEFFS, _p(out))
         return out
 
     def decode(self, plain):
         p = np.ascontiguousarray(plain, dtype=np.uint64)
-        return float(lib().fo_frac_decode(self.h, _p(p), self.INT_COEFFS, self.FRAC_COEFFS))
+        return float(self.L.fo_frac_decode(self.h, _p(p), self.INT_COEFFS, self.FRAC_COEFFS))
 
     # -- keys -------------------------------------------------------------
     def keygen(self, seed=1):
         sk = np.zeros((self.k, self.n), dtype=np.uint64)
         pk = np.zeros((2, self.k, self.n), dtype=np.uint64)
-        lib().fo_keygen(self.h, seed, _p(sk), _p(pk))
+        self.L.fo_keygen(self.h, seed, _p(sk), _p(pk))
         return sk, pk
 
     def encrypt(self, pk, plain, seed=7):
         p, ln = self._plain(plain)
         ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
-        lib().fo_encrypt(self.h, _p(pk), _p(p), ln, seed, _p(ct))
+        self.L.fo_encrypt(self.h, _p(pk), _p(p), ln, seed, _p(ct))
         return ct
 
     def decrypt(self, sk, ct):
         ct = np.ascontiguousarray(ct)
         plain = np.zeros(self.n, dtype=np.uint64)
-        budget = lib().fo_decrypt(self.h, _p(sk), _p(ct), ct.shape[0], _p(plain))
+        budget = self.L.fo_decrypt(self.h, _p(sk), _p(ct), ct.shape[0], _p(plain))
         return plain, int(budget)
 
     def decrypt_phase(self, sk, ct):
         ct = np.ascontiguousarray(ct)
         ph = np.zeros((self.k, self.n), dtype=np.uint64)
-        lib().fo_decrypt_phase(self.h, _p(sk), _p(ct), ct.shape[0], _p(ph))
+        self.L.fo_decrypt_phase(self.h, _p(sk), _p(ct), ct.shape[0], _p(ph))
         return ph
 
     def evk_gen(self, sk, dbc=30, seed=11):
-        nd = int(lib().fo_evk_digits(self.h, dbc))
+        nd = int(self.L.fo_evk_digits(self.h, dbc))
         evk = np.zeros((self.k, nd, 2, self.k, self.n), dtype=np.uint64)
-        lib().fo_evk_gen(self.h, _p(sk), dbc, seed, _p(evk))
+        self.L.fo_evk_gen(self.h, _p(sk), dbc, seed, _p(evk))
         return evk
 
     def relinearize(self, ct, evk, dbc=30):
         assert ct.shape[0] == 3
         out = np.ascontiguousarray(ct).copy()
-        lib().fo_relinearize3(self.h, _p(out), _p(evk), dbc)
+        self.L.fo_relinearize3(self.h, _p(out), _p(evk), dbc)
         return out[:2].copy()
 
     # -- circuits ---------------------------------------------------------
     def encrypted_dct(self, block):
         out = np.ascontiguousarray(block).copy()
         assert out.shape == (64, 2, self.k, self.n)
-        lib().fo_encrypted_dct(self.h, _p(out))
+        self.L.fo_encrypted_dct(self.h, _p(out))
         return out
 
     def quantize(self, block, quant=YQT):
         out = np.ascontiguousarray(block).copy()
         qv = (C.c_double * 64)(*[float(x) for x in quant])
-        lib().fo_quantize(self.h, _p(out), qv)
+        self.L.fo_quantize(self.h, _p(out), qv)
         return out
 
     def dct_quant(self, block, quant=YQT):
@@ -284,26 +298,26 @@ class Oracle:
         """dct_quant on [n_blocks, 64, 2, k, n], OpenMP over blocks; returns (result, threads used)"""
         out = np.ascontiguousarray(blocks).copy()
         qv = (C.c_double * 64)(*[float(x) for x in quant])
-        threads = lib().fo_dct_quant_blocks(self.h, _p(out), out.shape[0], qv)
+        threads = self.L.fo_dct_quant_blocks(self.h, _p(out), out.shape[0], qv)
         return out, int(threads)
 
     def rgb_to_ycc(self, r, g, b):
         r, g, b = (np.ascontiguousarray(x).copy() for x in (r, g, b))
-        lib().fo_rgb_to_ycc(self.h, _p(r), _p(g), _p(b))
+        self.L.fo_rgb_to_ycc(self.h, _p(r), _p(g), _p(b))
         return r, g, b
 
     def cubic(self, A, B, Cc, D, t):
         s = A.shape[0]
         out = np.zeros((s + 2, self.k, self.n), dtype=np.uint64)
         A, B, Cc, D, t = (np.ascontiguousarray(x) for x in (A, B, Cc, D, t))
-        lib().fo_cubic(self.h, _p(A), _p(B), _p(Cc), _p(D), s, _p(t), _p(out))
+        self.L.fo_cubic(self.h, _p(A), _p(B), _p(Cc), _p(D), s, _p(t), _p(out))
         return out
 
     def linear(self, A, B, t):
         s = A.shape[0]
         out = np.zeros((s + 1, self.k, self.n), dtype=np.uint64)
         A, B, t = (np.ascontiguousarray(x) for x in (A, B, t))
-        lib().fo_linear(self.h, _p(A), _p(B), s, _p(t), _p(out))
+        self.L.fo_linear(self.h, _p(A), _p(B), s, _p(t), _p(out))
         return out
 
 

@@ -139,3 +139,16 @@ def test_cubic_and_linear_known_answer(oracle_mod):
     lin = orc.linear(cA, cB, ct)
     assert lin.shape[0] == 3
     assert abs(orc.decode(orc.decrypt(sk, lin)[0]) - ((1 - t) * A + t * B)) < 1e-9
+
+
+def test_transform_constant_product_equals_plain_mulmod(oracle_mod):
+    """the oracle's butterflies multiply by table constants through a precomputed quotient (fhe_oracle.c mulmod_const);
+    it must be the canonical residue a * w mod q for any 64-bit a, at the smallest and largest primes in use"""
+    import random
+    L = oracle_mod.lib()
+    rng = random.Random(7)
+    for q in (0xFFFFEE001, 0x1FFFFE0001, 0x3FFFFFFF000001, 0x7FFFFFFF380001, 0x1FFFFFFFFFE00001, 12289):
+        cases = [(0, 0), (q - 1, q - 1), ((1 << 64) - 1, q - 1), (q, 1), (1, q - 1)]
+        cases += [(rng.getrandbits(64), rng.randrange(q)) for _ in range(2000)]
+        for a, w in cases:
+            assert L.fo_mulmod_const_check(a, w, q) == (a * w) % q, (a, w, q)

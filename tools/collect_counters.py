@@ -19,12 +19,11 @@ Derived figures (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles p
   valu_active_frac      = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES     fraction of a wave's residency spent issuing VALU
   wait_frac             = SQ_WAIT_ANY / SQ_WAVE_CYCLES             parked at s_waitcnt / barrier
   issue_stall_frac      = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES        wants to issue, pipe busy (other waves of the SIMD)
-  simd_valu_busy        = 4 * SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES * simds_per_se_counted) is NOT derived here: the per-SE
-                          aggregation of SQ_BUSY_CYCLES is not documented for gfx950; valu_issue_cycles_per_cu_cycle below uses
-                          the kernel's own duration instead:
-  valu_issue_share      = SQ_ACTIVE_INST_VALU * 4 / (duration_cycles * 4 SIMDs * 256 CUs)   share of all SIMD issue cycles of the
-                          chip that issued a VALU instruction while the kernel ran (duration from the kernel trace of the same pass,
-                          cycles at the effective clock of pass C)
+  effective_clock_ghz   = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (pass C)
+  simd_valu_busy        = SQ_ACTIVE_INST_VALU * 4 / (duration_cycles * 1024 SIMDs)   share of all SIMD cycles of the chip in which
+                          a VALU instruction held the issue port while the kernel ran (duration from the kernel trace of the same
+                          pass, cycles at the effective clock of pass C); simd_lds_busy likewise
+  mean_resident_waves_per_simd = SQ_WAVE_CYCLES * 4 / (duration_cycles * 1024)        achieved occupancy
 """
 import collections
 import csv
@@ -36,6 +35,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PY = sys.executable
+XCDS, SIMDS = 8, 1024            # MI355X: 8 XCDs, 256 CUs x 4 SIMDs
 WORKLOADS = {
     "bench": ([PY, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
               ["k_dct_rows", "k_dct_cols"]),
@@ -159,11 +159,18 @@ def main():
                         d[name] = m[c] / wc
             dur_c, gui = m.get("duration_us_in_this_pass_passC"), m.get("GRBM_GUI_ACTIVE")
             if dur_c and gui:
-                d["effective_clock_ghz"] = gui / dur_c / 1e3
+                # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (a 1.5 ms kernel reads 23.7 M "cycles": 8 x 1.87 GHz x 1.59 ms)
+                d["effective_clock_ghz"] = gui / XCDS / dur_c / 1e3
                 dur_a = m.get("duration_us_in_this_pass_passA")
                 if dur_a and "SQ_ACTIVE_INST_VALU" in m:
                     cycles = dur_a * 1e3 * d["effective_clock_ghz"]
-                    d["valu_issue_share_of_chip"] = m["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 4 * 256)
+                    # SQ_ACTIVE_INST_VALU: quad-cycles summed over every SIMD of the chip -> share of all SIMD cycles of the
+                    # kernel's run in which a VALU instruction occupied the SIMD's issue port
+                    d["simd_valu_busy"] = m["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * SIMDS)
+                    if "SQ_ACTIVE_INST_LDS" in m:
+                        d["simd_lds_busy"] = m["SQ_ACTIVE_INST_LDS"] * 4 / (cycles * SIMDS)
+                    if "SQ_WAVE_CYCLES" in m:
+                        d["mean_resident_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / (cycles * SIMDS)
             if "FETCH_SIZE" in m:
                 d["fetch_bytes_x2_guide_correction"] = m["FETCH_SIZE"] * 1024 * 2
             if "WRITE_SIZE" in m:
