@@ -73,6 +73,7 @@ SIGNATURES = {
     "fhe_dct_path": (_i, [_vp]),
     "fhe_dct8x8_quant": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
     "fhe_rgb_to_ycc": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _i, _vp]),
+    "fhe_rgb_to_ycc_blocks": (_i, [_vp, _vp, _u64, _i, _i, _vp]),
     "fhe_fill_random": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "fhe_digest": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
     # include/fhe_circuits.h

@@ -199,3 +199,102 @@ def rms_error(a, b):
     """compare_jpeg_jojpeg's number (homo/fhe_image.h:513-520) for two decoded uint8 images of equal shape"""
     d = np.asarray(a, dtype=np.int64) - np.asarray(b, dtype=np.int64)
     return math.sqrt(float((d * d).sum()) / d.size)
+
+
+# ------------------------------------------------------------------------------------------------
+# client halves of the resize and decode pipelines (homo/client_resize.cpp, homo/client_decode.cpp)
+# ------------------------------------------------------------------------------------------------
+def _encrypt_values(ctx, encryptor, encoder, values, f):
+    import torch
+    for v in values:
+        ct = encryptor.encrypt(encoder.encode(float(v)))
+        torch.cuda.synchronize()
+        server.write_ciphertext(f, ct.cpu().numpy().view(np.uint64))
+
+
+def send_resize(ctx, encryptor, encoder, rgb, out_path):
+    """homo/client_resize.cpp:141-158: every sample of the image encoded and encrypted, "RGBRGB... row by row" (:141),
+    the stream server.server_resize reads.  rgb: uint8 [H, W, 3].  Returns (width, height)."""
+    h, w, _ = rgb.shape
+    with open(out_path, "wb") as f:
+        _encrypt_values(ctx, encryptor, encoder, np.asarray(rgb, dtype=np.uint8).reshape(-1), f)
+    return w, h
+
+
+def to_pixel(value, clamp=True):
+    """`int pixel = encoder.decode(p); CLAMP(pixel, 0, 255); (uint8_t) pixel` (homo/client_resize.cpp:206-209,
+    homo/client_decode.cpp:205-207): truncation toward zero, saturated to int as x86 cvttsd2si does for values
+    outside the int range (INT_MIN), then the clamp.  clamp=False is the same conversion without the CLAMP line --
+    the client that produced the bicubic t = 11 entries of benchmark/results.txt."""
+    v = float(value)
+    pixel = int(v) if math.isfinite(v) and abs(v) < 2147483648.0 else -2147483648
+    if clamp:
+        pixel = 0 if pixel < 0 else 255 if pixel > 255 else pixel
+    return pixel & 0xFF
+
+
+def receive_pixels(ctx, decryptor, encoder, in_path, width, height, clamp=True, decoded=None):
+    """The receiving half shared by homo/client_resize.cpp:197-211 and homo/client_decode.cpp:200-209: width * height * 3
+    records (ciphertexts of any size: 4 or 6 polynomials after a resize, 22 after the run-length decoder), each
+    decrypted, decoded and converted by to_pixel.  Returns uint8 [height, width, 3]; `decoded` (a list) receives the
+    decoded doubles in stream order."""
+    import torch
+    out = np.zeros(width * height * 3, dtype=np.uint8)
+    with open(in_path, "rb") as f:
+        for i in range(out.size):
+            hdr = f.read(server.RECORD_HEADER)
+            if len(hdr) != server.RECORD_HEADER:
+                raise EOFError("ciphertext stream ended")
+            magic, size, k, n, _ = server.HEADER.unpack(hdr)
+            if magic != server.MAGIC or (k, n) != (ctx.k, ctx.n) or not 1 <= size <= 64:
+                raise ValueError("not a ciphertext record of this context")
+            ct = np.frombuffer(f.read(size * k * n * 8), dtype=np.uint64)
+            if ct.size != size * k * n:
+                raise EOFError("truncated ciphertext record")
+            plain = decryptor.decrypt(torch.from_numpy(ct.view(np.int64).reshape(size, k, n).copy()).to(ctx.device))
+            v = encoder.decode(plain)
+            if decoded is not None:
+                decoded.append(v)
+            out[i] = to_pixel(v, clamp)
+    return out.reshape(height, width, 3)
+
+
+def receive_resize(ctx, decryptor, encoder, in_path, width, height, clamp=True, decoded=None):
+    """homo/client_resize.cpp:163-222 without its OpenCV comparison: the resized image, uint8 [height, width, 3]"""
+    return receive_pixels(ctx, decryptor, encoder, in_path, width, height, clamp, decoded)
+
+
+def run_length_pairs(channel):
+    """The run-length encoder of homo/client_decode.cpp:126-148 for one colour channel (values in scan order):
+    [(value, count), ...]"""
+    vals = [int(v) for v in channel]
+    runs, curr, count = [], vals[0], 1
+    for v in vals[1:]:
+        if v == curr:
+            count += 1
+        else:
+            runs.append((curr, count))
+            curr, count = v, 1
+    runs.append((curr, count))
+    return runs
+
+
+def send_decode(ctx, encryptor, encoder, rgb, out_path):
+    """homo/client_decode.cpp:122-153: per colour channel the run-length pairs of the image, each as two ciphertexts
+    (value, count), channel after channel -- the stream server.server_decode reads.  Returns (width, height, pairs[3]),
+    the five integers the reference writes to keys/params.txt (:95-98,149)."""
+    h, w, _ = rgb.shape
+    flat = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    pairs = []
+    with open(out_path, "wb") as f:
+        for ch in range(3):
+            runs = run_length_pairs(flat[:, ch])
+            pairs.append(len(runs))
+            _encrypt_values(ctx, encryptor, encoder, [x for run in runs for x in run], f)
+    return w, h, pairs
+
+
+def receive_decode(ctx, decryptor, encoder, in_path, width, height, clamp=True, decoded=None):
+    """homo/client_decode.cpp:157-214: the decoded image, uint8 [height, width, 3] (position-major, channels interleaved:
+    the order homo/server_decode.cpp:139-143 saves)"""
+    return receive_pixels(ctx, decryptor, encoder, in_path, width, height, clamp, decoded)

@@ -518,7 +518,7 @@ template <int L, int LE>
 __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_rgb2ycc_f64(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc,
                                                                      const double *__restrict__ consts, const double *__restrict__ tw_all,
                                                                      const double *__restrict__ itw_all, const Modulus *__restrict__ mods,
-                                                                     const u64 *__restrict__ yoff, u32 yoff_len, u32 k) {
+                                                                     const u64 *__restrict__ yoff, u32 yoff_len, u32 k, u32 group, u64 gstride) {
     using SH = Shape<L, LE>;
     constexpr int N = SH::N, TP = SH::TP, E = SH::E, LASTP = SH::NP - 1;
     __shared__ double lds[2 * SH::LDS_WORDS];
@@ -527,11 +527,14 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_rgb2ycc
     const u32 per_prime = gridDim.x / k;
     const u32 prime = blockIdx.x / per_prime;
     const u32 pp = blockIdx.x - prime * per_prime;           // pixel * 2 + poly
-    const u32 poly = pp & 1;
+    const u32 poly = pp & 1, pix = pp >> 1;
     const u64 q = mods[prime].q;
     const double p = (double)q, pinv = 1.0 / p;
     const double *tw = tw_all + (size_t)prime * N, *itw = itw_all + (size_t)prime * N;
-    const size_t off = ((size_t)pp * k + prime) * N + tid;
+    // pixel `pix` of a plane: contiguous (group == 0), or `group` pixels every gstride words (the block layout of the
+    // ciphertext streams, [block][R G B][64]: fhe_rgb_to_ycc_blocks)
+    const size_t pix_off = group ? (size_t)(pix / group) * gstride + (size_t)(pix % group) * 2 * k * N : (size_t)pix * 2 * k * N;
+    const size_t off = pix_off + ((size_t)poly * k + prime) * N + tid;
     double w0[E - 1];
     load_tw<L, LE, 0>(w0, tw, tid);
     double x[3][E];
@@ -748,10 +751,10 @@ int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **ou
     return FHE_OK;
 }
 
-int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st) {
+int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st, u32 group, u64 gstride) {
     const u64 grid = count * 2 * c->k;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
-    k_rgb2ycc_f64<12, 3><<<(unsigned)grid, Shape<12, 3>::TP, 0, st>>>(r, g, b, consts, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, yoff, yoff_len, c->k);
+    k_rgb2ycc_f64<12, 3><<<(unsigned)grid, Shape<12, 3>::TP, 0, st>>>(r, g, b, consts, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod, yoff, yoff_len, c->k, group, gstride);
     KERNEL_CHECK();
     return FHE_OK;
 }

@@ -1072,13 +1072,17 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
 template <int L>
 __global__ __launch_bounds__(NttShape<L>::TP) void k_rgb2ycc(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc,
                                                               const ulonglong2 *__restrict__ consts, const u64 *__restrict__ yoff, u32 yoff_len,
-                                                              RnsBase base) {
+                                                              RnsBase base, u32 group, u64 gstride) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
     const int tid = threadIdx.x;
-    const u64 rp = blockIdx.x;                 // (pixel * 2 + poly) * k + prime
-    const u32 prime = (u32)(rp % base.count);
-    const u32 poly = (u32)((rp / base.count) & 1);
+    const u64 rp0 = blockIdx.x;                // (pixel * 2 + poly) * k + prime
+    const u32 prime = (u32)(rp0 % base.count);
+    const u32 poly = (u32)((rp0 / base.count) & 1);
+    // pixel of a plane: contiguous (group == 0), or `group` pixels every gstride words (fhe_rgb_to_ycc_blocks); rp is the
+    // residue-polynomial index inside the plane in units of N words
+    const u64 pix = rp0 / (2 * base.count);
+    const u64 rp = group ? ((pix / group) * gstride + (pix % group) * 2 * base.count * N) / N + (u64)poly * base.count + prime : rp0;
     const u64 q = base.mod[prime].q;
     const ulonglong2 *tw = base.tw + (size_t)prime * N, *itw = base.itw + (size_t)prime * N;
     const size_t cstride = (size_t)base.count * N;
@@ -1157,21 +1161,30 @@ static int rgb_consts(const fhe_ctx *c, int int_coeffs, int frac_coeffs, hipStre
     return FHE_OK;
 }
 
-extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int int_coeffs, int frac_coeffs, fhe_stream s) {
-    if (!c || !r || !g || !b) return fail(FHE_ERR_PARAM, "null argument");
-    if (!count) return FHE_OK;
-    hipStream_t st = (hipStream_t)s;
+static int rgb_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, uint64_t count, int int_coeffs, int frac_coeffs, hipStream_t st, u32 group, u64 gstride) {
     const fhe_ctx::RgbConsts *k9 = nullptr;
     int rc = rgb_consts(c, int_coeffs, frac_coeffs, st, &k9);
     if (rc) return rc;
     if (k9->d_c_f64 && !c->opt.force_u64)
-        return fhe_rgb_f64_launch(c, (u64 *)r, (u64 *)g, (u64 *)b, count, k9->d_c_f64, k9->d_off, k9->off_len, st);
+        return fhe_rgb_f64_launch(c, r, g, b, count, k9->d_c_f64, k9->d_off, k9->off_len, st, group, gstride);
     const u64 nrp = count * 2 * c->k;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
     const RnsBase base = c->qb.dev();
-    DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((u64 *)r, (u64 *)g, (u64 *)b, k9->d_c, k9->d_off, k9->off_len, base)));
+    DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>(r, g, b, k9->d_c, k9->d_off, k9->off_len, base, group, gstride)));
     KERNEL_CHECK();
     return FHE_OK;
+}
+extern "C" int fhe_rgb_to_ycc(const fhe_ctx *c, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count, int int_coeffs, int frac_coeffs, fhe_stream s) {
+    if (!c || !r || !g || !b) return fail(FHE_ERR_PARAM, "null argument");
+    if (!count) return FHE_OK;
+    return rgb_launch(c, (u64 *)r, (u64 *)g, (u64 *)b, count, int_coeffs, frac_coeffs, (hipStream_t)s, 0, 0);
+}
+// the same on the layout of the ciphertext streams: blocks [n_blocks][R G B][64][2][k][n], in place -> [n_blocks][Y Cb Cr][64]...
+extern "C" int fhe_rgb_to_ycc_blocks(const fhe_ctx *c, uint64_t *blocks, uint64_t n_blocks, int int_coeffs, int frac_coeffs, fhe_stream s) {
+    if (!c || !blocks) return fail(FHE_ERR_PARAM, "null argument");
+    if (!n_blocks) return FHE_OK;
+    const u64 plane = (u64)64 * 2 * c->k * c->n;           // words of one channel of one block
+    return rgb_launch(c, (u64 *)blocks, (u64 *)blocks + plane, (u64 *)blocks + 2 * plane, n_blocks * 64, int_coeffs, frac_coeffs, (hipStream_t)s, 64, 3 * plane);
 }
 
 // ------------------------------------------------------------------------------------------------

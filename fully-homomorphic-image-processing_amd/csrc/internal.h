@@ -123,4 +123,4 @@ int fhe_dct_u64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
 bool fhe_rgb_f64_supported(const fhe_ctx *c);
 int fhe_poly_f64_launch(int mode, const fhe_ctx *c, const u64 *in, u64 *out, u64 n_polys, const ulonglong2 *plain, hipStream_t st);
 int fhe_rgb_f64_make_consts(const fhe_ctx *c, const ulonglong2 *d_c, double **out, hipStream_t st);
-int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st);
+int fhe_rgb_f64_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, u64 count, const double *consts, const u64 *yoff, u32 yoff_len, hipStream_t st, u32 group = 0, u64 gstride = 0);

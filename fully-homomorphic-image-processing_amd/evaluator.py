@@ -416,3 +416,10 @@ class Evaluator:
         count = r.numel() // (2 * self.ctx.k * self.ctx.n)
         _lib.call("fhe_rgb_to_ycc", self.ctx.h, _ptr(r), _ptr(g), _ptr(b), count, int_coeffs, frac_coeffs, _stream())
         return r, g, b
+
+    def rgb_to_ycc_blocks(self, blocks, int_coeffs=100, frac_coeffs=100):
+        """rgb_to_ycc_fhe on the stream layout [n_blocks, 3, 64, 2, k, n] (64 R, 64 G, 64 B per block), in place."""
+        assert blocks.shape[-5:] == (3, 64, 2, self.ctx.k, self.ctx.n) and blocks.is_contiguous()
+        n_blocks = blocks.numel() // (3 * 64 * 2 * self.ctx.k * self.ctx.n)
+        _lib.call("fhe_rgb_to_ycc_blocks", self.ctx.h, _ptr(blocks), n_blocks, int_coeffs, frac_coeffs, _stream())
+        return blocks

@@ -220,6 +220,11 @@ int fhe_dct8x8_quant(const fhe_ctx *ctx, const fhe_dct_plan *plan, const uint64_
 /* rgb_to_ycc_fhe (homo/fhe_image.h:310-325) on `count` pixels; r,g,b: [count][2][k][n], in place. */
 int fhe_rgb_to_ycc(const fhe_ctx *ctx, uint64_t *r, uint64_t *g, uint64_t *b, uint64_t count,
                    int int_coeffs, int frac_coeffs, fhe_stream stream);
+/* The same on the layout of the reference's ciphertext streams (homo/server_jpeg.cpp:115-124: per 8x8 block 64 R, 64 G,
+ * 64 B ciphertexts): blocks [n_blocks][3][64][2][k][n], in place -> [n_blocks][Y, Cb, Cr][64][2][k][n], which read as
+ * [3 n_blocks][64][2][k][n] is the input layout of fhe_dct8x8_quant and the order homo/server_jpeg.cpp:146-153 saves. */
+int fhe_rgb_to_ycc_blocks(const fhe_ctx *ctx, uint64_t *blocks, uint64_t n_blocks, int int_coeffs, int frac_coeffs,
+                          fhe_stream stream);
 
 /* ---- synthetic inputs and digests (bench / parity harness) --------------------------------------
  * fill: value = splitmix64(seed ^ (first_linear_index + linear index)) mod q_i */
