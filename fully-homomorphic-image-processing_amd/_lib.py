@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfhe_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
-HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h")]
+HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h"), os.path.join(os.path.dirname(_HERE), "include", "fhe_stream.h")]
 
 FHE_OK = 0
 
@@ -97,6 +97,10 @@ SIGNATURES = {
     "fhe_approximated_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "fhe_decode_channel_scratch_bytes": (_sz, [_vp, _i, _u32, _u32]),
     "fhe_decode_channel": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _sz, _vp]),
+    # include/fhe_stream.h
+    "fhe_io_record_bytes": (_sz, [_u32, _u32, _u32]),
+    "fhe_io_read_records": (_i, [_i, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
+    "fhe_io_write_records": (_i, [_i, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
 _COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path"}

@@ -12,6 +12,7 @@ Stream format = the facade's Ciphertext::save records (seal/seal.h: "FHEHIP1" ma
 u32 k, u32 n, u32 reserved, raw little-endian u64).  SEAL 2.3's own wire format is not pinned by
 anything in the reference (no sample files).
 """
+import ctypes as C
 import os
 import struct
 
@@ -82,80 +83,136 @@ def _pwrite_records(fd, views, first_record, rec_bytes, hdr):
             raise IOError("short write on the ciphertext stream")
 
 
-def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True):
+def _io(name, fd, first_record, count, polys, ctx, tensor, threads):
+    """fhe_io_read_records / fhe_io_write_records (include/fhe_stream.h) on a pinned staging tensor: C threads, preadv /
+    pwritev over many records per call; ctypes releases the GIL for the duration"""
+    from . import _lib
+    _lib.call(name, fd, first_record, count, polys, ctx.k, ctx.n, C.c_void_p(tensor.data_ptr()), threads)
+
+
+def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None):
     """Process `n_blocks` colour blocks.  Input order per block: 64 R, 64 G, 64 B ciphertexts
     (homo/server_jpeg.cpp:115-124).  Output order per block: 64 Y, 64 Cb, 64 Cr
     (homo/server_jpeg.cpp:146-153; read back channel-major by homo/client_jpeg.cpp:266-271).  quant=None reproduces the reference server (no quantize_fhe call);
     a 64-entry table applies quantize_fhe to every channel as well.  Returns blocks processed.
 
-    Pipeline per wave of blocks: a pool of I/O threads reads the next wave's fixed-size records with
-    positional reads straight into a pinned buffer and writes the previous wave's results, while
-    the GPU converts and transforms the current one (file -> pinned -> HBM -> pinned -> file)."""
-    from concurrent.futures import ThreadPoolExecutor
+    Five stages run concurrently on waves of `wave_blocks` blocks:
+      file -> pinned   a reader thread: fhe_io_read_records (C threads, positional scatter reads straight into one of
+                       `slots` page-locked buffers)
+      pinned -> HBM    its own HIP stream, two device input buffers
+      compute          fhe_rgb_to_ycc_blocks in place on the stream layout, then fhe_dct8x8_quant over the 3 * wave
+                       channel-blocks -- the result already has the output stream's order; no gather / copy kernels
+      HBM -> pinned    its own HIP stream, `slots` page-locked output buffers
+      pinned -> file   a writer thread: fhe_io_write_records
+    Events order the hand-overs; the host never waits for the device except where a buffer is about to be reused.
+    stats (a dict), if given, receives wall seconds, device compute seconds and byte counts."""
+    import queue
+    import threading
+    import time
     ev = Evaluator(ctx)
     plan = DctPlan(ctx, quant) if do_dct else None
-    shape = (3, 64, 2, ctx.k, ctx.n)                       # one block: channel, pixel, poly, prime, coeff
     wave_blocks = max(1, min(wave_blocks, n_blocks))
-    host = [_pinned(("in", i), (wave_blocks,) + shape) for i in range(2)]
-    host_out = [_pinned(("out", i), (wave_blocks,) + shape) for i in range(2)]
-    copy_stream = torch.cuda.Stream()
-    rec_bytes = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
-    expect = (2, ctx.k, ctx.n)
-    out_hdr = HEADER.pack(MAGIC, 2, ctx.k, ctx.n, 0)
-    if os.path.getsize(in_path) < n_blocks * 192 * rec_bytes:
+    slots = max(2, slots)
+    shape = (wave_blocks, 3, 64, 2, ctx.k, ctx.n)            # wave: block, channel, pixel, poly, prime, coeff
+    hin = [_pinned(("in", i), shape) for i in range(slots)]
+    hout = [_pinned(("out", i), shape) for i in range(slots)]
+    din = [torch.empty(shape, dtype=torch.int64, device=ctx.device) for _ in range(2)]
+    dout = [torch.empty(shape, dtype=torch.int64, device=ctx.device) for _ in range(2)] if do_dct else din
+    main = torch.cuda.current_stream()
+    h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+    rec = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+    if os.path.getsize(in_path) < n_blocks * 192 * rec:
         raise EOFError("ciphertext stream ended")
-
-    def read_wave(pool, fd, buf, first_block, nb):
-        arr = buf.numpy().view(np.uint64)
-        # one task per (block, channel): 64 consecutive records
-        return [pool.submit(_pread_records, fd, [arr[b, ch, i] for i in range(64)],
-                            ((first_block + b) * 3 + ch) * 64, rec_bytes, expect)
-                for b in range(nb) for ch in range(3)]
-
-    def write_wave(pool, fd, buf, first_block, nb):
-        arr = buf.numpy().view(np.uint64)
-        # record index (first_block + b) * 192 + ch * 64 + i: one task per (block, channel)
-        return [pool.submit(_pwrite_records, fd, [arr[b, ch, i] for i in range(64)],
-                            ((first_block + b) * 3 + ch) * 64, rec_bytes, out_hdr)
-                for b in range(nb) for ch in range(3)]
-
-    def wait(futs):
-        for f in futs:
-            f.result()
-
     waves = [(s, min(s + wave_blocks, n_blocks)) for s in range(0, n_blocks, wave_blocks)]
     fin = os.open(in_path, os.O_RDONLY)
     fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    try:
-        os.ftruncate(fout, n_blocks * 192 * rec_bytes)
-        # separate pools: reads of the next wave must not queue behind the writes of the previous one
-        with ThreadPoolExecutor(_IO_THREADS) as pool, ThreadPoolExecutor(_IO_THREADS) as wpool:
-            wait(read_wave(pool, fin, host[0], 0, waves[0][1] - waves[0][0]))
-            pending = [[], []]
+    free_in, ready_in, free_out, to_write = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+    for i in range(slots):
+        free_in.put((i, None))
+        free_out.put(i)
+    errors = []
+
+    def reader():
+        try:
             for wi, (s, e) in enumerate(waves):
-                nb = e - s
-                cur = host[wi & 1]
-                reading = []
-                if wi + 1 < len(waves):                     # prefetch the next wave from the file
-                    ns, ne = waves[wi + 1]
-                    reading = read_wave(pool, fin, host[(wi + 1) & 1], ns, ne - ns)
-                with torch.cuda.stream(copy_stream):
-                    dev = cur[:nb].to(ctx.device, non_blocking=True)
-                torch.cuda.current_stream().wait_stream(copy_stream)
-                r, g, b = (dev[:, ch].reshape(nb * 64, 2, ctx.k, ctx.n).contiguous() for ch in range(3))
-                ev.rgb_to_ycc(r, g, b)                      # in place: r,g,b now hold Y, Cb, Cr
-                chans = []
-                for t in (r, g, b):
-                    t = t.reshape(nb, 64, 2, ctx.k, ctx.n)
-                    chans.append(ev.dct8x8_quant(plan, t) if do_dct else t)
-                res = torch.stack(chans, dim=1)             # [nb, 3, 64, 2, k, n]
-                wait(pending[wi & 1])                       # host_out[wi & 1] was queued two waves ago
-                host_out[wi & 1][:nb].copy_(res, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                pending[wi & 1] = write_wave(wpool, fout, host_out[wi & 1], s, nb)
-                wait(reading)
-            wait(pending[0])
-            wait(pending[1])
+                slot, copied = free_in.get()
+                if copied is not None:
+                    copied.synchronize()                        # the previous wave in this slot has left for the device
+                _io("fhe_io_read_records", fin, s * 192, (e - s) * 192, 2, ctx, hin[slot], io_threads)
+                ready_in.put((wi, slot))
+        except BaseException as exc:                           # surfaced by the main loop
+            errors.append(exc)
+            ready_in.put((None, None))
+
+    def writer():
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                (s, e), slot, landed = item
+                landed.synchronize()
+                _io("fhe_io_write_records", fout, s * 192, (e - s) * 192, 2, ctx, hout[slot], io_threads)
+                free_out.put(slot)
+        except BaseException as exc:
+            errors.append(exc)
+            free_out.put(None)
+
+    t0 = time.perf_counter()
+    try:
+        os.ftruncate(fout, n_blocks * 192 * rec)
+        rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+        rt.start()
+        wt.start()
+        computed, drained = [None, None], [None, None]       # per device buffer: compute finished / left for the host
+        t_start, t_stop = [], []
+        for wi, (s, e) in enumerate(waves):
+            nb, d = e - s, wi & 1
+            got, slot = ready_in.get()
+            if got is None:
+                raise errors[0]
+            with torch.cuda.stream(h2d):
+                for evt in (computed[d], drained[d]):           # the device buffer is free again
+                    if evt is not None:
+                        h2d.wait_event(evt)
+                din[d][:nb].copy_(hin[slot][:nb], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(h2d)
+            free_in.put((slot, copied))
+            main.wait_event(copied)
+            if drained[d] is not None:
+                main.wait_event(drained[d])                      # dout[d] has been copied out
+            if stats is not None:
+                t_start.append(torch.cuda.Event(enable_timing=True))
+                t_start[-1].record(main)
+            ev.rgb_to_ycc_blocks(din[d][:nb])                    # in place: Y, Cb, Cr in the stream's block layout
+            if do_dct:
+                ev.dct8x8_quant(plan, din[d][:nb].view(nb * 3, 64, 2, ctx.k, ctx.n), out=dout[d][:nb].view(nb * 3, 64, 2, ctx.k, ctx.n))
+            if stats is not None:
+                t_stop.append(torch.cuda.Event(enable_timing=True))
+                t_stop[-1].record(main)
+            done = torch.cuda.Event()
+            done.record(main)
+            computed[d] = done
+            oslot = free_out.get()
+            if oslot is None:
+                raise errors[0]
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(done)
+                hout[oslot][:nb].copy_(dout[d][:nb], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(d2h)
+            drained[d] = landed
+            to_write.put(((s, e), oslot, landed))
+        to_write.put(None)
+        wt.join()
+        rt.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.synchronize()
+        if stats is not None:
+            stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
+                         bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves))
     finally:
         os.close(fin)
         os.close(fout)

@@ -1,0 +1,35 @@
+/*
+ * fhe_stream.h -- C ABI of libfhe_hip.so, part 3: ciphertext STREAM records <-> host staging buffers.
+ *
+ * The reference's servers read and write their ciphertexts one `Ciphertext::load` / `save` at a time from a
+ * std::fstream (homo/server_jpeg.cpp:115-124,150-152; homo/fhe_resize.h:335-341; homo/server_decode.cpp:131-143).
+ * A stream is a concatenation of records of FIXED size -- "FHEHIP1\0", u32 polys, u32 k, u32 n, u32 reserved, then
+ * polys * k * n little-endian u64 (seal/seal.h save_words) -- so a batch of them can be moved with positional scatter /
+ * gather I/O by several threads at once, payloads landing contiguously in (page-locked) staging memory that the GPU
+ * copies from.  Host-only code (no device work): `threads` POSIX threads each issue preadv / pwritev calls that cover
+ * many records per system call.  Blocking; callable from any thread (the Python host calls it with the GIL released).
+ */
+#ifndef FHE_STREAM_H
+#define FHE_STREAM_H
+
+#include "fhe_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bytes of one record holding a ciphertext of `polys` polynomials */
+size_t fhe_io_record_bytes(uint32_t polys, uint32_t k, uint32_t n);
+/* Read records [first_record, first_record + count) of the open file `fd` into dst (count * polys * k * n u64, payloads
+ * only, in order); every header is checked against (polys, k, n).  FHE_ERR_PARAM on a foreign / mismatching record or a
+ * short file. */
+int fhe_io_read_records(int fd, uint64_t first_record, uint64_t count, uint32_t polys, uint32_t k, uint32_t n, void *dst,
+                        uint32_t threads);
+/* Write `count` records at record index first_record (headers generated, payloads taken from src in order). */
+int fhe_io_write_records(int fd, uint64_t first_record, uint64_t count, uint32_t polys, uint32_t k, uint32_t n,
+                         const void *src, uint32_t threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
