@@ -101,6 +101,10 @@ SIGNATURES = {
     "fhe_io_record_bytes": (_sz, [_u32, _u32, _u32]),
     "fhe_io_read_records": (_i, [_i, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
     "fhe_io_write_records": (_i, [_i, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
+    "fhe_io_open": (_i, [C.c_char_p, _i, _u64, C.POINTER(_vp)]),
+    "fhe_io_close": (_i, [_vp]),
+    "fhe_io_size": (_u64, [_vp]),
+    "fhe_io_transfer": (_i, [_vp, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
 _COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path"}

@@ -83,11 +83,27 @@ def _pwrite_records(fd, views, first_record, rec_bytes, hdr):
             raise IOError("short write on the ciphertext stream")
 
 
-def _io(name, fd, first_record, count, polys, ctx, tensor, threads):
-    """fhe_io_read_records / fhe_io_write_records (include/fhe_stream.h) on a pinned staging tensor: C threads, preadv /
-    pwritev over many records per call; ctypes releases the GIL for the duration"""
-    from . import _lib
-    _lib.call(name, fd, first_record, count, polys, ctx.k, ctx.n, C.c_void_p(tensor.data_ptr()), threads)
+class StreamFile:
+    """fhe_io_open / fhe_io_transfer (include/fhe_stream.h): one shared mapping of a ciphertext stream file; records move
+    between it and a page-locked staging tensor by parallel memcpy in C threads (ctypes releases the GIL for the call).
+    For writing, an existing file of exactly `size` bytes keeps its pages (a reused spool file is memcpy-bound; a fresh
+    file is bound by the kernel's page allocation whatever the method)."""
+
+    def __init__(self, path, write=False, size=0):
+        from . import _lib
+        self._lib = _lib
+        h = C.c_void_p()
+        _lib.call("fhe_io_open", os.fsencode(path), int(write), size, C.byref(h))
+        self.h = h
+        self.size = int(_lib.load().fhe_io_size(h))
+
+    def transfer(self, first_record, count, polys, ctx, tensor, threads):
+        self._lib.call("fhe_io_transfer", self.h, first_record, count, polys, ctx.k, ctx.n, C.c_void_p(tensor.data_ptr()), threads)
+
+    def close(self):
+        if self.h:
+            self._lib.load().fhe_io_close(self.h)
+            self.h = None
 
 
 def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None):
@@ -124,9 +140,10 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
     if os.path.getsize(in_path) < n_blocks * 192 * rec:
         raise EOFError("ciphertext stream ended")
     waves = [(s, min(s + wave_blocks, n_blocks)) for s in range(0, n_blocks, wave_blocks)]
-    fin = os.open(in_path, os.O_RDONLY)
-    fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    fin = StreamFile(in_path)
+    fout = StreamFile(out_path, write=True, size=n_blocks * 192 * rec)
     free_in, ready_in, free_out, to_write = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+    io_seconds = {"read": 0.0, "write": 0.0}
     for i in range(slots):
         free_in.put((i, None))
         free_out.put(i)
@@ -138,7 +155,9 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                 slot, copied = free_in.get()
                 if copied is not None:
                     copied.synchronize()                        # the previous wave in this slot has left for the device
-                _io("fhe_io_read_records", fin, s * 192, (e - s) * 192, 2, ctx, hin[slot], io_threads)
+                t_io = time.perf_counter()
+                fin.transfer(s * 192, (e - s) * 192, 2, ctx, hin[slot], io_threads)
+                io_seconds["read"] += time.perf_counter() - t_io
                 ready_in.put((wi, slot))
         except BaseException as exc:                           # surfaced by the main loop
             errors.append(exc)
@@ -152,7 +171,9 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                     return
                 (s, e), slot, landed = item
                 landed.synchronize()
-                _io("fhe_io_write_records", fout, s * 192, (e - s) * 192, 2, ctx, hout[slot], io_threads)
+                t_io = time.perf_counter()
+                fout.transfer(s * 192, (e - s) * 192, 2, ctx, hout[slot], io_threads)
+                io_seconds["write"] += time.perf_counter() - t_io
                 free_out.put(slot)
         except BaseException as exc:
             errors.append(exc)
@@ -160,7 +181,6 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
 
     t0 = time.perf_counter()
     try:
-        os.ftruncate(fout, n_blocks * 192 * rec)
         rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
         rt.start()
         wt.start()
@@ -212,10 +232,11 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         torch.cuda.synchronize()
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
-                         bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves))
+                         bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves),
+                         file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"])
     finally:
-        os.close(fin)
-        os.close(fout)
+        fin.close()
+        fout.close()
     return n_blocks
 
 

@@ -29,6 +29,20 @@ int fhe_io_read_records(int fd, uint64_t first_record, uint64_t count, uint32_t 
 int fhe_io_write_records(int fd, uint64_t first_record, uint64_t count, uint32_t polys, uint32_t k, uint32_t n,
                          const void *src, uint32_t threads);
 
+/* The same transfers through ONE long-lived shared mapping of the whole file -- the form the streaming servers use.
+ * pwritev holds the file's inode lock exclusively, so any number of writer threads move data at the rate of one; stores
+ * into a mapping scale with the threads.  fhe_io_open(path, write = 0) maps an existing stream for reading;
+ * write = 1 creates the file if needed and gives it size_bytes -- an existing file of exactly that size keeps its pages
+ * (a reused spool file: overwriting allocated page-cache pages is memcpy-bound, while first-touch allocation of fresh
+ * pages is serialised inside the kernel whatever the method).  fhe_io_transfer reads (handle opened for reading) or
+ * writes (opened for writing) `count` records from / to buf with `threads` threads. */
+typedef struct fhe_io_file fhe_io_file;
+int fhe_io_open(const char *path, int write, uint64_t size_bytes, fhe_io_file **out);
+int fhe_io_close(fhe_io_file *file);
+uint64_t fhe_io_size(const fhe_io_file *file);
+int fhe_io_transfer(fhe_io_file *file, uint64_t first_record, uint64_t count, uint32_t polys, uint32_t k, uint32_t n,
+                    void *buf, uint32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,21 +29,29 @@ blocks = max(a.wave, min(a.blocks, int((free * 0.85 - staging) // (2 * per_block
 fin, fout = os.path.join(a.dir, "fhe_in.ct"), os.path.join(a.dir, "fhe_out.ct")
 # input stream: random-residue ciphertexts generated on the device, wave by wave, written with fhe_io_write_records
 host = torch.empty((a.wave, 3, 64, 2, ctx.k, ctx.n), dtype=torch.int64).pin_memory()
-fd = os.open(fin, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+fd = os.open(fin, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+os.ftruncate(fd, blocks * per_block)
 t0 = time.time()
 for s in range(0, blocks, a.wave):
     host.copy_(ctx.random_ct(a.wave, 3, 64, seed=fhe.SEED, first_index=s * 192 * 2 * ctx.k * ctx.n))
-    fhe._lib.call("fhe_io_write_records", fd, s * 192, a.wave * 192, 2, ctx.k, ctx.n, C.c_void_p(host.data_ptr()), a.io_threads)
+    fhe._lib.call("fhe_io_write_records", fd, s * 192, a.wave * 192, 2, ctx.k, ctx.n, C.c_void_p(host.data_ptr()), 8)
 os.close(fd)
 gen_s = time.time() - t0
 del host
 in_bytes = os.path.getsize(fin)
 try:
-    fhe.server.server_jpeg(ctx, fin, fout, min(blocks, 3 * a.wave), wave_blocks=a.wave, io_threads=a.io_threads, slots=a.slots)     # warm-up: page-locking, constants
+    warm = os.path.join(a.dir, "fhe_warm.ct")
+    fhe.server.server_jpeg(ctx, fin, warm, min(blocks, 3 * a.wave), wave_blocks=a.wave, io_threads=a.io_threads, slots=a.slots)     # warm-up: page-locking, constants
+    os.remove(warm)
     torch.cuda.synchronize()
+    fresh = {}
+    t0 = time.time()
+    fhe.server.server_jpeg(ctx, fin, fout, blocks, wave_blocks=a.wave, io_threads=a.io_threads, slots=a.slots, stats=fresh)          # output file does not exist yet
+    torch.cuda.synchronize()
+    fresh_dt = time.time() - t0
     stats = {}
     t0 = time.time()
-    done = fhe.server.server_jpeg(ctx, fin, fout, blocks, wave_blocks=a.wave, io_threads=a.io_threads, slots=a.slots, stats=stats)
+    done = fhe.server.server_jpeg(ctx, fin, fout, blocks, wave_blocks=a.wave, io_threads=a.io_threads, slots=a.slots, stats=stats)  # the same file again: its pages exist
     torch.cuda.synchronize()
     dt = time.time() - t0
     out_bytes = os.path.getsize(fout)
@@ -66,4 +74,8 @@ print(json.dumps({"workload": "server_jpeg stream (rgb_to_ycc + encrypted_dct pe
                   "seconds": dt, "colour_blocks_per_s": done / dt, "block_channels_per_s": 3 * done / dt,
                   "stream_GB_per_s_in_plus_out": (in_bytes + out_bytes) / dt / 1e9, "stream_GiB_in": in_bytes / 2**30,
                   "device_compute_seconds": stats.get("device_compute_seconds"), "device_compute_share": stats.get("device_compute_seconds", 0) / dt,
+                  "file_read_GB_per_s_while_reading": in_bytes / max(stats.get("file_read_seconds", 0), 1e-9) / 1e9,
+                  "file_write_GB_per_s_while_writing": out_bytes / max(stats.get("file_write_seconds", 0), 1e-9) / 1e9,
+                  "fresh_output_file": {"seconds": fresh_dt, "colour_blocks_per_s": blocks / fresh_dt, "file_write_GB_per_s_while_writing": out_bytes / max(fresh.get("file_write_seconds", 0), 1e-9) / 1e9,
+                                        "note": "first pass: every output page is allocated by the kernel on first touch (tmpfs), which is serialised inside the kernel; the headline figures are the second pass into the same file (a reused spool file)"},
                   "input_generation_seconds": gen_s, "first_block_equals_direct_kernels": ok, "host_cpus": os.cpu_count()}))
