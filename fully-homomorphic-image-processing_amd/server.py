@@ -107,7 +107,8 @@ class StreamFile:
 
 
 def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None):
-    """Process `n_blocks` colour blocks.  Input order per block: 64 R, 64 G, 64 B ciphertexts
+    """Process `n_blocks` colour blocks.  in_path / out_path: file names, or StreamFile objects a long-lived server keeps
+    open (their mappings, and the page-table entries behind them, are then reused from call to call).  Input order per block: 64 R, 64 G, 64 B ciphertexts
     (homo/server_jpeg.cpp:115-124).  Output order per block: 64 Y, 64 Cb, 64 Cr
     (homo/server_jpeg.cpp:146-153; read back channel-major by homo/client_jpeg.cpp:266-271).  quant=None reproduces the reference server (no quantize_fhe call);
     a 64-entry table applies quantize_fhe to every channel as well.  Returns blocks processed.
@@ -137,11 +138,15 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
     main = torch.cuda.current_stream()
     h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
     rec = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
-    if os.path.getsize(in_path) < n_blocks * 192 * rec:
+    if (in_path.size if isinstance(in_path, StreamFile) else os.path.getsize(in_path)) < n_blocks * 192 * rec:
         raise EOFError("ciphertext stream ended")
     waves = [(s, min(s + wave_blocks, n_blocks)) for s in range(0, n_blocks, wave_blocks)]
-    fin = StreamFile(in_path)
-    fout = StreamFile(out_path, write=True, size=n_blocks * 192 * rec)
+    own_in, own_out = not isinstance(in_path, StreamFile), not isinstance(out_path, StreamFile)
+    fin = StreamFile(in_path) if own_in else in_path
+    fout = StreamFile(out_path, write=True, size=n_blocks * 192 * rec) if own_out else out_path
+    if fout.size < n_blocks * 192 * rec:
+        raise ValueError("output stream file is smaller than the result")
+    trace = [] if stats is not None else None
     free_in, ready_in, free_out, to_write = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
     io_seconds = {"read": 0.0, "write": 0.0}
     for i in range(slots):
@@ -158,6 +163,8 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                 t_io = time.perf_counter()
                 fin.transfer(s * 192, (e - s) * 192, 2, ctx, hin[slot], io_threads)
                 io_seconds["read"] += time.perf_counter() - t_io
+                if trace is not None:
+                    trace.append(("read", wi, t_io - t0, time.perf_counter() - t0))
                 ready_in.put((wi, slot))
         except BaseException as exc:                           # surfaced by the main loop
             errors.append(exc)
@@ -174,6 +181,8 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                 t_io = time.perf_counter()
                 fout.transfer(s * 192, (e - s) * 192, 2, ctx, hout[slot], io_threads)
                 io_seconds["write"] += time.perf_counter() - t_io
+                if trace is not None:
+                    trace.append(("write", s // wave_blocks, t_io - t0, time.perf_counter() - t0))
                 free_out.put(slot)
         except BaseException as exc:
             errors.append(exc)
@@ -214,9 +223,12 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
             done = torch.cuda.Event()
             done.record(main)
             computed[d] = done
+            t_w = time.perf_counter()
             oslot = free_out.get()
             if oslot is None:
                 raise errors[0]
+            if trace is not None:
+                trace.append(("main", wi, t_w - t0, time.perf_counter() - t0))
             with torch.cuda.stream(d2h):
                 d2h.wait_event(done)
                 hout[oslot][:nb].copy_(dout[d][:nb], non_blocking=True)
@@ -233,10 +245,12 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
                          bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves),
-                         file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"])
+                         file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"], trace=trace)
     finally:
-        fin.close()
-        fout.close()
+        if own_in:
+            fin.close()
+        if own_out:
+            fout.close()
     return n_blocks
 
 
