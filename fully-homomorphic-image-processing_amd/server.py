@@ -285,25 +285,29 @@ def _row_windows(H, h, init_rows):
     return out
 
 
-def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4):
+def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None):
     """homo/server_resize.cpp:127-146 + ResizeImage (homo/fhe_resize.h:308-392) on the GPU.
 
     Input stream: src_w * src_h pixels, row by row, three ciphertext records (R, G, B) per pixel
     (homo/client_resize.cpp:141-150).  Output stream: dst_w * dst_h pixels, row by row, three
     records of size 4 (bilinear) or 6 (bicubic) per pixel (homo/server_resize.cpp:141-146).
+    in_path / out_path: file names or open StreamFile objects.
 
     The reference keeps a sliding window of init_rows = 2 / 4 source rows resident (`for memory
     reasons`, :324-379), walks the destination rows serially and samples one pixel at a time
     (SampleLinear / SampleBicubic, :381-388).  Here the same window logic decides which source rows
-    are resident in HBM (rows below the window's start are dropped, rows are read from the file
-    exactly once, in order); a step takes up to `rows_per_step` destination rows whose windows are
-    loaded, samples ALL their pixels and channels as one batch per channel through the batched
-    circuits (circuits.sample_bicubic / sample_linear), and a writer pool drains the previous
-    step's results from a pinned buffer while the GPU works on the next.
+    are resident in HBM -- a ring of row slots; rows are read from the file exactly once, in order, rows no
+    destination row needs are skipped like :353-357 -- and a step takes up to `rows_per_step` destination rows,
+    samples ALL their pixels per channel as one batch through the library's circuits (fhe_sample_bicubic /
+    fhe_sample_linear; the taps index the interleaved R, G, B records of the ring directly, nothing is
+    gathered), while a reader thread brings in the next step's rows (file -> page-locked -> HBM on its own
+    stream) and a writer thread drains the previous step's results (HBM -> page-locked on its own stream -> file).
 
     encrypt_fractions(values) -> [len, 2, k, n] supplies the circuit's server-side encryptions in
     the reference's call order (per destination pixel: frac(x), then frac(y))."""
-    from concurrent.futures import ThreadPoolExecutor
+    import queue
+    import threading
+    import time
     from . import circuits
     ev = Evaluator(ctx)
     pc = circuits.PlainCache(ctx)
@@ -313,35 +317,12 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         raise ValueError("image too small for the sampler")
     rec_in = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
     rec_out = RECORD_HEADER + out_size * ctx.k * ctx.n * 8
-    if os.path.getsize(in_path) < src_w * src_h * 3 * rec_in:
+    own_in, own_out = not isinstance(in_path, StreamFile), not isinstance(out_path, StreamFile)
+    if (in_path.size if not own_in else os.path.getsize(in_path)) < src_w * src_h * 3 * rec_in:
         raise EOFError("ciphertext stream ended")
-    expect = (2, ctx.k, ctx.n)
-    out_hdr = HEADER.pack(MAGIC, out_size, ctx.k, ctx.n, 0)
     windows = _row_windows(src_h, dst_h, init_rows)
     f32 = np.float32
     us = [f32(f32(x) / f32(dst_w - 1) * f32(src_w)) - f32(0.5) for x in range(dst_w)]
-    row_shape = (src_w, 3, 2, ctx.k, ctx.n)
-    resident = {}                                   # source row index -> device tensor [src_w, 3, 2, k, n]
-    next_row = 0                                    # rows are consumed from the stream in order, once
-    staging = [_pinned(("rs_in", i), (init_rows + rows_per_step,) + row_shape) for i in range(2)]
-    host_out = [_pinned(("rs_out", i, out_size), (rows_per_step * dst_w, 3, out_size, ctx.k, ctx.n)) for i in range(2)]
-    copy_stream = torch.cuda.Stream()
-
-    def read_rows(pool, fd, buf, first_row, count):
-        arr = buf.numpy().view(np.uint64)
-        return [pool.submit(_pread_records, fd, [arr[r, x, c] for x in range(src_w) for c in range(3)],
-                            (first_row + r) * src_w * 3, rec_in, expect) for r in range(count)]
-
-    def write_rows(pool, fd, buf, first_pixel, count):
-        arr = buf.numpy().view(np.uint64)
-        step = max(1, count // _IO_THREADS)
-        return [pool.submit(_pwrite_records, fd, [arr[p, c] for p in range(s, min(s + step, count)) for c in range(3)],
-                            (first_pixel + s) * 3, rec_out, out_hdr) for s in range(0, count, step)]
-
-    def wait(futs):
-        for f in futs:
-            f.result()
-
     # steps: consecutive destination rows whose source rows fit `init_rows + rows_per_step` resident rows
     steps, y = [], 0
     while y < dst_h:
@@ -350,69 +331,148 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
             e += 1
         steps.append((y, e))
         y = e
-    fin = os.open(in_path, os.O_RDONLY)
-    fout = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    try:
-        os.ftruncate(fout, dst_w * dst_h * 3 * rec_out)
-        with ThreadPoolExecutor(_IO_THREADS) as rpool, ThreadPoolExecutor(_IO_THREADS) as wpool:
-            def rows_needed(step):
-                lo, hi = windows[step[0]][1], windows[step[1] - 1][1] + init_rows
-                return lo, hi
+    span = [(windows[a][1], windows[b - 1][1] + init_rows) for a, b in steps]            # source rows [lo, hi) a step needs
+    # rows each step has to bring in: those not yet read (rows are consumed from the stream in order, once)
+    reads, next_row = [], 0
+    for lo, hi in span:
+        first = max(next_row, lo)
+        reads.append((first, max(0, hi - first)))
+        next_row = max(next_row, hi)
+    max_rows = max(hi - lo for lo, hi in span)
+    max_new = max(cnt for _, cnt in reads)
+    max_px = max((b - a) * dst_w for a, b in steps)
+    R = 2 * max_rows + max_new + 1                                                       # ring of resident source rows: row r lives in slot r % R
+    ring = torch.empty((R, src_w, 3, 2, ctx.k, ctx.n), dtype=torch.int64, device=ctx.device)
+    ring_flat = ring.view(-1, 2, ctx.k, ctx.n)                                           # record (slot, x, channel) = pixel index (slot * src_w + x) * 3 + channel
+    slots = max(2, slots)
+    hin = [_pinned(("rs_in", i), (max_new, src_w, 3, 2, ctx.k, ctx.n)) for i in range(slots)]
+    hout = [_pinned(("rs_out", i, out_size), (max_px, 3, out_size, ctx.k, ctx.n)) for i in range(slots)]
+    dout = [torch.empty((max_px, 3, out_size, ctx.k, ctx.n), dtype=torch.int64, device=ctx.device) for _ in range(2)]
+    main = torch.cuda.current_stream()
+    h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+    fin = StreamFile(in_path) if own_in else in_path
+    fout = StreamFile(out_path, write=True, size=dst_w * dst_h * 3 * rec_out) if own_out else out_path
+    if fout.size < dst_w * dst_h * 3 * rec_out:
+        raise ValueError("output stream file is smaller than the result")
+    free_in, ready_in, free_out, to_write = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+    for i in range(slots):
+        free_in.put((i, None))
+        free_out.put(i)
+    errors = []
+    io_seconds = {"read": 0.0, "write": 0.0}
 
-            def start_read(si, first_new):
-                lo, hi = rows_needed(steps[si])
-                cnt = hi - max(first_new, lo)
-                skip_to = max(first_new, lo)            # rows between first_new and lo are skipped like :353-357
-                return (skip_to, cnt, read_rows(rpool, fin, staging[si & 1], skip_to, cnt)) if cnt > 0 else (skip_to, 0, [])
-
-            pending_w = [[], []]
-            reading = start_read(0, next_row)
-            for si, (y0, y1) in enumerate(steps):
-                first, cnt, futs = reading
-                wait(futs)
+    def reader():
+        try:
+            for si, (first, cnt) in enumerate(reads):
+                slot, copied = free_in.get()
+                if copied is not None:
+                    copied.synchronize()
                 if cnt:
-                    with torch.cuda.stream(copy_stream):
-                        dev = staging[si & 1][:cnt].to(ctx.device, non_blocking=True)
-                    torch.cuda.current_stream().wait_stream(copy_stream)
-                    copy_stream.synchronize()            # staging[si & 1] may be refilled two steps later
-                    for r in range(cnt):
-                        resident[first + r] = dev[r]
-                    next_row = first + cnt
-                lo, hi = rows_needed((y0, y1))
-                for r in [r for r in resident if r < lo]:
-                    del resident[r]
-                if si + 1 < len(steps):                  # prefetch the next step's new rows from the file
-                    reading = start_read(si + 1, next_row)
-                # sample plan of these destination rows, in terms of the resident window
-                base = lo
-                window = torch.stack([resident[r] for r in range(lo, hi)])           # [rows, src_w, 3, 2, k, n]
-                taps, fracs = [], []
-                for yy in range(y0, y1):
-                    v = windows[yy][0]
-                    yi = int(v)
-                    for xx in range(dst_w):
-                        u = us[xx]
-                        xi = int(u)
-                        offs = ([(dx, dy) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)] if bicubic
-                                else [(0, 0), (1, 0), (0, 1), (1, 1)])
-                        taps.append([(min(max(yi + dy, 0), src_h - 1) - base) * src_w + min(max(xi + dx, 0), src_w - 1) for dx, dy in offs])
-                        fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
-                fr = encrypt_fractions(fracs)                                        # xfract, yfract per pixel, in order
-                xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
-                npx = (y1 - y0) * dst_w
-                sampler = circuits.sample_bicubic if bicubic else circuits.sample_linear
-                wait(pending_w[si & 1])
-                for ch in range(3):
-                    pix = window[:, :, ch].reshape(-1, 2, ctx.k, ctx.n).contiguous()
-                    res = sampler(ev, pc, pix, taps, xf, yf)                         # [npx, out_size, k, n]
-                    host_out[si & 1][:npx, ch].copy_(res, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                pending_w[si & 1] = write_rows(wpool, fout, host_out[si & 1], y0 * dst_w, npx)
-            wait(pending_w[0])
-            wait(pending_w[1])
+                    t_io = time.perf_counter()
+                    fin.transfer(first * src_w * 3, cnt * src_w * 3, 2, ctx, hin[slot], io_threads)
+                    io_seconds["read"] += time.perf_counter() - t_io
+                ready_in.put((si, slot))
+        except BaseException as exc:
+            errors.append(exc)
+            ready_in.put((None, None))
+
+    def writer():
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                first_px, npx, slot, landed = item
+                landed.synchronize()
+                t_io = time.perf_counter()
+                fout.transfer(first_px * 3, npx * 3, out_size, ctx, hout[slot], io_threads)
+                io_seconds["write"] += time.perf_counter() - t_io
+                free_out.put(slot)
+        except BaseException as exc:
+            errors.append(exc)
+            free_out.put(None)
+
+    t0 = time.perf_counter()
+    try:
+        rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+        rt.start()
+        wt.start()
+        computed, drained = [], [None, None]
+        t_start, t_stop = [], []
+        sampler = circuits.sample_bicubic if bicubic else circuits.sample_linear
+        offs = ([(dx, dy) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)] if bicubic else [(0, 0), (1, 0), (0, 1), (1, 1)])
+        for si, (y0, y1) in enumerate(steps):
+            got, slot = ready_in.get()
+            if got is None:
+                raise errors[0]
+            first, cnt = reads[si]
+            with torch.cuda.stream(h2d):
+                if si >= 2:
+                    h2d.wait_event(computed[si - 2])            # the slots these rows overwrite were last read two steps ago ...
+                if si >= 1 and cnt and {(first + i) % R for i in range(cnt)} & {r % R for r in range(*span[si - 1])}:
+                    h2d.wait_event(computed[si - 1])            # ... unless the window jumped (strong down-scaling): then wait for the previous step
+                done_rows = 0
+                while done_rows < cnt:                          # consecutive rows sit in consecutive slots modulo R
+                    s0 = (first + done_rows) % R
+                    part = min(cnt - done_rows, R - s0)
+                    ring[s0:s0 + part].copy_(hin[slot][done_rows:done_rows + part], non_blocking=True)
+                    done_rows += part
+                copied = torch.cuda.Event()
+                copied.record(h2d)
+            free_in.put((slot, copied))
+            main.wait_event(copied)
+            # sample plan of these destination rows in terms of ring slots
+            taps, fracs = [], []
+            for yy in range(y0, y1):
+                v = windows[yy][0]
+                yi = int(v)
+                for xx in range(dst_w):
+                    u = us[xx]
+                    xi = int(u)
+                    taps.append([((min(max(yi + dy, 0), src_h - 1) % R) * src_w + min(max(xi + dx, 0), src_w - 1)) * 3 for dx, dy in offs])
+                    fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
+            taps = np.asarray(taps, dtype=np.uint32)
+            fr = encrypt_fractions(fracs)                                            # xfract, yfract per pixel, in order
+            xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
+            npx, d = (y1 - y0) * dst_w, si & 1
+            if drained[d] is not None:
+                main.wait_event(drained[d])                                          # dout[d] has left for the host
+            if stats is not None:
+                t_start.append(torch.cuda.Event(enable_timing=True))
+                t_start[-1].record(main)
+            for ch in range(3):
+                dout[d][:npx, ch].copy_(sampler(ev, pc, ring_flat, taps + ch, xf, yf))   # [npx, out_size, k, n] into the interleaved record order
+            if stats is not None:
+                t_stop.append(torch.cuda.Event(enable_timing=True))
+                t_stop[-1].record(main)
+            done = torch.cuda.Event()
+            done.record(main)
+            computed.append(done)
+            oslot = free_out.get()
+            if oslot is None:
+                raise errors[0]
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(done)
+                hout[oslot][:npx].copy_(dout[d][:npx], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(d2h)
+            drained[d] = landed
+            to_write.put((y0 * dst_w, npx, oslot, landed))
+        to_write.put(None)
+        wt.join()
+        rt.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.synchronize()
+        if stats is not None:
+            stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
+                         bytes_in=sum(c for _, c in reads) * src_w * 3 * rec_in, bytes_out=dst_w * dst_h * 3 * rec_out, steps=len(steps),
+                         file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"])
     finally:
-        os.close(fin)
-        os.close(fout)
+        if own_in:
+            fin.close()
+        if own_out:
+            fout.close()
     return dst_w * dst_h
 
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""End-to-end rate of the streaming server_resize loop (homo/fhe_resize.h:308-392 over a ciphertext stream):
-file -> pinned host -> HBM (sliding row window) -> batched SampleBicubic / SampleLinear -> pinned host -> file.
-Files live in /dev/shm.  The circuit's server-side encryptions are pre-made ciphertexts (inputs).
-Prints one JSON line (NOT the bench.py metric: I/O-inclusive)."""
-import argparse, json, os, sys, time
+"""End-to-end rate of the streaming server_resize loop (homo/fhe_resize.h:308-392 over a ciphertext stream) at the
+size of BASELINE.json configs[2]: 128x128 -> 64x64, three channels, n = 8192 (24 GiB in, 18 GiB out for bicubic):
+file -> page-locked host -> HBM (ring of source rows) -> fhe_sample_bicubic / fhe_sample_linear -> page-locked host -> file.
+Files live in a tmpfs and stay mapped (a long-lived server's spool files); the circuit's server-side encryptions are
+pre-made ciphertexts (inputs).  Prints one JSON line (NOT the bench.py metric: I/O-inclusive)."""
+import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,19 +13,26 @@ import fhip_amd as fhe
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--preset", default="P8192")
-ap.add_argument("--src", type=int, default=48)
-ap.add_argument("--dst", type=int, default=24)
+ap.add_argument("--src", type=int, default=128)
+ap.add_argument("--dst", type=int, default=64)
 ap.add_argument("--bilinear", action="store_true")
 ap.add_argument("--rows", type=int, default=4)
+ap.add_argument("--io-threads", type=int, default=16)
 ap.add_argument("--dir", default="/dev/shm")
 a = ap.parse_args()
 ctx = fhe.SEALContext.preset(a.preset)
 fin, fout = os.path.join(a.dir, "fhe_rs_in.ct"), os.path.join(a.dir, "fhe_rs_out.ct")
-rng = np.random.default_rng(1)
-one = np.stack([rng.integers(0, q, size=(2, ctx.n), dtype=np.uint64) for q in ctx.q], axis=1)   # [2, k, n]
-with open(fin, "wb") as f:
-    for _ in range(a.src * a.src * 3):
-        fhe.server.write_ciphertext(f, one)
+out_size = 4 if a.bilinear else 6
+rec_in = fhe.server.RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+rec_out = fhe.server.RECORD_HEADER + out_size * ctx.k * ctx.n * 8
+n_in, n_out = a.src * a.src * 3, a.dst * a.dst * 3
+# input stream generated on the device, one source row at a time
+row = torch.empty((a.src, 3, 2, ctx.k, ctx.n), dtype=torch.int64).pin_memory()
+sin = fhe.server.StreamFile(fin, write=True, size=n_in * rec_in)
+for r in range(a.src):
+    row.copy_(ctx.random_ct(a.src, 3, size=2, seed=fhe.SEED, first_index=r * a.src * 3 * 2 * ctx.k * ctx.n))
+    sin.transfer(r * a.src * 3, a.src * 3, 2, ctx, row, 8)
+sin.close()
 bank = ctx.random_ct(a.rows * a.dst * 2, size=2, seed=5)
 
 
@@ -33,15 +41,25 @@ def fractions(values):
 
 
 try:
+    sin = fhe.server.StreamFile(fin)
+    sout = fhe.server.StreamFile(fout, write=True, size=n_out * rec_out)
+    fresh = {}
+    fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=fresh)   # first pass: page-locking, page allocation
+    torch.cuda.synchronize()
+    stats = {}
     t0 = time.time()
-    done = fhe.server.server_resize(ctx, fin, fout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows)
+    done = fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=stats)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    in_bytes, out_bytes = os.path.getsize(fin), os.path.getsize(fout)
+    sin.close()
+    sout.close()
 finally:
     for p in (fin, fout):
         if os.path.exists(p):
             os.remove(p)
-print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset),
+print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s, files in %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset, a.dir),
                   "output_pixels": done, "rows_per_step": a.rows, "seconds": dt, "pixels_per_s": done / dt,
-                  "stream_GB_in": in_bytes / 1e9, "stream_GB_out": out_bytes / 1e9, "files": a.dir}))
+                  "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
+                  "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
+                  "file_read_seconds": stats["file_read_seconds"], "file_write_seconds": stats["file_write_seconds"],
+                  "first_pass_seconds_incl_page_locking_and_page_allocation": fresh.get("seconds")}))
