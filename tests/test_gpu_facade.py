@@ -74,3 +74,34 @@ def test_reference_cli_pipeline_unmodified(tmp_path):
     got = np.asarray(Image.open(str(tmp_path / "image" / "out.jpg")).convert("RGB"), dtype=np.int32)
     assert got.shape == (h, w, 3)
     assert np.sqrt(np.mean((got - rgb.astype(np.int32)) ** 2)) < 12.0
+
+
+def test_reference_quantize_fhe_known_answer_through_decrypt(oracle_mod, tmp_path):
+    """quantize_fhe sits outside every published pipeline (the reference's server never calls it).  Here the reference's OWN
+    encrypted_dct + quantize_fhe code (homo/fhe_image.h:196-305, unchanged, through the facade on the GPU) runs on real
+    encryptions of a pixel block; the decrypted, decoded outputs must be the plaintext DCT of homo/fhe_image.h:400-484 divided
+    by the quantisation table -- a known answer for the product of the two circuits, independent of the oracle's restatement."""
+    if not os.path.exists(REF_BIN):
+        pytest.skip("oracle/_ref/ref_jpeg_circuit not built (needs /root/reference at build time)")
+    from oracle import bigint_model as bm
+    orc = oracle_mod.Oracle.preset("P4096")
+    sk, pk = orc.keygen(42)
+    vals = [float((37 * x + 101 * y + 13) % 256) - 128.0 for y in range(8) for x in range(8)]
+    cts = np.stack([orc.encrypt(pk, orc.encode(v), seed=2000 + i) for i, v in enumerate(vals)] +
+                   [orc.encrypt(pk, orc.encode(float(v)), seed=3000 + i) for i, v in enumerate((200, 100, 50))])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    cts.tofile(str(fin))
+    r = subprocess.run([REF_BIN, "4096", str(fin), str(fout)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = np.fromfile(str(fout), dtype=np.uint64).reshape(cts.shape)
+    expect = bm.plain_dct(vals)
+    for i in range(64):
+        plain, budget = orc.decrypt(sk, out[i])
+        assert budget > 0
+        assert abs(orc.decode(plain) - expect[i] / oracle_mod.YQT[i]) < 1e-6, i
+    # and rgb_to_ycc_fhe on the three extra ciphertexts (homo/fhe_image.h:310-325)
+    R, G, B = 200.0, 100.0, 50.0
+    want = (0.299 * R + 0.587 * G + 0.114 * B - 128.0, -0.168736 * R - 0.331264 * G + 0.5 * B, 0.5 * R - 0.418688 * G - 0.081312 * B)
+    for j in range(3):
+        plain, budget = orc.decrypt(sk, out[64 + j])
+        assert budget > 0 and abs(orc.decode(plain) - want[j]) < 1e-6, j
