@@ -28,6 +28,15 @@ ref_ntt = ctx.digest(ev.ntt_inverse(ev.ntt_forward(a)).view(-1))
 assert ref_ntt == ctx.digest(a.view(-1))
 ma, mb = ctx.random_ct(256, seed=21), ctx.random_ct(256, seed=22)
 ref_mul = ctx.digest(ev.multiply(ma, mb).view(-1))
+# the library circuits (csrc/circuits.hip): index arrays through the page-locked staging ring, scratch arena reuse, back to back without a
+# host synchronisation in between -- a stale index slot or an arena overlap would change a digest
+pc = fhe.circuits.PlainCache(ctx)
+W, H, w, h = 12, 10, 7, 6
+pix = ctx.random_ct(W * H, seed=31)
+taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+xf, yf = ctx.random_ct(w * h, seed=32), ctx.random_ct(w * h, seed=33)
+half = (w * h) // 2
+ref_bic = [ctx.digest(fhe.circuits.sample_bicubic(ev, pc, pix, taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous()).view(-1)) for s, e in ((0, half), (half, w * h))]
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -48,5 +57,11 @@ for i in range(iters):
         if ctx.digest(ev.multiply(ma, mb).view(-1)) != ref_mul:
             bad += 1
             print("multiply digest mismatch at iteration", i, flush=True)
+    if i % 16 == 0:
+        o1 = fhe.circuits.sample_bicubic(ev, pc, pix, taps[:half], xf[:half].contiguous(), yf[:half].contiguous())      # two calls queued back to back
+        o2 = fhe.circuits.sample_bicubic(ev, pc, pix, taps[half:], xf[half:].contiguous(), yf[half:].contiguous())
+        if [ctx.digest(o1.view(-1)), ctx.digest(o2.view(-1))] != ref_bic:
+            bad += 1
+            print("sample_bicubic digest mismatch at iteration", i, flush=True)
 print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
