@@ -99,3 +99,80 @@ def test_ctx_create_rejects_bad_parameters(fhe):
     assert lib.fhe_ctx_create(4095, q, 3, 1 << 14, 0, C.byref(h)) == -1      # not a power of two
     assert lib.fhe_ctx_create(4096, q, 0, 1 << 14, 0, C.byref(h)) == -1      # no moduli
     assert lib.fhe_ctx_create(4096, q, 9, 1 << 14, 0, C.byref(h)) == -1      # too many
+
+
+def test_resize_sample_plan_matches_the_reference_index_arithmetic(fhe):
+    """fhe_resize_sample_plan (host only) against an independent float32 restatement of homo/fhe_resize.h:350-351,381-382
+    (tests/refrun.sample_origins) and of GetPixelClamped / the tap order of SampleBicubic and SampleLinear"""
+    from refrun import sample_origins
+    for (W, H, w, h) in ((48, 48, 17, 17), (128, 128, 64, 64), (9, 7, 17, 13), (6, 5, 2, 2)):
+        origins = sample_origins(W, H, w, h)
+        for bicubic in (True, False):
+            taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=bicubic)
+            assert taps.shape == (w * h, 16 if bicubic else 4) and len(fx) == len(fy) == w * h
+            offs = [(dx, dy) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)] if bicubic else [(0, 0), (1, 0), (0, 1), (1, 1)]
+            for o in range(w * h):
+                xi, yi = origins[o]
+                want = [min(max(yi + dy, 0), H - 1) * W + min(max(xi + dx, 0), W - 1) for dx, dy in offs]
+                assert list(map(int, taps[o])) == want, (W, H, w, h, bicubic, o)
+                assert 0.0 <= fx[o] < 1.0 and 0.0 <= fy[o] < 1.0
+            f32 = np.float32
+            u = f32(f32(w - 1) / f32(w - 1) * f32(W)) - f32(0.5)
+            assert fx[w - 1] == float(u - np.floor(u))
+    lib = fhe._lib.load()
+    assert lib.fhe_resize_sample_plan(4, 4, 1, 4, 1, None, None, None) < 0        # the reference divides by width - 1
+    assert lib.fhe_approximated_step_out_size(12) == 22 and lib.fhe_approximated_step_out_size(0) == 3
+
+
+def test_stream_record_io(fhe, tmp_path):
+    """include/fhe_stream.h on the CPU: positional record reads / writes from threads and the mapped-file transfers
+    produce and consume exactly the records the Python writer makes; foreign, mismatching and short streams are refused"""
+    lib = fhe._lib.load()
+    k, n, polys, cnt = 3, 1024, 2, 300
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 1 << 60, size=(cnt, polys, k, n), dtype=np.uint64)
+    p1, p2, p3 = (str(tmp_path / x) for x in "abc")
+    with open(p1, "wb") as f:
+        for i in range(cnt):
+            fhe.server.write_ciphertext(f, data[i])
+    assert lib.fhe_io_record_bytes(polys, k, n) == os.path.getsize(p1) // cnt
+    fd = os.open(p1, os.O_RDONLY)
+    out = np.zeros_like(data)
+    fhe._lib.call("fhe_io_read_records", fd, 0, cnt, polys, k, n, out.ctypes.data_as(C.c_void_p), 7)
+    assert np.array_equal(out, data)
+    part = np.zeros((13, polys, k, n), dtype=np.uint64)
+    fhe._lib.call("fhe_io_read_records", fd, 250, 13, polys, k, n, part.ctypes.data_as(C.c_void_p), 3)
+    assert np.array_equal(part, data[250:263])
+    with pytest.raises(fhe.FheError, match="stream ended"):
+        fhe._lib.call("fhe_io_read_records", fd, 290, 13, polys, k, n, part.ctypes.data_as(C.c_void_p), 3)
+    with pytest.raises(fhe.FheError, match="does not match"):
+        fhe._lib.call("fhe_io_read_records", fd, 0, 2, 3, k, n, part.ctypes.data_as(C.c_void_p), 1)
+    os.close(fd)
+    fd = os.open(p2, os.O_WRONLY | os.O_CREAT, 0o644)
+    fhe._lib.call("fhe_io_write_records", fd, 0, cnt, polys, k, n, data.ctypes.data_as(C.c_void_p), 5)
+    os.close(fd)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+
+    class Shape:
+        pass
+    ctx = Shape()
+    ctx.k, ctx.n = k, n
+    import torch
+    t = torch.from_numpy(data.view(np.int64))
+    w = fhe.server.StreamFile(p3, write=True, size=cnt * lib.fhe_io_record_bytes(polys, k, n))
+    w.transfer(0, 100, polys, ctx, t, 5)
+    w.transfer(100, 200, polys, ctx, t[100:], 7)
+    w.close()
+    assert open(p1, "rb").read() == open(p3, "rb").read()
+    r = fhe.server.StreamFile(p1)
+    back = torch.zeros_like(t)
+    r.transfer(0, cnt, polys, ctx, back, 6)
+    assert torch.equal(back, t)
+    with pytest.raises(fhe.FheError, match="stream ended"):
+        r.transfer(290, 20, polys, ctx, back, 2)
+    r.close()
+    open(p2, "r+b").write(b"NOTACIPH")
+    bad = fhe.server.StreamFile(p2)
+    with pytest.raises(fhe.FheError, match="not a ciphertext record"):
+        bad.transfer(0, 1, polys, ctx, back, 1)
+    bad.close()
