@@ -345,6 +345,51 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
     }
 }
 
+// The same step on the pseudo-Mersenne inverse passes (ntt_core.h; C = the class of the base), M ciphertext pairs
+// (M cc + h) per workgroup.  The lazy Barrett products are summed as integers (at most 12 x 5q), one fold_pm brings a sum
+// below (17/16) q, and the transform leaves its outputs below C::RQ / 16 q: k_behz_floor_back<.., WIDE_CHUNK> takes them
+// as they are (its Shoup products accept any 64-bit value, its 128-bit sums a start value below 4 b_j).
+template <int L, int M, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
+                                                                             RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u32 nb = base.count, so = sa + sb - 1;
+    const u64 bid = blockIdx.x, chunk = bid / (8 * so), rem = bid % (8 * so);      // same XCD-aware order as k_behz_tensor_intt
+    const u32 o = (u32)(rem >> 3);
+    const u64 g = chunk * 8 + (rem & 7);               // cc * nb + j
+    if (g >= groups) return;
+    const u32 j = (u32)(g % nb);
+    const u64 cc = g / nb;
+    const BarrettLazy bl = barrett_lazy(base.mod[j]);
+    const PmMod m = base.pm[j];
+    u64 acc[M][16];
+    const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
+#pragma unroll
+    for (int h = 0; h < M; h++) {
+        const u64 c = M * cc + h, cb = bm(c);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][r] = 0;
+        for (u32 ja = lo; ja <= hi; ja++) {
+            const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {       // eight slots at a time: 64 accumulator + 32 operand VGPRs
+                u64 xa[8], xb[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) acc[h][r0 + r] += mul_barrett_lazy5(xa[r], xb[r], bl);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][r] = fold_pm(acc[h][r], m);
+    }
+    ntt_inv_regs_pm<L, M, PM_FOLDED, C::XB, C::LIM, C::RQ>(acc, base.itw_pm + (size_t)j * N, m, lds, tid);
+#pragma unroll
+    for (int h = 0; h < M; h++) store_coeff<L>(acc[h], D + (((M * cc + h) * so + o) * nb + j) * N, tid);
+}
+
 // steps 2(tail: times t) + 3 + 4: Dq [polys][k][n], Db [polys][k+1][n] (coefficient form) -> out [polys][k][n]
 template <int K, int CH>
 __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
@@ -633,12 +678,15 @@ static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 
 // tensor product fused into the inverse transforms over one base: pairs of ciphertext pairs per workgroup at n >= 8192
 // (P8192 inverse transform +19 % with shared twiddles), the odd one out and the smaller degrees one per workgroup
 static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, const RnsBase base, u32 sa, u32 sb, u64 count, hipStream_t st, BMap bm,
-                       bool wide_base) {
+                       bool wide_base, int pm_class) {
     const u32 nb = base.count, so = sa + sb - 1;
     const bool wide = wide_base && (sa < sb ? sa : sb) <= 12 && !c->opt.behz_tensor_canon;     // terms per output <= min(sa, sb); 12 x 5q < 2^64
     const bool single = c->opt.ntt_single || c->opt.behz_tensor_single;      // behz_tensor_single: only this step on the one-polynomial kernel (which has the range-tracking inverse)
     u64 done = 0;
-    if (c->logn >= 13 && !single && count >= 2) {
+    const int pmc = (wide && c->behz->wide_dot && !c->opt.ntt_nopm && base.pm) ? pm_class : 0;     // pseudo-Mersenne inverse passes
+    if (pmc) {
+        // one ciphertext pair per workgroup, below (see fhe_ntt_launch: the two-polynomial shape buys nothing on these passes)
+    } else if (c->logn >= 13 && !single && count >= 2) {
         const u64 pairs = count / 2;
         switch (c->logn) {
 #define GO2(LL, WW) k_behz_tensor_intt2<LL, WW><<<(unsigned)(((pairs * nb + 7) / 8) * 8 * so), NttShape<LL>::TP, 0, st>>>(A, Bm, D, base, sa, sb, pairs * nb, bm)
@@ -655,7 +703,13 @@ static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, co
         const u64 *A2 = A + done * sa * nb * n, *B2 = bm.cnt ? Bm : Bm + done * sb * nb * n;
         u64 *D2 = D + done * so * nb * n;
         if (bm.cnt) bm.off += done;
-        if (wide) { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, true><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
+        if (pmc) {
+            const unsigned grid = (unsigned)(((rest * nb + 7) / 8) * 8 * so);
+            DISPATCH_L(c->logn, {
+                if (pmc == 1) k_behz_tensor_intt_pm<L, 1, PmA><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+                else k_behz_tensor_intt_pm<L, 1, PmB><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+            });
+        } else if (wide) { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, true><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
         else { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, false><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
     }
     KERNEL_CHECK();
@@ -674,9 +728,9 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
         if ((rc = qbase_ntt(true, c, Dq, Dq, count * so, st))) return rc;
     } else {
         const RnsBase qb = c->qb.dev();
-        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm, c->max_prime_bits <= 58))) return rc;
+        if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm, c->max_prime_bits <= 58, c->qb.pm_class))) return rc;
     }
-    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm, c->behz->aux_bits <= 58))) return rc;
+    if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm, c->behz->aux_bits <= 58, c->behz->aux.pm_class))) return rc;
     switch (k) {
 #define GO(KK) case KK: if (c->behz->wide_dot) k_behz_floor_back<KK, WIDE_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); \
                         else k_behz_floor_back<KK, DOT_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;

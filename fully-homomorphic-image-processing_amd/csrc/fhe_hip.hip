@@ -72,6 +72,44 @@ int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 log
     HIP_TRY(hipMemcpy(B.d_tw, tw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(B.d_itw, itw.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(B.d_mod, B.h_mod.data(), sizeof(Modulus) * cnt, hipMemcpyHostToDevice));
+    // pseudo-Mersenne class of the base (ntt_core.h): q = 2^b - delta, product bound 2^b + 2^32 delta, fold bound 2^b + 2^(64-b) delta
+    bool a_all = true, b_all = true;
+    std::vector<PmMod> pm(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+        const u64 q = primes[i];
+        const int b = bit_length(q);
+        if (b < 34 || b > 58) { a_all = b_all = false; break; }
+        const u64 delta = (1ULL << b) - q;
+        const u128 prod = ((u128)1 << b) + ((u128)delta << 32), folded = ((u128)1 << b) + ((u128)delta << (64 - b));
+        if ((delta >> 31) || folded * 16 > (u128)q * PM_FOLDED) { a_all = b_all = false; break; }
+        const u128 vv = ((u128)1 << b) + ((u128)delta << (85 - b));       // mulvv_pm's result bound
+        a_all = a_all && b <= 55 && b >= 52 && prod * 16 <= (u128)q * PmA::RQ && vv * 16 <= (u128)q * PmA::RQ;
+        b_all = b_all && b >= 52 && prod * 16 <= (u128)q * PmB::RQ && vv * 16 <= (u128)q * PmB::RQ;
+        pm[i].q = q;
+        pm[i].delta = (u32)delta;
+        pm[i].sh = (u32)(b - 32);
+        pm[i].mb = (1u << (b - 32)) - 1;
+        pm[i].pad = 0;
+    }
+    const int cls = a_all ? 1 : b_all ? 2 : 0;
+    B.pm_class = cls;
+    if (cls) {
+        std::vector<ulonglong2> twp(cnt * n), itwp(cnt * n);
+        for (size_t i = 0; i < cnt; ++i) {
+            const u64 q = primes[i];
+            for (u32 j = 0; j < n; ++j) {
+                const u32 jp = pm_tw_index((int)logn, j);
+                twp[i * n + jp] = make_ulonglong2(tw[i * n + j].x, (u64)(((u128)tw[i * n + j].x << 31) % q));
+                itwp[i * n + jp] = make_ulonglong2(itw[i * n + j].x, (u64)(((u128)itw[i * n + j].x << 31) % q));
+            }
+        }
+        HIP_TRY(hipMalloc(&B.d_tw_pm, sizeof(ulonglong2) * cnt * n));
+        HIP_TRY(hipMalloc(&B.d_itw_pm, sizeof(ulonglong2) * cnt * n));
+        HIP_TRY(hipMalloc(&B.d_pm, sizeof(PmMod) * cnt));
+        HIP_TRY(hipMemcpy(B.d_tw_pm, twp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(B.d_itw_pm, itwp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(B.d_pm, pm.data(), sizeof(PmMod) * cnt, hipMemcpyHostToDevice));
+    }
     if (want_f64) {
         // the same twiddles as centred doubles for the exact-FP64 kernels (dct_fused.hip)
         std::vector<double> twd(cnt * n), itwd(cnt * n);
@@ -96,6 +134,12 @@ void fhe_free_base(BaseTables &B) {
     if (B.d_mod) (void)hipFree(B.d_mod);
     if (B.d_tw_f64) (void)hipFree(B.d_tw_f64);
     if (B.d_itw_f64) (void)hipFree(B.d_itw_f64);
+    if (B.d_tw_pm) (void)hipFree(B.d_tw_pm);
+    if (B.d_itw_pm) (void)hipFree(B.d_itw_pm);
+    if (B.d_pm) (void)hipFree(B.d_pm);
+    B.d_tw_pm = B.d_itw_pm = nullptr;
+    B.d_pm = nullptr;
+    B.pm_class = 0;
     B.d_tw_f64 = B.d_itw_f64 = nullptr;
     B.d_tw = B.d_itw = nullptr;
     B.d_mod = nullptr;
@@ -164,6 +208,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.dct_u64_fused = !off("FHE_DCT_U64_FUSED");
         o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
         o.ntt_single = env_on("FHE_NTT_SINGLE");
+        o.ntt_nopm = env_on("FHE_NTT_NOPM");
         o.behz_aux61 = env_on("FHE_BEHZ_AUX61");
         o.behz_chunk3 = env_on("FHE_BEHZ_CHUNK3");
         o.behz_tensor_canon = env_on("FHE_BEHZ_TENSOR_CANON");
@@ -537,6 +582,47 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv2(const u64 *__re
     store_coeff<L>(x[1], out + rp1 * NttShape<L>::N, tid);
 }
 
+// The same transforms on the pseudo-Mersenne passes (ntt_core.h), M polynomials of one prime per workgroup
+// (residue polynomials (M g + j) pair_stride + prime); C = PmA / PmB, the class of the base.
+template <int L, int M, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_fwd_pm(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base, u32 pair_stride) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const u64 g = blockIdx.x / base.count;
+    const PmMod m = base.pm[prime];
+    u64 x[M][16];
+#pragma unroll
+    for (int j = 0; j < M; j++) load_coeff<L>(x[j], in + ((M * g + j) * pair_stride + prime) * N, tid);
+    ntt_fwd_regs_pm<L, M, 16, C::LIM, C::CS>(x, base.tw_pm + (size_t)prime * N, m, lds, tid);
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[j][r] = canon_pm(x[j][r], m);
+        store_slots<L>(x[j], out + ((M * g + j) * pair_stride + prime) * N, tid);
+    }
+}
+template <int L, int M, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_ntt_inv_pm(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base, u32 pair_stride) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const u64 g = blockIdx.x / base.count;
+    const PmMod m = base.pm[prime];
+    u64 x[M][16];
+#pragma unroll
+    for (int j = 0; j < M; j++) load_slots<L>(x[j], in + ((M * g + j) * pair_stride + prime) * N, tid);
+    ntt_inv_regs_pm<L, M, 16, C::XB, C::LIM, C::RQ>(x, base.itw_pm + (size_t)prime * N, m, lds, tid);      // canonical in
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[j][r] = canon_rq_pm<C::RQ>(x[j][r], m);
+        store_coeff<L>(x[j], out + ((M * g + j) * pair_stride + prime) * N, tid);
+    }
+}
+
 // multiply_plain: NTT -> dyadic product with a prepared plaintext (Shoup pairs) -> inverse NTT
 template <int L, bool LAZY>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain(const u64 *__restrict__ in, u64 *__restrict__ out,
@@ -564,6 +650,38 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain(const u64 *__re
     store_coeff<L>(x, out + rp * N, tid);
 }
 
+// multiply_plain on the pseudo-Mersenne passes, M polynomials of one prime per workgroup (they share every twiddle and
+// every plaintext slot); the dyadic product takes the plaintext value alone (mulvv_pm), not its Shoup companion
+template <int L, int M, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain_pm(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                                  const ulonglong2 *__restrict__ plain, RnsBase base, u32 pair_stride) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const u64 g = blockIdx.x / base.count;
+    const PmMod m = base.pm[prime];
+    u64 x[M][16];
+#pragma unroll
+    for (int j = 0; j < M; j++) load_coeff<L>(x[j], in + ((M * g + j) * pair_stride + prime) * N, tid);
+    ntt_fwd_regs_pm<L, M, 16, C::LIM, C::CS>(x, base.tw_pm + (size_t)prime * N, m, lds, tid);
+    PM_FENCE();                          // keep the 16 plaintext values from being fetched before the transform
+    const ulonglong2 *pl = plain + (size_t)prime * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u64 w = pl[r * TP + tid].x;
+#pragma unroll
+        for (int j = 0; j < M; j++) x[j][r] = mulvv_pm(fold_pm(x[j][r], m), w, m);
+    }
+    ntt_inv_regs_pm<L, M, C::RQ, C::XB, C::LIM, C::RQ>(x, base.itw_pm + (size_t)prime * N, m, lds, tid);
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[j][r] = canon_rq_pm<C::RQ>(x[j][r], m);
+        store_coeff<L>(x[j], out + ((M * g + j) * pair_stride + prime) * N, tid);
+    }
+}
+
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st) {
     if (n_res_polys == 0) return FHE_OK;
     if (n_res_polys > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
@@ -573,6 +691,22 @@ int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u6
     // inverse +19 %; at n = 4096 the pair kernels spill and are slower, so single polynomials stay there)
     const bool pair = c->logn >= 13 && (n_res_polys / base.count) % 2 == 0 && !c->opt.ntt_single;
     for (u64 p : B.primes) lazy = lazy && (p >> 58) == 0 && (p >> 33) != 0;      // canon_below_64q needs q >= 2^33
+    if (B.pm_class && !c->opt.ntt_nopm) {
+        // pseudo-Mersenne passes, ONE polynomial per workgroup at every n: with the twiddles of a stage laid out for
+        // coalesced loads the pair kernel's shared twiddle fetch buys nothing, and its 128 VGPRs spill (P8192 forward
+        // 0.59 against 0.62 ms per 2048 ciphertexts, inverse 0.66 against 0.72)
+        const unsigned grid = (unsigned)n_res_polys;
+#define GO_PM(CC)                                                                                                                  \
+    DISPATCH_L(c->logn, {                                                                                                          \
+        if (inverse) k_ntt_inv_pm<L, 1, CC><<<grid, NttShape<L>::TP, 0, st>>>(in, out, base, base.count);                           \
+        else k_ntt_fwd_pm<L, 1, CC><<<grid, NttShape<L>::TP, 0, st>>>(in, out, base, base.count);                                   \
+    })
+        if (B.pm_class == 1) { GO_PM(PmA); }
+        else { GO_PM(PmB); }
+#undef GO_PM
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     DISPATCH_L(c->logn, {
         if (inverse && pair && lazy) k_ntt_inv2<L, true><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
         else if (inverse && pair) k_ntt_inv2<L, false><<<(unsigned)(n_res_polys / 2), NttShape<L>::TP, 0, st>>>(in, out, base, base.count);
@@ -607,7 +741,12 @@ extern "C" int fhe_multiply_plain(const fhe_ctx *c, const uint64_t *in, uint64_t
         return fhe_poly_f64_launch(2, c, (const u64 *)in, (u64 *)out, n_polys, (const ulonglong2 *)d_plain_ntt, (hipStream_t)s);
     const RnsBase base = c->qb.dev();
     hipStream_t st = (hipStream_t)s;
-    if (c->max_prime_bits <= 58) {
+    if (c->qb.pm_class && !c->opt.ntt_nopm) {
+#define GO_PM(CC) DISPATCH_L(c->logn, (k_mulplain_pm<L, 1, CC><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base, base.count)))
+        if (c->qb.pm_class == 1) { GO_PM(PmA); }
+        else { GO_PM(PmB); }
+#undef GO_PM
+    } else if (c->max_prime_bits <= 58) {
         DISPATCH_L(c->logn, (k_mulplain<L, true><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));
     } else {
         DISPATCH_L(c->logn, (k_mulplain<L, false><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>((const u64 *)in, (u64 *)out, (const ulonglong2 *)d_plain_ntt, base)));

@@ -31,7 +31,11 @@ struct BaseTables {
     std::vector<Modulus> h_mod;
     // exact-FP64 companion tables (only when every prime is below 2^48): centred twiddles as doubles
     double *d_tw_f64 = nullptr, *d_itw_f64 = nullptr;   // [count][n]
-    RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size()}; }
+    // pseudo-Mersenne tables (ntt_core.h): (w, w 2^31 mod q) pairs; pm_class 0 = the base does not qualify
+    ulonglong2 *d_tw_pm = nullptr, *d_itw_pm = nullptr;
+    PmMod *d_pm = nullptr;
+    int pm_class = 0;
+    RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size(), d_tw_pm, d_itw_pm, d_pm}; }
 };
 
 // Experiment switches.  Read from the environment ONCE, in fhe_ctx_create, and fixed for the life of the context: no
@@ -48,6 +52,7 @@ struct FheOptions {
     bool dct_u64_fused = true;       // FHE_DCT_U64_FUSED=0: three-launch general path instead of the fused u64 pair
     bool ntt_nolazy = false;         // FHE_NTT_NOLAZY=1: Harvey butterflies with conditional subtractions everywhere
     bool ntt_single = false;         // FHE_NTT_SINGLE=1: one polynomial per workgroup at n >= 8192 as well
+    bool ntt_nopm = false;           // FHE_NTT_NOPM=1: Shoup butterflies where the pseudo-Mersenne ones would run
     bool behz_aux61 = false;         // FHE_BEHZ_AUX61=1: 61-bit auxiliary base (SEAL 2.3's size) where 58 bits suffice
     bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
     bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions

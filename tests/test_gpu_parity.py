@@ -902,16 +902,19 @@ def test_randomised_op_sequences_vs_oracle(fhe, oracle_mod, preset):
 # ---------------------------------------------------------------------------------------------
 # the kernels behind the experiment switches (former defaults, fallbacks): same bits as the default path
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("switch", ["FHE_BEHZ_AUX61", "FHE_BEHZ_CHUNK3", "FHE_NTT_NOLAZY", "FHE_NTT_SINGLE", "FHE_BEHZ_TENSOR_CANON",
-                                    "FHE_BEHZ_TENSOR_SINGLE"])
+@pytest.mark.parametrize("switch", ["FHE_NTT_NOPM", "FHE_BEHZ_AUX61", "FHE_BEHZ_CHUNK3", "FHE_NTT_NOPM+FHE_BEHZ_AUX61", "FHE_NTT_NOPM+FHE_BEHZ_CHUNK3",
+                                    "FHE_NTT_NOPM+FHE_NTT_NOLAZY", "FHE_NTT_NOPM+FHE_NTT_SINGLE", "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_CANON",
+                                    "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_SINGLE"])
 def test_fallback_kernels_give_the_same_bits(fhe, oracle_mod, switch):
-    """61-bit auxiliary base, three-term dot-product schedule, Harvey butterflies with conditional subtractions, one
-    polynomial per workgroup, canonical tensor sum: each selected for a second context (the switches are read in
-    fhe_ctx_create), each bit-equal to the default kernels and to the oracle on transforms, multiply_plain and ct x ct
-    products of sizes 2x2, 3x2 and a square, at n = 8192 with 54/55-bit primes (where all of them differ from the default)."""
+    """Shoup butterflies where the pseudo-Mersenne ones run by default (FHE_NTT_NOPM), and under them the 61-bit
+    auxiliary base, the three-term dot-product schedule, Harvey butterflies with conditional subtractions, one polynomial
+    per workgroup, the canonical tensor sum; the 61-bit auxiliary base and the three-term schedule also beside the
+    pseudo-Mersenne q-base kernels.  Each is selected for a second context (the switches are read in fhe_ctx_create) and is
+    bit-equal to the default kernels and to the oracle on transforms, multiply_plain and ct x ct products of sizes 2x2, 3x2
+    and a square, at n = 8192 with 54/55-bit primes (where all of them differ from the default)."""
     import torch
     ctx, orc = _pair(fhe, oracle_mod, "P8192")
-    alt = _variant(fhe, ctx, **{switch: 1})
+    alt = _variant(fhe, ctx, **{name: 1 for name in switch.split("+")})
     ev, ev2 = fhe.Evaluator(ctx), fhe.Evaluator(alt)
     a, b, c3 = ctx.random_ct(4, size=2, seed=41), ctx.random_ct(4, size=2, seed=42), ctx.random_ct(4, size=3, seed=43)
     a[0] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=a.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
