@@ -52,12 +52,28 @@ struct BehzDev {   // lives in device memory; every access is wave-uniform (scal
 
 typedef unsigned __int128 u128;
 
+// Constants of k_behz_floor_back_pm (below): every modulus of the step is pseudo-Mersenne (ntt_core.h), every constant sits
+// beside its multiple by the power of two its variable operand is split at.
+constexpr int PM_SPLIT_Y = 28, PM_SPLIT_Z = 29;      // y_i < 2^55 = yl + 2^28 yh;  z_j, folded D_b < 2^59 = zl + 2^29 zh
+struct BehzPmDev {
+    PmMod q[BK], b[BK + 1];
+    ulonglong2 t_inv_punct[BK];            // (w, w 2^31 mod q_i): mul_pm
+    ulonglong2 flo_t_b[BK + 1];            // (c, c 2^29 mod b_j)
+    ulonglong2 flo_q2b[BK][BK + 1];        // (c, c 2^28 mod b_j)
+    ulonglong2 inv_punct_B[BK];            // (w, w 2^31 mod b_j): mul_pm
+    ulonglong2 back_B2msk[BK];             // (c, c 2^29 mod m_sk)
+    ulonglong2 inv_B_mod_msk;              // (w, w 2^31 mod m_sk): mul_pm
+    ulonglong2 back_pos[BK], back_neg[BK]; // (c, c 2^29 mod q_i)
+    ulonglong2 back_B2q[BK][BK];           // [j][i]: (c, c 2^29 mod q_i)
+};
+
 struct BehzTables {
     BaseTables aux;     // NTT tables of Bsk (k+1 primes)
     BehzDev host;       // host copy (k, moduli)
     BehzDev *dev = nullptr;
     int aux_bits = 61;
     bool wide_dot = false;   // 58-bit auxiliary primes and q-primes <= 58 bits: dot products of <= 8 terms need no inner reduction
+    BehzPmDev *pm_dev = nullptr;     // tables of k_behz_floor_back_pm; null when a modulus does not qualify or a sum could overflow
 };
 
 namespace {
@@ -476,6 +492,141 @@ __global__ __launch_bounds__(256) void k_behz_floor_back(const u64 *__restrict__
     }
 }
 
+// The same step on pseudo-Mersenne arithmetic (ntt_core.h).  A dot product sum_t x_t c_t mod m with context constants c_t
+// is kept as TWO 64-bit columns, S = A + 2^32 B with
+//     A = sum xl cl + xh c2l,   B = sum xl ch + xh c2h      (x = xl + 2^s xh, c2 = c 2^s mod m; four v_mad_u64_u32 per term)
+// -- no carry chain and no 128-bit accumulator -- and reduced once: S = zl + 2^b zh, result zl + zh delta (one
+// multiply-add), where the 128-bit form spends a four-word add per term and a seven-multiply Barrett reduction per sum.
+// Products with one constant are mul_pm; canonical values (the y_i, z_j, alpha and the outputs -- SEAL's fast base
+// conversions take the canonical residues, and bit-exactness rests on that) are fold_pm + one conditional subtraction.
+// The host checks with the actual constants that no column can overflow and that every zh stays below 2^32
+// (behz_pm_tables); sums over the z_j go two terms at a time for that reason.  PCPT coefficients per thread.
+struct PmAcc { u64 A, B; };
+__device__ __forceinline__ void pm_mac(PmAcc &s, u32 xl, u32 xh, const ulonglong2 c) {
+    s.A = (u64)xl * (u32)c.x + s.A;
+    s.A = (u64)xh * (u32)c.y + s.A;
+    s.B = (u64)xl * (u32)(c.x >> 32) + s.B;
+    s.B = (u64)xh * (u32)(c.y >> 32) + s.B;
+}
+__device__ __forceinline__ u64 pm_acc_reduce(const PmAcc &s, const PmMod &m) {
+    const u64 B = s.B + (s.A >> 32);
+    const u32 zh = __builtin_amdgcn_alignbit((u32)(B >> 32), (u32)B, m.sh);
+    u64 zl = pm_pack((u32)s.A, (u32)B & m.mb);
+    asm("" : "+v"(zl));
+    return (u64)zh * m.delta + zl;
+}
+__device__ __forceinline__ u64 canon_fold_pm(u64 v, const PmMod &m) { return csub(fold_pm(v, m), m.q); }
+constexpr int PCPT = 2;
+template <int K>
+__global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
+                                                            const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzPmDev &T = *Tp;     // wave-uniform: scalar loads at compile-time offsets
+    const u32 stride = gridDim.x * blockDim.x;             // n == PCPT * stride
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr u32 MY = (1u << PM_SPLIT_Y) - 1, MZ = (1u << PM_SPLIT_Z) - 1;
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        u32 yl[PCPT][K], yh[PCPT][K], zl[PCPT][K], zh[PCPT][K];
+        u64 f[PCPT][K + 1];
+#pragma unroll
+        for (int i = 0; i < K; i++) {          // [t D]_q (q/q_i)^-1, canonical
+            const PmMod m = T.q[i];
+            const ulonglong2 w = T.t_inv_punct[i];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                const u64 y = canon_fold_pm(mul_pm(Dq[(p * K + i) * n + c0 + e * stride], w, m), m);
+                yl[e][i] = (u32)y & MY;
+                yh[e][i] = (u32)(y >> PM_SPLIT_Y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= K; j++) {         // fast floor: (t D - FastBConv([t D]_q)) q^-1 in Bsk, one two-column sum per prime
+            const PmMod m = T.b[j];
+            const ulonglong2 ft = T.flo_t_b[j];
+            PmAcc acc[PCPT];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                const u64 d = fold_pm(Db[(p * (K + 1) + j) * n + c0 + e * stride], m);       // any 64-bit value -> below (17/16) b_j
+                acc[e].A = 0; acc[e].B = 0;
+                pm_mac(acc[e], (u32)d & MZ, (u32)(d >> PM_SPLIT_Z), ft);
+            }
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const ulonglong2 c = T.flo_q2b[i][j];
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) pm_mac(acc[e], yl[e][i], yh[e][i], c);
+            }
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) f[e][j] = pm_acc_reduce(acc[e], m);               // below 1.5 b_j
+        }
+        const PmMod mk = T.b[K];
+        u64 conv[PCPT];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) conv[e] = 0;
+#pragma unroll
+        for (int j0 = 0; j0 < K; j0 += 2) {
+            PmAcc acc[PCPT];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) { acc[e].A = 0; acc[e].B = 0; }
+#pragma unroll
+            for (int j = j0; j < j0 + 2 && j < K; j++) {
+                const PmMod m = T.b[j];
+                const ulonglong2 w = T.inv_punct_B[j], cj = T.back_B2msk[j];
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) {
+                    const u64 z = canon_fold_pm(mul_pm(f[e][j], w, m), m);                   // canonical integer in [0, b_j)
+                    zl[e][j] = (u32)z & MZ;
+                    zh[e][j] = (u32)(z >> PM_SPLIT_Z);
+                    pm_mac(acc[e], zl[e][j], zh[e][j], cj);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) conv[e] += pm_acc_reduce(acc[e], mk);             // each below 1.5 m_sk
+        }
+        u32 al[PCPT], ah[PCPT];                // |alpha_sk| (at most k for a product; split like the z_j all the same)
+        bool neg[PCPT];
+        {
+            const ulonglong2 ib = T.inv_B_mod_msk;
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                const u64 alpha = canon_fold_pm(mul_pm(conv[e] + 2 * mk.q - f[e][K], ib, mk), mk);
+                neg[e] = alpha > (mk.q >> 1);
+                const u64 a_abs = neg[e] ? mk.q - alpha : alpha;
+                al[e] = (u32)a_abs & MZ;
+                ah[e] = (u32)(a_abs >> PM_SPLIT_Z);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const PmMod m = T.q[i];
+            const ulonglong2 bn = T.back_neg[i], bp = T.back_pos[i];
+            u64 tot[PCPT];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                PmAcc a0;
+                a0.A = 0; a0.B = 0;
+                pm_mac(a0, al[e], ah[e], neg[e] ? bn : bp);
+                tot[e] = pm_acc_reduce(a0, m);
+            }
+#pragma unroll
+            for (int j0 = 0; j0 < K; j0 += 2) {
+                PmAcc acc[PCPT];
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) { acc[e].A = 0; acc[e].B = 0; }
+#pragma unroll
+                for (int j = j0; j < j0 + 2 && j < K; j++) {
+                    const ulonglong2 cji = T.back_B2q[j][i];
+#pragma unroll
+                    for (int e = 0; e < PCPT; e++) pm_mac(acc[e], zl[e][j], zh[e][j], cji);
+                }
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) tot[e] += pm_acc_reduce(acc[e], m);
+            }
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) out[(p * K + i) * n + c0 + e * stride] = canon_fold_pm(tot[e], m);
+        }
+    }
+}
+
 // relinearisation ------------------------------------------------------------------------------
 // digits: for ciphertext c, source prime i, digit d, target prime ii: ((c2_i >> (dbc d)) & mask) mod q_ii
 __global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, const BehzDev *__restrict__ Tp,
@@ -534,6 +685,79 @@ __global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 str
 inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(rows < 32768 ? (rows ? rows : 1) : 32768)); }
 
 }  // namespace
+
+// Tables of k_behz_floor_back_pm, when every modulus of the step is pseudo-Mersenne and -- checked here with the actual
+// constants and the largest values the variables can take -- no column of a two-column sum can pass 2^64 and every
+// quotient part stays below 2^32.  Otherwise pm_dev stays null and the 128-bit kernel runs.
+static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, const std::vector<u64> &bsk) {
+    using namespace hostmath;
+    const u32 k = c->k;
+    if (!c->qb.pm_class || !T->aux.pm_class || !T->wide_dot || k > 6 || c->opt.ntt_nopm) return;
+    BehzPmDev P;
+    std::memset(&P, 0, sizeof P);
+    const std::vector<u64> &q = c->qb.primes;
+    auto pmmod = [](u64 m) {
+        PmMod o;
+        const int b = bit_length(m);
+        o.q = m; o.delta = (u32)((1ULL << b) - m); o.sh = (u32)(b - 32); o.mb = (1u << (b - 32)) - 1; o.pad = 0;
+        return o;
+    };
+    auto with = [](u64 v, int s, u64 m) { return make_ulonglong2(v, (u64)(((u128)v << s) % m)); };
+    for (u32 i = 0; i < k; ++i) {
+        P.q[i] = pmmod(q[i]);
+        P.t_inv_punct[i] = with(D.t_inv_punct[i].x, 31, q[i]);
+        P.back_pos[i] = with(D.back_pos[i], PM_SPLIT_Z, q[i]);
+        P.back_neg[i] = with(D.back_neg[i], PM_SPLIT_Z, q[i]);
+        for (u32 j = 0; j < k; ++j) P.back_B2q[j][i] = with(D.back_B2q[j][i], PM_SPLIT_Z, q[i]);
+    }
+    for (u32 j = 0; j <= k; ++j) {
+        P.b[j] = pmmod(bsk[j]);
+        P.flo_t_b[j] = with(D.flo_t_b[j], PM_SPLIT_Z, bsk[j]);
+        for (u32 i = 0; i < k; ++i) P.flo_q2b[i][j] = with(D.flo_q2b[i][j], PM_SPLIT_Y, bsk[j]);
+    }
+    for (u32 j = 0; j < k; ++j) {
+        P.inv_punct_B[j] = with(D.inv_punct_B[j].x, 31, bsk[j]);
+        P.back_B2msk[j] = with(D.back_B2msk[j], PM_SPLIT_Z, bsk[k]);
+    }
+    P.inv_B_mod_msk = with(D.inv_B_mod_msk.x, 31, bsk[k]);
+    // worst case of a group of terms (largest variable, its split, its constant pair) under modulus m
+    struct Term { u64 vmax; int split; ulonglong2 c; };
+    auto fits = [](const std::vector<Term> &g, const PmMod &m) {
+        u128 A = 0, B = 0;
+        for (const Term &t : g) {
+            const u64 xl = (t.vmax >> t.split) ? ((1ULL << t.split) - 1) : t.vmax, xh = t.vmax >> t.split;
+            if (xh >> 32) return false;
+            A += (u128)xl * (u32)t.c.x + (u128)xh * (u32)t.c.y;
+            B += (u128)xl * (u32)(t.c.x >> 32) + (u128)xh * (u32)(t.c.y >> 32);
+        }
+        if (A >> 64) return false;
+        B += A >> 32;
+        return !(B >> 64) && !((B >> m.sh) >> 32);
+    };
+    auto folded = [](const PmMod &m) { const int b = (int)m.sh + 32; return (1ULL << b) + ((u64)m.delta << (64 - b)); };   // fold_pm's bound
+    bool ok = true;
+    for (u32 i = 0; i < k; ++i) ok = ok && bit_length(q[i]) <= 55;
+    for (u32 j = 0; j <= k && ok; ++j) {
+        std::vector<Term> g{{folded(P.b[j]), PM_SPLIT_Z, P.flo_t_b[j]}};
+        for (u32 i = 0; i < k; ++i) g.push_back({q[i] - 1, PM_SPLIT_Y, P.flo_q2b[i][j]});
+        ok = fits(g, P.b[j]);
+    }
+    for (u32 j0 = 0; j0 < k && ok; j0 += 2) {
+        std::vector<Term> g;
+        for (u32 j = j0; j < j0 + 2 && j < k; ++j) g.push_back({bsk[j] - 1, PM_SPLIT_Z, P.back_B2msk[j]});
+        ok = fits(g, P.b[k]);
+        for (u32 i = 0; i < k && ok; ++i) {
+            std::vector<Term> h;
+            for (u32 j = j0; j < j0 + 2 && j < k; ++j) h.push_back({bsk[j] - 1, PM_SPLIT_Z, P.back_B2q[j][i]});
+            ok = fits(h, P.q[i]);
+        }
+    }
+    for (u32 i = 0; i < k && ok; ++i)
+        ok = fits({{bsk[k] >> 1, PM_SPLIT_Z, P.back_pos[i]}}, P.q[i]) && fits({{bsk[k] >> 1, PM_SPLIT_Z, P.back_neg[i]}}, P.q[i]);
+    if (!ok) return;
+    if (hipMalloc((void **)&T->pm_dev, sizeof(BehzPmDev)) != hipSuccess) { T->pm_dev = nullptr; (void)hipGetLastError(); return; }
+    if (hipMemcpy(T->pm_dev, &P, sizeof(BehzPmDev), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(T->pm_dev); T->pm_dev = nullptr; }
+}
 
 int fhe_behz_build(fhe_ctx *c) {
     using namespace hostmath;
@@ -622,6 +846,7 @@ int fhe_behz_build(fhe_ctx *c) {
         }
     }
     for (u32 j = 0; j < k; ++j) D.back_B2msk[j] = D.punct_B_mod_msk[j].x;
+    behz_pm_tables(c, T, D, bsk);
     if (hipMalloc((void **)&T->dev, sizeof(BehzDev)) != hipSuccess ||
         hipMemcpy(T->dev, &D, sizeof(BehzDev), hipMemcpyHostToDevice) != hipSuccess) {
         fhe_free_base(T->aux);
@@ -635,6 +860,7 @@ int fhe_behz_build(fhe_ctx *c) {
 void fhe_behz_free(fhe_ctx *c) {
     if (c && c->behz) {
         fhe_free_base(c->behz->aux);
+        if (c->behz->pm_dev) (void)hipFree(c->behz->pm_dev);
         if (c->behz->dev) (void)hipFree(c->behz->dev);
         delete c->behz;
         c->behz = nullptr;
@@ -731,6 +957,16 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
         if ((rc = tensor_intt(c, Aq, Bq, Dq, qb, sa, sb, count, st, bm, c->max_prime_bits <= 58, c->qb.pm_class))) return rc;
     }
     if ((rc = tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm, c->behz->aux_bits <= 58, c->behz->aux.pm_class))) return rc;
+    if (c->behz->pm_dev) {
+        switch (k) {
+#define GO(KK) case KK: k_behz_floor_back_pm<KK><<<grid2(n / PCPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->pm_dev, n, count * so); break;
+            GO(1) GO(2) GO(3) GO(4) GO(5) GO(6)
+#undef GO
+            default: return fail(FHE_ERR_PARAM, "pseudo-Mersenne floor / back conversion is built for up to 6 coefficient moduli, not %u", k);
+        }
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     switch (k) {
 #define GO(KK) case KK: if (c->behz->wide_dot) k_behz_floor_back<KK, WIDE_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); \
                         else k_behz_floor_back<KK, DOT_CHUNK><<<grid2(n / CPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->dev, n, count * so); break;
