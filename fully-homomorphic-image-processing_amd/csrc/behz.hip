@@ -63,6 +63,10 @@ struct BehzPmDev {
     ulonglong2 inv_punct_B[BK];            // (w, w 2^31 mod b_j): mul_pm
     ulonglong2 back_B2msk[BK];             // (c, c 2^29 mod m_sk)
     ulonglong2 inv_B_mod_msk;              // (w, w 2^31 mod m_sk): mul_pm
+    ulonglong2 mt_inv_punct[BK];           // (w, w 2^31 mod q_i): mul_pm            (k_behz_to_bsk_pm)
+    ulonglong2 ext_q_b[BK + 1];            // (c, c 2^29 mod b_j)
+    ulonglong2 ext_q2b[BK][BK + 1];        // (c, c 2^28 mod b_j)
+    u64 punct_q_mod_mt[BK], neg_inv_q_mod_mt;
     ulonglong2 back_pos[BK], back_neg[BK]; // (c, c 2^29 mod q_i)
     ulonglong2 back_B2q[BK][BK];           // [j][i]: (c, c 2^29 mod q_i)
 };
@@ -517,6 +521,56 @@ __device__ __forceinline__ u64 pm_acc_reduce(const PmAcc &s, const PmMod &m) {
 }
 __device__ __forceinline__ u64 canon_fold_pm(u64 v, const PmMod &m) { return csub(fold_pm(v, m), m.q); }
 constexpr int PCPT = 2;
+// steps 0 + 1 the same way: in [polys][k][n] (canonical) -> out [polys][k+1][n] (canonical: the forward transforms take it so)
+template <int K>
+__global__ __launch_bounds__(256) void k_behz_to_bsk_pm(const u64 *__restrict__ in, u64 *__restrict__ out, const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzPmDev &T = *Tp;
+    const u32 stride = gridDim.x * blockDim.x;             // n == PCPT * stride
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr u32 MY = (1u << PM_SPLIT_Y) - 1, MZ = (1u << PM_SPLIT_Z) - 1;
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        u32 yl[PCPT][K], yh[PCPT][K];
+        u64 r[PCPT];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) r[e] = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const PmMod m = T.q[i];
+            const ulonglong2 w = T.mt_inv_punct[i];
+            const u64 pm = T.punct_q_mod_mt[i];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                const u64 y = canon_fold_pm(mul_pm(in[(p * K + i) * n + c0 + e * stride], w, m), m);      // canonical: used as an integer below
+                r[e] += (y & 0xffffffffULL) * pm;
+                yl[e][i] = (u32)y & MY;
+                yh[e][i] = (u32)(y >> PM_SPLIT_Y);
+            }
+        }
+        const u64 nq = T.neg_inv_q_mod_mt;
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) r[e] = ((r[e] & 0xffffffffULL) * nq) & 0xffffffffULL;
+#pragma unroll
+        for (int j = 0; j <= K; j++) {
+            const PmMod m = T.b[j];
+            const ulonglong2 eq = T.ext_q_b[j];
+            PmAcc acc[PCPT];
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) {
+                const u64 rb = r[e] >= 0x80000000ULL ? r[e] + m.q - 0x100000000ULL : r[e];    // centred remainder
+                acc[e].A = 0; acc[e].B = 0;
+                pm_mac(acc[e], (u32)rb & MZ, (u32)(rb >> PM_SPLIT_Z), eq);
+            }
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const ulonglong2 c = T.ext_q2b[i][j];
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) pm_mac(acc[e], yl[e][i], yh[e][i], c);
+            }
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) out[(p * (K + 1) + j) * n + c0 + e * stride] = canon_fold_pm(pm_acc_reduce(acc[e], m), m);
+        }
+    }
+}
 template <int K>
 __global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
                                                             const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
@@ -706,6 +760,8 @@ static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, co
     for (u32 i = 0; i < k; ++i) {
         P.q[i] = pmmod(q[i]);
         P.t_inv_punct[i] = with(D.t_inv_punct[i].x, 31, q[i]);
+        P.mt_inv_punct[i] = with(D.mt_inv_punct[i].x, 31, q[i]);
+        P.punct_q_mod_mt[i] = D.punct_q_mod_mt[i];
         P.back_pos[i] = with(D.back_pos[i], PM_SPLIT_Z, q[i]);
         P.back_neg[i] = with(D.back_neg[i], PM_SPLIT_Z, q[i]);
         for (u32 j = 0; j < k; ++j) P.back_B2q[j][i] = with(D.back_B2q[j][i], PM_SPLIT_Z, q[i]);
@@ -713,13 +769,18 @@ static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, co
     for (u32 j = 0; j <= k; ++j) {
         P.b[j] = pmmod(bsk[j]);
         P.flo_t_b[j] = with(D.flo_t_b[j], PM_SPLIT_Z, bsk[j]);
-        for (u32 i = 0; i < k; ++i) P.flo_q2b[i][j] = with(D.flo_q2b[i][j], PM_SPLIT_Y, bsk[j]);
+        P.ext_q_b[j] = with(D.ext_q_b[j], PM_SPLIT_Z, bsk[j]);
+        for (u32 i = 0; i < k; ++i) {
+            P.flo_q2b[i][j] = with(D.flo_q2b[i][j], PM_SPLIT_Y, bsk[j]);
+            P.ext_q2b[i][j] = with(D.ext_q2b[i][j], PM_SPLIT_Y, bsk[j]);
+        }
     }
     for (u32 j = 0; j < k; ++j) {
         P.inv_punct_B[j] = with(D.inv_punct_B[j].x, 31, bsk[j]);
         P.back_B2msk[j] = with(D.back_B2msk[j], PM_SPLIT_Z, bsk[k]);
     }
     P.inv_B_mod_msk = with(D.inv_B_mod_msk.x, 31, bsk[k]);
+    P.neg_inv_q_mod_mt = D.neg_inv_q_mod_mt;
     // worst case of a group of terms (largest variable, its split, its constant pair) under modulus m
     struct Term { u64 vmax; int split; ulonglong2 c; };
     auto fits = [](const std::vector<Term> &g, const PmMod &m) {
@@ -741,6 +802,9 @@ static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, co
         std::vector<Term> g{{folded(P.b[j]), PM_SPLIT_Z, P.flo_t_b[j]}};
         for (u32 i = 0; i < k; ++i) g.push_back({q[i] - 1, PM_SPLIT_Y, P.flo_q2b[i][j]});
         ok = fits(g, P.b[j]);
+        std::vector<Term> x{{bsk[j] - 1, PM_SPLIT_Z, P.ext_q_b[j]}};      // base extension: centred remainder + the y_i
+        for (u32 i = 0; i < k; ++i) x.push_back({q[i] - 1, PM_SPLIT_Y, P.ext_q2b[i][j]});
+        ok = ok && fits(x, P.b[j]);
     }
     for (u32 j0 = 0; j0 < k && ok; j0 += 2) {
         std::vector<Term> g;
@@ -891,7 +955,8 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
 static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
     const u32 k = c->k, n = c->n;
     switch (k) {
-#define GO(KK) case KK: if (c->behz->wide_dot) k_behz_to_bsk<KK, TO_BSK_CPT, WIDE_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); \
+#define GO(KK) case KK: if (c->behz->pm_dev && KK <= 6) k_behz_to_bsk_pm<(KK <= 6 ? KK : 1)><<<grid2(n / PCPT, count * s), 256, 0, st>>>(src, xb, c->behz->pm_dev, n, count * s); \
+                        else if (c->behz->wide_dot) k_behz_to_bsk<KK, TO_BSK_CPT, WIDE_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); \
                         else k_behz_to_bsk<KK, TO_BSK_CPT, DOT_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
