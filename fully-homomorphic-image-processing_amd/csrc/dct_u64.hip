@@ -67,16 +67,33 @@ __device__ __forceinline__ void load_stage(ulonglong2 (&w)[4], const ulonglong2 
     for (int i = 0; i < T::count(U); i++) w[i] = tw[(1 << (LE * P + U)) + ((th << (LE - 1 - T::rb(U))) | i)];
 }
 
+// the same for the pseudo-Mersenne tables of this geometry (BaseTables::d_tw_pm3: (w, w 2^31 mod q) pairs, the twiddles
+// of a stage as [i][th] so that consecutive lanes read consecutive pairs)
+template <int L, int P, int U>
+__device__ __forceinline__ void load_stage_pm(ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, int tid) {
+    using T = Tw<L, P>;
+    constexpr int sigma = LE * P + U;
+    const int th = (P == 0) ? 0 : (tid >> T::LO);
+#pragma unroll
+    for (int i = 0; i < T::count(U); i++) w[i] = tw[(1 << sigma) + (i << (sigma - (LE - 1 - T::rb(U)))) + th];
+}
+template <int L, int P, int U, bool PM>
+__device__ __forceinline__ void load_stage_any(ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, int tid) {
+    if constexpr (PM) load_stage_pm<L, P, U>(w, tw, tid);
+    else load_stage<L, P, U>(w, tw, tid);
+}
+
 // per-workgroup constants of one prime
-struct Prime { u64 q, nq, q4, one_p; u32 zero; };     // nq = 2^64 - q, q4 = 4q, one_p = floor(2^64 / q), zero: modarith.h
+struct Prime { u64 q, nq, q4, one_p; u32 zero; PmMod pm; };     // nq = 2^64 - q, q4 = 4q, one_p = floor(2^64 / q), zero: modarith.h
 __device__ __forceinline__ Prime prime_of(const Modulus &m) {
     Prime o;
     o.q = m.q; o.nq = 0 - m.q; o.q4 = 4 * m.q; o.zero = fhe_opaque_zero;
     o.one_p = one_companion(m);
+    o.pm.q = m.q; o.pm.delta = (u32)((1ULL << (m.s1 + 1)) - m.q); o.pm.sh = m.s1 + 1 - 32; o.pm.mb = (1u << (m.s1 + 1 - 32)) - 1; o.pm.pad = 0;
     return o;
 }
 // bound (in units of q) of the forward transform's outputs
-template <int L, bool LAZY> struct Bn { static constexpr u64 V = LAZY ? 2 + 4 * L : 8; };
+template <int L, bool LAZY, bool PM = false> struct Bn { static constexpr u64 V = PM ? 2 + (L << PmA::CS) : LAZY ? 2 + 4 * L : 8; };
 
 // Cooley-Tukey stage U of pass P on four polynomials.  LAZY: values grow by 4q per stage; otherwise [0, 8q) in and out
 template <int L, int P, int U, bool LAZY>
@@ -96,15 +113,37 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
         }
     }
 }
-template <int L, int P, bool LAZY, int U = 0>
+// The same on the pseudo-Mersenne product (ntt_core.h; every prime <= 55 bits, class PmA): values grow by 2^CS q = 8q per
+// stage from 2q, no conditional subtraction and no fold up to n = 8192 ((2 + 8 x 13) q < 128 q, the product's operand limit)
+template <int L, int P, int U>
+__device__ __forceinline__ void fwd_stage_pm(u64 (&x)[4][E], const ulonglong2 (&w)[4], const Prime &pr) {
+    using T = Tw<L, P>;
+    constexpr int rb = T::rb(U);
+    static_assert(32 + ((L - 1) << (4 + PmA::CS)) <= PmA::LIM, "forward operands pass the product's limit");
+    const u64 off = pr.q << PmA::CS;
+#pragma unroll
+    for (int b = 0; b < E / 2; b++) {
+        const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+        const ulonglong2 wv = w[r0 >> (rb + 1)];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const u64 X = x[m][r0], T2 = mul_pm(x[m][r1], wv, pr.pm);
+            x[m][r0] = X + T2;
+            x[m][r1] = X - T2 + off;
+        }
+    }
+}
+template <int L, int P, bool LAZY, bool PM, int U = 0>
 __device__ __forceinline__ void fwd_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, const Prime &pr, int tid) {
     if constexpr (U + 1 < Tw<L, P>::S) {
         ulonglong2 wn[4];
-        load_stage<L, P, U + 1>(wn, tw, tid);
-        fwd_stage<L, P, U, LAZY>(x, w, pr);
-        fwd_pass<L, P, LAZY, U + 1>(x, wn, tw, pr, tid);
+        load_stage_any<L, P, U + 1, PM>(wn, tw, tid);
+        if constexpr (PM) fwd_stage_pm<L, P, U>(x, w, pr);
+        else fwd_stage<L, P, U, LAZY>(x, w, pr);
+        fwd_pass<L, P, LAZY, PM, U + 1>(x, wn, tw, pr, tid);
     } else {
-        fwd_stage<L, P, U, LAZY>(x, w, pr);
+        if constexpr (PM) fwd_stage_pm<L, P, U>(x, w, pr);
+        else fwd_stage<L, P, U, LAZY>(x, w, pr);
     }
 }
 // Bound (in units of q) of register r after the stages S-1 ... U of inverse pass P have run (U = S: at entry).  A sum
@@ -153,15 +192,81 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[4][E], const ulonglong2 (&w)[
         }
     }
 }
-template <int L, int P, int U = Tw<L, P>::S - 1>
+// Pseudo-Mersenne inverse (class PmA) with the ranges tracked in sixteenths of q like ntt_core.h's pm_inv_plan, for this
+// file's geometry (8 registers, passes of three stages): entry 4q (the scale products) for the first pass executed, XB
+// after an exchange; a sum stays unreduced, a difference gets 2^s q >= bound(Y) added, an operand is folded (one
+// multiply-add) only when the difference would pass the product's limit; registers above XB are folded at a pass's end.
+constexpr int PM3_E0 = 64, PM3_XB = 192;
+struct Pm3Plan { bool fold_y[LE][E], fold_x[LE][E]; int shift[LE][E]; bool fold_exit[E]; };
+template <int L, int P>
+__host__ __device__ constexpr Pm3Plan pm3_plan() {
+    Pm3Plan pl{};
+    int bd[E] = {};
+    for (int r = 0; r < E; r++) bd[r] = (P == Sh<L>::NP - 1) ? PM3_E0 : PM3_XB;
+    for (int u = Tw<L, P>::S - 1; u >= 0; u--) {
+        const int sigma = LE * P + u, rb = Tw<L, P>::rb(u);
+        for (int r0 = 0; r0 < E; r0++) {
+            if (r0 & (1 << rb)) continue;
+            const int r1 = r0 | (1 << rb);
+            if (bd[r0] + (16 << pm_ceil_log2_q(bd[r1])) > PmA::LIM) { pl.fold_y[u][r0] = true; bd[r1] = PM_FOLDED; }
+            if (bd[r0] + (16 << pm_ceil_log2_q(bd[r1])) > PmA::LIM) { pl.fold_x[u][r0] = true; bd[r0] = PM_FOLDED; }
+            pl.shift[u][r0] = pm_ceil_log2_q(bd[r1]);
+            bd[r0] = sigma == 0 ? PmA::RQ : bd[r0] + bd[r1];
+            bd[r1] = PmA::RQ;
+        }
+    }
+    for (int r = 0; r < E; r++) pl.fold_exit[r] = P > 0 && bd[r] > PM3_XB;
+    return pl;
+}
+template <int L, int P, int U, int B>
+__device__ __forceinline__ void inv_bfly_pm(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, const Prime &pr) {
+    constexpr Pm3Plan pl = pm3_plan<L, P>();
+    constexpr int sigma = LE * P + U, rb = Tw<L, P>::rb(U);
+    constexpr int r0 = ((B >> rb) << (rb + 1)) | (B & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+    const ulonglong2 wv = w[r0 >> (rb + 1)];
+    const u64 off = pr.q << pl.shift[U][r0];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        u64 X = x[m][r0], Y = x[m][r1];
+        if constexpr (pl.fold_y[U][r0]) Y = fold_pm(Y, pr.pm);
+        if constexpr (pl.fold_x[U][r0]) X = fold_pm(X, pr.pm);
+        const u64 Tm = X + Y;
+        const u64 D = X - Y + off;
+        if constexpr (sigma == 0) x[m][r0] = mul_pm(Tm, ninv, pr.pm);
+        else x[m][r0] = Tm;
+        x[m][r1] = mul_pm(D, wv, pr.pm);
+    }
+}
+template <int L, int P, int R>
+__device__ __forceinline__ void inv_exit_pm(u64 (&x)[4][E], const Prime &pr) {
+    constexpr Pm3Plan pl = pm3_plan<L, P>();
+    if constexpr (pl.fold_exit[R]) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m][R] = fold_pm(x[m][R], pr.pm);
+    }
+}
+template <int L, int P, int U>
+__device__ __forceinline__ void inv_stage_pm(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 ninv, const Prime &pr) {
+    inv_bfly_pm<L, P, U, 0>(x, w, ninv, pr);
+    inv_bfly_pm<L, P, U, 1>(x, w, ninv, pr);
+    inv_bfly_pm<L, P, U, 2>(x, w, ninv, pr);
+    inv_bfly_pm<L, P, U, 3>(x, w, ninv, pr);
+    if constexpr (U == 0 && P > 0) {
+        inv_exit_pm<L, P, 0>(x, pr); inv_exit_pm<L, P, 1>(x, pr); inv_exit_pm<L, P, 2>(x, pr); inv_exit_pm<L, P, 3>(x, pr);
+        inv_exit_pm<L, P, 4>(x, pr); inv_exit_pm<L, P, 5>(x, pr); inv_exit_pm<L, P, 6>(x, pr); inv_exit_pm<L, P, 7>(x, pr);
+    }
+}
+template <int L, int P, bool PM, int U = Tw<L, P>::S - 1>
 __device__ __forceinline__ void inv_pass(u64 (&x)[4][E], const ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, const Prime &pr, int tid) {
     if constexpr (U > 0) {
         ulonglong2 wn[4];
-        load_stage<L, P, U - 1>(wn, itw, tid);
-        inv_stage<L, P, U>(x, w, ninv, pr);
-        inv_pass<L, P, U - 1>(x, wn, itw, ninv, pr, tid);
+        load_stage_any<L, P, U - 1, PM>(wn, itw, tid);
+        if constexpr (PM) inv_stage_pm<L, P, U>(x, w, ninv, pr);
+        else inv_stage<L, P, U>(x, w, ninv, pr);
+        inv_pass<L, P, PM, U - 1>(x, wn, itw, ninv, pr, tid);
     } else {
-        inv_stage<L, P, U>(x, w, ninv, pr);
+        if constexpr (PM) inv_stage_pm<L, P, U>(x, w, ninv, pr);
+        else inv_stage<L, P, U>(x, w, ninv, pr);
     }
 }
 
@@ -191,24 +296,24 @@ __device__ __forceinline__ void transpose(u64 (&x)[4][E], u64 *lds, int tid, int
 
 // `w` holds the twiddles of the first stage of pass P; the first stage of the next pass is fetched before the
 // LDS exchange so that its latency hides behind it
-template <int L, bool LAZY, int P = 0>
+template <int L, bool LAZY, bool PM, int P = 0>
 __device__ __forceinline__ void ntt_fwd(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ tw, const Prime &pr, u64 *lds, int tid, int &phase) {
-    fwd_pass<L, P, LAZY>(x, w, tw, pr, tid);
+    fwd_pass<L, P, LAZY, PM>(x, w, tw, pr, tid);
     if constexpr (P + 1 < Sh<L>::NP) {
         ulonglong2 wn[4];
-        load_stage<L, P + 1, 0>(wn, tw, tid);
+        load_stage_any<L, P + 1, 0, PM>(wn, tw, tid);
         transpose<L, p_lo(L, P), p_lo(L, P + 1)>(x, lds, tid, phase);
-        ntt_fwd<L, LAZY, P + 1>(x, wn, tw, pr, lds, tid, phase);
+        ntt_fwd<L, LAZY, PM, P + 1>(x, wn, tw, pr, lds, tid, phase);
     }
 }
-template <int L, int P = Sh<L>::NP - 1>
+template <int L, bool PM, int P = Sh<L>::NP - 1>
 __device__ __forceinline__ void ntt_inv(u64 (&x)[4][E], ulonglong2 (&w)[4], const ulonglong2 *__restrict__ itw, const ulonglong2 ninv, const Prime &pr, u64 *lds, int tid, int &phase) {
-    inv_pass<L, P>(x, w, itw, ninv, pr, tid);
+    inv_pass<L, P, PM>(x, w, itw, ninv, pr, tid);
     if constexpr (P > 0) {
         ulonglong2 wn[4];
-        load_stage<L, P - 1, Tw<L, P - 1>::S - 1>(wn, itw, tid);
+        load_stage_any<L, P - 1, Tw<L, P - 1>::S - 1, PM>(wn, itw, tid);
         transpose<L, p_lo(L, P), p_lo(L, P - 1)>(x, lds, tid, phase);
-        ntt_inv<L, P - 1>(x, wn, itw, ninv, pr, lds, tid, phase);
+        ntt_inv<L, PM, P - 1>(x, wn, itw, ninv, pr, lds, tid, phase);
     }
 }
 
@@ -240,7 +345,7 @@ __device__ __forceinline__ void line_half(u64 &x0, u64 &x1, u64 &x2, u64 &x3, co
     }
 }
 
-template <int L, int HALF, bool LAZY>
+template <int L, int HALF, bool LAZY, bool PM>
 __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__restrict__ mid, const ulonglong2 *__restrict__ consts,
                                           const ulonglong2 *__restrict__ tw, const Work &wk, const Prime &pr, u32 k, u64 *lds) {
     constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
@@ -248,7 +353,7 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__res
     const size_t poly_words = (size_t)k * N, ct_words = 2 * poly_words;
     const size_t base = ((size_t)wk.blk * 64 + 8 * wk.line) * ct_words + (size_t)wk.poly * poly_words + (size_t)wk.prime * N;
     ulonglong2 w0[4];
-    load_stage<L, 0, 0>(w0, tw, tid);
+    load_stage_any<L, 0, 0, PM>(w0, tw, tid);
     u64 x[4][E];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -260,13 +365,13 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__res
         }
     }
     int phase = 0;
-    ntt_fwd<L, LAZY>(x, w0, tw, pr, lds, tid, phase);    // below Bn q, slot j = (tid << 3) + r at position r*TP + tid
+    ntt_fwd<L, LAZY, PM>(x, w0, tw, pr, lds, tid, phase);    // below Bn q, slot j = (tid << 3) + r at position r*TP + tid
     const ulonglong2 *cp = consts + (size_t)wk.prime * N + tid;
     const size_t cstride = (size_t)k * N;
 #pragma unroll
     for (int r = 0; r < E; r++) {
         auto C = [&](int cid) { return cp[(size_t)cid * cstride + r * TP]; };
-        line_half<HALF, true>(x[0][r], x[1][r], x[2][r], x[3][r], pr, Bn<L, LAZY>::V * pr.q, C);
+        line_half<HALF, true>(x[0][r], x[1][r], x[2][r], x[3][r], pr, Bn<L, LAZY, PM>::V * pr.q, C);
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {                    // row outputs below 16 q
@@ -276,7 +381,7 @@ __device__ __forceinline__ void rows_body(const u64 *__restrict__ in, u64 *__res
     }
 }
 
-template <int L, int HALF>
+template <int L, int HALF, bool PM>
 __device__ __forceinline__ void cols_body(const u64 *__restrict__ mid, u64 *__restrict__ out, const ulonglong2 *__restrict__ consts,
                                           const ulonglong2 *__restrict__ itw, const Work &wk, const Prime &pr, u32 k, u64 *lds) {
     constexpr int N = Sh<L>::N, TP = Sh<L>::TP;
@@ -311,37 +416,38 @@ __device__ __forceinline__ void cols_body(const u64 *__restrict__ mid, u64 *__re
     }
     int phase = 0;
     ulonglong2 wl[4];
-    load_stage<L, Sh<L>::NP - 1, Tw<L, Sh<L>::NP - 1>::S - 1>(wl, itw, tid);
-    ntt_inv<L>(x, wl, itw, itw[0], pr, lds, tid, phase);
+    load_stage_any<L, Sh<L>::NP - 1, Tw<L, Sh<L>::NP - 1>::S - 1, PM>(wl, itw, tid);
+    ntt_inv<L, PM>(x, wl, itw, itw[0], pr, lds, tid, phase);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         u64 *o = out + base + (size_t)(2 * m + HALF) * row_stride + tid;
 #pragma unroll
-        for (int r = 0; r < E; r++) o[r * TP] = csub(csub(x[m][r], 2 * pr.q), pr.q);
+        for (int r = 0; r < E; r++) o[r * TP] = PM ? csub(fold_pm(x[m][r], pr.pm), pr.q) : csub(csub(x[m][r], 2 * pr.q), pr.q);
     }
 }
 
 __host__ __device__ constexpr int occ_w(int tp, int lds_words) { return ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256 < 1 ? 1 : ((2 * 2 * lds_words * 8 <= 160 * 1024) ? 2 : 1) * tp / 256; }
 
-template <int L, bool LAZY>
+// PM: pseudo-Mersenne butterflies (every prime <= 55 bits, class PmA) on the tables tw3 / itw3
+template <int L, bool LAZY, bool PM>
 __global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_rows_u64(const u64 *__restrict__ in, u64 *__restrict__ mid,
-                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
+                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, const ulonglong2 *__restrict__ tw3, u32 k) {
     __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);
     const Prime pr = prime_of(base.mod[wk.prime]);
-    const ulonglong2 *tw = base.tw + (size_t)wk.prime * Sh<L>::N;
-    if (wk.half) rows_body<L, 1, LAZY>(in, mid, consts, tw, wk, pr, k, lds);
-    else rows_body<L, 0, LAZY>(in, mid, consts, tw, wk, pr, k, lds);
+    const ulonglong2 *tw = (PM ? tw3 : base.tw) + (size_t)wk.prime * Sh<L>::N;
+    if (wk.half) rows_body<L, 1, LAZY, PM>(in, mid, consts, tw, wk, pr, k, lds);
+    else rows_body<L, 0, LAZY, PM>(in, mid, consts, tw, wk, pr, k, lds);
 }
-template <int L>
+template <int L, bool PM>
 __global__ __launch_bounds__((Sh<L>::TP), (occ_w(Sh<L>::TP, Sh<L>::LDS_WORDS))) void k_dct_cols_u64(const u64 *__restrict__ mid, u64 *__restrict__ out,
-                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, u32 k) {
+                                                                                      const ulonglong2 *__restrict__ consts, RnsBase base, const ulonglong2 *__restrict__ itw3, u32 k) {
     __shared__ u64 lds[2 * Sh<L>::LDS_WORDS];
     const Work wk = decode(blockIdx.x, k);
     const Prime pr = prime_of(base.mod[wk.prime]);
-    const ulonglong2 *itw = base.itw + (size_t)wk.prime * Sh<L>::N;
-    if (wk.half) cols_body<L, 1>(mid, out, consts, itw, wk, pr, k, lds);
-    else cols_body<L, 0>(mid, out, consts, itw, wk, pr, k, lds);
+    const ulonglong2 *itw = (PM ? itw3 : base.itw) + (size_t)wk.prime * Sh<L>::N;
+    if (wk.half) cols_body<L, 1, PM>(mid, out, consts, itw, wk, pr, k, lds);
+    else cols_body<L, 0, PM>(mid, out, consts, itw, wk, pr, k, lds);
 }
 
 // constants from the u64 kernels' slot order (16 slots per thread) to this file's (8 per thread):
@@ -373,10 +479,14 @@ int fhe_dct_u64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const RnsBase base = c->qb.dev();
     const bool lazy = c->max_prime_bits <= 56;     // (2 + 4 log2 n) q x 4 must stay below 2^64
+    const bool pm = c->qb.pm_class == 1 && c->qb.d_tw_pm3 && !c->opt.ntt_nopm;      // every prime <= 55 bits and pseudo-Mersenne: (2 + 8 log2 n) q x 4 < 2^64 too
+    const ulonglong2 *tw3 = c->qb.d_tw_pm3, *itw3 = c->qb.d_itw_pm3;
     switch (c->logn) {
-#define GO(LL) case LL: if (lazy) k_dct_rows_u64<LL, true><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
-                        else k_dct_rows_u64<LL, false><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, c->k); \
-                        k_dct_cols_u64<LL><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(mid, out, plan->d_consts_le3, base, c->k); break;
+#define GO(LL) case LL: if (pm) k_dct_rows_u64<LL, true, true><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, tw3, c->k); \
+                        else if (lazy) k_dct_rows_u64<LL, true, false><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, tw3, c->k); \
+                        else k_dct_rows_u64<LL, false, false><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(in, mid, plan->d_consts_le3, base, tw3, c->k); \
+                        if (pm) k_dct_cols_u64<LL, true><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(mid, out, plan->d_consts_le3, base, itw3, c->k); \
+                        else k_dct_cols_u64<LL, false><<<(unsigned)grid, Sh<LL>::TP, 0, st>>>(mid, out, plan->d_consts_le3, base, itw3, c->k); break;
         GO(11) GO(12) GO(13)
 #undef GO
         default: return fail(FHE_ERR_PARAM, "fused u64 path supports n in {2048, 4096, 8192}");

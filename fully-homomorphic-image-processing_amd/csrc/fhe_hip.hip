@@ -109,6 +109,30 @@ int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 log
         HIP_TRY(hipMemcpy(B.d_tw_pm, twp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(B.d_itw_pm, itwp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(B.d_pm, pm.data(), sizeof(PmMod) * cnt, hipMemcpyHostToDevice));
+        if (cls == 1 && logn >= 11 && logn <= 13) {
+            // the fused u64 DCT kernels (dct_u64.hip) hold 8 coefficients per thread: passes of three stages, so the [i][th]
+            // order inside a stage differs from the one above
+            auto p3 = [logn](u32 idx) -> u32 {
+                if (idx < 2) return idx;
+                int sigma = 0;
+                while ((2u << sigma) <= idx) sigma++;
+                const int LE = 3, P = sigma / LE, lo = ((int)logn - LE * P - LE) < 0 ? 0 : ((int)logn - LE * P - LE), rb = ((int)logn - 1 - sigma) - lo;
+                const u32 off = idx - (1u << sigma), cnt_i = 1u << (LE - 1 - rb), th = off / cnt_i, i = off % cnt_i;
+                return (1u << sigma) + i * ((1u << sigma) / cnt_i) + th;
+            };
+            for (size_t i = 0; i < cnt; ++i) {
+                const u64 q = primes[i];
+                for (u32 j = 0; j < n; ++j) {
+                    const u32 jp = p3(j);
+                    twp[i * n + jp] = make_ulonglong2(tw[i * n + j].x, (u64)(((u128)tw[i * n + j].x << 31) % q));
+                    itwp[i * n + jp] = make_ulonglong2(itw[i * n + j].x, (u64)(((u128)itw[i * n + j].x << 31) % q));
+                }
+            }
+            HIP_TRY(hipMalloc(&B.d_tw_pm3, sizeof(ulonglong2) * cnt * n));
+            HIP_TRY(hipMalloc(&B.d_itw_pm3, sizeof(ulonglong2) * cnt * n));
+            HIP_TRY(hipMemcpy(B.d_tw_pm3, twp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(B.d_itw_pm3, itwp.data(), sizeof(ulonglong2) * cnt * n, hipMemcpyHostToDevice));
+        }
     }
     if (want_f64) {
         // the same twiddles as centred doubles for the exact-FP64 kernels (dct_fused.hip)
@@ -137,7 +161,9 @@ void fhe_free_base(BaseTables &B) {
     if (B.d_tw_pm) (void)hipFree(B.d_tw_pm);
     if (B.d_itw_pm) (void)hipFree(B.d_itw_pm);
     if (B.d_pm) (void)hipFree(B.d_pm);
-    B.d_tw_pm = B.d_itw_pm = nullptr;
+    if (B.d_tw_pm3) (void)hipFree(B.d_tw_pm3);
+    if (B.d_itw_pm3) (void)hipFree(B.d_itw_pm3);
+    B.d_tw_pm = B.d_itw_pm = B.d_tw_pm3 = B.d_itw_pm3 = nullptr;
     B.d_pm = nullptr;
     B.pm_class = 0;
     B.d_tw_f64 = B.d_itw_f64 = nullptr;

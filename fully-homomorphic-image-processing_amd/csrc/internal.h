@@ -33,6 +33,7 @@ struct BaseTables {
     double *d_tw_f64 = nullptr, *d_itw_f64 = nullptr;   // [count][n]
     // pseudo-Mersenne tables (ntt_core.h): (w, w 2^31 mod q) pairs; pm_class 0 = the base does not qualify
     ulonglong2 *d_tw_pm = nullptr, *d_itw_pm = nullptr;
+    ulonglong2 *d_tw_pm3 = nullptr, *d_itw_pm3 = nullptr;   // the same pairs ordered for passes of three stages (dct_u64.hip), class 1 bases only
     PmMod *d_pm = nullptr;
     int pm_class = 0;
     RnsBase dev() const { return RnsBase{d_tw, d_itw, d_mod, (u32)primes.size(), d_tw_pm, d_itw_pm, d_pm}; }
