@@ -1326,6 +1326,77 @@ static int rgb_consts(const fhe_ctx *c, int int_coeffs, int frac_coeffs, hipStre
     return FHE_OK;
 }
 
+// Pseudo-Mersenne bases (C = the class of the q-base) take THREE launches instead: the one-launch kernel above keeps three
+// polynomials per thread (96 data VGPRs beside twiddles and constants: 256 VGPRs, one or two waves per SIMD, and at
+// n = 8192 another 640 B of scratch per lane) and runs at 0.08-0.11 of the HBM roofline; the transforms alone run at
+// 0.4, so the two extra passes over the planes cost less than that kernel loses.  plane_rp: residue polynomial of a plane
+// in units of N words -- contiguous (group == 0), or `group` pixels every gstride words (fhe_rgb_to_ycc_blocks).
+__device__ __forceinline__ u64 plane_rp(u64 rp0, u32 count, u32 group, u64 gstride, u32 n) {
+    if (!group) return rp0;
+    const u64 pix = rp0 / (2 * count), rest = rp0 % (2 * count);
+    return ((pix / group) * gstride + (pix % group) * 2 * count * n) / n + rest;
+}
+constexpr int rgb_sum_bound(int rq) { return rq + 2 * (16 << pm_ceil_log2_q(rq)); }      // bound of the y / u / v sums below
+template <int L, typename C, bool INVERSE>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_rgb_ntt_pm(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc,
+                                                                   const u64 *__restrict__ yoff, u32 yoff_len, RnsBase base, u32 group, u64 gstride, u32 nrp) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 plane = blockIdx.x / nrp, rp0 = blockIdx.x % nrp;
+    const u32 prime = rp0 % base.count, poly = (rp0 / base.count) & 1;
+    u64 *p = (plane == 0 ? R : plane == 1 ? G : Bc) + plane_rp(rp0, base.count, group, gstride, N) * N;
+    const PmMod m = base.pm[prime];
+    u64 x[1][16];
+    if constexpr (!INVERSE) {
+        load_coeff<L>(x[0], p, tid);
+        ntt_fwd_regs_pm<L, 1, 16, C::LIM, C::CS>(x, base.tw_pm + (size_t)prime * N, m, lds, tid);
+        store_slots<L>(x[0], p, tid);          // as they are (below 2^62): the combine step folds what it reads
+    } else {
+        load_slots<L>(x[0], p, tid);
+        ntt_inv_regs_pm<L, 1, rgb_sum_bound(C::RQ), C::XB, C::LIM, C::RQ>(x, base.itw_pm + (size_t)prime * N, m, lds, tid);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            x[0][i] = canon_pm(x[0][i], m);
+            if (plane == 0 && poly == 0) {
+                const int j = elem_index<L - 4>(tid, i);
+                if ((u32)j < yoff_len) x[0][i] = submod(x[0][i], yoff[(size_t)prime * yoff_len + j], m.q);
+            }
+        }
+        store_coeff<L>(x[0], p, tid);
+    }
+}
+// y, u, v from r, g, b slot by slot (NTT form, in place): nine products with the constants' values, sums left unreduced
+template <typename C>
+__global__ __launch_bounds__(256) void k_rgb_combine_pm(u64 *__restrict__ R, u64 *__restrict__ G, u64 *__restrict__ Bc, const ulonglong2 *__restrict__ consts,
+                                                        RnsBase base, u32 n, u32 group, u64 gstride, u32 nrp) {
+    const size_t cstride = (size_t)base.count * n;
+    for (u32 rp0 = blockIdx.y; rp0 < nrp; rp0 += gridDim.y) {
+        const u32 prime = rp0 % base.count;
+        const PmMod m = base.pm[prime];
+        const u64 off = m.q << pm_ceil_log2_q(C::RQ);         // a multiple of q above any product
+        const u64 base_w = plane_rp(rp0, base.count, group, gstride, n) * n;
+        for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
+            const ulonglong2 *cp = consts + (size_t)prime * n + pos;
+            const u64 rr = fold_pm(R[base_w + pos], m), gg = fold_pm(G[base_w + pos], m), bb = fold_pm(Bc[base_w + pos], m);
+            auto M = [&](u64 x, int cid) { return mulvv_pm(x, cp[cid * cstride].x, m); };
+            R[base_w + pos] = M(rr, 0) + M(gg, 1) + M(bb, 2);
+            G[base_w + pos] = M(rr, 3) + M(bb, 5) + (off - M(gg, 4));
+            Bc[base_w + pos] = M(rr, 6) + (off - M(gg, 7)) + (off - M(bb, 8));
+        }
+    }
+}
+template <typename C>
+static int rgb_launch_pm(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, const ulonglong2 *consts, const u64 *yoff, u32 yoff_len, u64 nrp, hipStream_t st, u32 group, u64 gstride) {
+    if (3 * nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
+    const RnsBase base = c->qb.dev();
+    DISPATCH_L(c->logn, (k_rgb_ntt_pm<L, C, false><<<(unsigned)(3 * nrp), NttShape<L>::TP, 0, st>>>(r, g, b, yoff, yoff_len, base, group, gstride, (u32)nrp)));
+    k_rgb_combine_pm<C><<<dim3((c->n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768)), 256, 0, st>>>(r, g, b, consts, base, c->n, group, gstride, (u32)nrp);
+    DISPATCH_L(c->logn, (k_rgb_ntt_pm<L, C, true><<<(unsigned)(3 * nrp), NttShape<L>::TP, 0, st>>>(r, g, b, yoff, yoff_len, base, group, gstride, (u32)nrp)));
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
 static int rgb_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, uint64_t count, int int_coeffs, int frac_coeffs, hipStream_t st, u32 group, u64 gstride) {
     const fhe_ctx::RgbConsts *k9 = nullptr;
     int rc = rgb_consts(c, int_coeffs, frac_coeffs, st, &k9);
@@ -1335,6 +1406,8 @@ static int rgb_launch(const fhe_ctx *c, u64 *r, u64 *g, u64 *b, uint64_t count, 
     const u64 nrp = count * 2 * c->k;
     if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many pixels for one launch");
     const RnsBase base = c->qb.dev();
+    if (c->qb.pm_class == 1 && !c->opt.ntt_nopm) return rgb_launch_pm<PmA>(c, r, g, b, k9->d_c, k9->d_off, k9->off_len, nrp, st, group, gstride);
+    if (c->qb.pm_class == 2 && !c->opt.ntt_nopm) return rgb_launch_pm<PmB>(c, r, g, b, k9->d_c, k9->d_off, k9->off_len, nrp, st, group, gstride);
     DISPATCH_L(c->logn, (k_rgb2ycc<L><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>(r, g, b, k9->d_c, k9->d_off, k9->off_len, base, group, gstride)));
     KERNEL_CHECK();
     return FHE_OK;

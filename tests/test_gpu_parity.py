@@ -205,9 +205,10 @@ def test_dct_via_evaluator_calls_matches_fused(fhe, oracle_mod):
     assert np.array_equal(fused[1], orc.dct_quant(fhe.to_host(blocks)[1], fhe.YQT))
 
 
-@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192"])
+@pytest.mark.parametrize("preset", ["SMALL", "P4096", "P8192", "SEAL23_4096"])
 def test_rgb_to_ycc(fhe, oracle_mod, preset):
-    """SMALL / P8192 run the general u64 kernel, P4096 the fused FP64 kernel (csrc/dct_fused.hip)."""
+    """SMALL runs the general u64 kernel, P8192 / SEAL23_4096 its pseudo-Mersenne form, P4096 the fused FP64 kernel
+    (csrc/dct_fused.hip)."""
     ctx, orc = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
     r, g, b = ctx.random_ct(3, seed=31), ctx.random_ct(3, seed=32), ctx.random_ct(3, seed=33)
@@ -218,6 +219,22 @@ def test_rgb_to_ycc(fhe, oracle_mod, preset):
         assert np.array_equal(fhe.to_host(r)[i], y)
         assert np.array_equal(fhe.to_host(g)[i], u)
         assert np.array_equal(fhe.to_host(b)[i], v)
+
+
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_4096", "P8192"])
+def test_rgb_to_ycc_blocks_layout_equals_planes(fhe, preset):
+    """fhe_rgb_to_ycc_blocks (the stream layout [blocks][3][64][2][k][n], planes 64 ciphertexts apart inside a block) gives
+    the same ciphertexts as fhe_rgb_to_ycc on three separate planes -- the FP64 kernel (P4096) and the three-launch
+    pseudo-Mersenne path (SEAL23_4096, P8192) with its strided plane addressing."""
+    import torch
+    ctx = fhe.SEALContext.preset(preset)
+    ev = fhe.Evaluator(ctx)
+    blocks = ctx.random_ct(2, 3, 64, seed=77)                   # [2, 3, 64, 2, k, n]
+    r, g, b = (blocks[:, p].reshape(128, 2, ctx.k, ctx.n).clone() for p in range(3))
+    ev.rgb_to_ycc(r, g, b)
+    ev.rgb_to_ycc_blocks(blocks)
+    for p, want in enumerate((r, g, b)):
+        assert torch.equal(blocks[:, p].reshape(128, 2, ctx.k, ctx.n), want), (preset, p)
 
 
 def test_rgb_to_ycc_fp64_path_equals_u64_path_and_extremes(fhe, oracle_mod, monkeypatch):

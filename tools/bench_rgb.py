@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import fhip_amd as fhe
 px = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-ctx = fhe.SEALContext.preset("P4096")
+preset = sys.argv[2] if len(sys.argv) > 2 else "P4096"
+ctx = fhe.SEALContext.preset(preset)
 ev = fhe.Evaluator(ctx)
 r, g, b = (ctx.random_ct(px, 1, seed=fhe.SEED + i).reshape(px, 2, ctx.k, ctx.n) for i in range(3))
 for _ in range(2):
@@ -22,5 +23,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / steps
 by = 6 * 2 * ctx.k * ctx.n * 8
-print(json.dumps({"workload": "rgb_to_ycc_fhe, n=4096 k=3", "pixels": px, "ms": ms, "pixels_per_s": px / ms * 1e3,
+print(json.dumps({"workload": "rgb_to_ycc_fhe, %s (n=%d k=%d)" % (preset, ctx.n, ctx.k), "pixels": px, "ms": ms, "pixels_per_s": px / ms * 1e3,
                   "algorithmic_GB_per_s": px * by / ms / 1e6, "hbm_frac": px * by / ms / 1e6 / 8000}))
