@@ -10,7 +10,7 @@ says little about how close they are to THEIR ceiling.  This script collects, pe
   pass D  FETCH_SIZE        pass E  WRITE_SIZE  (separate passes, MI355X_MICROARCH.md: 3 + 2 TCC slots)
 
 (counters this rocprofv3 does not list are dropped from a pass), for three workloads: the headline bench (k_dct_rows /
-k_dct_cols), tools/bench_ops.py at P8192 (k_ntt_fwd2 / k_ntt_inv2 / k_mulplain / k_behz_*) and the configs[2] resize
+k_dct_cols), tools/bench_ops.py at P8192 (k_ntt_fwd_pm / k_ntt_inv_pm / k_mulplain_pm / k_behz_*) and the configs[2] resize
 circuit.  Output: gpurun_out/<tag>/counters.json + counters.txt; every record carries the hash of ALL kernel sources
 (csrc/*.hip, *.h), so a file under profiles/ can be matched to the code it describes.
 
@@ -40,9 +40,9 @@ WORKLOADS = {
     "bench": ([PY, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
               ["k_dct_rows", "k_dct_cols"]),
     "ops8192": ([PY, os.path.join(ROOT, "tools", "bench_ops.py"), "P8192", "1024"],
-                ["k_ntt_fwd2", "k_ntt_inv2", "k_mulplain", "k_behz_tensor_intt2", "k_behz_floor_back", "k_behz_to_bsk", "k_eltwise", "k_dyadic"]),
+                ["k_ntt_fwd", "k_ntt_inv", "k_mulplain", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_eltwise", "k_dyadic"]),
     "resize": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--max-pixels", "512"],
-               ["k_ntt_fwd2", "k_behz_tensor_intt2", "k_behz_floor_back", "k_behz_to_bsk", "k_cubic_coeffs_g", "k_cubic_combine_g"]),
+               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_cubic_coeffs_g", "k_cubic_combine_g"]),
     "seal23": ([PY, os.path.join(ROOT, "bench.py"), "--preset", "SEAL23_4096", "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
                ["k_dct_rows_u64", "k_dct_cols_u64"]),
 }
