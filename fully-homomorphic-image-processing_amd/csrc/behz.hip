@@ -366,8 +366,8 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
 }
 
 // The same step on the pseudo-Mersenne inverse passes (ntt_core.h; C = the class of the base), M ciphertext pairs
-// (M cc + h) per workgroup.  The lazy Barrett products are summed as integers (at most 12 x 5q), one fold_pm brings a sum
-// below (17/16) q, and the transform leaves its outputs below C::RQ / 16 q: k_behz_floor_back<.., WIDE_CHUNK> takes them
+// (M cc + h) per workgroup.  The products (mulvv_pm: seven multiply-adds, each below C::RQ / 16 q <= 6q) are summed as
+// integers (at most 12 terms: 72 q < 2^62 on a 55-bit base, 18 q on a 58-bit one), one fold_pm brings a sum below (17/16) q, and the transform leaves its outputs below C::RQ / 16 q: k_behz_floor_back<.., WIDE_CHUNK> takes them
 // as they are (its Shoup products accept any 64-bit value, its 128-bit sums a start value below 4 b_j).
 template <int L, int M, typename C>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
@@ -382,7 +382,6 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
     if (g >= groups) return;
     const u32 j = (u32)(g % nb);
     const u64 cc = g / nb;
-    const BarrettLazy bl = barrett_lazy(base.mod[j]);
     const PmMod m = base.pm[j];
     u64 acc[M][16];
     const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
@@ -393,13 +392,17 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
         for (int r = 0; r < 16; r++) acc[h][r] = 0;
         for (u32 ja = lo; ja <= hi; ja++) {
             const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
+            // all 32 operand loads of a term in flight before its first product (M = 1: 32 accumulator + 64 operand VGPRs);
+            // left to itself hipcc keeps two or three in flight and every pair of slots waits out a memory round trip
+            constexpr int G = M == 1 ? 16 : 8;
 #pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {       // eight slots at a time: 64 accumulator + 32 operand VGPRs
-                u64 xa[8], xb[8];
+            for (int r0 = 0; r0 < 16; r0 += G) {
+                u64 xa[G], xb[G];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
+                for (int r = 0; r < G; r++) { xa[r] = pa[(r0 + r) * TP]; xb[r] = pb[(r0 + r) * TP]; }
+                PM_FENCE();
 #pragma unroll
-                for (int r = 0; r < 8; r++) acc[h][r0 + r] += mul_barrett_lazy5(xa[r], xb[r], bl);
+                for (int r = 0; r < G; r++) acc[h][r0 + r] += mulvv_pm(xa[r], xb[r], m);      // canonical operands; below C::RQ / 16 q
             }
         }
 #pragma unroll

@@ -155,6 +155,80 @@ int runp(const u64 *in, u64 *out, RnsBase base, u64 polys, unsigned grid) {
     printf("persistent, next polynomial prefetched, grid %5u  %8.3f ms   %6.0f GB/s read+write\n", grid, ms, 2.0 * polys * 65536 / ms / 1e6);
     return 0;
 }
+// the same forward transform with 2^LE coefficients per thread (LE = 3: 1024 threads per 8192-point polynomial, twice the waves)
+template <int L, int LE> struct G {
+    static constexpr int N = 1 << L, E = 1 << LE, TP = N >> LE, NP = (L + LE - 1) / LE, LDS_WORDS = N + (N >> LE);
+    static constexpr int lo(int p) { return (L - LE * p - LE) < 0 ? 0 : (L - LE * p - LE); }
+    static constexpr int stages(int p) { return (L - LE * p) > LE ? LE : (L - LE * p); }
+};
+template <int L, int LE, int P, int U>
+__device__ __forceinline__ void g_stage(u64 (&x)[1 << LE], const ulonglong2 *__restrict__ tw, const PmMod &m, u64 off, int tid) {
+    using T = G<L, LE>;
+    constexpr int E = T::E, LO = T::lo(P), sigma = LE * P + U, rb = (L - 1 - sigma) - LO, CNT = 1 << (LE - 1 - rb);
+    const int th = (P == 0) ? 0 : (tid >> LO);
+    ulonglong2 w[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; i++) w[i] = tw[(1 << sigma) + (i << (sigma - (LE - 1 - rb))) + th];
+#pragma unroll
+    for (int b = 0; b < E / 2; b++) {
+        const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+        const u64 X = x[r0], T2 = mul_pm(x[r1], w[r0 >> (rb + 1)], m);
+        x[r0] = X + T2;
+        x[r1] = X - T2 + off;
+    }
+}
+template <int L, int LE, int P, int U = 0>
+__device__ __forceinline__ void g_pass(u64 (&x)[1 << LE], const ulonglong2 *__restrict__ tw, const PmMod &m, u64 off, int tid) {
+    g_stage<L, LE, P, U>(x, tw, m, off, tid);
+    if constexpr (U + 1 < G<L, LE>::stages(P)) g_pass<L, LE, P, U + 1>(x, tw, m, off, tid);
+}
+template <int L, int LE, int P = 0>
+__device__ __forceinline__ void g_fwd(u64 (&x)[1 << LE], const ulonglong2 *__restrict__ tw, const PmMod &m, u64 off, u64 *lds, int tid) {
+    using T = G<L, LE>;
+    g_pass<L, LE, P>(x, tw, m, off, tid);
+    if constexpr (P + 1 < T::NP) {
+        constexpr int LF = T::lo(P), LT = T::lo(P + 1), PL = LF < LT ? LF : LT, E = T::E;
+        auto idx = [](int lo_, int tid_, int r) { return ((tid_ >> lo_) << (lo_ + LE)) | (r << lo_) | (tid_ & ((1 << lo_) - 1)); };
+        auto pad = [](int j) { return j + ((j >> (PL + LE)) << PL); };
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; r++) lds[pad(idx(LF, tid, r))] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; r++) x[r] = lds[pad(idx(LT, tid, r))];
+        g_fwd<L, LE, P + 1>(x, tw, m, off, lds, tid);
+    }
+}
+template <int L, int LE, int WPS>
+__global__ __launch_bounds__((G<L, LE>::TP), WPS) void kg(const u64 *__restrict__ in, u64 *__restrict__ out, RnsBase base) {
+    using T = G<L, LE>;
+    __shared__ u64 lds[T::LDS_WORDS];
+    const int tid = threadIdx.x;
+    const u64 rp = blockIdx.x;
+    const u32 prime = (u32)(rp % base.count);
+    const PmMod m = base.pm[prime];
+    u64 x[T::E];
+#pragma unroll
+    for (int r = 0; r < T::E; r++) x[r] = in[rp * T::N + r * T::TP + tid];
+    g_fwd<L, LE>(x, base.tw_pm + (size_t)prime * T::N, m, m.q << 3, lds, tid);
+#pragma unroll
+    for (int r = 0; r < T::E; r++) out[rp * T::N + r * T::TP + tid] = canon_pm(x[r], m);
+}
+template <int LE, int WPS> int rung(const u64 *in, u64 *out, RnsBase base, u64 polys) {
+    constexpr int L = 13;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    kg<L, LE, WPS><<<(unsigned)polys, G<L, LE>::TP>>>(in, out, base);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    for (int r = 0; r < 5; r++) kg<L, LE, WPS><<<(unsigned)polys, G<L, LE>::TP>>>(in, out, base);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    printf("%2d coefficients per thread (%4d threads), launch bound %d waves/SIMD   %8.3f ms   %6.0f GB/s read+write\n", 1 << LE, G<L, LE>::TP, WPS, ms, 2.0 * polys * 65536 / ms / 1e6);
+    return 0;
+}
 template <int M, int VAR> int run(const char *name, const u64 *in, u64 *out, RnsBase base, u64 polys) {
     constexpr int L = 13;
     hipEvent_t e0, e1;
@@ -188,6 +262,10 @@ int main() {
     run<2, 1>("butterflies, no LDS transposes", in, out, base, polys);
     run<2, 2>("LDS transposes, no butterflies", in, out, base, polys);
     run<2, 0>("load + store only", in, out, base, polys);
+    rung<4, 4>(in, out, base, polys);
+    rung<3, 4>(in, out, base, polys);
+    rung<3, 8>(in, out, base, polys);
+    rung<2, 8>(in, out, base, polys);
     runh<4, true, false>(in, out, base, polys);
     runh<4, false, false>(in, out, base, polys);
     runh<4, true, true>(in, out, base, polys);
