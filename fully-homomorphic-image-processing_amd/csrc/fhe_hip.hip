@@ -1086,6 +1086,76 @@ __global__ __launch_bounds__(256) void k_dct_slots(u64 *__restrict__ data, const
     }
 }
 
+// Pseudo-Mersenne bases (every prime <= 55 bits, class PmA of ntt_core.h) take the slot step as TWO launches of 8 values
+// per thread -- the rows of a block, then its columns with the per-output scale -- on lazy arithmetic: sums and differences
+// stay unreduced (a difference gets a power-of-two multiple of q above its subtrahend's bound added), every product is
+// mulvv_pm(fold_pm(x), c) -- any 64-bit x in, below 6q out --, row outputs are stored as they are (below 24 q) and only the
+// 64 final values are brought to canonical form.  The one-launch kernel above holds 64 values per thread (256 VGPRs, one wave
+// per SIMD) and moves 1.5 TB/s; its lazy form spills (202 VGPRs + 528 B).  I = bound of a line's inputs in units of q; the
+// largest value met is below 256 q < 2^63.
+__host__ __device__ constexpr int dct_pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+template <int I, typename CF>
+__device__ __forceinline__ void dct_line_pm(u64 (&d)[8], const PmMod &m, CF C) {
+    constexpr int IP = dct_pow2_at_least(I), S1 = dct_pow2_at_least(2 * I), S2 = dct_pow2_at_least(4 * I);
+    static_assert(4 * I + S2 <= 256 && 2 * (2 * I + S1) <= 256 && 4 * (I + IP) <= 256, "a sum would pass 256 q");
+    const u64 oi = m.q * IP, o1 = m.q * S1, o2 = m.q * S2;
+    auto MUL = [&](u64 x, int cid) { return mulvv_pm(fold_pm(x, m), C(cid).x, m); };
+    u64 tmp0 = d[0] + d[7], tmp7 = d[0] - d[7] + oi;
+    u64 tmp1 = d[1] + d[6], tmp6 = d[1] - d[6] + oi;
+    u64 tmp2 = d[2] + d[5], tmp5 = d[2] - d[5] + oi;
+    u64 tmp3 = d[3] + d[4], tmp4 = d[3] - d[4] + oi;
+    const u64 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3 + o1;
+    const u64 tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2 + o1;
+    d[0] = tmp10 + tmp11;
+    d[4] = tmp10 - tmp11 + o2;
+    u64 z1 = MUL(tmp12 + tmp13, 0);
+    d[2] = z1 + MUL(tmp13, 1);
+    d[6] = z1 + MUL(tmp12, 2);
+    z1 = tmp4 + tmp7;
+    u64 z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+    const u64 z5 = MUL(z3 + z4, 3);
+    tmp4 = MUL(tmp4, 4);
+    tmp5 = MUL(tmp5, 5);
+    tmp6 = MUL(tmp6, 6);
+    tmp7 = MUL(tmp7, 7);
+    z1 = MUL(z1, 8);
+    z2 = MUL(z2, 9);
+    z3 = MUL(z3, 10) + z5;
+    z4 = MUL(z4, 11) + z5;
+    d[7] = tmp4 + z1 + z3;
+    d[5] = tmp5 + z2 + z4;
+    d[3] = tmp6 + z2 + z3;
+    d[1] = tmp7 + z1 + z4;
+}
+// COLS = false: line `l` = row l of the block (ciphertexts 8 l .. 8 l + 7); true: column l (ciphertexts l, l + 8, ...) + scale
+template <bool COLS>
+__global__ __launch_bounds__(256) void k_dct_lines_pm(u64 *__restrict__ data, const ulonglong2 *__restrict__ consts,
+                                                      const PmMod *__restrict__ pm, u32 k, u32 n) {
+    const u32 line = blockIdx.y & 7, unit = blockIdx.y >> 3;      // unit = (block * 2 + poly) * k + prime
+    const u32 prime = unit % k;
+    const u32 bp = unit / k;
+    const u32 blk = bp >> 1, poly = bp & 1;
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const PmMod m = pm[prime];
+    const size_t ct_stride = (size_t)2 * k * n, step = COLS ? 8 * ct_stride : ct_stride;
+    u64 *p = data + ((size_t)blk * 64 + (COLS ? line : 8 * line)) * ct_stride + ((size_t)poly * k + prime) * n + slot;
+    const ulonglong2 *cp = consts + (size_t)prime * n + slot;
+    const size_t cstride = (size_t)k * n;
+    auto C = [&](int cid) { return cp[(size_t)cid * cstride]; };
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = p[(size_t)i * step];
+    if constexpr (!COLS) {
+        dct_line_pm<1>(v, m, C);
+#pragma unroll
+        for (int i = 0; i < 8; i++) p[(size_t)i * step] = v[i];
+    } else {
+        dct_line_pm<24>(v, m, C);
+#pragma unroll
+        for (int i = 0; i < 8; i++) p[(size_t)i * step] = canon_pm(mulvv_pm(fold_pm(v[i], m), C(12 + 8 * i + line).x, m), m);
+    }
+}
+
 extern "C" int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int int_coeffs, int frac_coeffs, fhe_stream s, fhe_dct_plan **out) {
     if (!c || !out) return fail(FHE_ERR_PARAM, "null argument");
     *out = nullptr;
@@ -1221,7 +1291,13 @@ extern "C" int fhe_dct8x8_quant(const fhe_ctx *c, const fhe_dct_plan *plan, cons
         int rc = fhe_ntt_launch(false, c, c->qb, (const u64 *)in + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
         if (rc) return rc;
         dim3 grid(c->n / 256, (unsigned)(nb * 2 * c->k));
-        k_dct_slots<<<grid, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_mod, c->k, c->n);
+        if (c->qb.pm_class == 1 && !c->opt.ntt_nopm) {
+            dim3 grid8(c->n / 256, (unsigned)(nb * 2 * c->k * 8));
+            k_dct_lines_pm<false><<<grid8, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_pm, c->k, c->n);
+            k_dct_lines_pm<true><<<grid8, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_pm, c->k, c->n);
+        } else {
+            k_dct_slots<<<grid, 256, 0, st>>>((u64 *)out + off, plan->d_consts, c->qb.d_mod, c->k, c->n);
+        }
         KERNEL_CHECK();
         rc = fhe_ntt_launch(true, c, c->qb, (const u64 *)out + off, (u64 *)out + off, nb * polys_per_block * c->k, st);
         if (rc) return rc;
