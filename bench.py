@@ -257,7 +257,9 @@ def main():
             else:
                 traffic_src = "profiles/pmc_traffic.json was measured on other kernel sources (%s); re-run tools/collect_traffic.py" % tj.get("kernel_source_hash")
         path = fhe._lib.load().fhe_dct_path(ctx.h)             # 1 fused FP64 pair, 2 fused u64 pair, 0 general three-launch path
-        kernels = {1: "k_dct_rows + k_dct_cols", 2: "k_dct_rows_u64 + k_dct_cols_u64", 0: "k_ntt_fwd + k_dct_slots + k_ntt_inv"}[path]
+        pm = fhe._lib.load().fhe_arith_path(ctx.h) & 3           # pseudo-Mersenne butterflies on the q-base (csrc/ntt_core.h)
+        kernels = {1: "k_dct_rows + k_dct_cols", 2: "k_dct_rows_u64 + k_dct_cols_u64",
+                   0: "k_ntt_fwd_pm + k_dct_lines_pm x 2 + k_ntt_inv_pm" if pm == 1 else "k_ntt_fwd + k_dct_slots + k_ntt_inv"}[path]
         res = {
             "metric": "encrypted 8x8 blocks/sec (homomorphic DCT+quant)",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -272,7 +274,8 @@ def main():
                                    ("blocks x%d, every %d-block wave of outputs sent to rank 0 (RCCL send/recv) and drained by digest" % (world, args.gather_wave_blocks)),
                        "gather": args.gather,
                        "arithmetic": {1: "exact integer residues carried by FP64 FMA (primes < 2^47), u64 ciphertexts in and out",
-                                      2: "u64 Shoup modular arithmetic, fused row / column kernels",
+                                      2: "u64 pseudo-Mersenne butterflies (primes 2^b - delta, <= 55 bits) + Shoup line products, fused row / column kernels" if pm == 1
+                                         else "u64 Shoup modular arithmetic, fused row / column kernels",
                                       0: "u64 Shoup modular arithmetic, general three-launch path"}[path]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

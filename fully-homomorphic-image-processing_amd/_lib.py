@@ -71,6 +71,7 @@ SIGNATURES = {
     "fhe_dct_plan_destroy": (_i, [_vp]),
     "fhe_dct8x8_scratch_bytes": (_sz, [_vp, _u64]),
     "fhe_dct_path": (_i, [_vp]),
+    "fhe_arith_path": (_i, [_vp]),
     "fhe_dct8x8_quant": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
     "fhe_rgb_to_ycc": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _i, _vp]),
     "fhe_rgb_to_ycc_blocks": (_i, [_vp, _vp, _u64, _i, _i, _vp]),
@@ -107,7 +108,7 @@ SIGNATURES = {
     "fhe_io_transfer": (_i, [_vp, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
-_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path"}
+_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path", "fhe_arith_path"}
 
 
 def load():

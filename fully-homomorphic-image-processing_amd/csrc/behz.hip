@@ -924,6 +924,14 @@ int fhe_behz_build(fhe_ctx *c) {
     return FHE_OK;
 }
 
+extern "C" int fhe_arith_path(const fhe_ctx *c) {
+    if (!c) return fail(FHE_ERR_PARAM, "null argument");
+    if (c->opt.ntt_nopm) return 0;
+    int r = c->qb.pm_class & 3;
+    if (c->behz) r |= ((c->behz->aux.pm_class & 3) << 2) | (c->behz->pm_dev ? 16 : 0);
+    return r;
+}
+
 void fhe_behz_free(fhe_ctx *c) {
     if (c && c->behz) {
         fhe_free_base(c->behz->aux);

@@ -214,6 +214,12 @@ size_t fhe_dct8x8_scratch_bytes(const fhe_ctx *ctx, uint64_t n_blocks);
  * pair k_dct_rows + k_dct_cols (primes < 2^47, n <= 8192), 2 = the fused u64 pair k_dct_rows_u64 + k_dct_cols_u64
  * (primes <= 57 bits, n in 2048..8192), 0 = the general path k_ntt_fwd + k_dct_slots + k_ntt_inv. */
 int fhe_dct_path(const fhe_ctx *ctx);
+/* which arithmetic the u64 kernels of this context run on (for labels in measurements and for tests that must know which
+ * kernels they exercised): bits 0-1 = class of the q-base, bits 2-3 = class of the auxiliary ct x ct base -- 0 Shoup / Harvey
+ * kernels, 1 pseudo-Mersenne kernels for primes <= 55 bits, 2 pseudo-Mersenne kernels for primes <= 58 bits
+ * (csrc/ntt_core.h) --, bit 4 = the ct x ct base conversions run as two-column sums (k_behz_to_bsk_pm,
+ * k_behz_floor_back_pm).  0 when FHE_NTT_NOPM=1 was set at fhe_ctx_create or no prime of a base qualifies. */
+int fhe_arith_path(const fhe_ctx *ctx);
 int fhe_dct8x8_quant(const fhe_ctx *ctx, const fhe_dct_plan *plan, const uint64_t *in, uint64_t *out,
                      uint64_t n_blocks, void *scratch, size_t scratch_bytes, fhe_stream stream);
 

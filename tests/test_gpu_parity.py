@@ -919,6 +919,19 @@ def test_randomised_op_sequences_vs_oracle(fhe, oracle_mod, preset):
 # ---------------------------------------------------------------------------------------------
 # the kernels behind the experiment switches (former defaults, fallbacks): same bits as the default path
 # ---------------------------------------------------------------------------------------------
+def test_presets_run_the_arithmetic_the_parity_tests_assume(fhe):
+    """fhe_arith_path: the SEAL 2.3 presets (54/55-bit primes) take the pseudo-Mersenne kernels on both bases and the
+    two-column base conversions, the 36/37-bit headline preset the Shoup / FP64 ones on its q-base and the pseudo-Mersenne
+    ones on the 58-bit auxiliary base, and FHE_NTT_NOPM=1 switches all of it off -- so the parity tests above exercise the
+    kernels their docstrings name."""
+    path = lambda ctx: fhe._lib.call("fhe_arith_path", ctx.h)
+    for preset in ("P8192", "SEAL23_4096", "SEAL23_2048"):
+        assert path(fhe.SEALContext.preset(preset)) == (1 | (2 << 2) | 16), preset
+    assert path(fhe.SEALContext.preset("P4096")) == (0 | (2 << 2) | 0)
+    assert path(_variant(fhe, fhe.SEALContext.preset("P8192"), FHE_NTT_NOPM=1)) == 0
+    assert path(_variant(fhe, fhe.SEALContext.preset("P8192"), FHE_BEHZ_AUX61=1)) == 1      # 61-bit auxiliary primes: Shoup kernels there, 128-bit conversions
+
+
 @pytest.mark.parametrize("switch", ["FHE_NTT_NOPM", "FHE_BEHZ_AUX61", "FHE_BEHZ_CHUNK3", "FHE_NTT_NOPM+FHE_BEHZ_AUX61", "FHE_NTT_NOPM+FHE_BEHZ_CHUNK3",
                                     "FHE_NTT_NOPM+FHE_NTT_NOLAZY", "FHE_NTT_NOPM+FHE_NTT_SINGLE", "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_CANON",
                                     "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_SINGLE"])
