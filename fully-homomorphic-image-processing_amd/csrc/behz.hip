@@ -739,6 +739,76 @@ __global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 str
     }
 }
 
+// Relinearisation on pseudo-Mersenne bases (C = class of the q-base): three launches instead of five.
+// (1) digit extraction fused into the forward transforms: workgroup (c, i, d, ii) reads c2_i, takes digit d and transforms it
+// modulo q_ii (the k workgroups of one digit sit next to each other: the repeated reads of c2_i hit L2); a digit of
+// dbc >= bits(q_ii) bits is folded first.  dig [count][k][nd][k][n], NTT form, canonical.
+template <int L, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, RnsBase base, u32 nd, u32 dbc) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 k = base.count, ii = blockIdx.x % k;
+    const u64 u = blockIdx.x / k;                  // (c * k + i) * nd + d
+    const u32 d = (u32)(u % nd), i = (u32)((u / nd) % k);
+    const u64 c = u / ((u64)nd * k);
+    const u64 mask = (1ULL << dbc) - 1;            // dbc <= 60
+    const PmMod m = base.pm[ii];
+    u64 x[1][16];
+    load_coeff<L>(x[0], ct + c * stride + ((u64)2 * k + i) * N, tid);
+    const bool wide = dbc >= m.sh + 32;            // the digit may reach q_ii
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        x[0][r] = (x[0][r] >> (dbc * d)) & mask;
+        if (wide) x[0][r] = fold_pm(x[0][r], m);
+    }
+    ntt_fwd_regs_pm<L, 1, PM_FOLDED, C::LIM, C::CS>(x, base.tw_pm + (size_t)ii * N, m, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[0][r] = canon_pm(x[0][r], m);
+    store_slots<L>(x[0], dig + (u * k + ii) * N, tid);
+}
+// (2) acc[c][pp][ii][s] = sum_{i,d} dig * evk with mulvv_pm products summed as integers (k nd <= 20 terms of at most 6q), one fold
+template <typename C>
+__global__ __launch_bounds__(256) void k_relin_accum_pm(const u64 *__restrict__ dig, const u64 *__restrict__ evk, u64 *__restrict__ acc,
+                                                        RnsBase base, u32 n, u32 nd, u64 count) {
+    const u32 k = base.count;
+    for (u64 u = blockIdx.y; u < count * k; u += gridDim.y) {
+        const u32 ii = (u32)(u % k);
+        const u64 c = u / k;
+        const PmMod m = base.pm[ii];
+        for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+            u64 a0 = 0, a1 = 0;
+            for (u32 i = 0; i < k; i++)
+                for (u32 d = 0; d < nd; d++) {
+                    const u64 x = dig[(((c * k + i) * nd + d) * k + ii) * n + s];
+                    const u64 *e = evk + ((((u64)i * nd + d) * 2) * k + ii) * n + s;
+                    a0 += mulvv_pm(x, e[0], m);
+                    a1 += mulvv_pm(x, e[(u64)k * n], m);
+                }
+            acc[((c * 2 + 0) * k + ii) * n + s] = fold_pm(a0, m);
+            acc[((c * 2 + 1) * k + ii) * n + s] = fold_pm(a1, m);
+        }
+    }
+}
+// (3) inverse transform of acc and the addition into c0 / c1 in one kernel
+template <int L, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_inv_add_pm(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 k = base.count, ii = blockIdx.x % k, pp = (blockIdx.x / k) & 1;
+    const u64 c = blockIdx.x / (2 * k);
+    const PmMod m = base.pm[ii];
+    u64 x[1][16], y[16];
+    u64 *dst = ct + c * stride + ((u64)pp * k + ii) * N;
+    load_slots<L>(x[0], acc + (u64)blockIdx.x * N, tid);
+    load_coeff<L>(y, dst, tid);
+    ntt_inv_regs_pm<L, 1, PM_FOLDED, C::XB, C::LIM, C::RQ>(x, base.itw_pm + (size_t)ii * N, m, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) y[r] = addmod(y[r], canon_rq_pm<C::RQ>(x[0][r], m), m.q);
+    store_coeff<L>(y, dst, tid);
+}
+
 inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(rows < 32768 ? (rows ? rows : 1) : 32768)); }
 
 }  // namespace
@@ -1173,6 +1243,20 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
     const BehzDev *T = c->behz->dev;
     u64 *dig = (u64 *)scratch, *acc = dig + count * k * nd * k * n;
+    const bool f64 = fhe_rgb_f64_supported(c) && !c->opt.force_u64;      // the q-base transforms run on the FP64 kernels there
+    if (c->qb.pm_class && !c->opt.ntt_nopm && !f64 && k * nd <= 20 && count * k * nd * k <= 0x7fffffffULL) {
+        const RnsBase base = c->qb.dev();
+#define GO_PM(CC)                                                                                                                          \
+    DISPATCH_L(c->logn, {                                                                                                                  \
+        k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc);      \
+        k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                           \
+        k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((u64 *)ct3, stride, acc, base);                      \
+    })
+        if (c->qb.pm_class == 1) { GO_PM(PmA); } else { GO_PM(PmB); }
+#undef GO_PM
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count);
     if ((rc = qbase_ntt(false, c, dig, dig, count * k * nd, st))) return rc;
     k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);

@@ -471,9 +471,12 @@ def test_multiply_edge_inputs(fhe, oracle_mod):
     assert np.array_equal(fhe.to_host(ev.square(da))[0], orc.square(a[0]))
 
 
-@pytest.mark.parametrize("dbc", [16, 30])
-def test_relinearize(fhe, oracle_mod, dbc):
-    ctx, orc = _pair(fhe, oracle_mod, "SMALL")
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("SMALL", 30), ("P8192", 30), ("P8192", 60), ("SEAL23_4096", 16)])
+def test_relinearize(fhe, oracle_mod, preset, dbc):
+    """SMALL: the five-launch Shoup path; P8192 / SEAL23_4096: the three fused pseudo-Mersenne launches (digit extraction
+    inside the forward transforms, lazy key products, inverse transform + addition), with digits narrower and -- dbc = 60 --
+    wider than the primes."""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
     ev = fhe.Evaluator(ctx)
     sk, pk = orc.keygen(77)
     evk = orc.evk_gen(sk, dbc=dbc)                       # oracle NTT form [k][nd][2][k][n]

@@ -51,3 +51,7 @@ Bm = max(1, B // 8)
 am, bm = a[:Bm].contiguous(), b[:Bm].contiguous()
 report("multiply 2x2->3", timed(lambda: ev.multiply(am, bm), 3), (2 + 2 + 3) * Bm * ct_bytes / 2, Bm)
 report("square 2->3", timed(lambda: ev.square(am), 3), (2 + 3) * Bm * ct_bytes / 2, Bm)
+dbc = 30
+evk = fhe.KeyGenerator(ctx, seed=3).generate_evaluation_keys(dbc)
+c3 = ctx.random_ct(Bm, size=3, seed=4)
+report("relinearize 3->2 (dbc 30)", timed(lambda: ev.relinearize(c3, evk, dbc), 3), (3 + 2) * Bm * ct_bytes / 2, Bm)
