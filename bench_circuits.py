@@ -39,19 +39,22 @@ def resize(args):
     # warm-up (builds BEHZ tables, caches plaintexts)
     fhe.circuits.sample_bicubic(ev, pc, pixels, taps[:min(P, 8)], xf[:min(P, 8)].contiguous(), yf[:min(P, 8)].contiguous())
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    for s in range(0, n_out, P):
-        e = min(s + P, n_out)
-        out = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf[: e - s].contiguous(), yf[: e - s].contiguous())
-        done += e - s
-        if args.max_pixels and done >= args.max_pixels:
-            break
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    passes = []
+    for _ in range(1 if args.max_pixels else 2):      # the first full-size pass sizes the allocator's pools (scratch of several GiB); the second is the steady state
+        t0 = time.perf_counter()
+        done = 0
+        for s in range(0, n_out, P):
+            e = min(s + P, n_out)
+            out = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf[: e - s].contiguous(), yf[: e - s].contiguous())
+            done += e - s
+            if args.max_pixels and done >= args.max_pixels:
+                break
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+    dt = passes[-1]
     res = {"workload": "bicubic resize %dx%d -> %dx%d, one channel, %s (n=%d, k=%d)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
            "output_pixels": done, "seconds": dt, "pixels_per_s": done / dt, "cubic_calls_per_s": 5 * done / dt,
-           "out_size": int(out.shape[-3]), "batch_pixels": P}
+           "out_size": int(out.shape[-3]), "batch_pixels": P, "first_pass_seconds": passes[0]}
     if args.shared:
         # SURVEY.md 8(d) config 3 input convention: one offset ciphertext per distinct fractional value, i.e. per output
         # column / row; every repeated ring element (row Cubics of overlapping windows, squares, prepared operands) is
