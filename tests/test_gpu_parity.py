@@ -677,6 +677,28 @@ def test_other_degrees(fhe, oracle_mod, n, q):
     assert np.array_equal(out, ref)
 
 
+def test_ct_x_ct_with_seven_and_eight_coefficient_moduli(fhe, oracle_mod):
+    """More than six coefficient moduli: the two-column base conversions are not built (fhe_arith_path bit 4 clear), so the
+    pseudo-Mersenne transforms and tensor step hand their unreduced outputs (below 6q / 1.5q) to the 128-bit
+    k_behz_to_bsk / k_behz_floor_back -- a combination no preset reaches.  n = 2048, the largest 54-bit primes = 1 (mod 2^16)."""
+    primes, cand = [], (1 << 54) + 1 - (1 << 16)
+    while len(primes) < 8:
+        if _is_prime(cand):
+            primes.append(cand)
+        cand -= 1 << 16
+    for k in (7, 8):
+        q = primes[:k]
+        ctx, orc = fhe.SEALContext(2048, q, 1 << 14), oracle_mod.Oracle(2048, q, 1 << 14)
+        assert fhe._lib.call("fhe_arith_path", ctx.h) == (1 | (2 << 2))
+        ev = fhe.Evaluator(ctx)
+        a, b = ctx.random_ct(3, seed=81), ctx.random_ct(3, seed=82)
+        ha, hb = fhe.to_host(a), fhe.to_host(b)
+        m = fhe.to_host(ev.multiply(a, b))
+        for i in (0, 2):
+            assert np.array_equal(m[i], orc.multiply(ha[i], hb[i])), (k, i)
+        assert np.array_equal(fhe.to_host(ev.square(a))[1], orc.square(ha[1])), k
+
+
 def _is_prime(m):
     if m < 2:
         return False
