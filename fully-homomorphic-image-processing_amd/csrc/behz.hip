@@ -54,6 +54,7 @@ typedef unsigned __int128 u128;
 
 // Constants of k_behz_floor_back_pm (below): every modulus of the step is pseudo-Mersenne (ntt_core.h), every constant sits
 // beside its multiple by the power of two its variable operand is split at.
+constexpr int PM_GROUP_Y = 4;                        // y-terms per group of columns (with the D_b / remainder term in the first)
 constexpr int PM_SPLIT_Y = 28, PM_SPLIT_Z = 29;      // y_i < 2^55 = yl + 2^28 yh;  z_j, folded D_b < 2^59 = zl + 2^29 zh
 struct BehzPmDev {
     PmMod q[BK], b[BK + 1];
@@ -557,20 +558,25 @@ __global__ __launch_bounds__(256) void k_behz_to_bsk_pm(const u64 *__restrict__ 
             const PmMod m = T.b[j];
             const ulonglong2 eq = T.ext_q_b[j];
             PmAcc acc[PCPT];
+            u64 tot[PCPT];
 #pragma unroll
             for (int e = 0; e < PCPT; e++) {
                 const u64 rb = r[e] >= 0x80000000ULL ? r[e] + m.q - 0x100000000ULL : r[e];    // centred remainder
                 acc[e].A = 0; acc[e].B = 0;
+                tot[e] = 0;
                 pm_mac(acc[e], (u32)rb & MZ, (u32)(rb >> PM_SPLIT_Z), eq);
             }
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const ulonglong2 c = T.ext_q2b[i][j];
 #pragma unroll
-                for (int e = 0; e < PCPT; e++) pm_mac(acc[e], yl[e][i], yh[e][i], c);
+                for (int e = 0; e < PCPT; e++) {
+                    if (i > 0 && i % PM_GROUP_Y == 0) { tot[e] += pm_acc_reduce(acc[e], m); acc[e].A = 0; acc[e].B = 0; }      // K > 4: a second group of columns
+                    pm_mac(acc[e], yl[e][i], yh[e][i], c);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < PCPT; e++) out[(p * (K + 1) + j) * n + c0 + e * stride] = canon_fold_pm(pm_acc_reduce(acc[e], m), m);
+            for (int e = 0; e < PCPT; e++) out[(p * (K + 1) + j) * n + c0 + e * stride] = canon_fold_pm(tot[e] + pm_acc_reduce(acc[e], m), m);
         }
     }
 }
@@ -604,16 +610,20 @@ __global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restric
             for (int e = 0; e < PCPT; e++) {
                 const u64 d = fold_pm(Db[(p * (K + 1) + j) * n + c0 + e * stride], m);       // any 64-bit value -> below (17/16) b_j
                 acc[e].A = 0; acc[e].B = 0;
+                f[e][j] = 0;
                 pm_mac(acc[e], (u32)d & MZ, (u32)(d >> PM_SPLIT_Z), ft);
             }
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 const ulonglong2 c = T.flo_q2b[i][j];
 #pragma unroll
-                for (int e = 0; e < PCPT; e++) pm_mac(acc[e], yl[e][i], yh[e][i], c);
+                for (int e = 0; e < PCPT; e++) {
+                    if (i > 0 && i % PM_GROUP_Y == 0) { f[e][j] += pm_acc_reduce(acc[e], m); acc[e].A = 0; acc[e].B = 0; }      // K > 4: a second group of columns
+                    pm_mac(acc[e], yl[e][i], yh[e][i], c);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < PCPT; e++) f[e][j] = pm_acc_reduce(acc[e], m);               // below 1.5 b_j
+            for (int e = 0; e < PCPT; e++) f[e][j] += pm_acc_reduce(acc[e], m);              // below 1.5 b_j per group: 3 b_j
         }
         const PmMod mk = T.b[K];
         u64 conv[PCPT];
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restric
             const ulonglong2 ib = T.inv_B_mod_msk;
 #pragma unroll
             for (int e = 0; e < PCPT; e++) {
-                const u64 alpha = canon_fold_pm(mul_pm(conv[e] + 2 * mk.q - f[e][K], ib, mk), mk);
+                const u64 alpha = canon_fold_pm(mul_pm(conv[e] + 4 * mk.q - f[e][K], ib, mk), mk);      // f_K below 3 m_sk, conv below 6 m_sk: below 2^62
                 neg[e] = alpha > (mk.q >> 1);
                 const u64 a_abs = neg[e] ? mk.q - alpha : alpha;
                 al[e] = (u32)a_abs & MZ;
@@ -819,7 +829,7 @@ inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(row
 static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, const std::vector<u64> &bsk) {
     using namespace hostmath;
     const u32 k = c->k;
-    if (!c->qb.pm_class || !T->aux.pm_class || !T->wide_dot || k > 6 || c->opt.ntt_nopm) return;
+    if (!c->qb.pm_class || !T->aux.pm_class || !T->wide_dot || k > 8 || c->opt.ntt_nopm) return;
     BehzPmDev P;
     std::memset(&P, 0, sizeof P);
     const std::vector<u64> &q = c->qb.primes;
@@ -872,12 +882,18 @@ static void behz_pm_tables(const fhe_ctx *c, BehzTables *T, const BehzDev &D, co
     bool ok = true;
     for (u32 i = 0; i < k; ++i) ok = ok && bit_length(q[i]) <= 55;
     for (u32 j = 0; j <= k && ok; ++j) {
-        std::vector<Term> g{{folded(P.b[j]), PM_SPLIT_Z, P.flo_t_b[j]}};
-        for (u32 i = 0; i < k; ++i) g.push_back({q[i] - 1, PM_SPLIT_Y, P.flo_q2b[i][j]});
-        ok = fits(g, P.b[j]);
-        std::vector<Term> x{{bsk[j] - 1, PM_SPLIT_Z, P.ext_q_b[j]}};      // base extension: centred remainder + the y_i
-        for (u32 i = 0; i < k; ++i) x.push_back({q[i] - 1, PM_SPLIT_Y, P.ext_q2b[i][j]});
-        ok = ok && fits(x, P.b[j]);
+        for (u32 i0 = 0; i0 < k && ok; i0 += PM_GROUP_Y) {      // groups of PM_GROUP_Y y-terms, the first with the extra term
+            std::vector<Term> g, x;
+            if (i0 == 0) {
+                g.push_back({folded(P.b[j]), PM_SPLIT_Z, P.flo_t_b[j]});
+                x.push_back({bsk[j] - 1, PM_SPLIT_Z, P.ext_q_b[j]});      // base extension: centred remainder + the y_i
+            }
+            for (u32 i = i0; i < i0 + PM_GROUP_Y && i < k; ++i) {
+                g.push_back({q[i] - 1, PM_SPLIT_Y, P.flo_q2b[i][j]});
+                x.push_back({q[i] - 1, PM_SPLIT_Y, P.ext_q2b[i][j]});
+            }
+            ok = fits(g, P.b[j]) && fits(x, P.b[j]);
+        }
     }
     for (u32 j0 = 0; j0 < k && ok; j0 += 2) {
         std::vector<Term> g;
@@ -1036,7 +1052,7 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
 static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
     const u32 k = c->k, n = c->n;
     switch (k) {
-#define GO(KK) case KK: if (c->behz->pm_dev && KK <= 6) k_behz_to_bsk_pm<(KK <= 6 ? KK : 1)><<<grid2(n / PCPT, count * s), 256, 0, st>>>(src, xb, c->behz->pm_dev, n, count * s); \
+#define GO(KK) case KK: if (c->behz->pm_dev) k_behz_to_bsk_pm<KK><<<grid2(n / PCPT, count * s), 256, 0, st>>>(src, xb, c->behz->pm_dev, n, count * s); \
                         else if (c->behz->wide_dot) k_behz_to_bsk<KK, TO_BSK_CPT, WIDE_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); \
                         else k_behz_to_bsk<KK, TO_BSK_CPT, DOT_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); break;
         GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
@@ -1106,9 +1122,9 @@ static int behz_finish(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, c
     if (c->behz->pm_dev) {
         switch (k) {
 #define GO(KK) case KK: k_behz_floor_back_pm<KK><<<grid2(n / PCPT, count * so), 256, 0, st>>>(Dq, Db, out, c->behz->pm_dev, n, count * so); break;
-            GO(1) GO(2) GO(3) GO(4) GO(5) GO(6)
+            GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
-            default: return fail(FHE_ERR_PARAM, "pseudo-Mersenne floor / back conversion is built for up to 6 coefficient moduli, not %u", k);
+            default: return fail(FHE_ERR_PARAM, "pseudo-Mersenne floor / back conversion is built for up to 8 coefficient moduli, not %u", k);
         }
         KERNEL_CHECK();
         return FHE_OK;

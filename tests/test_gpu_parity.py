@@ -678,18 +678,18 @@ def test_other_degrees(fhe, oracle_mod, n, q):
 
 
 def test_ct_x_ct_with_seven_and_eight_coefficient_moduli(fhe, oracle_mod):
-    """More than six coefficient moduli: the two-column base conversions are not built (fhe_arith_path bit 4 clear), so the
-    pseudo-Mersenne transforms and tensor step hand their unreduced outputs (below 6q / 1.5q) to the 128-bit
-    k_behz_to_bsk / k_behz_floor_back -- a combination no preset reaches.  n = 2048, the largest 54-bit primes = 1 (mod 2^16)."""
+    """More than four coefficient moduli: the two-column sums of the base conversions run in two groups of columns per output
+    (four y_i each), more than six: four groups of z_j -- shapes no preset reaches.  n = 2048, the largest 54-bit primes
+    = 1 (mod 2^16); products and a square against the oracle."""
     primes, cand = [], (1 << 54) + 1 - (1 << 16)
     while len(primes) < 8:
         if _is_prime(cand):
             primes.append(cand)
         cand -= 1 << 16
-    for k in (7, 8):
+    for k in (5, 7, 8):
         q = primes[:k]
         ctx, orc = fhe.SEALContext(2048, q, 1 << 14), oracle_mod.Oracle(2048, q, 1 << 14)
-        assert fhe._lib.call("fhe_arith_path", ctx.h) == (1 | (2 << 2))
+        assert fhe._lib.call("fhe_arith_path", ctx.h) == (1 | (2 << 2) | 16)
         ev = fhe.Evaluator(ctx)
         a, b = ctx.random_ct(3, seed=81), ctx.random_ct(3, seed=82)
         ha, hb = fhe.to_host(a), fhe.to_host(b)
