@@ -91,11 +91,18 @@ SIGNATURES = {
     "fhe_sample_linear": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
     "fhe_resize_bicubic_shared_scratch_bytes": (_sz, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _i]),
     "fhe_resize_bicubic_shared": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "fhe_resize_source_rows": (_i, [_u32, _u32, _u32, _u32, _i, C.POINTER(_u32), C.POINTER(_u32)]),
+    "fhe_resize_bicubic_shared_rows_scratch_bytes": (_sz, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i]),
+    "fhe_resize_bicubic_shared_rows": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "fhe_homomorphic_sincos_scratch_bytes": (_sz, [_vp, _u64]),
     "fhe_homomorphic_sincos": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _vp, _sz, _vp]),
     "fhe_approximated_step_out_size": (_u32, [_i]),
     "fhe_approximated_step_scratch_bytes": (_sz, [_vp, _i, _u32]),
     "fhe_approximated_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "fhe_approximated_step_range_scratch_bytes": (_sz, [_vp, _i, _u32, _u32, _u32]),
+    "fhe_approximated_step_range": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "fhe_decode_channel_range_scratch_bytes": (_sz, [_vp, _i, _u32, _u32, _u32, _u32]),
+    "fhe_decode_channel_range": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp]),
     "fhe_decode_channel_scratch_bytes": (_sz, [_vp, _i, _u32, _u32]),
     "fhe_decode_channel": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _i, _i, _dbl, _u32, _u32, _vp, _vp, _sz, _vp]),
     # include/fhe_stream.h

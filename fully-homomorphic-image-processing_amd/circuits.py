@@ -223,7 +223,15 @@ def sample_linear(ev, pc, pixels, taps, xfract, yfract):
 BAND_CONSUMER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
-def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None):
+def resize_source_rows(src_h, dst_h, row0, row1, bicubic=True):
+    """(first, count) of the source rows destination rows [row0, row1) read (fhe_resize_source_rows): the shard's rows plus
+    the sampler's halo, clamped -- what a GPU that owns those destination rows has to load."""
+    first, count = C.c_uint32(), C.c_uint32()
+    _lib.call("fhe_resize_source_rows", src_h, dst_h, row0, row1, int(bool(bicubic)), C.byref(first), C.byref(count))
+    return int(first.value), int(count.value)
+
+
+def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None, rows=None, src_rows=None):
     """ResizeImage with SampleBicubic (homo/fhe_resize.h:254-392) for one colour channel when the fractional
     offsets arrive as ONE ciphertext per output column (xfract [dst_w, 2, k, n]) and ONE per output row
     (yfract [dst_h, 2, k, n]) -- SURVEY.md section 8(d), config 3: "xfract/yfract ciphertexts are inputs generated
@@ -242,14 +250,22 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
     (server.server_resize does).  Source rows are visited as a sliding window (`band_rows` output rows at a
     time), like the reference's loader (:352-379).
 
-    Returns [dst_h * dst_w, 6, k, n] (row-major), or None when `consume(first_pixel, tensor)` takes the bands
-    (the tensor is a view of a buffer the library reuses: clone what must outlive the callback)."""
+    rows=(y0, y1) evaluates a SHARD of the destination rows (fhe_resize_bicubic_shared_rows; the multi-GPU partition of
+    the outer loop, :350): `pixels` then holds the source rows src_rows=(first, count) only (resize_source_rows: the
+    shard's rows +- the halo), yfract the offsets of rows [y0, y1) only, and the result the pixels of those rows -- each
+    bit-identical to the whole-image call's.
+
+    Returns [dst_h * dst_w, 6, k, n] (row-major; [(y1 - y0) * dst_w, ...] for a shard), or None when
+    `consume(first_pixel, tensor)` takes the bands (first_pixel is the global index y * dst_w; the tensor is a view of a
+    buffer the library reuses: clone what must outlive the callback)."""
     cc = circuits_of(pc)
     ctx = ev.ctx
-    assert _count(pixels, 2) == src_w * src_h and _count(xfract, 2) == dst_w and _count(yfract, 2) == dst_h
+    y0, y1 = rows if rows is not None else (0, dst_h)
+    s0, sc = src_rows if src_rows is not None else ((0, src_h) if rows is None else resize_source_rows(src_h, dst_h, y0, y1))
+    assert _count(pixels, 2) == src_w * sc and _count(xfract, 2) == dst_w and _count(yfract, 2) == y1 - y0, (pixels.shape, sc, yfract.shape, rows)
     L = _lib.load()
-    out = None if consume is not None else ctx.empty(dst_w * dst_h, size=6)
-    nbytes = L.fhe_resize_bicubic_shared_scratch_bytes(cc.h, src_w, src_h, dst_w, dst_h, batch, band_rows, int(out is not None))
+    out = None if consume is not None else ctx.empty(dst_w * (y1 - y0), size=6)
+    nbytes = L.fhe_resize_bicubic_shared_rows_scratch_bytes(cc.h, src_w, src_h, dst_w, dst_h, y0, y1, s0, sc, batch, band_rows, int(out is not None))
     scr = cc.scratch(nbytes)
     words = 6 * ctx.k * ctx.n
     err = []
@@ -266,7 +282,7 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
 
     cb = BAND_CONSUMER(on_band) if consume is not None else None
     try:
-        _lib.call("fhe_resize_bicubic_shared", cc.h, _ptr(pixels), src_w, src_h, dst_w, dst_h, _ptr(xfract), _ptr(yfract),
+        _lib.call("fhe_resize_bicubic_shared_rows", cc.h, _ptr(pixels), src_w, src_h, dst_w, dst_h, y0, y1, s0, sc, _ptr(xfract), _ptr(yfract),
                   _ptr(out) if out is not None else C.c_void_p(None), batch, band_rows, cb, None, _ptr(scr), nbytes, _stream())
     except _lib.FheError:
         if err:
@@ -300,13 +316,13 @@ def homomorphic_cos(ev, pc, x, zero):
     return _sincos(1, ev, pc, x, zero)
 
 
-def stack_zeros(zeros, npos, degree):
+def stack_zeros(zeros, npos, degree, pos0=0):
     """zeros: callable (i, j, which) -> [1, 2, k, n] -> one tensor [npos, degree, 2, 2, k, n] in the reference's
-    call order (position i, harmonic j = 1..degree, homomorphic_sin's Enc(0) then homomorphic_cos's)."""
-    return torch.cat([zeros(i, j, w) for i in range(npos) for j in range(1, degree + 1) for w in ("sin", "cos")]).contiguous()
+    call order (position i = pos0 .. pos0 + npos - 1, harmonic j = 1..degree, homomorphic_sin's Enc(0) then homomorphic_cos's)."""
+    return torch.cat([zeros(i, j, w) for i in range(pos0, pos0 + npos) for j in range(1, degree + 1) for w in ("sin", "cos")]).contiguous()
 
 
-def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros):
+def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros, positions=None):
     """The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run
     (fhe_approximated_step).  amplitude/index/count: [1, 2, k, n].  zeros: a tensor [npos, degree, 2, 2, k, n]
     (stack_zeros order) or a callable (i, j, which) -> [1, 2, k, n] encryption of zero for position i, harmonic j,
@@ -319,36 +335,45 @@ def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, wid
     (cheap) offset chain is serial.  All width*height*degree cosine polynomials are evaluated as ONE
     batch, the sine polynomial once per harmonic (its argument b * f_j does not depend on the
     position) -- the same ring operations on the same operands, so the same bits, but launches that
-    fill the GPU."""
+    fill the GPU.
+
+    positions=(p0, p1) evaluates a SHARD of the output positions (fhe_approximated_step_range; the multi-GPU partition of
+    the position loop, :224): zeros (tensor form) and the result then hold positions [p0, p1) only, each bit-identical
+    to the whole-run call's."""
     cc = circuits_of(pc)
     npos = width * height
+    p0, p1 = positions if positions is not None else (0, npos)
     if callable(zeros):
-        zeros = stack_zeros(zeros, npos, degree) if degree > 0 else None
+        zeros = stack_zeros(zeros, p1 - p0, degree, p0) if degree > 0 else None
     L = _lib.load()
     so = L.fhe_approximated_step_out_size(degree)
-    out = ev.ctx.empty(npos, size=so)
-    nbytes = L.fhe_approximated_step_scratch_bytes(cc.h, degree, npos)
+    out = ev.ctx.empty(p1 - p0, size=so)
+    nbytes = L.fhe_approximated_step_range_scratch_bytes(cc.h, degree, npos, p0, p1)
     scr = cc.scratch(nbytes)
-    _lib.call("fhe_approximated_step", cc.h, _ptr(amplitude), _ptr(index), _ptr(count), order, degree, float(delta), width, height,
+    _lib.call("fhe_approximated_step_range", cc.h, _ptr(amplitude), _ptr(index), _ptr(count), order, degree, float(delta), width, height, p0, p1,
               _ptr(zeros) if zeros is not None else C.c_void_p(None), _ptr(out), _ptr(scr), nbytes, _stream())
-    return [out[i:i + 1] for i in range(npos)]
+    return [out[i:i + 1] for i in range(p1 - p0)]
 
 
-def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height):
+def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=None):
     """One colour channel of the server_decode driver loop (homo/server_decode.cpp:120-137; fhe_decode_channel).
     runs: [pairs, 2, 2, k, n] (elem, count per run); index: [1, 2, k, n] or [2, k, n], UPDATED IN PLACE (index += count
     per run, :137); acc0: [npos, 2, k, n], the channel's Enc(0) accumulators (:126); zeros: [pairs, npos, degree, 2, 2, k, n].
-    Returns [npos, S, k, n], S = 22 for degree >= 1 and pairs > 0."""
+    Returns [npos, S, k, n], S = 22 for degree >= 1 and pairs > 0.
+
+    positions=(p0, p1): a SHARD of the channel's positions (fhe_decode_channel_range); acc0, zeros and the result hold
+    positions [p0, p1) only, and `index` is this shard's own copy of the chain (it ends at the same value on every shard)."""
     cc = circuits_of(pc)
     npos = width * height
+    p0, p1 = positions if positions is not None else (0, npos)
     pairs = int(runs.shape[0]) if runs is not None else 0
-    assert _count(acc0, 2) == npos and index.is_contiguous()
+    assert _count(acc0, 2) == p1 - p0 and index.is_contiguous()
     L = _lib.load()
     so = L.fhe_approximated_step_out_size(degree) if pairs else 2
-    out = ev.ctx.empty(npos, size=so)
-    nbytes = L.fhe_decode_channel_scratch_bytes(cc.h, degree, npos, pairs)
+    out = ev.ctx.empty(p1 - p0, size=so)
+    nbytes = L.fhe_decode_channel_range_scratch_bytes(cc.h, degree, npos, p0, p1, pairs)
     scr = cc.scratch(nbytes)
     null = C.c_void_p(None)
-    _lib.call("fhe_decode_channel", cc.h, _ptr(runs) if pairs else null, pairs, _ptr(index), _ptr(acc0),
-              _ptr(zeros) if (pairs and degree > 0) else null, order, degree, float(delta), width, height, _ptr(out), _ptr(scr), nbytes, _stream())
+    _lib.call("fhe_decode_channel_range", cc.h, _ptr(runs) if pairs else null, pairs, _ptr(index), _ptr(acc0),
+              _ptr(zeros) if (pairs and degree > 0) else null, order, degree, float(delta), width, height, p0, p1, _ptr(out), _ptr(scr), nbytes, _stream())
     return out

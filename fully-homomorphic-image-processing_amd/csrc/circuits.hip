@@ -262,6 +262,7 @@ struct Run {
     const fhe_ctx *c;
     hipStream_t st;
     bool dry;
+    bool query = false;                    // a *_scratch_bytes query: placeholder scalars, so constants are neither required to fit the encoder nor to be non-zero
     uintptr_t base = 0;
     size_t cap = 0, top = 0, high = 0;     // bytes
     u32 k, n;
@@ -285,6 +286,10 @@ struct Run {
 
     const CircConst *K(double v) {
         const CircConst *kc = get_const(cc, v);
+        if (!kc && query) {                // the arena's high-water mark does not depend on the constants' values
+            static const CircConst placeholder = [] { CircConst p; p.nnz = 1; return p; }();
+            return &placeholder;
+        }
         if (!kc) fail(FHE_ERR_PARAM, "constant %.17g does not fit the encoder", v);
         return kc;
     }
@@ -318,7 +323,7 @@ struct Run {
     }
     int mul_plain(const u64 *in, u64 *out, u64 polys, const CircConst *kc) {
         if (!kc) return FHE_ERR_PARAM;
-        if (!kc->nnz) return fail(FHE_ERR_PARAM, "plain cannot be zero");
+        if (!kc->nnz && !query) return fail(FHE_ERR_PARAM, "plain cannot be zero");
         if (dry || !polys) return FHE_OK;
         if (kc->sparse) return fhe_multiply_plain_sparse(c, cu(in), mu(out), polys, cu(kc->plain.data()), (u32)kc->plain.size(), st);
         TRY(ensure_ntt(cc, kc, st));
@@ -487,15 +492,14 @@ int run_sample_bicubic(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps,
     // laid out to match: T[i][r * count + c] = taps[c][4 r + i]
     const u64 rows = 4 * count;
     u32 *d_idx = R.alloc_u32(4 * rows);
+    if (taps && R.dry)                                                  // the validating pass of real_run: nothing is enqueued on a bad tap
+        for (u64 c = 0; c < count * 16; ++c)
+            if (taps[c] >= n_pixels) return fail(FHE_ERR_PARAM, "tap %u of pixel %llu is outside the %llu source pixels", (unsigned)(c % 16), (unsigned long long)(c / 16), (unsigned long long)n_pixels);
     if (!R.dry) {
         std::vector<u32> h(4 * rows);
         for (u64 c = 0; c < count; ++c)
             for (u32 r = 0; r < 4; ++r)
-                for (u32 i = 0; i < 4; ++i) {
-                    const u32 t = taps[c * 16 + 4 * r + i];
-                    if (t >= n_pixels) return fail(FHE_ERR_PARAM, "tap %u of pixel %llu is outside the %llu source pixels", 4 * r + i, (unsigned long long)c, (unsigned long long)n_pixels);
-                    h[i * rows + r * count + c] = t;
-                }
+                for (u32 i = 0; i < 4; ++i) h[i * rows + r * count + c] = taps[c * 16 + 4 * r + i];
         TRY(R.stage(h.data(), h.size(), d_idx));
     }
     u64 *px2, *px1;
@@ -515,14 +519,13 @@ int run_sample_linear(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps, 
     // the two row Linears as one batch of 2 * count: A = (p00 | p01), B = (p10 | p11)
     const u64 rows = 2 * count;
     u32 *d_idx = R.alloc_u32(2 * rows);
+    if (taps && R.dry)
+        for (u64 c = 0; c < count * 4; ++c)
+            if (taps[c] >= n_pixels) return fail(FHE_ERR_PARAM, "tap %u of pixel %llu is outside the %llu source pixels", (unsigned)(c % 4), (unsigned long long)(c / 4), (unsigned long long)n_pixels);
     if (!R.dry) {
         std::vector<u32> h(2 * rows);
         for (u64 c = 0; c < count; ++c)
-            for (u32 i = 0; i < 4; ++i) {
-                const u32 t = taps[c * 4 + i];
-                if (t >= n_pixels) return fail(FHE_ERR_PARAM, "tap %u of pixel %llu is outside the %llu source pixels", i, (unsigned long long)c, (unsigned long long)n_pixels);
-                h[(i & 1) * rows + (i >> 1) * count + c] = t;           // i = 0: p00, 1: p10, 2: p01, 3: p11
-            }
+            for (u32 i = 0; i < 4; ++i) h[(i & 1) * rows + (i >> 1) * count + c] = taps[c * 4 + i];      // i = 0: p00, 1: p10, 2: p01, 3: p11
         TRY(R.stage(h.data(), h.size(), d_idx));
     }
     u64 *A = R.alloc(rows * 2 * R.pw), *B = R.alloc(rows * 2 * R.pw);
@@ -560,25 +563,38 @@ void resize_index(u32 src_w, u32 src_h, u32 dst_w, u32 dst_h, ResizeIndex &ix) {
     }
 }
 
-int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w, u32 dst_h, const u64 *xfract, const u64 *yfract, u64 *out,
+// A shard of the destination rows (the whole image: row0 = 0, row1 = dst_h, src_row0 = 0, n_src_rows = src_h).  `pixels`
+// holds the source rows [src_row0, src_row0 + n_src_rows) only -- the shard's rows plus its halo (fhe_resize_source_rows) --
+// yfract the offsets of the rows [row0, row1) only, and out / the consumer's bands the pixels of those rows.
+struct RowShard {
+    u32 row0, row1, src_row0, n_src_rows;
+};
+int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w, u32 dst_h, RowShard sh, const u64 *xfract, const u64 *yfract, u64 *out,
                       u32 batch, u32 band_rows, fhe_band_consumer consume, void *user) {
     ResizeIndex ix;
     resize_index(src_w, src_h, dst_w, dst_h, ix);
     if (!band_rows) band_rows = 4;
     const u32 rows_per_call = batch / dst_w ? batch / dst_w : 1;
+    const u32 n_rows = sh.row1 - sh.row0;
+    for (u32 y = sh.row0; y < sh.row1; ++y)
+        for (int j = 0; j < 4; ++j) {
+            const u32 r = ix.rows_of[y * 4 + j];
+            if (r < sh.src_row0 || r - sh.src_row0 >= sh.n_src_rows)
+                return fail(FHE_ERR_PARAM, "destination row %u needs source row %u, outside the resident rows [%u, %u)", y, r, sh.src_row0, sh.src_row0 + sh.n_src_rows);
+        }
     // t2 (= t3) and the prepared operands once per column / row
     u64 *px2, *px1, *py2, *py1;
     TRY(cubic_powers(R, xfract, dst_w, &px2, &px1));
-    TRY(cubic_powers(R, yfract, dst_h, &py2, &py1));
+    TRY(cubic_powers(R, yfract, n_rows, &py2, &py1));
     // the row Cubics' cache: one slot of dst_w size-4 ciphertexts per live source row.  The window only moves down;
     // the number of slots is the largest number of rows alive at once, found by walking the bands
     std::vector<std::vector<u32>> band_need;
     u32 max_live = 0;
     {
         std::set<u32> live;
-        for (u32 y0 = 0; y0 < dst_h; y0 += band_rows) {
+        for (u32 y0 = sh.row0; y0 < sh.row1; y0 += band_rows) {
             std::vector<u32> need;
-            for (u32 y = y0; y < y0 + band_rows && y < dst_h; ++y)
+            for (u32 y = y0; y < y0 + band_rows && y < sh.row1; ++y)
                 for (int j = 0; j < 4; ++j) need.push_back(ix.rows_of[y * 4 + j]);
             std::sort(need.begin(), need.end());
             need.erase(std::unique(need.begin(), need.end()), need.end());
@@ -598,8 +614,8 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
     for (u32 s = max_live; s-- > 0;) free_slots.push_back(s);
     std::vector<u32> h((size_t)5 * call_px);
     size_t band_no = 0;
-    for (u32 y0 = 0; y0 < dst_h; y0 += band_rows, ++band_no) {
-        const u32 y1 = y0 + band_rows < dst_h ? y0 + band_rows : dst_h;
+    for (u32 y0 = sh.row0; y0 < sh.row1; y0 += band_rows, ++band_no) {
+        const u32 y1 = y0 + band_rows < sh.row1 ? y0 + band_rows : sh.row1;
         const std::vector<u32> &need = band_need[band_no];
         std::vector<u32> fresh;
         for (u32 r : need) if (!slot_of.count(r)) fresh.push_back(r);
@@ -613,7 +629,7 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
                 free_slots.pop_back();
                 slot_of[r] = slot;
                 for (u32 x = 0; x < dst_w; ++x) {
-                    for (u32 t = 0; t < 4; ++t) h[(size_t)t * cnt + i * dst_w + x] = r * src_w + ix.colx[x * 4 + t];
+                    for (u32 t = 0; t < 4; ++t) h[(size_t)t * cnt + i * dst_w + x] = (r - sh.src_row0) * src_w + ix.colx[x * 4 + t];
                     h[(size_t)4 * cnt + i * dst_w + x] = slot * dst_w + x;
                 }
             }
@@ -634,10 +650,10 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
                 for (u32 x = 0; x < dst_w; ++x)
                     for (u32 j = 0; j < 4; ++j) h[(size_t)j * cnt + i * dst_w + x] = slot_of[ix.rows_of[(ya + i) * 4 + j]] * dst_w + x;
             TRY(R.stage(h.data(), (size_t)4 * cnt, d_idx));
-            u64 *dst = out ? out + (size_t)ya * dst_w * 6 * R.pw : band;
-            // pixel c of the call sits in output row ya + c / dst_w: entry ya + c / dst_w of the prepared yfract batches
+            u64 *dst = out ? out + (size_t)(ya - sh.row0) * dst_w * 6 * R.pw : band;
+            // pixel c of the call sits in output row ya + c / dst_w: entry ya - row0 + c / dst_w of the prepared yfract batches
             TRY(cubic_core(R, Src{cache, by_index(d_idx)}, Src{cache, by_index(d_idx + cnt)}, Src{cache, by_index(d_idx + 2 * (size_t)cnt)},
-                           Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, 4, py2, py1, periodic(dst_w, dst_h, ya), dst, ident(), cnt));
+                           Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, 4, py2, py1, periodic(dst_w, n_rows, ya - sh.row0), dst, ident(), cnt));
             if (consume && !R.dry) {
                 const int rc = consume(user, (u64)ya * dst_w, cu(dst), cnt, (fhe_stream)R.st);
                 if (rc) return fail(rc < 0 ? rc : FHE_ERR_PARAM, "band consumer failed");
@@ -697,13 +713,16 @@ int run_sincos(Run &R, int cosine, const u64 *x, const u64 *zero, u64 *out, u64 
     return FHE_OK;
 }
 
-// approximated_step (:202-242) for one run.  Batch index of the cosine polynomials = (j - 1) * npos + i; only the
-// cheap offset chain (:228-229) is walked serially, the sine polynomial is evaluated once per harmonic.
-// zeros: [npos][degree][2][2][k][n]
-int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct, int order, int degree, double delta, u32 npos,
+// approximated_step (:202-242) for one run, output positions [pos0, pos1) of the npos = width * height the reference walks
+// (the whole run: pos0 = 0, pos1 = npos; a shard of the positions is the multi-GPU partition of the loop at :224).  Batch
+// index of the cosine polynomials = (j - 1) * np + (i - pos0), np = pos1 - pos0; only the cheap offset chain (:228-229) is
+// walked serially -- from position 0, so a shard replays the add_plain steps of the positions before it -- and the sine
+// polynomial is evaluated once per harmonic.  zeros: [np][degree][2][2][k][n], out: [np][so][k][n]
+int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct, int order, int degree, double delta, u32 pos0, u32 pos1,
              const u64 *zeros, u64 *out) {
     const size_t m = R.mark();
-    const u64 nb = (u64)npos * degree;
+    const u32 np = pos1 - pos0;
+    const u64 nb = (u64)np * degree;
     u64 *b = R.alloc(2 * R.pw), *offset = R.alloc(2 * R.pw);
     TRY(R.mul_plain(count_ct, b, 2, R.K(0.5)));                         // :214-215
     TRY(R.add(index, b, offset, 2));                                    // :216-217
@@ -711,35 +730,35 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
     TRY(R.neg(offset, offset, 2));                                      // :219
     TRY(R.add_plain(b, 2, 1, R.K(delta - 0.5)));                        // :220
     const u32 so = degree >= 1 ? 21 : 2;
-    u64 *cacc = R.alloc((u64)npos * so * R.pw);
+    u64 *cacc = R.alloc((u64)np * so * R.pw);
     {
         u64 *c0 = R.alloc(2 * R.pw);
         TRY(R.mul_plain(b, c0, 2, R.K(1.0 / (double)order)));           // :222-223, the same for every position
-        TRY(R.gather_pad(c0, 2, periodic(1, 1), cacc, so, npos));
+        TRY(R.gather_pad(c0, 2, periodic(1, 1), cacc, so, np));
     }
     if (degree >= 1) {
         const size_t m2 = R.mark();
         std::vector<double> factor(degree);
         for (int j = 1; j <= degree; ++j) factor[j - 1] = ((float)j) * M_PI / ((double)order);      // :225
         u64 *cos_arg = R.alloc(nb * 2 * R.pw), *sin_arg = R.alloc((u64)degree * 2 * R.pw);
-        for (u32 i = 0; i < npos; ++i)
+        for (u32 i = 0; i < pos1; ++i)
             for (int j = 0; j < degree; ++j) {
-                TRY(R.copy(cos_arg + ((u64)j * npos + i) * 2 * R.pw, offset, 2));            // :228 cos_arg(offset)
+                if (i >= pos0) TRY(R.copy(cos_arg + ((u64)j * np + (i - pos0)) * 2 * R.pw, offset, 2));   // :228 cos_arg(offset)
                 TRY(R.add_plain(offset, 2, 1, R.K((double)i)));                               // :229, inside the harmonic loop
             }
         for (int j = 0; j < degree; ++j) {
-            u64 *ca = cos_arg + (u64)j * npos * 2 * R.pw;
-            TRY(R.mul_plain(ca, ca, (u64)npos * 2, R.K(factor[j])));                          // :230
+            u64 *ca = cos_arg + (u64)j * np * 2 * R.pw;
+            TRY(R.mul_plain(ca, ca, (u64)np * 2, R.K(factor[j])));                            // :230
             TRY(R.mul_plain(b, sin_arg + (u64)j * 2 * R.pw, 2, R.K(factor[j])));              // :226-227
         }
         u64 *co = R.alloc(nb * 11 * R.pw), *si = R.alloc(nb * 11 * R.pw);
         u32 *d_idx = R.alloc_u32(2 * nb);
         if (!R.dry) {
             std::vector<u32> h(2 * nb);                                 // Enc(0) of (position i, harmonic j): sin at 2 (i * degree + j), cos next to it
-            for (u32 i = 0; i < npos; ++i)
+            for (u32 i = 0; i < np; ++i)
                 for (int j = 0; j < degree; ++j) {
-                    h[(u64)j * npos + i] = (u32)(2 * ((u64)i * degree + j));
-                    h[nb + (u64)j * npos + i] = (u32)(2 * ((u64)i * degree + j) + 1);
+                    h[(u64)j * np + i] = (u32)(2 * ((u64)i * degree + j));
+                    h[nb + (u64)j * np + i] = (u32)(2 * ((u64)i * degree + j) + 1);
                 }
             TRY(R.stage(h.data(), h.size(), d_idx));
         }
@@ -750,37 +769,40 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
             TRY(taylor_sum(R, zeros, by_index(d_idx + nb), 1.0, terms, ident(), co, nb));
             R.release(m3);
             TRY(taylor_terms(R, sin_arg, (u64)degree, kSinCoeffs, terms));
-            TRY(taylor_sum(R, zeros, by_index(d_idx), -1.0, terms, periodic(npos, degree), si, nb));
+            TRY(taylor_sum(R, zeros, by_index(d_idx), -1.0, terms, periodic(np, degree), si, nb));
             R.release(m3);
         }
         u64 *prod = R.alloc(nb * 21 * R.pw);
         TRY(R.multiply(si, 11, co, nullptr, 11, ident(), prod, nb));                           // :234-235
         for (int j = 0; j < degree; ++j) {
-            u64 *pj = prod + (u64)j * npos * 21 * R.pw;
-            TRY(R.mul_plain(pj, pj, (u64)npos * 21, R.K(2.0 / (M_PI * ((float)(j + 1))))));    // :236
-            TRY(R.add(cacc, pj, cacc, (u64)npos * 21));                                       // :237
+            u64 *pj = prod + (u64)j * np * 21 * R.pw;
+            TRY(R.mul_plain(pj, pj, (u64)np * 21, R.K(2.0 / (M_PI * ((float)(j + 1))))));      // :236
+            TRY(R.add(cacc, pj, cacc, (u64)np * 21));                                         // :237
         }
         R.release(m2);
     }
     u64 *pamp = R.prepare_alloc(2, 1);
     TRY(R.prepare(amplitude, 2, 1, pamp));
-    TRY(R.multiply(cacc, so, nullptr, pamp, 2, periodic(1, 1), out, npos));                    // :239
+    TRY(R.multiply(cacc, so, nullptr, pamp, 2, periodic(1, 1), out, np));                      // :239
     R.release(m);
     return FHE_OK;
 }
 
+// positions [pos0, pos1) of one channel: acc0, zeros and out hold those positions only; `index` (every shard's own copy)
+// advances through all runs exactly as in the whole-channel evaluation
 int run_decode_channel(Run &R, const u64 *runs, u32 pairs, u64 *index, const u64 *acc0, const u64 *zeros, int order, int degree, double delta,
-                       u32 npos, u64 *out) {
+                       u32 pos0, u32 pos1, u64 *out) {
+    const u32 np = pos1 - pos0;
     const u32 so = pairs ? fhe_approximated_step_out_size(degree) : 2;
-    TRY(R.gather_pad(acc0, 2, ident(), out, so, npos));                 // the channel's Enc(0) accumulators (server_decode.cpp:124-128)
+    TRY(R.gather_pad(acc0, 2, ident(), out, so, np));                   // the channel's Enc(0) accumulators (server_decode.cpp:124-128)
     if (!pairs) return FHE_OK;
     const size_t m = R.mark();
-    u64 *run = R.alloc((u64)npos * so * R.pw);
-    const size_t zstride = (size_t)npos * degree * 2 * 2 * R.pw;
+    u64 *run = R.alloc((u64)np * so * R.pw);
+    const size_t zstride = (size_t)np * degree * 2 * 2 * R.pw;
     for (u32 p = 0; p < pairs; ++p) {
         const u64 *elem = runs + (size_t)p * 4 * R.pw, *cnt = elem + 2 * R.pw;
-        TRY(run_step(R, elem, index, cnt, order, degree, delta, npos, zeros + p * zstride, run));       // :133
-        TRY(R.add(out, run, out, (u64)npos * so));                      // :134-136
+        TRY(run_step(R, elem, index, cnt, order, degree, delta, pos0, pos1, zeros + p * zstride, run));       // :133
+        TRY(R.add(out, run, out, (u64)np * so));                        // :134-136
         TRY(R.add(index, cnt, index, 2));                               // :137
     }
     R.release(m);
@@ -793,6 +815,7 @@ template <typename F>
 size_t dry_bytes(const fhe_circuits *cc, F &&f) {
     if (!args_ok(cc)) return 0;
     Run R(cc, nullptr, 0, nullptr, true);
+    R.query = true;
     if (f(R)) return 0;
     return R.high + 256;
 }
@@ -949,7 +972,7 @@ extern "C" size_t fhe_resize_bicubic_shared_scratch_bytes(const fhe_circuits *cc
                                                           uint32_t batch, uint32_t band_rows, int has_out) {
     if (resize_args(cc, src_w, src_h, dst_w, dst_h, batch)) return 0;
     return dry_bytes(cc, [&](Run &R) {
-        return run_resize_shared(R, nullptr, src_w, src_h, dst_w, dst_h, nullptr, nullptr, has_out ? (u64 *)256 : nullptr, batch, band_rows, nullptr, nullptr);
+        return run_resize_shared(R, nullptr, src_w, src_h, dst_w, dst_h, RowShard{0, dst_h, 0, src_h}, nullptr, nullptr, has_out ? (u64 *)256 : nullptr, batch, band_rows, nullptr, nullptr);
     });
 }
 extern "C" int fhe_resize_bicubic_shared(const fhe_circuits *cc, const uint64_t *pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h,
@@ -959,8 +982,51 @@ extern "C" int fhe_resize_bicubic_shared(const fhe_circuits *cc, const uint64_t 
     if (!pixels || !xfract || !yfract) return fail(FHE_ERR_PARAM, "null argument");
     if (!out && !consume) return fail(FHE_ERR_PARAM, "neither an output buffer nor a consumer");
     return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
-        return run_resize_shared(R, (const u64 *)pixels, src_w, src_h, dst_w, dst_h, (const u64 *)xfract, (const u64 *)yfract, (u64 *)out, batch, band_rows,
+        return run_resize_shared(R, (const u64 *)pixels, src_w, src_h, dst_w, dst_h, RowShard{0, dst_h, 0, src_h}, (const u64 *)xfract, (const u64 *)yfract, (u64 *)out, batch, band_rows,
                                  consume, user);
+    });
+}
+
+// ---- a shard of the destination rows (multi-GPU partition of ResizeImage's outer loop, homo/fhe_resize.h:350) ----
+extern "C" int fhe_resize_source_rows(uint32_t src_h, uint32_t dst_h, uint32_t row0, uint32_t row1, int bicubic, uint32_t *first, uint32_t *count) {
+    if (!src_h || dst_h < 2 || row0 >= row1 || row1 > dst_h || !first || !count) return fail(FHE_ERR_PARAM, "bad row range");
+    u32 lo = 0xffffffffu, hi = 0;
+    for (u32 y = row0; y < row1; ++y) {
+        const float v = (float)((float)y / (float)(dst_h - 1) * (float)src_h - 0.5);          // homo/fhe_resize.h:351
+        const int yi = (int)v;
+        const u32 a = (u32)clampi(bicubic ? yi - 1 : yi, 0, (int)src_h - 1), z = (u32)clampi(bicubic ? yi + 2 : yi + 1, 0, (int)src_h - 1);
+        if (a < lo) lo = a;
+        if (z > hi) hi = z;
+    }
+    *first = lo;
+    *count = hi - lo + 1;
+    return FHE_OK;
+}
+static int shard_args(uint32_t src_h, uint32_t dst_h, uint32_t row0, uint32_t row1, uint32_t src_row0, uint32_t n_src_rows) {
+    if (row0 >= row1 || row1 > dst_h) return fail(FHE_ERR_PARAM, "destination rows [%u, %u) are not a range of the %u output rows", row0, row1, dst_h);
+    if (!n_src_rows || src_row0 >= src_h || n_src_rows > src_h - src_row0) return fail(FHE_ERR_PARAM, "resident source rows [%u, +%u) are not a range of the %u source rows", src_row0, n_src_rows, src_h);
+    return FHE_OK;
+}
+extern "C" size_t fhe_resize_bicubic_shared_rows_scratch_bytes(const fhe_circuits *cc, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h,
+                                                               uint32_t row0, uint32_t row1, uint32_t src_row0, uint32_t n_src_rows, uint32_t batch,
+                                                               uint32_t band_rows, int has_out) {
+    if (resize_args(cc, src_w, src_h, dst_w, dst_h, batch) || shard_args(src_h, dst_h, row0, row1, src_row0, n_src_rows)) return 0;
+    return dry_bytes(cc, [&](Run &R) {
+        return run_resize_shared(R, nullptr, src_w, src_h, dst_w, dst_h, RowShard{row0, row1, src_row0, n_src_rows}, nullptr, nullptr, has_out ? (u64 *)256 : nullptr, batch,
+                                 band_rows, nullptr, nullptr);
+    });
+}
+extern "C" int fhe_resize_bicubic_shared_rows(const fhe_circuits *cc, const uint64_t *pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h,
+                                              uint32_t row0, uint32_t row1, uint32_t src_row0, uint32_t n_src_rows, const uint64_t *xfract,
+                                              const uint64_t *yfract, uint64_t *out, uint32_t batch, uint32_t band_rows, fhe_band_consumer consume,
+                                              void *user, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    TRY(resize_args(cc, src_w, src_h, dst_w, dst_h, batch));
+    TRY(shard_args(src_h, dst_h, row0, row1, src_row0, n_src_rows));
+    if (!pixels || !xfract || !yfract) return fail(FHE_ERR_PARAM, "null argument");
+    if (!out && !consume) return fail(FHE_ERR_PARAM, "neither an output buffer nor a consumer");
+    return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
+        return run_resize_shared(R, (const u64 *)pixels, src_w, src_h, dst_w, dst_h, RowShard{row0, row1, src_row0, n_src_rows}, (const u64 *)xfract, (const u64 *)yfract,
+                                 (u64 *)out, batch, band_rows, consume, user);
     });
 }
 
@@ -981,33 +1047,59 @@ static int step_args(const fhe_circuits *cc, int order, int degree, uint32_t npo
     if (!npos || (u64)npos * (degree ? degree : 1) > (1u << 24)) return fail(FHE_ERR_PARAM, "width * height * degree out of range");
     return FHE_OK;
 }
+static int range_args(uint32_t npos, uint32_t pos0, uint32_t pos1) {
+    if (pos0 >= pos1 || pos1 > npos) return fail(FHE_ERR_PARAM, "positions [%u, %u) are not a range of the %u output positions", pos0, pos1, npos);
+    return FHE_OK;
+}
+extern "C" size_t fhe_approximated_step_range_scratch_bytes(const fhe_circuits *cc, int degree, uint32_t npos, uint32_t pos0, uint32_t pos1) {
+    if (step_args(cc, 1, degree, npos) || range_args(npos, pos0, pos1)) return 0;
+    return dry_bytes(cc, [&](Run &R) { return run_step(R, nullptr, nullptr, nullptr, 64, degree, 0.5, pos0, pos1, nullptr, nullptr); });
+}
 extern "C" size_t fhe_approximated_step_scratch_bytes(const fhe_circuits *cc, int degree, uint32_t npos) {
-    if (step_args(cc, 1, degree, npos)) return 0;
-    return dry_bytes(cc, [&](Run &R) { return run_step(R, nullptr, nullptr, nullptr, 64, degree, 0.5, npos, nullptr, nullptr); });
+    return fhe_approximated_step_range_scratch_bytes(cc, degree, npos, 0, npos);
+}
+extern "C" int fhe_approximated_step_range(const fhe_circuits *cc, const uint64_t *amplitude, const uint64_t *index, const uint64_t *count_ct, int order,
+                                           int degree, double delta, uint32_t width, uint32_t height, uint32_t pos0, uint32_t pos1, const uint64_t *zeros,
+                                           uint64_t *out, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    const u64 np64 = (u64)width * height;
+    if (np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
+    TRY(step_args(cc, order, degree, (u32)np64));
+    TRY(range_args((u32)np64, pos0, pos1));
+    if (!amplitude || !index || !count_ct || !out || (degree > 0 && !zeros)) return fail(FHE_ERR_PARAM, "null argument");
+    return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
+        return run_step(R, (const u64 *)amplitude, (const u64 *)index, (const u64 *)count_ct, order, degree, delta, pos0, pos1, (const u64 *)zeros, (u64 *)out);
+    });
 }
 extern "C" int fhe_approximated_step(const fhe_circuits *cc, const uint64_t *amplitude, const uint64_t *index, const uint64_t *count_ct, int order,
                                      int degree, double delta, uint32_t width, uint32_t height, const uint64_t *zeros, uint64_t *out, void *scratch,
                                      size_t scratch_bytes, fhe_stream s) {
     const u64 np64 = (u64)width * height;
-    if (np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
-    TRY(step_args(cc, order, degree, (u32)np64));
-    if (!amplitude || !index || !count_ct || !out || (degree > 0 && !zeros)) return fail(FHE_ERR_PARAM, "null argument");
-    return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
-        return run_step(R, (const u64 *)amplitude, (const u64 *)index, (const u64 *)count_ct, order, degree, delta, (u32)np64, (const u64 *)zeros, (u64 *)out);
-    });
+    if (!np64 || np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
+    return fhe_approximated_step_range(cc, amplitude, index, count_ct, order, degree, delta, width, height, 0, (u32)np64, zeros, out, scratch, scratch_bytes, s);
+}
+extern "C" size_t fhe_decode_channel_range_scratch_bytes(const fhe_circuits *cc, int degree, uint32_t npos, uint32_t pos0, uint32_t pos1, uint32_t pairs) {
+    if (step_args(cc, 1, degree, npos) || range_args(npos, pos0, pos1)) return 0;
+    return dry_bytes(cc, [&](Run &R) { return run_decode_channel(R, nullptr, pairs ? 1 : 0, nullptr, nullptr, nullptr, 64, degree, 0.5, pos0, pos1, nullptr); });
 }
 extern "C" size_t fhe_decode_channel_scratch_bytes(const fhe_circuits *cc, int degree, uint32_t npos, uint32_t pairs) {
-    if (step_args(cc, 1, degree, npos)) return 0;
-    return dry_bytes(cc, [&](Run &R) { return run_decode_channel(R, nullptr, pairs ? 1 : 0, nullptr, nullptr, nullptr, 64, degree, 0.5, npos, nullptr); });
+    return fhe_decode_channel_range_scratch_bytes(cc, degree, npos, 0, npos, pairs);
+}
+extern "C" int fhe_decode_channel_range(const fhe_circuits *cc, const uint64_t *runs, uint32_t pairs, uint64_t *index, const uint64_t *acc0,
+                                        const uint64_t *zeros, int order, int degree, double delta, uint32_t width, uint32_t height, uint32_t pos0,
+                                        uint32_t pos1, uint64_t *out, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    const u64 np64 = (u64)width * height;
+    if (np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
+    TRY(step_args(cc, order, degree, (u32)np64));
+    TRY(range_args((u32)np64, pos0, pos1));
+    if (!acc0 || !out || (pairs && (!runs || !index || (degree > 0 && !zeros)))) return fail(FHE_ERR_PARAM, "null argument");
+    return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
+        return run_decode_channel(R, (const u64 *)runs, pairs, (u64 *)index, (const u64 *)acc0, (const u64 *)zeros, order, degree, delta, pos0, pos1, (u64 *)out);
+    });
 }
 extern "C" int fhe_decode_channel(const fhe_circuits *cc, const uint64_t *runs, uint32_t pairs, uint64_t *index, const uint64_t *acc0,
                                   const uint64_t *zeros, int order, int degree, double delta, uint32_t width, uint32_t height, uint64_t *out,
                                   void *scratch, size_t scratch_bytes, fhe_stream s) {
     const u64 np64 = (u64)width * height;
-    if (np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
-    TRY(step_args(cc, order, degree, (u32)np64));
-    if (!acc0 || !out || (pairs && (!runs || !index || (degree > 0 && !zeros)))) return fail(FHE_ERR_PARAM, "null argument");
-    return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) {
-        return run_decode_channel(R, (const u64 *)runs, pairs, (u64 *)index, (const u64 *)acc0, (const u64 *)zeros, order, degree, delta, (u32)np64, (u64 *)out);
-    });
+    if (!np64 || np64 > 0xffffffffULL) return fail(FHE_ERR_PARAM, "width * height out of range");
+    return fhe_decode_channel_range(cc, runs, pairs, index, acc0, zeros, order, degree, delta, width, height, 0, (u32)np64, out, scratch, scratch_bytes, s);
 }

@@ -1,4 +1,10 @@
-"""Block sharding across the GPUs of one node: one process per GPU, torch.distributed.
+"""Sharding of the three circuits across the GPUs of one node: one process per GPU, torch.distributed.
+
+| circuit | reference loop | unit | shard of rank r of R | replicated per rank | exchange |
+|---|---|---|---|---|---|
+| DCT + quant | homo/server_jpeg.cpp:113-138 (blocks) | 8x8 block | contiguous block range (block_range) | twiddles, 76 constants | none (optional output gather) |
+| resize | homo/fhe_resize.h:350-388 (rows y, pixels x) | destination row | contiguous row range (row_range) + source rows +- halo (source_rows) | xfract per column, constants | none (rows land in one file / optional gather) |
+| decode | homo/server_decode.cpp:120-137, homo/fhe_decode.h:224 | (channel, position) | contiguous unit range (decode_shards) | runs, the `index` chain (pairs additions), the offset chain, the sine polynomials | one broadcast of the three Enc(0) `index` ciphertexts |
 
 The reference is a single-threaded loop over blocks (homo/server_jpeg.cpp:113); blocks are
 independent, so rank r of R owns the contiguous range [r*N/R, (r+1)*N/R) and no collective is
@@ -20,6 +26,92 @@ def block_range(rank, world, n_blocks):
     base, rem = divmod(n_blocks, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def row_range(rank, world, dst_h):
+    """Destination rows [y0, y1) of ResizeImage's outer loop (homo/fhe_resize.h:350) owned by `rank`."""
+    return block_range(rank, world, dst_h)
+
+
+def source_rows(src_h, dst_h, row0, row1, bicubic=True):
+    """(first, count) of the source rows destination rows [row0, row1) read -- the shard's rows plus the sampler's halo
+    (yi - 1 .. yi + 2 for SampleBicubic, yi .. yi + 1 for SampleLinear, clamped to the image: homo/fhe_resize.h:264-290,
+    229-240,215-220) -- with v in float32 exactly as the reference computes it (:351).  The same figure as the C ABI's
+    fhe_resize_source_rows (tests/test_cabi.py compares them)."""
+    import numpy as np
+    if not (0 <= row0 < row1 <= dst_h) or dst_h < 2 or src_h < 1:
+        raise ValueError("bad row range [%d, %d) of %d" % (row0, row1, dst_h))
+    f32 = np.float32
+    lo, hi = src_h, -1
+    for y in range(row0, row1):
+        v = f32(f32(y) / f32(dst_h - 1) * f32(src_h)) - f32(0.5)
+        yi = int(v)
+        a, z = (yi - 1, yi + 2) if bicubic else (yi, yi + 1)
+        lo = min(lo, min(max(a, 0), src_h - 1))
+        hi = max(hi, min(max(z, 0), src_h - 1))
+    return lo, hi - lo + 1
+
+
+def decode_shards(rank, world, npos, channels=3):
+    """The (channel, pos0, pos1) pieces of `rank`'s contiguous range of the channels * npos (channel, position) units of
+    homo/server_decode.cpp:120-137 (channel-major).  A rank whose range crosses a channel boundary gets two pieces."""
+    u0, u1 = block_range(rank, world, channels * npos)
+    out = []
+    for ch in range(channels):
+        a, z = max(u0, ch * npos), min(u1, (ch + 1) * npos)
+        if a < z:
+            out.append((ch, a - ch * npos, z - ch * npos))
+    return out
+
+
+def broadcast_from_root(t, src=0, group=None):
+    """One small broadcast (the decode path's three Enc(0) `index` ciphertexts, drawn once on the root so that every
+    shard of a channel continues the same chain); a no-op without a process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        gsrc = src if group is None else dist.get_global_rank(group, src)
+        dist.broadcast(t, src=gsrc, group=group)
+    return t
+
+
+def rank_world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def run_resize_sharded(load_rows, sample_rows, src_h, dst_h, digest, bicubic=True, gather=False, group=None):
+    """Shard ResizeImage's destination rows over the process group.  pixels = load_rows(first, count) brings in the
+    source rows [first, first + count) (the shard's rows +- halo; every rank reads its own, inputs are read-only);
+    out = sample_rows(pixels, first, count, y0, y1) -> tensor [y1 - y0, dst_w, ...]; digest(out, y0) is the
+    order-independent digest with global indices.  Returns ((y0, y1), local_out, global_digest, gathered_or_None).
+    A rank without rows (world > dst_h) contributes an empty band."""
+    rank, world = rank_world(group)
+    y0, y1 = row_range(rank, world, dst_h)
+    if y1 > y0:
+        first, count = source_rows(src_h, dst_h, y0, y1, bicubic)
+        local_out = sample_rows(load_rows(first, count), first, count, y0, y1)
+        local_digest = digest(local_out, y0)
+    else:
+        local_out, local_digest = sample_rows(None, 0, 0, y0, y0), 0
+    total = combine_digests(local_digest, group)
+    method = gather if isinstance(gather, str) else "collective"
+    gathered = gather_outputs(local_out, dst_h, 0, group, method=method) if (gather and world > 1) else (local_out if gather else None)
+    return (y0, y1), local_out, total, gathered
+
+
+def run_decode_sharded(decode_piece, npos, digest, channels=3, group=None):
+    """Shard the (channel, position) units of the decode driver loop.  decode_piece(ch, pos0, pos1) -> tensor
+    [pos1 - pos0, S, k, n] (it replays the channel's `index` chain itself); digest(out, ch, pos0).  Returns
+    (pieces [(ch, pos0, pos1, out)], global_digest)."""
+    rank, world = rank_world(group)
+    pieces, local = [], 0
+    for ch, p0, p1 in decode_shards(rank, world, npos, channels):
+        out = decode_piece(ch, p0, p1)
+        local = (local + digest(out, ch, p0)) & 0xFFFFFFFFFFFFFFFF
+        pieces.append((ch, p0, p1, out))
+    return pieces, combine_digests(local, group)
 
 
 def words_per_block(k, n, size=2):

@@ -106,6 +106,19 @@ class StreamFile:
             self.h = None
 
 
+def _stop_pipeline(reader_thread, writer_thread, free_in, to_write):
+    """Bring a streaming pipeline to rest before its mappings and staging buffers go away (normal end and error paths
+    alike): both I/O threads get their end-of-work sentinel and are JOINED -- a thread may still be inside fhe_io_transfer,
+    copying into or out of the file mapping with the GIL released, and unmapping under it would be a use-after-unmap --
+    and the device is drained so that no asynchronous copy still targets the cached page-locked buffers."""
+    free_in.put(None)
+    to_write.put(None)
+    for th in (reader_thread, writer_thread):
+        if th.is_alive():
+            th.join()
+    torch.cuda.synchronize()
+
+
 def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None):
     """Process `n_blocks` colour blocks.  in_path / out_path: file names, or StreamFile objects a long-lived server keeps
     open (their mappings, and the page-table entries behind them, are then reused from call to call).  Input order per block: 64 R, 64 G, 64 B ciphertexts
@@ -157,7 +170,10 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
     def reader():
         try:
             for wi, (s, e) in enumerate(waves):
-                slot, copied = free_in.get()
+                item = free_in.get()
+                if item is None:                                # the main loop is shutting the pipeline down
+                    return
+                slot, copied = item
                 if copied is not None:
                     copied.synchronize()                        # the previous wave in this slot has left for the device
                 t_io = time.perf_counter()
@@ -189,8 +205,8 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
             free_out.put(None)
 
     t0 = time.perf_counter()
+    rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
     try:
-        rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
         rt.start()
         wt.start()
         computed, drained = [None, None], [None, None]       # per device buffer: compute finished / left for the host
@@ -247,6 +263,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                          bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves),
                          file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"], trace=trace)
     finally:
+        _stop_pipeline(rt, wt, free_in, to_write)
         if own_in:
             fin.close()
         if own_out:
@@ -257,17 +274,40 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
 # ------------------------------------------------------------------------------------------------
 # server_resize: ResizeImage (homo/fhe_resize.h:308-392) over a ciphertext stream
 # ------------------------------------------------------------------------------------------------
-def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None):
+class _IndexedEncryptions:
+    """Test-only reproducible form of the server-side encryptions: the i-th encryption of the reference's sequence is
+    drawn from a sampler seeded with (seed, i), so a process that starts in the middle of the sequence (a shard of the
+    rows / positions) produces the same ciphertexts as the whole-job run.  `seek(i)` sets the position of the next draw."""
+
+    def __init__(self, ctx, public_key, seed):
+        from .keys import Encryptor
+        self.ctx, self.seed, self.next = ctx, seed, 0
+        self.er = Encryptor(ctx, public_key, seed=seed)
+
+    def seek(self, i):
+        self.next = int(i)
+
+    def encrypt(self, plain):
+        from .keys import _Sampler
+        self.er._smp = _Sampler(self.ctx, seed=[int(self.seed), self.next])
+        self.next += 1
+        return self.er.encrypt(plain)
+
+
+def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False):
     """The circuit's server-side encryptions (homo/fhe_resize.h:230,234,262,266): a callable
     values -> [len(values), 2, k, n] of fresh encryptions of encode(v) under `public_key`
-    ([2, k, n] device tensor).  seed=None draws from the OS CSPRNG."""
+    ([2, k, n] device tensor).  seed=None draws from the OS CSPRNG.  indexed=True (tests; needs a seed): the callable has
+    `seek(i)` and the i-th encryption depends on (seed, i) only, so sharded and whole-image runs agree bit for bit."""
     from .evaluator import FractionalEncoder
     from .keys import Encryptor
     enc = encoder or FractionalEncoder(ctx)
-    er = Encryptor(ctx, public_key, seed=seed)
+    er = _IndexedEncryptions(ctx, public_key, seed) if indexed else Encryptor(ctx, public_key, seed=seed)
 
     def encrypt(values):
         return torch.stack([er.encrypt(enc.encode(float(v))) for v in values])
+    if indexed:
+        encrypt.seek = er.seek
     return encrypt
 
 
@@ -285,7 +325,7 @@ def _row_windows(H, h, init_rows):
     return out
 
 
-def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None):
+def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None, rows=None):
     """homo/server_resize.cpp:127-146 + ResizeImage (homo/fhe_resize.h:308-392) on the GPU.
 
     Input stream: src_w * src_h pixels, row by row, three ciphertext records (R, G, B) per pixel
@@ -304,7 +344,15 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     stream) and a writer thread drains the previous step's results (HBM -> page-locked on its own stream -> file).
 
     encrypt_fractions(values) -> [len, 2, k, n] supplies the circuit's server-side encryptions in
-    the reference's call order (per destination pixel: frac(x), then frac(y))."""
+    the reference's call order (per destination pixel: frac(x), then frac(y)).
+
+    rows=(y0, y1) processes a SHARD of the destination rows -- the multi-GPU partition of the reference's outer loop
+    (:350; parallel.row_range): this process reads only the source rows those destination rows need (its rows +- the
+    sampler's halo, the same sliding window started at its first row), and writes its band at the band's own position
+    of the output stream, so R processes with disjoint row ranges fill one output file (or R files) without any exchange.
+    If encrypt_fractions has a `seek(i)` attribute it is called with the position of the next encryption in the
+    reference's whole-image sequence (2 * pixel index) before every step -- reproducible test encryptors use it so that
+    any partition produces the same bytes; a randomised encryptor needs none.  Returns the number of pixels produced."""
     import queue
     import threading
     import time
@@ -320,20 +368,23 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     own_in, own_out = not isinstance(in_path, StreamFile), not isinstance(out_path, StreamFile)
     if (in_path.size if not own_in else os.path.getsize(in_path)) < src_w * src_h * 3 * rec_in:
         raise EOFError("ciphertext stream ended")
+    row0, row1 = (0, dst_h) if rows is None else (int(rows[0]), int(rows[1]))
+    if not (0 <= row0 < row1 <= dst_h):
+        raise ValueError("rows %r are not a range of the %d destination rows" % (rows, dst_h))
     windows = _row_windows(src_h, dst_h, init_rows)
     f32 = np.float32
     us = [f32(f32(x) / f32(dst_w - 1) * f32(src_w)) - f32(0.5) for x in range(dst_w)]
     # steps: consecutive destination rows whose source rows fit `init_rows + rows_per_step` resident rows
-    steps, y = [], 0
-    while y < dst_h:
+    steps, y = [], row0
+    while y < row1:
         e = y + 1
-        while e < dst_h and e - y < rows_per_step and windows[e][1] + init_rows - windows[y][1] <= init_rows + rows_per_step:
+        while e < row1 and e - y < rows_per_step and windows[e][1] + init_rows - windows[y][1] <= init_rows + rows_per_step:
             e += 1
         steps.append((y, e))
         y = e
     span = [(windows[a][1], windows[b - 1][1] + init_rows) for a, b in steps]            # source rows [lo, hi) a step needs
-    # rows each step has to bring in: those not yet read (rows are consumed from the stream in order, once)
-    reads, next_row = [], 0
+    # rows each step has to bring in: those not yet read (rows are consumed from the stream in order, once; a shard starts at its own first row)
+    reads, next_row = [], span[0][0]
     for lo, hi in span:
         first = max(next_row, lo)
         reads.append((first, max(0, hi - first)))
@@ -364,7 +415,10 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     def reader():
         try:
             for si, (first, cnt) in enumerate(reads):
-                slot, copied = free_in.get()
+                item = free_in.get()
+                if item is None:
+                    return
+                slot, copied = item
                 if copied is not None:
                     copied.synchronize()
                 if cnt:
@@ -393,8 +447,8 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
             free_out.put(None)
 
     t0 = time.perf_counter()
+    rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
     try:
-        rt, wt = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
         rt.start()
         wt.start()
         computed, drained = [], [None, None]
@@ -432,6 +486,8 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
                     taps.append([((min(max(yi + dy, 0), src_h - 1) % R) * src_w + min(max(xi + dx, 0), src_w - 1)) * 3 for dx, dy in offs])
                     fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
             taps = np.asarray(taps, dtype=np.uint32)
+            if hasattr(encrypt_fractions, "seek"):
+                encrypt_fractions.seek(2 * y0 * dst_w)
             fr = encrypt_fractions(fracs)                                            # xfract, yfract per pixel, in order
             xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
             npx, d = (y1 - y0) * dst_w, si & 1
@@ -466,35 +522,38 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         torch.cuda.synchronize()
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
-                         bytes_in=sum(c for _, c in reads) * src_w * 3 * rec_in, bytes_out=dst_w * dst_h * 3 * rec_out, steps=len(steps),
+                         bytes_in=sum(c for _, c in reads) * src_w * 3 * rec_in, bytes_out=dst_w * (row1 - row0) * 3 * rec_out, steps=len(steps),
                          file_read_seconds=io_seconds["read"], file_write_seconds=io_seconds["write"])
     finally:
+        _stop_pipeline(rt, wt, free_in, to_write)
         if own_in:
             fin.close()
         if own_out:
             fout.close()
-    return dst_w * dst_h
+    return (row1 - row0) * dst_w
 
 
 # ------------------------------------------------------------------------------------------------
 # server_decode: the run-length decoder's driver loop (homo/server_decode.cpp:113-148) over a ciphertext stream
 # ------------------------------------------------------------------------------------------------
-def make_zero_encryptor(ctx, public_key, encoder=None, seed=None):
+def make_zero_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False):
     """The decode path's server-side encryptions (homo/server_decode.cpp:121,126; homo/fhe_decode.h:54,134): a
     callable count -> [count, 2, k, n] of fresh encryptions of encode(0.0) under `public_key` ([2, k, n] device
-    tensor).  seed=None draws from the OS CSPRNG."""
+    tensor).  seed=None draws from the OS CSPRNG.  indexed=True: as make_fraction_encryptor."""
     from .evaluator import FractionalEncoder
     from .keys import Encryptor
     enc = encoder or FractionalEncoder(ctx)
-    er = Encryptor(ctx, public_key, seed=seed)
+    er = _IndexedEncryptions(ctx, public_key, seed) if indexed else Encryptor(ctx, public_key, seed=seed)
     zero = enc.encode(0.0)
 
     def encrypt(count):
         return torch.stack([er.encrypt(zero) for _ in range(count)]) if count else ctx.empty(0)
+    if indexed:
+        encrypt.seek = er.seek
     return encrypt
 
 
-def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, order=64, degree=12, delta=0.5):
+def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, order=64, degree=12, delta=0.5, shard=None, group=None):
     """homo/server_decode.cpp:113-148 on the GPU, with the HOMOMORPHIC overload of approximated_step
     (homo/fhe_decode.h:202-242; the reference's main passes its debugging Decryptor and thereby selects the
     decrypting overload, :244-282, which needs the secret key on the server -- out of scope).
@@ -510,8 +569,19 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
 
     encrypt_zeros(count) -> [count, 2, k, n] supplies the server-side encryptions of encode(0.0) in the reference's
     call order: per channel `index` (:121), the width * height accumulators (:126), then for every run the
-    Enc(0) of homomorphic_sin and homomorphic_cos per (position, harmonic) (homo/fhe_decode.h:231-232)."""
-    from . import circuits
+    Enc(0) of homomorphic_sin and homomorphic_cos per (position, harmonic) (homo/fhe_decode.h:231-232).
+
+    shard=(rank, world) processes this rank's contiguous range of the 3 * width * height (channel, position) units
+    (parallel.decode_shards; SURVEY.md section 8(e): "decode shards by (run, output position)") and writes their records at
+    their own positions of the output stream (every rank may open the same file: records have fixed offsets and a
+    positional write past the end extends the file, so no ordering between the ranks is needed).  Replicated per rank: the input runs (small), each touched channel's
+    `index` chain (pairs additions) and, inside the library, the offset chain and the sine polynomials.  The only
+    exchange: the three `index` ciphertexts are server-side encryptions every shard of a channel must share, so they
+    are drawn on rank 0 and broadcast over `group` (3 ciphertexts; parallel.broadcast_from_root).  If encrypt_zeros has a
+    `seek(i)` attribute it is called with the position of the next encryption in the reference's whole-job sequence
+    before every draw (reproducible test encryptors; any partition then writes the same bytes).  Returns the number
+    of (channel, position) units produced."""
+    from . import circuits, parallel
     ev = Evaluator(ctx)
     pc = circuits.PlainCache(ctx)
     npos = width * height
@@ -523,8 +593,26 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
     if os.path.getsize(in_path) < 2 * total * rec_in:
         raise EOFError("ciphertext stream ended")
     expect = (2, ctx.k, ctx.n)
+    rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
+    pieces = parallel.decode_shards(rank, world, npos)
+    seek = getattr(encrypt_zeros, "seek", None)
+    per_channel = [1 + npos + p * npos * degree * 2 for p in pairs]          # the reference's encryptions per channel, in order
+    base = [sum(per_channel[:ch]) for ch in range(3)]
+
+    def draw(at, count):
+        if seek is not None:
+            seek(at)
+        return encrypt_zeros(count)
+
+    # the three `index` ciphertexts (:121): one draw per channel on the root, shared by every shard of the channel
+    if world > 1:
+        index0 = torch.cat([draw(base[ch], 1) for ch in range(3)]) if rank == 0 else ctx.empty(3)
+        torch.cuda.synchronize()
+        parallel.broadcast_from_root(index0, 0, group)
+    else:
+        index0 = None
     dev = None
-    if total:
+    if total and pieces:
         host = _pinned(("dec_in",), (total, 2, 2, ctx.k, ctx.n))
         arr = host.numpy().view(np.uint64)
         fin = os.open(in_path, os.O_RDONLY)
@@ -533,23 +621,49 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
         finally:
             os.close(fin)
         dev = host.to(ctx.device, non_blocking=True)
-    res, first = [], 0
-    for ch in range(3):
-        p = pairs[ch]
-        z = encrypt_zeros(1 + npos + p * npos * degree * 2)
-        index = z[0:1].clone()
-        acc0 = z[1:1 + npos].contiguous()
-        zeros = z[1 + npos:].reshape(p, npos, degree, 2, 2, ctx.k, ctx.n).contiguous() if p and degree else None
-        runs = dev[first:first + p].contiguous() if p else None
-        res.append(circuits.decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height))
-        first += p
+    first_run = [sum(pairs[:ch]) for ch in range(3)]
+    res = []
+    for ch, p0, p1 in pieces:
+        p, np_ = pairs[ch], p1 - p0
+        if world == 1:                                       # the reference's order: index, accumulators, then the runs' zeros -- one draw
+            z = draw(base[ch], per_channel[ch])
+            index = z[0:1].clone()
+            acc0 = z[1:1 + npos].contiguous()
+            zeros = z[1 + npos:].reshape(p, npos, degree, 2, 2, ctx.k, ctx.n).contiguous() if p and degree else None
+        else:
+            index = index0[ch:ch + 1].clone()
+            acc0 = draw(base[ch] + 1 + p0, np_)
+            zeros = None
+            if p and degree:                                 # per run, this shard's positions are one contiguous stretch of the sequence
+                per_pos = degree * 2
+                zeros = torch.stack([draw(base[ch] + 1 + npos + (r * npos + p0) * per_pos, np_ * per_pos) for r in range(p)])
+                zeros = zeros.reshape(p, np_, degree, 2, 2, ctx.k, ctx.n).contiguous()
+        runs = dev[first_run[ch]:first_run[ch] + p].contiguous() if p else None
+        res.append(circuits.decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=(p0, p1)))
     torch.cuda.synchronize()
-    host_res = [to_host_array(r) for r in res]
-    with open(out_path, "wb") as f:
-        for i in range(npos):
-            for ch in range(3):
-                write_ciphertext(f, host_res[ch][i])
-    return npos
+    # output stream: position-major, the three channels interleaved; record sizes follow from `pairs`, so every record has a fixed offset
+    so = [int(_lib_out_size(degree)) if pairs[ch] else 2 for ch in range(3)]
+    rec = [RECORD_HEADER + so[ch] * ctx.k * ctx.n * 8 for ch in range(3)]
+    stride = sum(rec)
+    fd = os.open(out_path, os.O_RDWR | os.O_CREAT, 0o644)
+    try:
+        if os.fstat(fd).st_size != npos * stride and (world == 1 or rank == 0):
+            os.ftruncate(fd, npos * stride)
+        for (ch, p0, p1), r in zip(pieces, res):
+            host_r = to_host_array(r)
+            hdr = HEADER.pack(MAGIC, so[ch], ctx.k, ctx.n, 0)
+            for i in range(p0, p1):
+                payload = np.ascontiguousarray(host_r[i - p0], dtype="<u8")
+                if os.pwritev(fd, [hdr, memoryview(payload).cast("B")], i * stride + sum(rec[:ch])) != rec[ch]:
+                    raise IOError("short write on the ciphertext stream")
+    finally:
+        os.close(fd)
+    return sum(p1 - p0 for _, p0, p1 in pieces)
+
+
+def _lib_out_size(degree):
+    from . import _lib
+    return _lib.load().fhe_approximated_step_out_size(degree)
 
 
 def to_host_array(t):

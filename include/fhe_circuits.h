@@ -11,7 +11,9 @@
  * fhe_last_error()).  Ciphertext batches are device memory, u64 [count][size][k][n], residues fully
  * reduced.  Index arrays (`taps`) and scalars are HOST memory; they are consumed before the call returns.
  * Every circuit has a `*_scratch_bytes` query that runs the same host logic without launching anything, so
- * the figure is exact for the arguments given; scratch may be reused by the next call on the same stream.
+ * the figure is exact for the arguments given (it does not depend on the circuit's scalar arguments -- order,
+ * delta -- nor on whether a constant fits the encoder: those are checked by the call itself, before anything
+ * is enqueued, together with the taps); scratch may be reused by the next call on the same stream.
  * Results are bit-identical to the reference's op-by-op evaluation through seal::Evaluator with the same
  * server-side encryptions (which the reference draws inside the circuits and which are INPUTS here:
  * the fractional offsets of SampleLinear / SampleBicubic, the Enc(0) accumulators of homomorphic_sin/cos).
@@ -89,6 +91,28 @@ int fhe_resize_bicubic_shared(const fhe_circuits *circ, const uint64_t *pixels, 
                               uint64_t *out, uint32_t batch, uint32_t band_rows, fhe_band_consumer consume,
                               void *user, void *scratch, size_t scratch_bytes, fhe_stream stream);
 
+/* A SHARD of the destination rows: the multi-GPU partition of ResizeImage's outer loop (homo/fhe_resize.h:350 `for y`;
+ * BASELINE.json north_star: "the per-output-pixel bicubic-weight circuit [is] embarrassingly parallel ... partition ...
+ * across the 8 GPUs").  Destination rows [row0, row1) are independent of all others; they read the source rows
+ * fhe_resize_source_rows reports (the shard's rows plus the sampler's halo: yi-1 .. yi+2 for bicubic, yi .. yi+1 for
+ * bilinear, clamped; :264-290,229-240) and nothing else, so every GPU loads its rows +- the halo and no exchange is
+ * needed.  Host only. */
+int fhe_resize_source_rows(uint32_t src_h, uint32_t dst_h, uint32_t row0, uint32_t row1, int bicubic, uint32_t *first,
+                           uint32_t *count);
+/* fhe_resize_bicubic_shared for destination rows [row0, row1) only.  pixels: the source rows
+ * [src_row0, src_row0 + n_src_rows) ([n_src_rows * src_w][2][k][n]; must cover what fhe_resize_source_rows reports, else
+ * FHE_ERR_PARAM before anything is enqueued); xfract: [dst_w][2][k][n] as before; yfract: the offsets of rows
+ * [row0, row1) only ([row1 - row0][2][k][n]); out: [(row1 - row0) * dst_w][6][k][n].  The consumer's first_pixel stays the
+ * GLOBAL pixel index row * dst_w.  Every output equals the whole-image call's bit for bit. */
+size_t fhe_resize_bicubic_shared_rows_scratch_bytes(const fhe_circuits *circ, uint32_t src_w, uint32_t src_h, uint32_t dst_w,
+                                                    uint32_t dst_h, uint32_t row0, uint32_t row1, uint32_t src_row0,
+                                                    uint32_t n_src_rows, uint32_t batch, uint32_t band_rows, int has_out);
+int fhe_resize_bicubic_shared_rows(const fhe_circuits *circ, const uint64_t *pixels, uint32_t src_w, uint32_t src_h,
+                                   uint32_t dst_w, uint32_t dst_h, uint32_t row0, uint32_t row1, uint32_t src_row0,
+                                   uint32_t n_src_rows, const uint64_t *xfract, const uint64_t *yfract, uint64_t *out,
+                                   uint32_t batch, uint32_t band_rows, fhe_band_consumer consume, void *user, void *scratch,
+                                   size_t scratch_bytes, fhe_stream stream);
+
 /* ---- decode path ---------------------------------------------------------------------------------------
  * homomorphic_sin (cosine = 0, homo/fhe_decode.h:48-120) / homomorphic_cos (cosine = 1, :128-200; the value
  * the reference leaves in `res` before falling off the end without a return statement) for `count`
@@ -109,6 +133,18 @@ int fhe_approximated_step(const fhe_circuits *circ, const uint64_t *amplitude, c
                           uint32_t height, const uint64_t *zeros, uint64_t *out, void *scratch,
                           size_t scratch_bytes, fhe_stream stream);
 
+/* Output positions [pos0, pos1) of the same run: the multi-GPU partition of the position loop (homo/fhe_decode.h:224;
+ * "decode shards by (run, output position)").  zeros and out hold the shard's positions only
+ * ([pos1 - pos0][degree][2][2][k][n], [pos1 - pos0][S][k][n]).  The serial part of the loop -- `offset` advancing by
+ * add_plain inside the harmonic loop (:229) -- is replayed from position 0 by every shard (pos0 * degree polynomial
+ * additions, no products), so each output equals the whole-run call's bit for bit. */
+size_t fhe_approximated_step_range_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos, uint32_t pos0,
+                                                 uint32_t pos1);
+int fhe_approximated_step_range(const fhe_circuits *circ, const uint64_t *amplitude, const uint64_t *index,
+                                const uint64_t *count_ct, int order, int degree, double delta, uint32_t width,
+                                uint32_t height, uint32_t pos0, uint32_t pos1, const uint64_t *zeros, uint64_t *out,
+                                void *scratch, size_t scratch_bytes, fhe_stream stream);
+
 /* One colour channel of the server_decode driver loop (homo/server_decode.cpp:120-137): the channel's
  * accumulators start as acc0 ([npos][2][k][n], the Enc(0) of :126); for each of `pairs` runs
  * (runs: [pairs][2][2][k][n] = elem, count as loaded at :131-132) approximated_step is evaluated with the
@@ -120,6 +156,16 @@ int fhe_decode_channel(const fhe_circuits *circ, const uint64_t *runs, uint32_t 
                        const uint64_t *acc0, const uint64_t *zeros, int order, int degree, double delta,
                        uint32_t width, uint32_t height, uint64_t *out, void *scratch, size_t scratch_bytes,
                        fhe_stream stream);
+
+/* Positions [pos0, pos1) of one channel: acc0 ([pos1 - pos0][2][k][n]), zeros ([pairs][pos1 - pos0][degree][2][2][k][n])
+ * and out hold the shard's positions only; every shard owns a copy of `index` and advances it through all runs
+ * (`pairs` polynomial additions -- the replicated prefix chain). */
+size_t fhe_decode_channel_range_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos, uint32_t pos0,
+                                              uint32_t pos1, uint32_t pairs);
+int fhe_decode_channel_range(const fhe_circuits *circ, const uint64_t *runs, uint32_t pairs, uint64_t *index,
+                             const uint64_t *acc0, const uint64_t *zeros, int order, int degree, double delta,
+                             uint32_t width, uint32_t height, uint32_t pos0, uint32_t pos1, uint64_t *out, void *scratch,
+                             size_t scratch_bytes, fhe_stream stream);
 
 #ifdef __cplusplus
 }

@@ -601,6 +601,7 @@ uint32_t fo_frac_encode(const fo_ctx *c, double v, int int_coeffs, int frac_coef
             f *= 2.0;
             int64_t b = (int64_t)f;
             f -= (double)b;
+            if (b && (u32)i > n) return 0xffffffffu; /* the digit does not fit the ring (test-sized n): caller raises */
             if (b) plain[n - i] = neg ? 1 : t - 1; /* -x^(n-i) == x^(-i) */
         }
     }

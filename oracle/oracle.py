@@ -234,7 +234,8 @@ class Oracle:
     # -- encoder ----------------------------------------------------------
     def encode(self, v):
         out = np.zeros(self.n, dtype=np.uint64)
-        self.L.fo_frac_encode(self.h, float(v), self.INT_COEFFS, self.FRAC_COEFFS, _p(out))
+        if self.L.fo_frac_encode(self.h, float(v), self.INT_COEFFS, self.FRAC_COEFFS, _p(out)) == 0xFFFFFFFF:
+            raise ValueError("encode(%r) needs more fractional coefficients than n = %d holds" % (v, self.n))
         return out
 
     def decode(self, plain):
@@ -361,15 +362,22 @@ def oracle_homomorphic_cos(orc, x, zero):
     return _oracle_taylor(orc, x, zero, -1.0, 1.0)
 
 
-def oracle_approximated_step(orc, amplitude, index, count, order, degree, delta, width, height, zeros):
-    """homo/fhe_decode.h:202-242 (homomorphic overload), including the offset mutation at :229."""
+def oracle_approximated_step(orc, amplitude, index, count, order, degree, delta, width, height, zeros, positions=None):
+    """homo/fhe_decode.h:202-242 (homomorphic overload), including the offset mutation at :229.
+    positions=(p0, p1): only those output positions are evaluated (the checker for a shard of the position loop); the
+    positions before p0 still advance `offset` exactly as the reference's loop does."""
+    p0, p1 = positions if positions is not None else (0, width * height)
     b = orc.multiply_plain(count, orc.encode(0.5))                    # :214-215
     offset = orc.add(index, b)                                        # :216-217
     offset = orc.add_plain(offset, orc.encode(-0.5))                  # :218
     offset = orc.negate(offset)                                       # :219
     b = orc.add_plain(b, orc.encode(delta - 0.5))                     # :220
     run = []
-    for i in range(width * height):
+    for i in range(p1):
+        if i < p0:
+            for j in range(1, degree + 1):
+                offset = orc.add_plain(offset, orc.encode(float(i)))  # :229, the only effect of position i on later positions
+            continue
         c = orc.multiply_plain(b, orc.encode(1.0 / float(order)))     # :222-223
         for j in range(1, degree + 1):
             arg_factor = float(np.float32(j)) * _math.pi / float(order)   # :225
