@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Secondary measurements (not the driver's bench line): BASELINE.json configs[2] and configs[3].
+"""Secondary measurements (not the driver's bench line): BASELINE.json configs[2] and configs[3], in the BENCH schema.
 
-  python bench_circuits.py resize [--pixels P]   bicubic 128x128 -> 64x64 via the Cubic circuit of
-                                                 homo/fhe_resize.h:143-305, n=8192 (P8192), one channel
-                                                 batch of P output pixels per launch sequence
-  python bench_circuits.py decode                approximated_step (homo/fhe_decode.h:202-242), W*H=16,
-                                                 degree 12, n=8192: one run
+  python bench_circuits.py resize [--shared] [--gpus N]   bicubic 128x128 -> 64x64 via the Cubic circuit of
+                                                         homo/fhe_resize.h:143-392, n=8192 (P8192), one channel
+  python bench_circuits.py decode [--gpus N]             approximated_step (homo/fhe_decode.h:202-242), W*H=16,
+                                                         degree 12, n=8192: one run
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench_circuits.py <workload> --gpus N ...
 
-Inputs are synthetic random-residue ciphertexts; the server-side encryptions of the reference's
-circuits (fractional offsets, Enc(0)) are inputs.  Prints one JSON line per workload.
+Inputs are synthetic random-residue ciphertexts; the server-side encryptions of the reference's circuits (fractional
+offsets, Enc(0)) are inputs.  Multi-GPU (one process per GPU, RCCL for the barrier, the
+max-over-ranks time and the digest all-reduce only): resize shards the destination ROWS (parallel.row_range; every rank
+generates / loads its source rows +- the sampler's halo), decode shards the output POSITIONS of the run; both are fixed-size
+jobs, so the scaling is "strong".  Rank 0 prints ONE JSON line with `roofline` (HBM on algorithmic bytes: inputs read once,
+outputs written once) and, when asked for (--cpu-pixels / --cpu-terms), `cpu_baseline` (the oracle on one host core, on a
+bounded sample).  `output_digest` is the position-dependent digest of everything produced: equal for every GPU count.
 """
 import argparse
 import json
@@ -18,111 +23,225 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+M64 = (1 << 64) - 1
+
+
+def _dist_setup(args):
+    import torch
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_circuits.py needs a HIP device (no CPU path exists)")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local, dist
+
+
+def _timed(fn, dist, reps=1):
+    """barrier + synchronize on both sides, HIP events on the launch stream, max over ranks (seconds, device ms per rep)"""
+    import torch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        res = fn()
+    e1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    return res, wall / reps, e0.elapsed_time(e1) / reps
+
+
+def _cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _roofline(alg_bytes, dev_ms, kernels):
+    achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": dev_ms, "kernel": kernels,
+            "note": "a sequence of ct x ct launches (csrc/behz.hip), VALU-issue-bound: the per-kernel issue fractions and counter traffic are in profiles/*_issue_roofline.txt and profiles/pmc_traffic_ctct.json"}
 
 
 def resize(args):
+    import numpy as np
     import torch
     import fhip_amd as fhe
-    ctx = fhe.SEALContext.preset(args.preset)
+    rank, world, local, dist = _dist_setup(args)
+    ctx = fhe.SEALContext.preset(args.preset, device=local)
     ev = fhe.Evaluator(ctx)
     pc = fhe.circuits.PlainCache(ctx)
     W = H = args.src
     w = h = args.dst
-    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
-    # one colour channel of the source image, resident in HBM
-    pixels = ctx.random_ct(W * H, size=2, seed=fhe.SEED)
-    n_out = w * h
-    P = min(args.pixels, n_out)
-    xf = ctx.random_ct(P, size=2, seed=11)     # Enc(frac(u)), Enc(frac(v)) are inputs
-    yf = ctx.random_ct(P, size=2, seed=12)
-    torch.cuda.synchronize()
-    # warm-up (builds BEHZ tables, caches plaintexts)
-    fhe.circuits.sample_bicubic(ev, pc, pixels, taps[:min(P, 8)], xf[:min(P, 8)].contiguous(), yf[:min(P, 8)].contiguous())
-    torch.cuda.synchronize()
-    passes = []
-    for _ in range(1 if args.max_pixels else 2):      # the first full-size pass sizes the allocator's pools (scratch of several GiB); the second is the steady state
-        t0 = time.perf_counter()
-        done = 0
-        for s in range(0, n_out, P):
-            e = min(s + P, n_out)
-            out = fhe.circuits.sample_bicubic(ev, pc, pixels, taps[s:e], xf[: e - s].contiguous(), yf[: e - s].contiguous())
-            done += e - s
-            if args.max_pixels and done >= args.max_pixels:
-                break
-        torch.cuda.synchronize()
-        passes.append(time.perf_counter() - t0)
-    dt = passes[-1]
-    res = {"workload": "bicubic resize %dx%d -> %dx%d, one channel, %s (n=%d, k=%d)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
-           "output_pixels": done, "seconds": dt, "pixels_per_s": done / dt, "cubic_calls_per_s": 5 * done / dt,
-           "out_size": int(out.shape[-3]), "batch_pixels": P, "first_pass_seconds": passes[0]}
+    ctw = 2 * ctx.k * ctx.n                                     # words of a ct(2)
+    y0, y1 = fhe.parallel.row_range(rank, world, h)
+    if y1 == y0:
+        raise SystemExit("more GPUs than destination rows")
+    if args.max_pixels:                                          # profiling runs: only the first rows of the (single) shard
+        if world > 1:
+            raise SystemExit("--max-pixels is a single-GPU profiling switch")
+        y1 = min(y1, y0 + (args.max_pixels + w - 1) // w)
+    first, count = fhe.parallel.source_rows(H, h, y0, y1, True)
+    # this rank's rows +- halo of ONE colour channel, resident in HBM; the global pixel index seeds the bytes, so any GPU count sees the same image
+    pixels = ctx.random_ct(count * W, size=2, seed=fhe.SEED, first_index=first * W * ctw)
+    taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+    my_taps = (taps[y0 * w:y1 * w].astype(np.int64) - first * W).astype(np.uint32)
+    n_mine = (y1 - y0) * w
+    n_out = n_mine if args.max_pixels else w * h
+    P = min(args.pixels, n_mine)
+    words = 6 * ctx.k * ctx.n
     if args.shared:
-        # SURVEY.md 8(d) config 3 input convention: one offset ciphertext per distinct fractional value, i.e. per output
-        # column / row; every repeated ring element (row Cubics of overlapping windows, squares, prepared operands) is
-        # then formed once -- bit-identical to the per-pixel evaluation with those ciphertexts (tests/test_gpu_configs.py)
-        xc, yc = ctx.random_ct(w, size=2, seed=11), ctx.random_ct(h, size=2, seed=12)
-        fhe.circuits.resize_bicubic_shared(ev, pc, pixels[: 16 * W], W, 16, w, 4, xc, yc[:4].contiguous(), batch=P)       # warm-up
-        torch.cuda.synchronize()
-        for _ in range(2):            # the first full-size pass sizes the allocator's pools; the second is the steady state
-            sink = []
+        # SURVEY.md 8(d) configs[2] input convention: one offset ciphertext per distinct fractional value, i.e. per output column / row
+        xc = ctx.random_ct(w, size=2, seed=11)
+        yc = ctx.random_ct(y1 - y0, size=2, seed=12, first_index=y0 * ctw)
+        acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+
+        def consume(first_px, t):
+            part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+            ctx.digest_into(t, part, index0=first_px * words)
+            acc.add_(part)
+
+        def job():
+            acc.zero_()
+            fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=consume, rows=(y0, y1), src_rows=(first, count))
+            return None
+        alg = (W * (H if not args.max_pixels else count) + w + h) * ctw * 8 + n_out * words * 8
+        form = "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"
+    else:
+        # one offset ciphertext pair per output pixel, as the reference's server draws them (homo/fhe_resize.h:262,266)
+        xf = ctx.random_ct(n_mine, size=2, seed=11, first_index=y0 * w * ctw)
+        yf = ctx.random_ct(n_mine, size=2, seed=12, first_index=y0 * w * ctw)
+        acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+
+        def job():
+            acc.zero_()
+            for s in range(0, n_mine, P):
+                e = min(s + P, n_mine)
+                out = fhe.circuits.sample_bicubic(ev, pc, pixels, my_taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous())
+                part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+                ctx.digest_into(out, part, index0=(y0 * w + s) * words)
+                acc.add_(part)
+            return None
+        alg = (W * (H if not args.max_pixels else count) + 2 * n_out) * ctw * 8 + n_out * words * 8
+        form = "one offset ciphertext pair per output pixel (five Cubic evaluations per pixel)"
+    job()                                                       # warm-up at full size: ct x ct tables, cached plaintexts, the allocator's pools
+    _, first_pass, _ = _timed(job, dist)
+    _, wall, dev_ms = _timed(job, dist)
+    digest = fhe.parallel.combine_digests(int(acc.cpu().numpy().view(np.uint64)[0]))
+    if rank == 0:
+        res = {"metric": "bicubic-resized output pixels/sec (one colour channel)", "value": n_out / wall, "unit": "pixels/s", "n_gpus": world,
+               "steps": 1, "warmup": 2, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "bicubic resize %dx%d -> %dx%d via the Cubic circuit, one channel, %s (n=%d, %d coeff moduli)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
+                          "offsets": form, "batch_pixels": P, "sharding": "destination rows x%d, source rows +- halo per rank, no data-path collective" % world},
+               "seconds": wall, "first_pass_seconds": first_pass, "cubic_calls_per_s": 5 * n_out / wall, "out_size": 6,
+               "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm, k_cubic_combine_g"),
+               "output_digest": "%016x" % digest}
+        if args.cpu_pixels:
+            from oracle import oracle as om
+            orc = om.Oracle.preset(args.preset)
+            hp = fhe.to_host(pixels[:16])
+            t = fhe.to_host(ctx.random_ct(1, size=2, seed=11))[0]
             t0 = time.perf_counter()
-            fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=lambda first, t: sink.append(int(t.shape[0])))
-            torch.cuda.synchronize()
-            sdt = time.perf_counter() - t0
-            assert sum(sink) == n_out
-        rows_touched = len({taps[y * w][4 * j] // W for y in range(h) for j in range(4)})
-        res["shared_offsets"] = {"seconds": sdt, "pixels_per_s": n_out / sdt, "row_cubics": rows_touched * w, "column_cubics": n_out,
-                                 "note": "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"}
-    if args.cpu_pixels:
-        from oracle import oracle as om
-        orc = om.Oracle.preset(args.preset)
-        hp = fhe.to_host(pixels[: 16])
-        t = fhe.to_host(xf[0])
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_pixels):
-            cols = [orc.cubic(hp[4 * r], hp[4 * r + 1], hp[4 * r + 2], hp[4 * r + 3], t) for r in range(4)]
-            orc.cubic(cols[0], cols[1], cols[2], cols[3], t)
-        cdt = time.perf_counter() - t0
-        res["cpu_oracle_pixels_per_s"] = args.cpu_pixels / cdt
-    print(json.dumps(res), flush=True)
+            for _ in range(args.cpu_pixels):
+                cols = [orc.cubic(hp[4 * r], hp[4 * r + 1], hp[4 * r + 2], hp[4 * r + 3], t) for r in range(4)]
+                orc.cubic(cols[0], cols[1], cols[2], cols[3], t)
+            cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": args.cpu_pixels / cdt, "unit": "pixels/s", "cores": 1, "kind": "port",
+                                   "sample": "%d output pixels (5 Cubic each) of the same workload, oracle/libfhe_oracle.so op at a time, 1 thread of %d on %s"
+                                             % (args.cpu_pixels, os.cpu_count() or 0, _cpu_name())}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def decode(args):
+    import numpy as np
     import torch
     import fhip_amd as fhe
-    ctx = fhe.SEALContext.preset(args.preset)
+    rank, world, local, dist = _dist_setup(args)
+    ctx = fhe.SEALContext.preset(args.preset, device=local)
     ev = fhe.Evaluator(ctx)
     pc = fhe.circuits.PlainCache(ctx)
+    npos, degree = args.positions, args.degree
+    p0, p1 = fhe.parallel.block_range(rank, world, npos)
+    if p1 == p0:
+        raise SystemExit("more GPUs than output positions")
     amp, idx, cnt = (ctx.random_ct(1, size=2, seed=900 + i) for i in range(3))
+    ctw = 2 * ctx.k * ctx.n
+    # the Enc(0) accumulators are inputs (SURVEY.md section 8d, config 4): [position][harmonic][sin, cos], seeded by the global position
+    zeros = ctx.random_ct((p1 - p0) * degree * 2, size=2, seed=1000, first_index=p0 * degree * 2 * ctw).reshape(p1 - p0, degree, 2, 2, ctx.k, ctx.n) if degree else None
+    so = int(fhe._lib.load().fhe_approximated_step_out_size(degree))
 
-    # the Enc(0) accumulators are inputs: generated before the timed region
-    bank = {(i, j, w): ctx.random_ct(1, size=2, seed=1000 + 100 * i + 10 * j + (w == "cos"))
-            for i in range(max(args.positions, 1)) for j in range(1, max(args.degree, 1) + 1) for w in ("sin", "cos")}
-
-    def zeros(i, j, which):
-        return bank[(i, j, which)]
-
-    # warm-up at full size: scratch buffers and the allocator cache reach their steady state
-    fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=args.degree, delta=0.5, width=args.positions, height=1, zeros=zeros)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=args.degree, delta=0.5,
-                                         width=args.positions, height=1, zeros=zeros)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(json.dumps({"workload": "approximated_step W*H=%d degree=%d, %s (n=%d, k=%d)" % (args.positions, args.degree, args.preset, ctx.n, ctx.k),
-                      "seconds": dt, "steps_per_s": 1 / dt, "out_size": int(run[0].shape[-3]), "outputs": len(run)}), flush=True)
+    def job():
+        return fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, positions=(p0, p1))
+    job()                                                       # warm-up at full size: scratch buffers and the allocator cache reach their steady state
+    run, wall, dev_ms = _timed(job, dist)
+    out = torch.cat(run)
+    digest = fhe.parallel.combine_digests(ctx.digest(out, index0=p0 * so * ctx.k * ctx.n))
+    if rank == 0:
+        alg = (3 + npos * degree * 2) * ctw * 8 + npos * so * ctx.k * ctx.n * 8
+        res = {"metric": "approximated_step runs/sec (all W*H output positions of one run)", "value": 1 / wall, "unit": "runs/s", "n_gpus": world,
+               "steps": 1, "warmup": 1, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "approximated_step W*H=%d degree=%d, %s (n=%d, %d coeff moduli)" % (npos, degree, args.preset, ctx.n, ctx.k),
+                          "sharding": "output positions x%d; run operands, offset chain and sine polynomials replicated; no data-path collective" % world},
+               "seconds": wall, "steps_per_s": 1 / wall, "out_size": so, "outputs": npos,
+               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_add_general"),
+               "output_digest": "%016x" % digest}
+        if args.cpu_terms:
+            from oracle import oracle as om
+            orc = om.Oracle.preset(args.preset)
+            h_amp, h_idx, h_cnt = (fhe.to_host(t)[0] for t in (amp, idx, cnt))
+            hz = fhe.to_host(zeros[:1, :args.cpu_terms].reshape(-1, 2, ctx.k, ctx.n))
+            t0 = time.perf_counter()
+            om.oracle_approximated_step(orc, h_amp, h_idx, h_cnt, 64, args.cpu_terms, 0.5, 1, 1, lambda i, j, wh: hz[2 * (j - 1) + (wh == "cos")])
+            cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": 1 / (cdt * npos * max(degree, 1) / args.cpu_terms), "unit": "runs/s", "cores": 1, "kind": "port",
+                                   "sample": "one output position with %d of the %d harmonics (sin + cos Taylor polynomials and their 11 x 11 product each), scaled by positions x harmonics; "
+                                             "oracle/libfhe_oracle.so op at a time, 1 thread of %d on %s" % (args.cpu_terms, degree, os.cpu_count() or 0, _cpu_name())}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("workload", choices=["resize", "decode"])
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--preset", default="P8192")
     ap.add_argument("--src", type=int, default=128)
     ap.add_argument("--dst", type=int, default=64)
-    ap.add_argument("--pixels", type=int, default=256)
-    ap.add_argument("--max-pixels", type=int, default=0)
-    ap.add_argument("--cpu-pixels", type=int, default=0)
-    ap.add_argument("--shared", action="store_true", help="resize: also time the shared-offset form (one offset ciphertext per output column / row)")
+    ap.add_argument("--pixels", type=int, default=256, help="output pixels per launch sequence")
+    ap.add_argument("--max-pixels", type=int, default=0, help="resize: stop after the rows holding this many output pixels (profiling runs)")
+    ap.add_argument("--cpu-pixels", type=int, default=0, help="resize: CPU baseline sample (output pixels through the oracle; ~0.6 s each at n = 8192)")
+    ap.add_argument("--cpu-terms", type=int, default=0, help="decode: CPU baseline sample (harmonics of one position through the oracle; ~5 s each at n = 8192)")
+    ap.add_argument("--shared", action="store_true", help="resize: one offset ciphertext per output column / row (SURVEY.md 8d) instead of one pair per pixel")
     ap.add_argument("--degree", type=int, default=12)
     ap.add_argument("--positions", type=int, default=16)
     a = ap.parse_args()

@@ -30,6 +30,11 @@ SIGNATURES = {
     "fhe_abi_version": (_u32, []),
     "fhe_ctx_create": (_i, [_u32, C.POINTER(_u64), _u32, _u64, _i, C.POINTER(_vp)]),
     "fhe_ctx_destroy": (_i, [_vp]),
+    "fhe_ctx_has_ctct_tables": (_i, [_vp]),
+    "fhe_ctx_device": (_i, [_vp]),
+    "fhe_ctx_bind_thread": (_i, [_vp]),
+    "fhe_stream_create": (_i, [C.POINTER(_vp)]),
+    "fhe_stream_destroy": (_i, [_vp]),
     "fhe_ctx_n": (_u32, [_vp]),
     "fhe_ctx_k": (_u32, [_vp]),
     "fhe_ctx_t": (_u64, [_vp]),
@@ -115,7 +120,7 @@ SIGNATURES = {
     "fhe_io_transfer": (_i, [_vp, _u64, _u64, _u32, _u32, _u32, _vp, _u32]),
 }
 # entry points whose int return value is a count (>= 0) or an error (< 0)
-_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path", "fhe_arith_path"}
+_COUNT_RETURN = {"fhe_default_coeff_modulus", "fhe_frac_encode", "fhe_dct_path", "fhe_arith_path", "fhe_ctx_device", "fhe_ctx_has_ctct_tables"}
 
 
 def load():

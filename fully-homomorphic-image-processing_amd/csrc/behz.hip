@@ -1010,11 +1010,28 @@ int fhe_behz_build(fhe_ctx *c) {
     return FHE_OK;
 }
 
+int fhe_behz_ensure(const fhe_ctx *cc) {
+    fhe_ctx *c = const_cast<fhe_ctx *>(cc);
+    std::call_once(c->behz_once, [c] {
+        // the calling thread may be bound to another device (a host driving several GPUs): the tables belong to the context's
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != c->device) (void)hipSetDevice(c->device);
+        c->behz_rc = fhe_behz_build(c);
+        if (c->behz_rc) c->behz_err = fhe_last_error();
+        if (cur >= 0 && cur != c->device) (void)hipSetDevice(cur);
+    });
+    if (c->behz_rc) return fail(c->behz_rc, "ct x ct tables: %s", c->behz_err.c_str());
+    return FHE_OK;
+}
+
+extern "C" int fhe_ctx_has_ctct_tables(const fhe_ctx *c) { return c && c->behz ? 1 : 0; }
+
 extern "C" int fhe_arith_path(const fhe_ctx *c) {
     if (!c) return fail(FHE_ERR_PARAM, "null argument");
     if (c->opt.ntt_nopm) return 0;
     int r = c->qb.pm_class & 3;
-    if (c->behz) r |= ((c->behz->aux.pm_class & 3) << 2) | (c->behz->pm_dev ? 16 : 0);
+    if (fhe_behz_ensure(c) == FHE_OK) r |= ((c->behz->aux.pm_class & 3) << 2) | (c->behz->pm_dev ? 16 : 0);
     return r;
 }
 
@@ -1148,7 +1165,7 @@ static int behz_multiply(const fhe_ctx *cc, const u64 *a, const u64 *ap, u32 sa,
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
     int rc;
-    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (int erc = fhe_behz_ensure(c)) return erc;
     const bool square = !ap && !bp && a == b && sa == sb;
     if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, square) * sizeof(u64))
         return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
@@ -1184,7 +1201,7 @@ extern "C" int fhe_multiply_prepare(const fhe_ctx *cc, const uint64_t *a, uint32
     if (!size) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
-    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (int erc = fhe_behz_ensure(c)) return erc;
     u64 *xq = (u64 *)prepared, *xb = xq + count * size * (size_t)c->k * c->n;
     return behz_prepare(c, (const u64 *)a, size, count, xq, xb, (hipStream_t)s);
 }
@@ -1204,7 +1221,7 @@ extern "C" int fhe_multiply_prepared_shared(const fhe_ctx *cc, const uint64_t *a
     if (!b_count || !b_div) return fail(FHE_ERR_PARAM, "shared operand: b_count and b_div must be positive");
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
-    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (int erc = fhe_behz_ensure(c)) return erc;
     if (!scratch || scratch_bytes < mul_words(c, sa, sb, count, false) * sizeof(u64))
         return fail(FHE_ERR_PARAM, "scratch too small: need fhe_multiply_scratch_bytes()");
     hipStream_t st = (hipStream_t)s;
@@ -1252,7 +1269,7 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
     int rc;
-    if (!c->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (int erc = fhe_behz_ensure(c)) return erc;
     if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
     hipStream_t st = (hipStream_t)s;

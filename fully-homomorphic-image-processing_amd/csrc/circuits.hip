@@ -844,7 +844,7 @@ extern "C" int fhe_circuits_create(const fhe_ctx *ctx, int int_coeffs, int frac_
     if (!ctx || !out) return fail(FHE_ERR_PARAM, "null argument");
     *out = nullptr;
     if (int_coeffs < 1 || frac_coeffs < 0 || (u32)(int_coeffs + frac_coeffs) > ctx->n) return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");
-    if (!ctx->behz) return fail(FHE_ERR_PARAM, "context has no ct x ct tables");
+    if (int erc = fhe_behz_ensure(ctx)) return erc;                     // a circuits handle is a statement of intent to multiply ciphertexts
     std::unique_ptr<fhe_circuits> cc(new fhe_circuits);
     cc->c = ctx;
     cc->ic = int_coeffs;

@@ -259,10 +259,10 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         c->upper_half_increment[i] = q_mod_t % qi;
         c->delta_mod[i] = mulmod(submod(0, q_mod_t % qi, qi), invmod(t % qi, qi), qi);
     }
-    // everything a compute entry point needs is built here, so that a context is immutable afterwards
-    // (apart from the mutex-guarded rgb constant cache) and may be shared by threads: the ct x ct
-    // tables (auxiliary base, conversion constants) and the second stream of the pipelined DCT path
-    if ((rc = fhe_behz_build(c))) { fhe_ctx_destroy(c); return rc; }
+    // what the linear circuits need is built here; the ct x ct tables (auxiliary base, conversion constants) are built by the
+    // first entry point that multiplies ciphertexts (fhe_behz_ensure, call_once), so a DCT-only server neither pays for them
+    // nor can fail on the auxiliary-prime search.  FHE_BEHZ_EAGER=1 restores construction at create time.
+    if (env_on("FHE_BEHZ_EAGER") && (rc = fhe_behz_ensure(c))) { fhe_ctx_destroy(c); return rc; }
     bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
         ok = hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess &&
@@ -288,6 +288,23 @@ extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     fhe_behz_free(c);
     fhe_free_base(c->qb);
     delete c;
+    return FHE_OK;
+}
+extern "C" int fhe_ctx_device(const fhe_ctx *c) { return c ? c->device : -1; }
+extern "C" int fhe_ctx_bind_thread(const fhe_ctx *c) {
+    if (!c) return fail(FHE_ERR_PARAM, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return FHE_OK;
+}
+extern "C" int fhe_stream_create(fhe_stream *out) {
+    if (!out) return fail(FHE_ERR_PARAM, "null argument");
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (fhe_stream)s;
+    return FHE_OK;
+}
+extern "C" int fhe_stream_destroy(fhe_stream s) {
+    if (s) HIP_TRY(hipStreamDestroy((hipStream_t)s));
     return FHE_OK;
 }
 extern "C" uint32_t fhe_ctx_n(const fhe_ctx *c) { return c->n; }

@@ -72,7 +72,14 @@ struct fhe_ctx {
     u64 plain_upper_half_increment[FHE_MAX_K] = {0};   // (q - t) mod q_i
     u64 delta_mod[FHE_MAX_K] = {0};                    // floor(q/t) mod q_i
     u64 upper_half_increment[FHE_MAX_K] = {0};         // (q mod t) mod q_i
-    struct BehzTables *behz = nullptr;                 // ct x ct tables (behz.hip)
+    // ct x ct tables (behz.hip): auxiliary base, its twiddles, base-conversion constants.  Built by the FIRST entry point that
+    // needs them (fhe_behz_ensure, std::call_once): a context that only runs the linear circuits (DCT, colour conversion,
+    // add / multiply_plain) never searches for auxiliary primes and cannot fail on them.  After the once-flag has fired the
+    // pointer never changes again, so the context is as immutable for its users as before.
+    struct BehzTables *behz = nullptr;
+    mutable std::once_flag behz_once;
+    int behz_rc = 0;
+    std::string behz_err;
     // second stream + events for overlapping the column kernel of one wave of blocks with the row
     // kernel of the next (fhe_dct8x8_quant); created with the context
     hipStream_t aux_stream = nullptr;
@@ -115,7 +122,8 @@ struct fhe_dct_plan {
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
 int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
 void fhe_free_base(BaseTables &B);
-int fhe_behz_build(fhe_ctx *c);   // called once from fhe_ctx_create
+int fhe_behz_build(fhe_ctx *c);   // called once per context, through fhe_behz_ensure
+int fhe_behz_ensure(const fhe_ctx *c);   // thread-safe: builds the ct x ct tables on first use; later calls cost one atomic load
 void fhe_behz_free(fhe_ctx *c);
 // fused FP64 DCT path (dct_fused.hip)
 bool fhe_dct_f64_supported(const fhe_ctx *c);

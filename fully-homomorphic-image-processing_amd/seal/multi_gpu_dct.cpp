@@ -1,0 +1,251 @@
+// multi_gpu_dct.cpp -- the N > 1 path from a C++ host, no Python and no torch: the block loop of homo/server_jpeg.cpp:113-138
+// (encrypted_dct + quantize_fhe on independent 8x8 blocks) partitioned over the GPUs of one node through the C ABI
+// (include/fhe_hip.h) -- one host thread, one fhe_ctx, one stream per rank -- with the optional final ciphertext gather
+// as RCCL point-to-point transfers over xGMI (BASELINE.json north_star: "RCCL over xGMI only for the final ciphertext gather").
+//
+//   rank r of R owns the contiguous block range [r N / R, (r + 1) N / R) (the same split as parallel.block_range);
+//   its synthetic inputs are seeded by the GLOBAL block index, so any R produces the same bytes;
+//   every rank digests its own outputs with global indices: the sum of the rank digests is the digest of the whole output
+//   and must equal what ONE rank computes alone over all N blocks (checked here, wave by wave, on rank 0's device);
+//   gather (ranks on distinct devices only -- RCCL refuses two ranks on one device): every rank r > 0 sends each finished
+//   wave of output ciphertexts to rank 0 with ncclSend while it computes the next wave; rank 0 posts the matching ncclRecv
+//   of a wave from all peers as one group (each peer arrives over its own xGMI link) and digests what it received: that
+//   digest must equal the sum of the senders' own digests.
+//
+// Ranks may outnumber devices (rank r runs on device r % devices): with one GPU the partition logic, the threading
+// contract of the C ABI (contexts shared by nothing, fhe_ctx_bind_thread, per-rank streams) and the digests are still
+// exercised; only the RCCL transfers need two devices.
+//
+// usage: multi_gpu_dct [total_blocks=512] [ranks=<device count>] [wave_blocks=64] [gather=1]
+// prints one JSON line; exit code 0 iff every check held.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fhe_hip.h"
+
+namespace {
+const double YQT[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                        18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};   // homo/fhe_image.h:99
+constexpr uint64_t SEED = 0x5EA12026ULL;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Fail {
+    std::string what;
+};
+void check(int rc, const char *what) {
+    if (rc < 0) throw Fail{std::string(what) + ": " + fhe_last_error()};
+}
+void hcheck(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Fail{std::string(what) + ": " + hipGetErrorString(e)};
+}
+void ncheck(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw Fail{std::string(what) + ": " + ncclGetErrorString(r)};
+}
+
+// [start, end) of rank r: sizes differ by at most one (parallel.block_range)
+void block_range(uint64_t r, uint64_t world, uint64_t n, uint64_t &start, uint64_t &end) {
+    const uint64_t base = n / world, rem = n % world;
+    start = r * base + (r < rem ? r : rem);
+    end = start + base + (r < rem ? 1 : 0);
+}
+
+struct Rank {
+    int rank = 0, device = 0;
+    uint64_t start = 0, end = 0, digest = 0, received_digest = 0;
+    double seconds = 0;
+    std::string error;
+};
+
+struct Job {
+    uint32_t n = 4096, k = 3;
+    uint64_t q[FHE_MAX_K] = {0}, t = 1 << 14;
+    uint64_t total = 512, wave = 64, words_per_block = 0;
+    int world = 1, devices = 1;
+    bool gather = false;
+    std::vector<ncclComm_t> comms;
+};
+
+// one device buffer of `words` u64 through the ABI's allocator (the calling thread's current device)
+uint64_t *dalloc(uint64_t words) {
+    void *p = nullptr;
+    check(fhe_dev_alloc(words * 8, &p), "fhe_dev_alloc");
+    return (uint64_t *)p;
+}
+
+uint64_t digest_of(const fhe_ctx *ctx, const uint64_t *d, uint64_t words, uint64_t index0, uint64_t *d_slot, fhe_stream st) {
+    uint64_t h = 0;
+    check(fhe_digest(ctx, d, words, index0, d_slot, st), "fhe_digest");
+    check(fhe_download(&h, d_slot, 8, st), "fhe_download");
+    check(fhe_stream_sync(st), "fhe_stream_sync");
+    return h;
+}
+
+void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
+    fhe_ctx *ctx = nullptr;
+    fhe_dct_plan *plan = nullptr;
+    fhe_stream st = nullptr, st_comm = nullptr;
+    try {
+        hcheck(hipSetDevice(R.device), "hipSetDevice");
+        check(fhe_ctx_create(J.n, J.q, J.k, J.t, R.device, &ctx), "fhe_ctx_create");     // one context per rank: nothing is shared between ranks
+        check(fhe_ctx_bind_thread(ctx), "fhe_ctx_bind_thread");
+        check(fhe_stream_create(&st), "fhe_stream_create");
+        check(fhe_stream_create(&st_comm), "fhe_stream_create");
+        check(fhe_dct_plan_create(ctx, YQT, 100, 100, st, &plan), "fhe_dct_plan_create");
+        const uint64_t wpb = J.words_per_block, mine = R.end - R.start;
+        const uint64_t n_waves = (mine + J.wave - 1) / J.wave;
+        uint64_t *in = dalloc(J.wave * wpb), *out[2] = {dalloc(J.wave * wpb), dalloc(J.wave * wpb)}, *d_slot = dalloc(1);
+        const size_t scr_bytes = fhe_dct8x8_scratch_bytes(ctx, J.wave);
+        void *scr = nullptr;
+        check(fhe_dev_alloc(scr_bytes, &scr), "fhe_dev_alloc(scratch)");
+        hipEvent_t computed[2], sent[2];
+        for (int i = 0; i < 2; ++i) {
+            hcheck(hipEventCreateWithFlags(&computed[i], hipEventDisableTiming), "event");
+            hcheck(hipEventCreateWithFlags(&sent[i], hipEventDisableTiming), "event");
+        }
+        // the root's receive buffers: one wave per peer
+        std::vector<uint64_t *> rx;
+        // every rank has the same number of waves up to one: the root posts receives for the longest peer shard, peers send
+        // zero-length nothing for a missing last wave (wave counts are computed from the same split on both sides)
+        std::vector<uint64_t> peer_blocks(J.world, 0);
+        uint64_t max_waves = n_waves;
+        for (int r = 0; r < J.world; ++r) {
+            uint64_t s, e;
+            block_range(r, J.world, J.total, s, e);
+            peer_blocks[r] = e - s;
+            const uint64_t w = (e - s + J.wave - 1) / J.wave;
+            if (w > max_waves) max_waves = w;
+        }
+        if (J.gather && R.rank == 0)
+            for (int r = 1; r < J.world; ++r) rx.push_back(dalloc(J.wave * wpb));
+        arrived.fetch_add(1);
+        while (arrived.load() < J.world) std::this_thread::yield();                      // every rank is set up: start the clock together
+        const double t0 = now();
+        for (uint64_t w = 0; w < max_waves; ++w) {
+            const int slot = (int)(w & 1);
+            const uint64_t b0 = R.start + w * J.wave, nb = w < n_waves ? (b0 + J.wave <= R.end ? J.wave : R.end - b0) : 0;
+            if (nb) {
+                if (w >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st, sent[slot], 0), "wait(sent)");      // out[slot] has left for the root
+                check(fhe_fill_random(ctx, in, nb * 64 * 2, SEED, b0 * wpb, st), "fhe_fill_random");       // block g = splitmix64(seed ^ global index)
+                check(fhe_dct8x8_quant(ctx, plan, in, out[slot], nb, scr, scr_bytes, st), "fhe_dct8x8_quant");
+                R.digest += digest_of(ctx, out[slot], nb * wpb, b0 * wpb, d_slot, st);
+                hcheck(hipEventRecord(computed[slot], (hipStream_t)st), "record");
+            }
+            if (!J.gather) continue;
+            if (R.rank != 0) {
+                if (nb) {                                                                // the transfer overlaps the next wave's compute
+                    hcheck(hipStreamWaitEvent((hipStream_t)st_comm, computed[slot], 0), "wait(computed)");
+                    ncheck(ncclSend(out[slot], nb * wpb, ncclUint64, 0, J.comms[R.rank], (hipStream_t)st_comm), "ncclSend");
+                    hcheck(hipEventRecord(sent[slot], (hipStream_t)st_comm), "record");
+                }
+            } else {
+                // wave w of every peer that has one, as ONE group: the transfers arrive concurrently, each over its peer's own link
+                std::vector<std::pair<int, uint64_t>> got;
+                ncheck(ncclGroupStart(), "ncclGroupStart");
+                for (int r = 1; r < J.world; ++r) {
+                    const uint64_t done = w * J.wave;
+                    if (done >= peer_blocks[r]) continue;
+                    const uint64_t cnt = peer_blocks[r] - done < J.wave ? peer_blocks[r] - done : J.wave;
+                    ncheck(ncclRecv(rx[r - 1], cnt * wpb, ncclUint64, r, J.comms[0], (hipStream_t)st_comm), "ncclRecv");
+                    got.push_back({r, cnt});
+                }
+                ncheck(ncclGroupEnd(), "ncclGroupEnd");
+                for (auto &g : got) {
+                    uint64_t s, e;
+                    block_range(g.first, J.world, J.total, s, e);
+                    R.received_digest += digest_of(ctx, rx[g.first - 1], g.second * wpb, (s + w * J.wave) * wpb, d_slot, st_comm);
+                }
+            }
+        }
+        check(fhe_stream_sync(st), "sync");
+        check(fhe_stream_sync(st_comm), "sync");
+        R.seconds = now() - t0;
+    } catch (const Fail &f) {
+        R.error = f.what;
+        arrived.fetch_add(J.world);                                                       // release the others' start barrier
+    }
+    if (plan) fhe_dct_plan_destroy(plan);
+    if (st) fhe_stream_destroy(st);
+    if (st_comm) fhe_stream_destroy(st_comm);
+    if (ctx) fhe_ctx_destroy(ctx);                                                        // device buffers die with the process
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    Job J;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        std::fprintf(stderr, "multi_gpu_dct needs a HIP device (no CPU path exists)\n");
+        return 2;
+    }
+    J.devices = ndev;
+    J.total = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 512;
+    J.world = argc > 2 ? std::atoi(argv[2]) : ndev;
+    J.wave = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 64;
+    const bool want_gather = argc > 4 ? std::atoi(argv[4]) != 0 : true;
+    if (J.world < 1 || !J.wave || !J.total) return 2;
+    J.gather = want_gather && J.world > 1 && J.world <= ndev;                             // RCCL: one rank per device
+    const int kk = fhe_default_coeff_modulus(J.n, 0, J.q);
+    if (kk < 1) return 2;
+    J.k = (uint32_t)kk;
+    J.words_per_block = (uint64_t)64 * 2 * J.k * J.n;
+    int rc = 0;
+    try {
+        if (J.gather) {
+            std::vector<int> devs(J.world);
+            for (int r = 0; r < J.world; ++r) devs[r] = r;
+            J.comms.resize(J.world);
+            ncheck(ncclCommInitAll(J.comms.data(), J.world, devs.data()), "ncclCommInitAll");
+        }
+        std::vector<Rank> ranks(J.world);
+        std::atomic<int> arrived{0};
+        std::vector<std::thread> pool;
+        for (int r = 0; r < J.world; ++r) {
+            ranks[r].rank = r;
+            ranks[r].device = r % ndev;
+            block_range(r, J.world, J.total, ranks[r].start, ranks[r].end);
+            pool.emplace_back(run_rank, std::cref(J), std::ref(ranks[r]), std::ref(arrived));
+        }
+        for (auto &t : pool) t.join();
+        for (auto &c : J.comms) ncclCommDestroy(c);
+        double slowest = 0;
+        uint64_t sum = 0, peers = 0;
+        for (auto &R : ranks) {
+            if (!R.error.empty()) throw Fail{"rank " + std::to_string(R.rank) + ": " + R.error};
+            if (R.seconds > slowest) slowest = R.seconds;
+            sum += R.digest;
+            if (R.rank) peers += R.digest;
+        }
+        // the reference point: ONE rank over all N blocks (rank 0's device, the same wave loop)
+        Job one = J;
+        one.world = 1;
+        one.gather = false;
+        Rank solo;
+        block_range(0, 1, J.total, solo.start, solo.end);
+        std::atomic<int> a1{0};
+        run_rank(one, solo, a1);
+        if (!solo.error.empty()) throw Fail{"single-rank run: " + solo.error};
+        const bool digests_ok = solo.digest == sum, gather_ok = !J.gather || ranks[0].received_digest == peers;
+        std::printf("{\"workload\": \"homomorphic 8x8 DCT+quant, %llu blocks over %d ranks on %d device(s), C++ host over include/fhe_hip.h (n=%u, k=%u)\", "
+                    "\"ranks\": %d, \"devices\": %d, \"wave_blocks\": %llu, \"seconds\": %.4f, \"blocks_per_s\": %.1f, \"single_rank_blocks_per_s\": %.1f, "
+                    "\"output_digest\": \"%016llx\", \"single_rank_digest\": \"%016llx\", \"digests_equal\": %s, "
+                    "\"gather\": \"%s\", \"gathered_digest_equals_senders\": %s}\n",
+                    (unsigned long long)J.total, J.world, ndev, J.n, J.k, J.world, ndev, (unsigned long long)J.wave, slowest, J.total / slowest,
+                    J.total / solo.seconds, (unsigned long long)sum, (unsigned long long)solo.digest, digests_ok ? "true" : "false",
+                    J.gather ? "rccl send/recv per wave to rank 0" : (want_gather && J.world > 1 ? "skipped: ranks share a device" : "none"),
+                    J.gather ? (gather_ok ? "true" : "false") : "null");
+        rc = digests_ok && gather_ok ? 0 : 1;
+    } catch (const Fail &f) {
+        std::fprintf(stderr, "multi_gpu_dct: %s\n", f.what.c_str());
+        rc = 1;
+    }
+    return rc;
+}

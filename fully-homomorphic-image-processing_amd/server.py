@@ -605,12 +605,16 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
         return encrypt_zeros(count)
 
     # the three `index` ciphertexts (:121): one draw per channel on the root, shared by every shard of the channel
+    index0 = None
     if world > 1:
-        index0 = torch.cat([draw(base[ch], 1) for ch in range(3)]) if rank == 0 else ctx.empty(3)
-        torch.cuda.synchronize()
-        parallel.broadcast_from_root(index0, 0, group)
-    else:
-        index0 = None
+        import torch.distributed as dist
+        connected = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) == world
+        # without a process group (shards run one after the other, or by unrelated processes) every shard draws the three
+        # itself: identical with an indexed encryptor, independent (and equally valid) encryptions of 0 otherwise
+        index0 = torch.cat([draw(base[ch], 1) for ch in range(3)]) if (rank == 0 or not connected) else ctx.empty(3)
+        if connected:
+            torch.cuda.synchronize()
+            parallel.broadcast_from_root(index0, 0, group)
     dev = None
     if total and pieces:
         host = _pinned(("dec_in",), (total, 2, 2, ctx.k, ctx.n))

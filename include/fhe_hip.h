@@ -18,20 +18,28 @@
  *    compute entry point fails with FHE_ERR_HIP.
  *  - ciphertext layout (SEAL-logical): u64 [ciphertext][poly j][prime i][coeff c], every residue
  *    fully reduced to [0, q_i).  "n_polys" counts RNS polynomials, i.e. size * number of cts.
- *  - threading: a context is immutable after fhe_ctx_create (every table, including the ct x ct
- *    auxiliary base, is built there) and may be shared by any number of host threads issuing calls on
- *    their own streams; the only state created later is the rgb_to_ycc constant cache, which is
- *    mutex-guarded and never frees an entry while the context lives.  Two restrictions: (1) the
- *    pipelined DCT mode (FHE_DCT_PIPELINE=1) uses one second stream owned by the context, so at most
+ *  - threading: a context is immutable for its users after fhe_ctx_create and may be shared by any number of
+ *    host threads issuing calls on their own streams.  Two pieces of state are created later, both behind
+ *    their own synchronisation and never freed or moved while the context lives: the ct x ct tables
+ *    (auxiliary base, its twiddles, base-conversion constants), built under std::call_once by the FIRST
+ *    entry point that multiplies ciphertexts (fhe_multiply*, fhe_square, fhe_relinearize,
+ *    fhe_circuits_create, fhe_arith_path) -- threads racing that first call are safe, all see the same
+ *    tables or the same error --, and the rgb_to_ycc constant cache (mutex-guarded).  Two restrictions:
+ *    (1) the pipelined DCT mode (FHE_DCT_PIPELINE=1) uses one second stream owned by the context, so at most
  *    one fhe_dct8x8_quant call per context may be in flight in that mode; (2) fhe_ctx_destroy must not
  *    race with any other call on the same context.  Plans and scratch buffers belong to their caller.
+ *  - devices: a context belongs to the device given to fhe_ctx_create; launches, fhe_dev_alloc and
+ *    fhe_stream_create act on the CALLING THREAD's current HIP device.  fhe_ctx_create makes its device
+ *    current for the creating thread; a host that drives several GPUs from one process uses one thread per
+ *    device (or calls fhe_ctx_bind_thread before switching): seal/multi_gpu_dct.cpp is the worked example.
  *  - experiment switches (FHE_DCT_*, FHE_NTT_*, FHE_BEHZ_* environment variables; csrc/internal.h lists
  *    them) are read ONCE, by fhe_ctx_create, and are fixed for the life of that context: no launch path
  *    reads the environment.  The defaults are the measured-best kernels; every alternative gives the same
  *    bits (the parity tests create a second context with the variable set).  Creating a context costs a few
- *    milliseconds and a few MB of device tables (twiddles for the coefficient base and for the k+1 auxiliary
- *    primes of the ct x ct path, base-conversion constants, one stream, four events), whether or not the
- *    caller ever multiplies ciphertexts.
+ *    milliseconds and a few MB of device tables (twiddles of the coefficient base, one stream, four
+ *    events); the ct x ct tables (twiddles for the k+1 auxiliary primes, base-conversion constants) are added
+ *    by the first call that multiplies ciphertexts, so a DCT-only server neither pays for them nor can fail on
+ *    the auxiliary-prime search (FHE_BEHZ_EAGER=1 builds them in fhe_ctx_create as before round 4).
  *  - "NTT form" buffers use a library-internal slot order; they are only meaningful to this
  *    library (produced by fhe_plain_prepare / fhe_ntt_forward, consumed by the matching calls).
  */
@@ -67,6 +75,14 @@ uint32_t fhe_abi_version(void);
  * built on the host and uploaded to `device`. */
 int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int device, fhe_ctx **out);
 int fhe_ctx_destroy(fhe_ctx *ctx);
+/* 1 once the lazily built ct x ct tables exist (diagnostic: a context that only ran linear circuits reports 0) */
+int fhe_ctx_has_ctct_tables(const fhe_ctx *ctx);
+/* the device the context was created on; fhe_ctx_bind_thread makes it the calling thread's current device (hipSetDevice) */
+int fhe_ctx_device(const fhe_ctx *ctx);
+int fhe_ctx_bind_thread(const fhe_ctx *ctx);
+/* a non-blocking stream on the calling thread's current device, for hosts without HIP headers (pass it as `stream`) */
+int fhe_stream_create(fhe_stream *out);
+int fhe_stream_destroy(fhe_stream stream);
 uint32_t fhe_ctx_n(const fhe_ctx *ctx);
 uint32_t fhe_ctx_k(const fhe_ctx *ctx);
 uint64_t fhe_ctx_t(const fhe_ctx *ctx);
