@@ -580,6 +580,96 @@ __global__ __launch_bounds__(256) void k_behz_to_bsk_pm(const u64 *__restrict__ 
         }
     }
 }
+// Steps 0 + 1 FUSED INTO THE FORWARD TRANSFORMS (round 4; opt-in, FHE_BEHZ_FUSED_PREPARE=1): one launch prepares an operand in
+// both bases.  MEASURED (P8192, 256 products, profiles/EXPERIMENTS.md): HBM traffic per 2x2 product 14.6 MB -> 11.0 MB (7.9x ->
+// 6.0x the algorithmic bytes), launch 274 us against 57 + 102 + 78 us for the three launches it replaces, multiply 2x2 -5 %:
+// the product's kernels are VALU-issue-bound at 0.5-0.6 of their issue floor, so the recomputed y_i cost more than the saved
+// bytes return.  The default therefore stays k_behz_to_bsk_pm + two transform launches; this kernel is kept for parameter
+// sets / chips where the balance differs, and parity-tested (tests/test_gpu_parity.py fallback switches).  A workgroup is
+// (input polynomial p, role r): role r < K + 1 is auxiliary prime b_r -- it reads the K residue polynomials x_i of p at its
+// threads' sixteen coefficient positions, forms the canonical y_i, the small-Montgomery remainder and ITS column of the
+// base extension exactly as k_behz_to_bsk_pm does (same constants, same grouping: same integers), and runs straight into the
+// forward transform mod b_r with the extended residues still in registers; role K + 1 + i is the plain forward transform
+// of x_i mod q_i.  The extended polynomials never exist in memory in coefficient form: per input polynomial the separate
+// launches moved K + (K+1) [k_behz_to_bsk_pm] + 2 (K+1) + 2 K [two transform launches] = 6 K + 3 residue polynomials
+// through HBM, this one K (read once: the 2 K + 1 workgroups of p sit 8 apart in blockIdx -- same XCD, dispatched back to
+// back, the re-reads hit its L2 -- same placement as k_behz_tensor_intt) + 2 K + 1 written.  The price is the y_i
+// computed K + 1 times instead of once (K mul_pm + canonicalisation per coefficient and auxiliary prime).
+// Sixteen coefficients per thread in two halves of eight, so that the two-column accumulators of a half (32 VGPRs), the
+// operand of the term in flight (16) and the finished residues (32) stay inside the transform's register budget.
+template <int L, int K, typename CQ, typename CB>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_prepare_pm(const u64 *__restrict__ in, u64 *__restrict__ xq, u64 *__restrict__ xb,
+                                                                         RnsBase qbase, RnsBase bbase, const BehzPmDev *__restrict__ Tp, u64 n_polys) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, R = 2 * K + 1;
+    const int tid = threadIdx.x;
+    const u64 bid = blockIdx.x, chunk = bid / (8 * R), rem = bid % (8 * R);
+    const u32 role = (u32)(rem >> 3);
+    const u64 p = chunk * 8 + (rem & 7);
+    if (p >= n_polys) return;
+    u64 x[1][16];
+    if (role > K) {                                         // q-base: the plain forward transform (k_ntt_fwd_pm)
+        const u32 i = role - (K + 1);
+        const PmMod m = qbase.pm[i];
+        load_coeff<L>(x[0], in + (p * K + i) * N, tid);
+        ntt_fwd_regs_pm<L, 1, 16, CQ::LIM, CQ::CS>(x, qbase.tw_pm + (size_t)i * N, m, lds, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[0][r] = canon_pm(x[0][r], m);
+        store_slots<L>(x[0], xq + (p * K + i) * N, tid);
+        return;
+    }
+    const BehzPmDev &T = *Tp;
+    const u32 j = role;
+    const PmMod mb = T.b[j];
+    constexpr u32 MY = (1u << PM_SPLIT_Y) - 1, MZ = (1u << PM_SPLIT_Z) - 1;
+    // the 2 K groups of eight operand loads (half h, residue i) run one group AHEAD of the arithmetic: a group's round trip to
+    // L2 / HBM is covered by the previous group's products instead of being waited out 2 K times per workgroup
+    u64 v[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[0][e] = in[(p * K + 0) * N + elem_index<L - 4>(tid, e)];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        PmAcc acc[8];
+        u64 tot[8], rm[8];                                  // rm: the small-Montgomery column mod 2^32 (only its low word is used)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { acc[e].A = 0; acc[e].B = 0; tot[e] = 0; rm[e] = 0; }
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const int g = h * K + i;                        // this group; the next one is (h, i + 1) or (1, 0)
+            if (g + 1 < 2 * K) {
+                const int hn = (i + 1 < K) ? h : 1, in_ = (i + 1 < K) ? i + 1 : 0;
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[(g + 1) & 1][e] = in[(p * K + in_) * N + elem_index<L - 4>(tid, 8 * hn + e)];
+            }
+            PM_FENCE();
+            const PmMod m = T.q[i];
+            const ulonglong2 w = T.mt_inv_punct[i], c = T.ext_q2b[i][j];
+            const u32 pm = (u32)T.punct_q_mod_mt[i];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (i > 0 && i % PM_GROUP_Y == 0) { tot[e] += pm_acc_reduce(acc[e], mb); acc[e].A = 0; acc[e].B = 0; }      // K > 4: a second group of columns
+                const u64 y = canon_fold_pm(mul_pm(v[g & 1][e], w, m), m);                    // canonical: used as an integer below
+                rm[e] = (u64)(u32)y * pm + rm[e];                                              // one multiply-add; mod 2^32 at the end
+                pm_mac(acc[e], (u32)y & MY, (u32)(y >> PM_SPLIT_Y), c);
+            }
+            PM_FENCE();
+        }
+        const u32 nq = (u32)T.neg_inv_q_mod_mt;
+        const ulonglong2 eq = T.ext_q_b[j];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 r = (u64)((u32)rm[e] * nq);
+            const u64 rb = r >= 0x80000000ULL ? r + mb.q - 0x100000000ULL : r;                 // centred remainder
+            pm_mac(acc[e], (u32)rb & MZ, (u32)(rb >> PM_SPLIT_Z), eq);
+            x[0][8 * h + e] = canon_fold_pm(tot[e] + pm_acc_reduce(acc[e], mb), mb);           // the value k_behz_to_bsk_pm stores
+        }
+    }
+    ntt_fwd_regs_pm<L, 1, 16, CB::LIM, CB::CS>(x, bbase.tw_pm + (size_t)j * N, mb, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[0][r] = canon_pm(x[0][r], mb);
+    store_slots<L>(x[0], xb + (p * (K + 1) + j) * N, tid);
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
                                                             const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
@@ -1066,8 +1156,30 @@ static int qbase_ntt(bool inverse, const fhe_ctx *c, const u64 *in, u64 *out, u6
 
 // operand preparation (steps 0-2 up to the forward transforms): src [count][s][k][n] -> xq [count][s][k][n] (NTT),
 // xb [count][s][k+1][n] (NTT)
+template <int K>
+static int behz_prepare_fused(const fhe_ctx *c, const u64 *src, u64 n_polys, u64 *xq, u64 *xb, hipStream_t st) {
+    const RnsBase qb = c->qb.dev(), bb = c->behz->aux.dev();
+    if ((n_polys + 8) * (2 * K + 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    const unsigned grid = (unsigned)(((n_polys + 7) / 8) * 8 * (2 * K + 1));
+    DISPATCH_L(c->logn, {
+        if (c->qb.pm_class == 1) k_behz_prepare_pm<L, K, PmA, PmB><<<grid, NttShape<L>::TP, 0, st>>>(src, xq, xb, qb, bb, c->behz->pm_dev, n_polys);
+        else k_behz_prepare_pm<L, K, PmB, PmB><<<grid, NttShape<L>::TP, 0, st>>>(src, xq, xb, qb, bb, c->behz->pm_dev, n_polys);
+    });
+    KERNEL_CHECK();
+    return FHE_OK;
+}
 static int behz_prepare(const fhe_ctx *c, const u64 *src, u32 s, u64 count, u64 *xq, u64 *xb, hipStream_t st) {
     const u32 k = c->k, n = c->n;
+    // both bases on pseudo-Mersenne arithmetic with two-column conversions: base extension fused into the forward transforms
+    if (c->behz->pm_dev && c->qb.pm_class && c->behz->aux.pm_class == 2 && !c->opt.ntt_nopm && c->opt.behz_fused_prepare && k <= 4 &&
+        !(fhe_rgb_f64_supported(c) && !c->opt.force_u64)) {
+        switch (k) {
+            case 1: return behz_prepare_fused<1>(c, src, count * s, xq, xb, st);
+            case 2: return behz_prepare_fused<2>(c, src, count * s, xq, xb, st);
+            case 3: return behz_prepare_fused<3>(c, src, count * s, xq, xb, st);
+            default: return behz_prepare_fused<4>(c, src, count * s, xq, xb, st);
+        }
+    }
     switch (k) {
 #define GO(KK) case KK: if (c->behz->pm_dev) k_behz_to_bsk_pm<KK><<<grid2(n / PCPT, count * s), 256, 0, st>>>(src, xb, c->behz->pm_dev, n, count * s); \
                         else if (c->behz->wide_dot) k_behz_to_bsk<KK, TO_BSK_CPT, WIDE_CHUNK><<<grid2(n / TO_BSK_CPT, count * s), 256, 0, st>>>(src, xb, c->behz->dev, n, count * s); \

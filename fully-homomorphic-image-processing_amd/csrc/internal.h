@@ -58,6 +58,8 @@ struct FheOptions {
     bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
     bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions
     bool behz_tensor_single = false; // FHE_BEHZ_TENSOR_SINGLE=1: tensor + inverse transform one polynomial per workgroup
+    bool behz_fused_prepare = false; // FHE_BEHZ_FUSED_PREPARE=1: base extension fused into the forward transforms (k_behz_prepare_pm: 25 % less HBM traffic per
+                                     // product, 5 % slower -- the y_i are recomputed per auxiliary prime and the kernels are issue-bound; profiles/EXPERIMENTS.md)
 };
 
 struct fhe_ctx {

@@ -50,6 +50,16 @@ report("dyadic_multiply", timed(lambda: ev.dyadic_multiply(a, b, out=out)), 3 * 
 Bm = max(1, B // 8)
 am, bm = a[:Bm].contiguous(), b[:Bm].contiguous()
 report("multiply 2x2->3", timed(lambda: ev.multiply(am, bm), 3), (2 + 2 + 3) * Bm * ct_bytes / 2, Bm)
+if preset == "P8192":      # counter traffic of the product's launches (tools/collect_traffic.py ctct), quoted only for the sources it was measured on
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_ctct.json")
+    if os.path.exists(tpath):
+        import collect_traffic
+        tj = json.load(open(tpath))
+        same = tj.get("kernel_source_hash") == collect_traffic.ctct_source_hash()
+        print(json.dumps({"preset": preset, "op": "multiply 2x2->3 traffic", "hbm_bytes_per_product": round(tj["hbm_bytes_per_product"]) if same else None,
+                          "algorithmic_bytes_per_product": tj["algorithmic_bytes_per_product"], "ratio_to_algorithmic": round(tj["ratio_to_algorithmic"], 2) if same else None,
+                          "note": None if same else "profiles/pmc_traffic_ctct.json was measured on other kernel sources; re-run tools/collect_traffic.py ctct"}), flush=True)
 report("square 2->3", timed(lambda: ev.square(am), 3), (2 + 3) * Bm * ct_bytes / 2, Bm)
 dbc = 30
 evk = fhe.KeyGenerator(ctx, seed=3).generate_evaluation_keys(dbc)

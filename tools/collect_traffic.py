@@ -8,6 +8,10 @@ a kernel with the same access pattern and a known byte count: k_poly_f64<MODE 0>
 forward NTT, `src[r * TP + tid]` u64 loads like k_dct_rows) over a buffer far larger than the Infinity
 Cache, which must read exactly its input and write exactly its output.
 
+`collect_traffic.py ctct` measures the ct x ct launch set instead (a batch of 2x2 products at P8192, every launch of
+fhe_multiply summed) and writes profiles/pmc_traffic_ctct.json, tied to behz.hip + ntt_core.h by hash; tools/bench_ops.py
+prints it beside its multiply line.
+
 Writes profiles/pmc_traffic.json (tracked; read by bench.py) with the kernel names it saw and the hash of the
 kernel sources it measured: bench.py prints `traffic: null` when the running sources differ."""
 import collections
@@ -59,12 +63,77 @@ def run_pass(counters, tag, cmd, match):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, names
 
 
+# ---- ct x ct (csrc/behz.hip): every launch of a batch of 2x2 products at P8192 ------------------------------------------
+MUL_BATCH, MUL_REPS = 256, 3
+MUL = [sys.executable, "-c",
+       "import sys; sys.path.insert(0, %r); import torch, fhip_amd as fhe; ctx = fhe.SEALContext.preset('P8192'); ev = fhe.Evaluator(ctx); "
+       "a, b = ctx.random_ct(%d, seed=1), ctx.random_ct(%d, seed=2); [ev.multiply(a, b) for _ in range(%d)]; torch.cuda.synchronize()"
+       % (ROOT, MUL_BATCH, MUL_BATCH, MUL_REPS)]
+MUL_KERNELS = ["k_behz_prepare_pm", "k_behz_to_bsk", "k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back"]
+
+
+def ctct_source_hash():
+    """the sources the ct x ct record belongs to: behz.hip and the headers its kernels are built from, plus fhe_hip.hip (the
+    transform kernels and their launch plan)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
+    for n in ("behz.hip", "fhe_hip.hip", "internal.h", "modarith.h", "ntt_core.h", "host_math.h"):
+        h.update(n.encode())
+        h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_pass_sum(counters, tag, cmd, match):
+    """like run_pass, but SUMS the counter over every dispatch of a kernel family (a product is several launches)"""
+    out = os.path.join(ROOT, "gpurun_out", "traffic_" + tag)
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--pmc", *counters, "--"] + cmd,
+                   check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tot, calls = collections.defaultdict(float), collections.defaultdict(int)
+    with open(os.path.join(out, "p_counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            for m in match:
+                if m in row["Kernel_Name"]:
+                    tot[m] += float(row["Counter_Value"])
+                    calls[m] += 1
+                    break
+    return tot, calls
+
+
+def ctct(f_read, f_write):
+    k, n = 4, 8192
+    alg = (2 + 2 + 3) * k * n * 8                                  # read two ct(2), write one ct(3): 1,835,008 B
+    rd, calls = run_pass_sum(["FETCH_SIZE"], "mul_fetch", MUL, MUL_KERNELS)
+    wr, _ = run_pass_sum(["WRITE_SIZE"], "mul_write", MUL, MUL_KERNELS)
+    products = MUL_BATCH * MUL_REPS
+    per_kernel, total = {}, 0.0
+    for m in MUL_KERNELS:
+        if not calls.get(m):
+            continue
+        r, w = rd[m] * 1024 * f_read / products, wr[m] * 1024 * f_write / products
+        per_kernel[m] = {"read_bytes_per_product": r, "write_bytes_per_product": w, "launches_per_product_batch": calls[m] / MUL_REPS}
+        total += r + w
+    res = {"hbm_bytes_per_product": total, "algorithmic_bytes_per_product": alg, "ratio_to_algorithmic": total / alg,
+           "residue_polynomials_moved_per_product": total / (n * 8), "per_kernel": per_kernel, "products_per_dispatch": MUL_BATCH,
+           "kernel_source_hash": ctct_source_hash(), "read_factor": f_read, "write_factor": f_write,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), summed over every launch of %d x fhe_multiply of %d 2x2 "
+                     "products at P8192 (n = 8192, four 54/55-bit moduli), per product; factors as calibrated for pmc_traffic.json; "
+                     "tools/collect_traffic.py ctct" % (MUL_REPS, MUL_BATCH)}
+    for d in ("profiles", "gpurun_out"):
+        os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+        with open(os.path.join(ROOT, d, "pmc_traffic_ctct.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
 def main():
     cal_bytes = CAL_CTS * 2 * 3 * 4096 * 8
     crd, cnames = run_pass(["FETCH_SIZE"], "cal_fetch", CAL, ["k_poly_f64"])
     cwr, _ = run_pass(["WRITE_SIZE"], "cal_write", CAL, ["k_poly_f64"])
     f_read = cal_bytes / (crd["k_poly_f64"]["FETCH_SIZE"] * 1024)
     f_write = cal_bytes / (cwr["k_poly_f64"]["WRITE_SIZE"] * 1024)
+    if "ctct" in sys.argv[1:]:
+        return ctct(f_read, f_write)
     rd, names = run_pass(["FETCH_SIZE"], "fetch", CMD, ["k_dct_rows", "k_dct_cols"])
     wr, _ = run_pass(["WRITE_SIZE"], "write", CMD, ["k_dct_rows", "k_dct_cols"])
     per_kernel, total = {}, 0.0
