@@ -46,6 +46,7 @@ SIGNATURES = {
     "fhe_download": (_i, [_vp, _vp, _sz, _vp]),
     "fhe_copy": (_i, [_vp, _vp, _sz, _vp]),
     "fhe_stream_sync": (_i, [_vp]),
+    "fhe_gather": (_i, [_vp, _u64, _u64, _vp, _u64, _vp]),
     "fhe_frac_encode": (_i, [_u32, _u64, _dbl, _i, _i, _vp]),
     "fhe_frac_decode": (_dbl, [_u32, _u64, _vp, _i, _i]),
     "fhe_add": (_i, [_vp, _vp, _vp, _vp, _u64, _vp]),

@@ -339,6 +339,39 @@ extern "C" int fhe_copy(void *dst, const void *src, size_t bytes, fhe_stream s) 
 }
 extern "C" int fhe_stream_sync(fhe_stream s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return FHE_OK; }
 
+// fhe_gather: `count` scattered device buffers of words_each u64 -> one strided batch, ONE launch per 256 sources.  The
+// source addresses travel in the kernel arguments (2 KB), so the call needs no staging copy and no host synchronisation.
+// This is what turns the facade's one-ciphertext-at-a-time calls into batched launches (seal/seal.h, lazy evaluation).
+namespace {
+constexpr int GATHER_PTRS = 256;
+struct GatherArgs { const ulonglong2 *src[GATHER_PTRS]; };
+__global__ __launch_bounds__(256) void k_gather(GatherArgs a, ulonglong2 *__restrict__ dst, u64 pairs_each, u64 dst_stride_pairs) {
+    const ulonglong2 *__restrict__ s = a.src[blockIdx.y];
+    ulonglong2 *__restrict__ d = dst + (u64)blockIdx.y * dst_stride_pairs;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < pairs_each; i += (u64)gridDim.x * blockDim.x) d[i] = s[i];
+}
+}  // namespace
+extern "C" int fhe_gather(const uint64_t *const *src_host, uint64_t count, uint64_t words_each, uint64_t *dst, uint64_t dst_stride_words, fhe_stream s) {
+    if (!count || !words_each) return FHE_OK;
+    if (!src_host || !dst) return fail(FHE_ERR_PARAM, "null argument");
+    if ((words_each & 1) || (dst_stride_words & 1) || dst_stride_words < words_each || ((uintptr_t)dst & 15))
+        return fail(FHE_ERR_PARAM, "gather moves 16-byte units: even word counts and 16-byte aligned buffers");
+    const u64 pairs = words_each / 2;
+    const unsigned bx = (unsigned)std::min<u64>((pairs + 255) / 256, 64);
+    for (u64 done = 0; done < count; done += GATHER_PTRS) {
+        const unsigned part = (unsigned)std::min<u64>(GATHER_PTRS, count - done);
+        GatherArgs a;
+        for (unsigned i = 0; i < part; ++i) {
+            if (!src_host[done + i] || ((uintptr_t)src_host[done + i] & 15)) return fail(FHE_ERR_PARAM, "gather source %llu is null or not 16-byte aligned", (unsigned long long)(done + i));
+            a.src[i] = (const ulonglong2 *)src_host[done + i];
+        }
+        for (unsigned i = part; i < GATHER_PTRS; ++i) a.src[i] = nullptr;
+        k_gather<<<dim3(bx, part), 256, 0, (hipStream_t)s>>>(a, (ulonglong2 *)(dst + done * dst_stride_words), pairs, dst_stride_words / 2);
+        KERNEL_CHECK();
+    }
+    return FHE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // FractionalEncoder (host)
 // ------------------------------------------------------------------------------------------------

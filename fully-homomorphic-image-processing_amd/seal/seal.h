@@ -8,10 +8,19 @@
 // FractionalEncoder, coeff_modulus_128.  Semantics follow SEAL 2.3: value-type ciphertexts with deep
 // copies, in-place Evaluator operations on the first argument, std::invalid_argument on misuse.
 //
-// Ciphertexts live in HBM; every Evaluator call is one or a few asynchronous kernel launches on the
-// default stream, and the host synchronises only in save()/decrypt().  This is the drop-in,
-// one-ciphertext-at-a-time mode; the throughput path is the batched/fused C ABI (fhe_dct8x8_quant
-// etc.), which the facade exposes through seal::hip::* helpers at the bottom of this file.
+// Ciphertexts live in HBM.  LAZY EVALUATION (round 4, the default): an Evaluator call records a node of a per-context
+// expression graph -- a Ciphertext is a handle to an immutable value, so the copies the reference makes around every
+// call (homo/fhe_image.h:207 `Ciphertext boaz1(data[i])`, `tmp0 = boaz1`) are aliases, not device copies -- and nothing
+// is launched until a value is observed (save, decrypt, ptr()).  The flush then levels the graph (operands before
+// consumers), drops values nothing can reach any more, and issues every level's calls of one kind -- same operation,
+// same sizes, same plaintext -- as ONE batched launch of the C ABI over operands brought together by fhe_gather: the
+// eight row lines and eight column lines of encrypted_dct (homo/fhe_image.h:206-284) and the three channels
+// server_jpeg transforms before it saves (homo/server_jpeg.cpp:127-153) are independent, so ~2,500 launches per colour
+// block become ~150.  Every operation is the same exact ring arithmetic on the same operands, so the ciphertext bytes do
+// not depend on the mode: FHE_FACADE_EAGER=1 executes each call when it is made (tests run the reference's mains in both
+// modes and compare the streams byte for byte).  Values are materialised in creation order within a level, on the default
+// stream; the host synchronises only in save()/decrypt().  The throughput path proper is the batched/fused C ABI
+// (fhe_dct8x8_quant etc.), which the facade exposes through seal::hip::* helpers at the bottom of this file.
 //
 // The reference headers rely on `using namespace std` leaking out of SEAL's headers
 // (homo/fhe_image.h:286 `chrono::duration<double, milli>`), hence the
@@ -24,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -31,11 +41,13 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <new>
 #include <random>
 #include <sys/random.h>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "fhe_hip.h"
@@ -75,17 +87,41 @@ struct Big {                                  // fixed 768-bit unsigned integer 
 class Pool {
 public:
     static Pool &instance() { static Pool p; return p; }
+    // batch buffers of the lazy mode come in many sizes: classes of (1, 1.5) x 2^e words keep them reusable
+    static size_t size_class(size_t words) {
+        if (words <= 4096) return words;
+        size_t c = 4096;
+        while (c < words) { if (c + c / 2 >= words) return c + c / 2; c *= 2; }
+        return c;
+    }
     uint64_t *get(size_t words) {
         auto &fl = free_[words];
         if (!fl.empty()) { uint64_t *p = fl.back(); fl.pop_back(); return p; }
         void *q = nullptr;
-        check(fhe_dev_alloc(words * 8, &q), "device alloc");
+        check(fhe_dev_alloc((words + (guard() ? 2 : 0)) * 8, &q), "device alloc");
+        if (guard()) {                                       // FHE_FACADE_GUARD=1 (debugging): a canary behind every buffer, checked when it comes back
+            const uint64_t canary[2] = {kCanary, kCanary};
+            check(fhe_upload((uint64_t *)q + words, canary, 16, nullptr), "upload");
+            check(fhe_stream_sync(nullptr), "sync");
+        }
         return (uint64_t *)q;
     }
-    void put(uint64_t *p, size_t words) { free_[words].push_back(p); }
+    void put(uint64_t *p, size_t words) {
+        if (guard()) {
+            uint64_t canary[2] = {0, 0};
+            if (fhe_stream_sync(nullptr) == 0 && fhe_download(canary, p + words, 16, nullptr) == 0 && fhe_stream_sync(nullptr) == 0 &&
+                (canary[0] != kCanary || canary[1] != kCanary)) {
+                std::fprintf(stderr, "[seal facade] a kernel wrote past the end of a %zu-word buffer\n", words);
+                std::abort();
+            }
+        }
+        free_[words].push_back(p);
+    }
     // buffers are returned to the driver at process exit (the HIP runtime may already be gone when
     // static destructors run, so nothing is freed explicitly here)
 private:
+    static bool guard() { static const bool g = [] { const char *e = std::getenv("FHE_FACADE_GUARD"); return e && *e == '1'; }(); return g; }
+    static constexpr uint64_t kCanary = 0x5AFE5AFE5AFE5AFEULL;
     std::map<size_t, std::vector<uint64_t *>> free_;
 };
 
@@ -196,6 +232,40 @@ namespace detail {
 // lazy Shoup bounds values below q_i) -- where SEAL's load + is_valid_for checks would reject them.
 struct KnownModuli { uint32_t k, n; std::vector<uint64_t> q; };
 inline std::vector<KnownModuli> &known_moduli() { static std::vector<KnownModuli> v; return v; }
+
+// ---- the expression graph of the lazy mode ---------------------------------------------------------------------------
+struct Storage {                       // a refcounted device allocation; a batched launch's results are slices of one
+    uint64_t *p;
+    size_t words;
+    explicit Storage(size_t w) : p(nullptr), words(Pool::size_class(w)) { p = Pool::instance().get(words); }
+    ~Storage() { Pool::instance().put(p, words); }
+    Storage(const Storage &) = delete;
+    Storage &operator=(const Storage &) = delete;
+};
+struct PlainEntry {                    // one distinct plaintext an Evaluator has seen: the group key of its products
+    std::vector<uint64_t> coeffs;      // significant coefficients
+    int nnz;
+    DevBuf prepared;                   // fhe_plain_prepare form, built when the first dense product runs
+    PlainEntry() : nnz(0) {}
+};
+struct CtxState;
+struct Node {                          // an immutable ciphertext VALUE: materialised (st) or the recipe for it (op, a, b, plain)
+    enum Op { VALUE, ADD, SUB, NEG, ADDP, SUBP, MULP, MUL, SQR };
+    Op op;
+    uint32_t size, k, n;
+    std::shared_ptr<Node> a, b;
+    std::shared_ptr<PlainEntry> plain;
+    std::shared_ptr<Storage> st;
+    size_t off;
+    CtxState *ctx;
+    int handles;                       // Ciphertext objects holding this value
+    int level;
+    bool needed;
+    Node() : op(VALUE), size(0), k(0), n(0), off(0), ctx(nullptr), handles(0), level(0), needed(false) {}
+    bool done() const { return (bool)st; }
+    uint64_t *ptr() const { return st->p + off; }
+    size_t words() const { return (size_t)size * k * n; }
+};
 struct CtxState {
     fhe_ctx *h;
     uint32_t n, k;
@@ -204,10 +274,32 @@ struct CtxState {
     Big Q, Qhalf;
     std::vector<Big> punct;            // Q / q_i
     std::vector<uint64_t> inv_punct;   // (Q/q_i)^-1 mod q_i
-    CtxState() : h(nullptr), n(0), k(0), t(0) {}
-    ~CtxState() { if (h) fhe_ctx_destroy(h); }
+    // lazy mode: values recorded and not yet computed, in creation order (operands before consumers)
+    std::vector<std::shared_ptr<Node>> pending;
+    size_t pending_words;
+    bool eager, flushing;
+    struct Stats { uint64_t recorded, computed, dropped, flushes, groups, launches, gathers; Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0) {} } stats;
+    CtxState() : h(nullptr), n(0), k(0), t(0), pending_words(0), eager(false), flushing(false) {
+        const char *e = std::getenv("FHE_FACADE_EAGER");
+        eager = e && *e == '1';
+    }
+    ~CtxState() {
+        pending.clear();
+        if (h) fhe_ctx_destroy(h);
+        // FHE_FACADE_STATS=1: one line on stderr when the context goes away; any other value: appended to the file of that name
+        if (const char *e = std::getenv("FHE_FACADE_STATS")) {
+            FILE *f = (e[0] == '1' && !e[1]) ? stderr : std::fopen(e, "a");
+            if (f) {
+                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu\n",
+                             eager ? "eager" : "lazy", (unsigned long long)stats.recorded, (unsigned long long)stats.computed, (unsigned long long)stats.dropped,
+                             (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers);
+                if (f != stderr) std::fclose(f);
+            }
+        }
+    }
     size_t poly_words() const { return (size_t)k * n; }
 };
+void flush(CtxState &s);               // defined below Ciphertext
 }  // namespace detail
 
 class SEALContext {
@@ -279,17 +371,19 @@ private:
 // not pinned by anything in the reference -- SURVEY.md App. A.6): magic "FHEHIP1\0", u32 polys,
 // u32 k, u32 n, u32 reserved, then polys*k*n little-endian u64.
 namespace detail {
-inline void save_words(std::ostream &os, const DevBuf &buf, uint32_t polys, uint32_t k, uint32_t n) {
+inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32_t polys, uint32_t k, uint32_t n) {
     const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
     uint32_t hdr[4] = {polys, k, n, 0};
     os.write(magic, 8);
     os.write((const char *)hdr, sizeof hdr);
-    std::vector<uint64_t> h(buf.words());
-    if (!h.empty()) buf.download(h.data(), h.size());
+    std::vector<uint64_t> h(words);
+    if (words) check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
     os.write((const char *)h.data(), (std::streamsize)(h.size() * 8));
 }
+inline void save_words(std::ostream &os, const DevBuf &buf, uint32_t polys, uint32_t k, uint32_t n) { save_raw(os, buf.ptr(), buf.words(), polys, k, n); }
 #define FHE_FACADE_MAX_POLYS 64      /* the deepest reference circuit reaches size 22 (homo/fhe_decode.h:239) */
-inline void load_words(std::istream &is, DevBuf &buf, uint32_t &polys, uint32_t &k, uint32_t &n, uint32_t want_polys = 0) {
+// header + payload of one record into host memory, every field bounded and every residue checked (the stream is untrusted)
+inline void load_host(std::istream &is, std::vector<uint64_t> &h, uint32_t &polys, uint32_t &k, uint32_t &n, uint32_t want_polys = 0) {
     char magic[8];
     uint32_t hdr[4];
     is.read(magic, 8);
@@ -303,7 +397,7 @@ inline void load_words(std::istream &is, DevBuf &buf, uint32_t &polys, uint32_t 
     for (const auto &m : known_moduli()) if (m.k == hdr[1] && m.n == hdr[2]) km = &m;
     if (!known_moduli().empty() && !km) throw std::invalid_argument("ciphertext/key does not match any context of this process");
     polys = hdr[0]; k = hdr[1]; n = hdr[2];
-    std::vector<uint64_t> h((size_t)polys * k * n);
+    h.resize((size_t)polys * k * n);
     is.read((char *)h.data(), (std::streamsize)(h.size() * 8));
     if (!is) throw std::invalid_argument("truncated ciphertext/key stream");
     if (km) {
@@ -321,29 +415,266 @@ inline void load_words(std::istream &is, DevBuf &buf, uint32_t &polys, uint32_t 
         }
         if (!ok) throw std::invalid_argument("ciphertext/key holds residues that are not reduced modulo the coefficient moduli");
     }
+}
+inline void load_words(std::istream &is, DevBuf &buf, uint32_t &polys, uint32_t &k, uint32_t &n, uint32_t want_polys = 0) {
+    std::vector<uint64_t> h;
+    load_host(is, h, polys, k, n, want_polys);
     buf.resize(h.size());
     if (!h.empty()) buf.upload(h.data(), h.size());
 }
+// what Ciphertext::buffer() hands out: the materialised words of one ciphertext (a slice of a device allocation)
+struct CtView {
+    uint64_t *p;
+    size_t nwords;
+    uint64_t *ptr() const { return p; }
+    size_t words() const { return nwords; }
+    void upload(const uint64_t *src, size_t words, size_t at = 0) const {
+        check(fhe_upload(p + at, src, words * 8, nullptr), "upload");
+        check(fhe_stream_sync(nullptr), "sync");
+    }
+    void download(uint64_t *dst, size_t words, size_t at = 0) const { check(fhe_download(dst, p + at, words * 8, nullptr), "download"); }
+};
 }  // namespace detail
 
+// A Ciphertext is a HANDLE to an immutable value (detail::Node).  Copy construction / assignment alias the value (SEAL's
+// deep-copy semantics hold because no operation ever changes a value in place: an Evaluator call points its first argument
+// at a NEW value); the value is computed when somebody looks at it.
 class Ciphertext {
 public:
-    Ciphertext() : size_(0), k_(0), n_(0) {}
-    int size() const { return (int)size_; }
-    void save(std::ostream &os) const { detail::save_words(os, buf_, size_, k_, n_); }
-    void load(std::istream &is) { detail::load_words(is, buf_, size_, k_, n_); }
-    // facade internals
-    void shape(uint32_t size, uint32_t k, uint32_t n) { size_ = size; k_ = k; n_ = n; buf_.resize((size_t)size * k * n); }
-    uint64_t *ptr() { return buf_.ptr(); }
-    const uint64_t *ptr() const { return buf_.ptr(); }
-    uint32_t k() const { return k_; }
-    uint32_t n() const { return n_; }
-    detail::DevBuf &buffer() { return buf_; }
-    const detail::DevBuf &buffer() const { return buf_; }
+    Ciphertext() : tag_(kTag) {}
+    Ciphertext(const Ciphertext &o) : tag_(kTag) { h_.p = o.h_.p; retain(); }
+    Ciphertext(Ciphertext &&o) noexcept : tag_(kTag) { h_.p = std::move(o.h_.p); o.h_.p.reset(); }
+    Ciphertext &operator=(const Ciphertext &o) {
+        if (h_.p != o.h_.p) { release(); h_.p = o.h_.p; retain(); }
+        return *this;
+    }
+    Ciphertext &operator=(Ciphertext &&o) noexcept {
+        if (this != &o) { release(); h_.p = std::move(o.h_.p); o.h_.p.reset(); }
+        return *this;
+    }
+    // The reference's homomorphic_cos is declared to return a Ciphertext and falls off its end without a return statement
+    // (homo/fhe_decode.h:128-200), so its caller destroys an object that was never constructed -- whatever bytes the stack
+    // slot held (gcc hands that slot to Plaintext temporaries as well: the stale image of a freed std::vector).  Every
+    // constructor writes a tag and the destructor clears it; an object without the tag is left alone -- which is why the
+    // handle sits in a union: a member's destructor would run on the garbage whatever the body decides.
+    ~Ciphertext() {
+        if (tag_ != kTag) return;
+        release();
+        h_.p.~shared_ptr();
+        *(volatile uint64_t *)&tag_ = 0;
+    }
+    int size() const { return h_.p ? (int)h_.p->size : 0; }
+    void save(std::ostream &os) const {
+        if (!h_.p) { detail::save_raw(os, nullptr, 0, 0, 0, 0); return; }
+        materialize();
+        detail::save_raw(os, h_.p->ptr(), h_.p->words(), h_.p->size, h_.p->k, h_.p->n);
+    }
+    void load(std::istream &is) {
+        std::vector<uint64_t> h;
+        uint32_t polys, k, n;
+        detail::load_host(is, h, polys, k, n);
+        shape(polys, k, n);
+        if (!h.empty()) buffer().upload(h.data(), h.size());
+    }
+    // ---- facade internals --------------------------------------------------------------------------------------
+    // a fresh, materialised value with uninitialised contents, owned by this handle alone
+    void shape(uint32_t size, uint32_t k, uint32_t n) {
+        std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
+        v->size = size; v->k = k; v->n = n;
+        v->st = std::make_shared<detail::Storage>(v->words());
+        set_node(std::move(v));
+    }
+    // mutable access: the value is computed, and copied first if another handle shares it (copy on write)
+    uint64_t *ptr() {
+        if (!h_.p) return nullptr;
+        materialize();
+        if (h_.p->handles > 1 || h_.p.use_count() > 1) {
+            std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
+            v->size = h_.p->size; v->k = h_.p->k; v->n = h_.p->n;
+            v->st = std::make_shared<detail::Storage>(v->words());
+            detail::check(fhe_copy(v->ptr(), h_.p->ptr(), v->words() * 8, nullptr), "device copy");
+            set_node(std::move(v));
+        }
+        return h_.p->ptr();
+    }
+    const uint64_t *ptr() const { if (!h_.p) return nullptr; materialize(); return h_.p->ptr(); }
+    uint32_t k() const { return h_.p ? h_.p->k : 0; }
+    uint32_t n() const { return h_.p ? h_.p->n : 0; }
+    detail::CtView buffer() { uint64_t *p = ptr(); return detail::CtView{p, h_.p ? h_.p->words() : 0}; }
+    detail::CtView buffer() const { const uint64_t *p = ptr(); return detail::CtView{const_cast<uint64_t *>(p), h_.p ? h_.p->words() : 0}; }
+    const std::shared_ptr<detail::Node> &node() const { return h_.p; }
+    void set_node(std::shared_ptr<detail::Node> v) { release(); h_.p = std::move(v); retain(); }
+    void materialize() const {
+        if (!h_.p || h_.p->done()) return;
+        if (h_.p->ctx) detail::flush(*h_.p->ctx);
+        if (!h_.p->done()) throw std::runtime_error("ciphertext value was never computed (an earlier evaluation failed)");
+    }
 private:
-    detail::DevBuf buf_;
-    uint32_t size_, k_, n_;
+    void retain() { if (h_.p) ++h_.p->handles; }
+    void release() { if (h_.p) { --h_.p->handles; h_.p.reset(); } }
+    static constexpr uint64_t kTag = 0xC1F7E87A5EA1FACEULL;
+    uint64_t tag_;
+    union Hold {
+        std::shared_ptr<detail::Node> p;
+        Hold() { new (&p) std::shared_ptr<detail::Node>(); }
+        ~Hold() {}
+    } h_;
 };
+
+namespace detail {
+// ---- flush: compute everything that is pending and still reachable ----------------------------------------------------
+inline bool contiguous(const std::vector<Node *> &g, size_t lo, size_t hi, bool second) {
+    const Node *first = second ? g[lo]->b.get() : g[lo]->a.get();
+    for (size_t i = lo; i < hi; ++i) {
+        const Node *x = second ? g[i]->b.get() : g[i]->a.get();
+        if (x->ptr() != first->ptr() + (i - lo) * first->words()) return false;
+    }
+    return true;
+}
+// operand `second ? b : a` of the group as one contiguous batch: the operands themselves when they already lie back to
+// back (results of an earlier batched launch consumed in order), else gathered into `into` (or a temporary)
+inline const uint64_t *batch_operand(CtxState &s, const std::vector<Node *> &g, size_t lo, size_t hi, bool second, uint64_t *into, std::shared_ptr<Storage> &tmp) {
+    const Node *first = second ? g[lo]->b.get() : g[lo]->a.get();
+    if (hi - lo == 1 || contiguous(g, lo, hi, second)) return first->ptr();
+    const size_t w = first->words();
+    if (!into) { tmp = std::make_shared<Storage>((hi - lo) * w); into = tmp->p; }
+    std::vector<const uint64_t *> src(hi - lo);
+    for (size_t i = lo; i < hi; ++i) src[i - lo] = (second ? g[i]->b : g[i]->a)->ptr();
+    check(fhe_gather(src.data(), hi - lo, w, into, w, nullptr), "gather");
+    s.stats.launches += (hi - lo + 255) / 256;
+    s.stats.gathers += (hi - lo + 255) / 256;
+    return into;
+}
+inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size_t hi) {
+    const Node &f = *g[lo];
+    const size_t pw = s.poly_words(), cnt = hi - lo;
+    const uint32_t sa = f.a->size, sb = f.b ? f.b->size : 0, so = f.size;
+    std::shared_ptr<Storage> out = std::make_shared<Storage>(cnt * so * pw), ta, tb;
+    uint64_t *o = out->p;
+    ++s.stats.groups;
+    ++s.stats.launches;
+    switch (f.op) {
+        case Node::ADD:
+        case Node::SUB: {
+            const bool sub = f.op == Node::SUB;
+            if (sa == sb) {
+                const uint64_t *A = batch_operand(s, g, lo, hi, false, o, ta), *B = batch_operand(s, g, lo, hi, true, nullptr, tb);
+                check((sub ? fhe_sub : fhe_add)(s.h, A, B, o, (uint64_t)cnt * sa, nullptr), sub ? "sub" : "add");
+            } else {                       // destination grows (homo/fhe_resize.h:181-184, homo/fhe_decode.h:114-118,237); one value per group
+                const uint32_t m = std::min(sa, sb);
+                const uint64_t *A = f.a->ptr(), *B = f.b->ptr();
+                check((sub ? fhe_sub : fhe_add)(s.h, A, B, o, m, nullptr), sub ? "sub" : "add");
+                if (sa > sb) check(fhe_copy(o + m * pw, A + m * pw, (size_t)(sa - m) * pw * 8, nullptr), "copy");
+                else if (sub) check(fhe_negate(s.h, B + m * pw, o + m * pw, (uint64_t)(sb - m), nullptr), "negate");
+                else check(fhe_copy(o + m * pw, B + m * pw, (size_t)(sb - m) * pw * 8, nullptr), "copy");
+                ++s.stats.launches;
+            }
+            break;
+        }
+        case Node::NEG: {
+            const uint64_t *A = batch_operand(s, g, lo, hi, false, o, ta);
+            check(fhe_negate(s.h, A, o, (uint64_t)cnt * sa, nullptr), "negate");
+            break;
+        }
+        case Node::ADDP:
+        case Node::SUBP: {
+            const uint64_t *A = batch_operand(s, g, lo, hi, false, o, ta);
+            if (A != o) { check(fhe_copy(o, A, cnt * sa * pw * 8, nullptr), "copy"); ++s.stats.launches; }
+            check(fhe_add_plain(s.h, o, (uint64_t)sa * pw, cnt, f.plain->coeffs.data(), (uint32_t)f.plain->coeffs.size(), f.op == Node::ADDP ? +1 : -1, nullptr), "add_plain");
+            break;
+        }
+        case Node::MULP: {
+            const uint64_t *A = batch_operand(s, g, lo, hi, false, o, ta);
+            PlainEntry &pe = *f.plain;
+            if (pe.nnz <= FHE_SPARSE_MAX_TERMS && s.n <= 8192) {      // x+1, x^2+1, -x^(n-1), ...: signed rotations, no transform
+                check(fhe_multiply_plain_sparse(s.h, A, o, (uint64_t)cnt * sa, pe.coeffs.data(), (uint32_t)pe.coeffs.size(), nullptr), "multiply_plain");
+            } else {
+                if (!pe.prepared.words()) {
+                    pe.prepared.resize(fhe_plain_ntt_words(s.h));
+                    check(fhe_plain_prepare(s.h, pe.coeffs.data(), (uint32_t)pe.coeffs.size(), pe.prepared.ptr(), nullptr), "plain_prepare");
+                }
+                check(fhe_multiply_plain(s.h, A, o, (uint64_t)cnt * sa, pe.prepared.ptr(), nullptr), "multiply_plain");
+            }
+            break;
+        }
+        case Node::MUL:
+        case Node::SQR: {
+            const uint64_t *A = batch_operand(s, g, lo, hi, false, nullptr, ta);
+            const size_t bytes = fhe_multiply_scratch_bytes(s.h, sa, f.op == Node::SQR ? sa : sb, cnt);
+            Storage scratch((bytes + 7) / 8);
+            if (f.op == Node::SQR) check(fhe_square(s.h, A, sa, o, cnt, scratch.p, bytes, nullptr), "square");
+            else {
+                const uint64_t *B = batch_operand(s, g, lo, hi, true, nullptr, tb);
+                check(fhe_multiply(s.h, A, sa, B, sb, o, cnt, scratch.p, bytes, nullptr), "multiply");
+            }
+            s.stats.launches += f.op == Node::SQR ? 5 : 8;
+            break;
+        }
+        default: throw std::logic_error("facade: unknown pending operation");
+    }
+    for (size_t i = lo; i < hi; ++i) {
+        Node &n = *g[i];
+        n.st = out;
+        n.off = (i - lo) * so * pw;
+        n.a.reset(); n.b.reset(); n.plain.reset();          // operands may go once nobody else needs them
+        n.op = Node::VALUE;
+    }
+    s.stats.computed += cnt;
+}
+inline void flush(CtxState &s) {
+    if (s.flushing || s.pending.empty()) return;
+    s.flushing = true;
+    std::vector<std::shared_ptr<Node>> work;
+    work.swap(s.pending);
+    s.pending_words = 0;
+    ++s.stats.flushes;
+    try {
+        // what can still be observed: values with a live handle, and the operands of such values
+        for (size_t i = work.size(); i-- > 0;) {
+            Node &n = *work[i];
+            if (n.handles > 0) n.needed = true;
+            if (!n.needed) continue;
+            if (n.a && !n.a->done()) n.a->needed = true;
+            if (n.b && !n.b->done()) n.b->needed = true;
+        }
+        // levels: operands before consumers; the calls of one level are independent of each other
+        int top = 0;
+        for (auto &sp : work) {
+            Node &n = *sp;
+            if (!n.needed) { ++s.stats.dropped; continue; }
+            const int la = n.a && !n.a->done() ? n.a->level : 0, lb = n.b && !n.b->done() ? n.b->level : 0;
+            n.level = 1 + std::max(la, lb);
+            top = std::max(top, n.level);
+        }
+        std::vector<std::vector<Node *>> by_level((size_t)top + 1);
+        for (auto &sp : work) if (sp->needed) by_level[(size_t)sp->level].push_back(sp.get());
+        typedef std::tuple<int, uint32_t, uint32_t, const PlainEntry *> Key;
+        for (int lv = 1; lv <= top; ++lv) {
+            std::vector<Key> order;
+            std::map<Key, std::vector<Node *>> groups;
+            for (Node *n : by_level[(size_t)lv]) {
+                Key key((int)n->op, n->a->size, n->b ? n->b->size : 0, n->plain.get());
+                std::vector<Node *> &g = groups[key];
+                if (g.empty()) order.push_back(key);
+                g.push_back(n);
+            }
+            for (const Key &key : order) {
+                const std::vector<Node *> &g = groups[key];
+                const Node &f = *g[0];
+                const bool unequal = (f.op == Node::ADD || f.op == Node::SUB) && f.a->size != f.b->size;
+                // bound the staging memory of one launch (~1 GiB of operands); unequal-size additions go one at a time
+                const size_t words_each = (size_t)std::max(f.a->size, f.size) * s.poly_words();
+                const size_t chunk = unequal ? 1 : std::max<size_t>(1, std::min<size_t>(g.size(), ((size_t)1 << 27) / words_each));
+                for (size_t lo = 0; lo < g.size(); lo += chunk) run_group(s, g, lo, std::min(g.size(), lo + chunk));
+            }
+        }
+    } catch (...) {
+        s.flushing = false;
+        throw;
+    }
+    s.flushing = false;
+}
+}  // namespace detail
 
 class PublicKey {
 public:
@@ -697,12 +1028,9 @@ class Evaluator {
 public:
     explicit Evaluator(const SEALContext &ctx) : st_(ctx.state()) {}
 
-    void add(Ciphertext &a, const Ciphertext &b) { addsub(a, b, false); }
-    void sub(Ciphertext &a, const Ciphertext &b) { addsub(a, b, true); }
-    void negate(Ciphertext &a) {
-        need(a);
-        detail::check(fhe_negate(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), nullptr), "negate");
-    }
+    void add(Ciphertext &a, const Ciphertext &b) { need(a); need(b); record(detail::Node::ADD, a, &b, nullptr, (uint32_t)std::max(a.size(), b.size())); }
+    void sub(Ciphertext &a, const Ciphertext &b) { need(a); need(b); record(detail::Node::SUB, a, &b, nullptr, (uint32_t)std::max(a.size(), b.size())); }
+    void negate(Ciphertext &a) { need(a); record(detail::Node::NEG, a, nullptr, nullptr, (uint32_t)a.size()); }
     void add_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, +1); }
     void sub_plain(Ciphertext &a, const Plaintext &p) { plain_addsub(a, p, -1); }
     // The reference re-encodes the same few constants on every call (13 for the DCT,
@@ -711,37 +1039,15 @@ public:
         need(a);
         const int len = p.significant_coeff_count();
         if (len == 0) throw std::invalid_argument("plain cannot be zero");     // SEAL 2.3 rejects the zero plaintext
-        int nnz = 0;
-        for (int i = 0; i < len && nnz <= FHE_SPARSE_MAX_TERMS; ++i) nnz += p[i] != 0;
-        if (nnz <= FHE_SPARSE_MAX_TERMS && st_->n <= 8192) {      // x+1, x^2+1, -x^(n-1), ...: signed rotations, no transform
-            detail::check(fhe_multiply_plain_sparse(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), p.data().data(), (uint32_t)len, nullptr), "multiply_plain");
-            return;
-        }
-        const detail::DevBuf &prepared = prepared_plain(p, len);
-        detail::check(fhe_multiply_plain(st_->h, a.ptr(), a.ptr(), (uint64_t)a.size(), prepared.ptr(), nullptr), "multiply_plain");
+        record(detail::Node::MULP, a, nullptr, plain_entry(p, len), (uint32_t)a.size());
     }
     void multiply(Ciphertext &a, const Ciphertext &b) {
         need(a); need(b);
-        Ciphertext out;
-        out.shape((uint32_t)(a.size() + b.size() - 1), st_->k, st_->n);
-        const size_t bytes = fhe_multiply_scratch_bytes(st_->h, (uint32_t)a.size(), (uint32_t)b.size(), 1);
-        scratch_.resize((bytes + 7) / 8);
-        if (&a == &b || a.ptr() == b.ptr())
-            detail::check(fhe_square(st_->h, a.ptr(), (uint32_t)a.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "square");
-        else
-            detail::check(fhe_multiply(st_->h, a.ptr(), (uint32_t)a.size(), b.ptr(), (uint32_t)b.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "multiply");
-        a = std::move(out);
+        if (&a == &b || a.node() == b.node()) { square(a); return; }           // one value: the product of a ciphertext with itself
+        record(detail::Node::MUL, a, &b, nullptr, (uint32_t)(a.size() + b.size() - 1));
     }
-    void square(Ciphertext &a) {
-        need(a);
-        Ciphertext out;
-        out.shape((uint32_t)(2 * a.size() - 1), st_->k, st_->n);
-        const size_t bytes = fhe_multiply_scratch_bytes(st_->h, (uint32_t)a.size(), (uint32_t)a.size(), 1);
-        scratch_.resize((bytes + 7) / 8);
-        detail::check(fhe_square(st_->h, a.ptr(), (uint32_t)a.size(), out.ptr(), 1, scratch_.ptr(), bytes, nullptr), "square");
-        a = std::move(out);
-    }
-    // repeated until size 2, as SEAL does
+    void square(Ciphertext &a) { need(a); record(detail::Node::SQR, a, nullptr, nullptr, (uint32_t)(2 * a.size() - 1)); }
+    // repeated until size 2, as SEAL does.  Not deferred (the reference never calls it; the keys are the caller's object).
     void relinearize(Ciphertext &a, const EvaluationKeys &evk) {
         need(a);
         if (a.size() > 3) throw std::invalid_argument("relinearize: only size-3 ciphertexts are supported (keys for s^2)");
@@ -749,53 +1055,58 @@ public:
         const size_t bytes = fhe_relinearize_scratch_bytes(st_->h, evk.dbc, 1);
         scratch_.resize((bytes + 7) / 8);
         const size_t pw = st_->poly_words();
-        detail::check(fhe_relinearize(st_->h, a.ptr(), 3 * pw, 1, evk.buf.ptr(), evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
-        Ciphertext out;
-        out.shape(2, st_->k, st_->n);
-        detail::check(fhe_copy(out.ptr(), a.ptr(), 2 * pw * 8, nullptr), "copy");
-        a = std::move(out);
+        const uint64_t *src = static_cast<const Ciphertext &>(a).ptr();        // computes the value; no copy-on-write
+        std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
+        v->size = 2; v->k = st_->k; v->n = st_->n;
+        v->st = std::make_shared<detail::Storage>(3 * pw);                     // the key switch works in place on three polynomials
+        detail::check(fhe_copy(v->ptr(), src, 3 * pw * 8, nullptr), "copy");
+        detail::check(fhe_relinearize(st_->h, v->ptr(), 3 * pw, 1, evk.buf.ptr(), evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
+        a.set_node(std::move(v));
     }
+    // compute everything recorded so far (observing a value does this implicitly)
+    void flush() { detail::flush(*st_); }
 private:
     void need(const Ciphertext &c) const {
         if (c.size() < 1 || c.k() != st_->k || c.n() != st_->n) throw std::invalid_argument("ciphertext is empty or does not match the context");
     }
-    void addsub(Ciphertext &a, const Ciphertext &b, bool sub) {
-        need(a); need(b);
-        const size_t pw = st_->poly_words();
-        const int m = std::min(a.size(), b.size());
-        if (b.size() > a.size()) {            // destination grows; the tail is b (add) or -b (sub)
-            Ciphertext out;
-            out.shape((uint32_t)b.size(), st_->k, st_->n);
-            detail::check(fhe_copy(out.ptr(), a.ptr(), (size_t)a.size() * pw * 8, nullptr), "copy");
-            const uint64_t *tail = b.ptr() + (size_t)m * pw;
-            if (sub) detail::check(fhe_negate(st_->h, tail, out.ptr() + (size_t)m * pw, (uint64_t)(b.size() - m), nullptr), "negate");
-            else detail::check(fhe_copy(out.ptr() + (size_t)m * pw, tail, (size_t)(b.size() - m) * pw * 8, nullptr), "copy");
-            a = std::move(out);
-        }
-        detail::check((sub ? fhe_sub : fhe_add)(st_->h, a.ptr(), b.ptr(), a.ptr(), (uint64_t)m, nullptr), sub ? "sub" : "add");
+    // a <- op(a, b): a new value; a's old value stays what it was for every other handle
+    void record(detail::Node::Op op, Ciphertext &a, const Ciphertext *b, std::shared_ptr<detail::PlainEntry> plain, uint32_t size) {
+        detail::CtxState &s = *st_;
+        std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
+        v->op = op; v->size = size; v->k = s.k; v->n = s.n; v->ctx = &s;
+        v->a = a.node();
+        if (b) v->b = b->node();
+        v->plain = std::move(plain);
+        s.pending.push_back(v);
+        s.pending_words += v->words();
+        ++s.stats.recorded;
+        a.set_node(std::move(v));
+        // eager mode: now.  Lazy mode: bound what a long loop without observations can pile up (~6 GiB of results)
+        if (s.eager || s.pending.size() >= 32768 || s.pending_words >= ((size_t)6 << 27)) detail::flush(s);
     }
     void plain_addsub(Ciphertext &a, const Plaintext &p, int sign) {
         need(a);
         const int len = p.significant_coeff_count();
-        if (len) detail::check(fhe_add_plain(st_->h, a.ptr(), (uint64_t)a.size() * st_->poly_words(), 1, p.data().data(), (uint32_t)len, sign, nullptr), "add_plain");
+        if (len) record(sign > 0 ? detail::Node::ADDP : detail::Node::SUBP, a, nullptr, plain_entry(p, len), (uint32_t)a.size());
     }
-    const detail::DevBuf &prepared_plain(const Plaintext &p, int len) {
+    std::shared_ptr<detail::PlainEntry> plain_entry(const Plaintext &p, int len) {
         uint64_t h = 1469598103934665603ULL;                               // FNV-1a over the significant coefficients
         for (int i = 0; i < len; ++i) { h ^= p[i] + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1); h *= 1099511628211ULL; }
         auto range = plain_cache_.equal_range(h);
         for (auto it = range.first; it != range.second; ++it) {
-            const std::vector<uint64_t> &key = it->second.first;
-            if ((int)key.size() == len && std::equal(key.begin(), key.end(), p.data().begin())) return it->second.second;
+            const std::vector<uint64_t> &key = it->second->coeffs;
+            if ((int)key.size() == len && std::equal(key.begin(), key.end(), p.data().begin())) return it->second;
         }
-        if (plain_cache_.size() > 4096) plain_cache_.clear();
-        auto it = plain_cache_.emplace(h, std::make_pair(std::vector<uint64_t>(p.data().begin(), p.data().begin() + len), detail::DevBuf()));
-        it->second.second.resize(fhe_plain_ntt_words(st_->h));
-        detail::check(fhe_plain_prepare(st_->h, p.data().data(), (uint32_t)len, it->second.second.ptr(), nullptr), "plain_prepare");
-        return it->second.second;
+        if (plain_cache_.size() > 4096) plain_cache_.clear();              // entries in use stay alive through their values
+        std::shared_ptr<detail::PlainEntry> e = std::make_shared<detail::PlainEntry>();
+        e->coeffs.assign(p.data().begin(), p.data().begin() + len);
+        for (uint64_t c : e->coeffs) e->nnz += c != 0;
+        plain_cache_.emplace(h, e);
+        return e;
     }
     std::shared_ptr<detail::CtxState> st_;
     detail::DevBuf scratch_;
-    std::multimap<uint64_t, std::pair<std::vector<uint64_t>, detail::DevBuf>> plain_cache_;
+    std::multimap<uint64_t, std::shared_ptr<detail::PlainEntry>> plain_cache_;
 };
 
 // ---- throughput helpers: the fused/batched C ABI behind SEAL-typed arguments ---------------------

@@ -99,6 +99,12 @@ int fhe_upload(void *dst_dev, const void *src_host, size_t bytes, fhe_stream str
 int fhe_download(void *dst_host, const void *src_dev, size_t bytes, fhe_stream stream);
 int fhe_copy(void *dst_dev, const void *src_dev, size_t bytes, fhe_stream stream);
 int fhe_stream_sync(fhe_stream stream);
+/* `count` scattered device buffers (addresses in HOST memory, consumed before the call returns) of words_each u64 ->
+ * dst[i * dst_stride_words ...], one launch per 256 sources, no staging copy.  The SEAL facade's lazy mode uses it to
+ * run the reference's one-ciphertext-at-a-time Evaluator calls (homo/fhe_image.h:206-284) as batched launches.  16-byte
+ * units: even word counts, 16-byte aligned buffers. */
+int fhe_gather(const uint64_t *const *src_host, uint64_t count, uint64_t words_each, uint64_t *dst,
+               uint64_t dst_stride_words, fhe_stream stream);
 
 /* ---- seal::FractionalEncoder(t, poly_modulus, int_coeffs, frac_coeffs, base=2) ------------------
  * (ctor homo/server_jpeg.cpp:100; encode() call sites homo/fhe_image.h:221-236,259,301,317-319).

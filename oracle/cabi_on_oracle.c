@@ -91,6 +91,11 @@ int fhe_upload(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memc
 int fhe_download(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
 int fhe_copy(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memmove(d, s, b); return FHE_OK; }
 int fhe_stream_sync(fhe_stream st) { (void)st; return FHE_OK; }
+int fhe_gather(const uint64_t *const *src, uint64_t count, uint64_t words, uint64_t *dst, uint64_t stride, fhe_stream st) {
+    (void)st;
+    for (uint64_t i = 0; i < count; i++) memmove(dst + i * stride, src[i], words * 8);
+    return FHE_OK;
+}
 
 /* encode/decode depend on (n, t) only; keep one small oracle context per pair */
 static fo_ctx *codec_ctx(uint32_t n, uint64_t t) {
