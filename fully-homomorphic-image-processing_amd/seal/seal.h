@@ -248,6 +248,8 @@ struct PlainEntry {                    // one distinct plaintext an Evaluator ha
     DevBuf prepared;                   // fhe_plain_prepare form, built when the first dense product runs
     PlainEntry() : nnz(0) {}
 };
+inline double *io_seconds() { static double t[2] = {0, 0}; return t; }     // process-wide: host time in Ciphertext::load / save
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct CtxState;
 struct Node {                          // an immutable ciphertext VALUE: materialised (st) or the recipe for it (op, a, b, plain)
     enum Op { VALUE, ADD, SUB, NEG, ADDP, SUBP, MULP, MUL, SQR };
@@ -278,7 +280,11 @@ struct CtxState {
     std::vector<std::shared_ptr<Node>> pending;
     size_t pending_words;
     bool eager, flushing;
-    struct Stats { uint64_t recorded, computed, dropped, flushes, groups, launches, gathers; Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0) {} } stats;
+    struct Stats {
+        uint64_t recorded, computed, dropped, flushes, groups, launches, gathers;
+        double flush_s;                // host time inside flush (launch overhead: the launches are asynchronous)
+        Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0), flush_s(0) {}
+    } stats;
     CtxState() : h(nullptr), n(0), k(0), t(0), pending_words(0), eager(false), flushing(false) {
         const char *e = std::getenv("FHE_FACADE_EAGER");
         eager = e && *e == '1';
@@ -290,9 +296,10 @@ struct CtxState {
         if (const char *e = std::getenv("FHE_FACADE_STATS")) {
             FILE *f = (e[0] == '1' && !e[1]) ? stderr : std::fopen(e, "a");
             if (f) {
-                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu\n",
+                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu save_ms=%llu\n",
                              eager ? "eager" : "lazy", (unsigned long long)stats.recorded, (unsigned long long)stats.computed, (unsigned long long)stats.dropped,
-                             (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers);
+                             (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers,
+                             (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3));
                 if (f != stderr) std::fclose(f);
             }
         }
@@ -467,14 +474,18 @@ public:
     void save(std::ostream &os) const {
         if (!h_.p) { detail::save_raw(os, nullptr, 0, 0, 0, 0); return; }
         materialize();
+        const double t0 = detail::now_s();
         detail::save_raw(os, h_.p->ptr(), h_.p->words(), h_.p->size, h_.p->k, h_.p->n);
+        detail::io_seconds()[1] += detail::now_s() - t0;
     }
     void load(std::istream &is) {
+        const double t0 = detail::now_s();
         std::vector<uint64_t> h;
         uint32_t polys, k, n;
         detail::load_host(is, h, polys, k, n);
         shape(polys, k, n);
         if (!h.empty()) buffer().upload(h.data(), h.size());
+        detail::io_seconds()[0] += detail::now_s() - t0;
     }
     // ---- facade internals --------------------------------------------------------------------------------------
     // a fresh, materialised value with uninitialised contents, owned by this handle alone
@@ -624,6 +635,7 @@ inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size
 inline void flush(CtxState &s) {
     if (s.flushing || s.pending.empty()) return;
     s.flushing = true;
+    const double t_flush = now_s();
     std::vector<std::shared_ptr<Node>> work;
     work.swap(s.pending);
     s.pending_words = 0;
@@ -673,6 +685,7 @@ inline void flush(CtxState &s) {
         throw;
     }
     s.flushing = false;
+    s.stats.flush_s += now_s() - t_flush;
 }
 }  // namespace detail
 

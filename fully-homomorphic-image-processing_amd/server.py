@@ -579,8 +579,8 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
     exchange: the three `index` ciphertexts are server-side encryptions every shard of a channel must share, so they
     are drawn on rank 0 and broadcast over `group` (3 ciphertexts; parallel.broadcast_from_root).  If encrypt_zeros has a
     `seek(i)` attribute it is called with the position of the next encryption in the reference's whole-job sequence
-    before every draw (reproducible test encryptors; any partition then writes the same bytes).  Returns the number
-    of (channel, position) units produced."""
+    before every draw (reproducible test encryptors; any partition then writes the same bytes).  Returns width * height
+    for a whole run (as before round 4), the number of (channel, position) units this shard produced otherwise."""
     from . import circuits, parallel
     ev = Evaluator(ctx)
     pc = circuits.PlainCache(ctx)
@@ -662,7 +662,7 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
                     raise IOError("short write on the ciphertext stream")
     finally:
         os.close(fd)
-    return sum(p1 - p0 for _, p0, p1 in pieces)
+    return npos if shard is None else sum(p1 - p0 for _, p0, p1 in pieces)
 
 
 def _lib_out_size(degree):

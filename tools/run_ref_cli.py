@@ -23,7 +23,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
                        ("server_jpeg", [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt", "--cmod", "4096"] + extra),
                        ("client --recieve", [cl, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg", "--cmod", "4096"] + extra)):
         t0 = time.time()
-        r = subprocess.run(argv, cwd=d, capture_output=True, text=True)
+        r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=dict(os.environ, FHE_FACADE_STATS="1"))
         dt = time.time() - t0
         print(f"{name}: rc={r.returncode} {dt:.2f} s", flush=True)
         if r.returncode: print(r.stdout[-1500:], r.stderr[-1500:]); sys.exit(1)
@@ -33,4 +33,6 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
             print(f"  reference's own timers: encrypted_dct mean {np.mean(dct):.2f} ms x{len(dct)}, rgb_to_ycc mean {np.mean(ycc):.3f} ms x{len(ycc)}")
         for ln in r.stdout.splitlines():
             if ln.startswith("RMSError"): print(" ", ln)
+        for ln in r.stderr.splitlines():
+            if ln.startswith("[seal facade]") and name == "server_jpeg": print(" ", ln)
     print("ct file MB:", os.path.getsize(d + "/image/ct_in.txt") / 1e6)
