@@ -2,6 +2,8 @@
 and the bilinear sampler (homo/fhe_resize.h:222-252)."""
 import io
 import os
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -254,3 +256,83 @@ def test_server_resize_with_real_encryptions_decrypts_to_the_plain_sampler(fhe, 
             expect = (1 - fy) * ((1 - fx) * P(0, 0, c) + fx * P(1, 0, c)) + fy * ((1 - fx) * P(0, 1, c) + fx * P(1, 1, c))
             plain, budget = orc.decrypt(sk, out[o * 3 + c])
             assert budget > 0 and abs(orc.decode(plain) - expect) < 1e-6, (o, c)
+
+
+# ---------------------------------------------------------------------------------------------
+# the same streaming loop from a C++ host (seal/server_jpeg_hip.cpp): no Python, no torch
+# ---------------------------------------------------------------------------------------------
+def _server_jpeg_hip(*argv, env=None):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fully-homomorphic-image-processing_amd", "seal", "server_jpeg_hip")
+    if not os.path.exists(exe):
+        pytest.skip("seal/server_jpeg_hip not built")
+    r = subprocess.run([exe] + [str(a) for a in argv], capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+    return r.returncode, (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else r.stderr)
+
+
+@pytest.mark.parametrize("quant", [0, 1])
+def test_cpp_streaming_server_writes_the_python_servers_bytes(fhe, oracle_mod, tmp_path, quant):
+    """five colour blocks at the BASELINE parameter set in waves of two (ragged last wave), two passes over mapped files:
+    the C++ host's output stream == server.server_jpeg's, byte for byte, and its first block equals the oracle's op-by-op result"""
+    ctx = fhe.SEALContext.preset("P4096")
+    orc = oracle_mod.Oracle.preset("P4096")
+    n_blocks = 5
+    fin, mine, cpp = tmp_path / "in.ct", tmp_path / "py.ct", tmp_path / "cpp.ct"
+    cts = orc.random_ct(n_blocks * 192, seed=77)
+    with open(fin, "wb") as f:
+        for c in cts:
+            fhe.server.write_ciphertext(f, c)
+    assert fhe.server.server_jpeg(ctx, str(fin), str(mine), n_blocks, wave_blocks=2, quant=list(fhe.YQT) if quant else None) == n_blocks
+    rc, res = _server_jpeg_hip(fin, cpp, n_blocks, 2, 4, 2, quant, 1 << 14, 4096)
+    assert rc == 0, res
+    assert res["blocks"] == n_blocks and len(res["seconds_per_pass"]) == 2
+    got = open(cpp, "rb").read()
+    assert got == open(mine, "rb").read()
+    blk = cts[:192].reshape(3, 64, 2, orc.k, orc.n)
+    ycc = np.zeros_like(blk)
+    for i in range(64):
+        ycc[0, i], ycc[1, i], ycc[2, i] = orc.rgb_to_ycc(blk[0, i], blk[1, i], blk[2, i])
+    rec = 24 + 2 * orc.k * orc.n * 8
+    first = np.frombuffer(got[24:rec], dtype=np.uint64).reshape(2, orc.k, orc.n)
+    want = orc.dct_quant(ycc[0], oracle_mod.YQT) if quant else orc.encrypted_dct(ycc[0])
+    assert np.array_equal(first, want[0])
+
+
+def test_cpp_streaming_server_rejects_a_short_or_foreign_stream(fhe, tmp_path):
+    ctx = fhe.SEALContext.preset("P4096")
+    fin = tmp_path / "in.ct"
+    with open(fin, "wb") as f:
+        for c in fhe.to_host(ctx.random_ct(192, seed=3)):
+            fhe.server.write_ciphertext(f, c)
+    rc, err = _server_jpeg_hip(fin, tmp_path / "o.ct", 2)                    # two blocks asked for, one present
+    assert rc == 1 and "stream ended" in err
+    raw = bytearray(open(fin, "rb").read())
+    raw[5 * (24 + 2 * ctx.k * ctx.n * 8)] ^= 0xFF                            # break the magic of the sixth record
+    open(fin, "wb").write(bytes(raw))
+    rc, err = _server_jpeg_hip(fin, tmp_path / "o.ct", 1)
+    assert rc == 1 and "not a ciphertext record" in err
+
+
+def test_cpp_streaming_server_feeds_the_reference_client(fhe, tmp_path):
+    """the reference's client --send, the C++ streaming server, the reference's client --recieve: the published RMSError"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    client = os.path.join(root, "oracle", "_ref", "ref_client_jpeg")
+    if not os.path.exists(client):
+        pytest.skip("oracle/_ref/ref_client_jpeg not built (needs /root/reference at build time)")
+    (tmp_path / "keys").mkdir()
+    (tmp_path / "image").mkdir()
+    shutil.copy(os.path.join(root, "tests", "golden", "boazbarak.jpg"), str(tmp_path / "image" / "in.jpg"))
+    par = ["--cmod", "4096", "--pmod", "3001"]
+
+    def run(argv):
+        r = subprocess.run(argv, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, " ".join(argv) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+
+    run([client, "--send", "-f", "image/in.jpg", "-c", "image/ct_in.txt"] + par)
+    rc, res = _server_jpeg_hip(tmp_path / "image" / "ct_in.txt", tmp_path / "image" / "ct_out.txt", 36, 12, 8, 1, 0, 3001, 4096)
+    assert rc == 0, res
+    out = run([client, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg"] + par)
+    line = [ln for ln in out.splitlines() if ln.startswith("RMSError,")]
+    assert line and line[0].split(",")[1] == "1.71767", out[-500:]

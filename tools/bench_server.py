@@ -65,6 +65,18 @@ try:
         for row in sorted(stats["trace"], key=lambda r: r[2]):
             print("%-6s wave %3d  %8.1f -> %8.1f ms" % (row[0], row[1], row[2] * 1e3, row[3] * 1e3), file=sys.stderr)
     out_bytes = os.path.getsize(fout)
+    # the same job from the C++ host (seal/server_jpeg_hip.cpp): three passes over its own mappings, the last one reported
+    cpp = None
+    exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_jpeg_hip")
+    if os.path.exists(exe):
+        import subprocess
+        want_bytes = open(fout, "rb").read(4 * per_block)
+        r = subprocess.run([exe, fin, fout, str(blocks), str(a.wave), str(a.io_threads), "3"], capture_output=True, text=True)
+        if r.returncode == 0:
+            cpp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            cpp["first_blocks_equal_python_server"] = open(fout, "rb").read(4 * per_block) == want_bytes
+        else:
+            cpp = {"error": r.stderr[-500:]}
     # spot check: the first block of the output stream against the kernels run directly on the first block of the input
     ev = fhe.Evaluator(ctx)
     first = ctx.random_ct(1, 3, 64, seed=fhe.SEED, first_index=0)
@@ -88,4 +100,4 @@ print(json.dumps({"workload": "server_jpeg stream (rgb_to_ycc + encrypted_dct pe
                   "file_write_GB_per_s_while_writing": out_bytes / max(stats.get("file_write_seconds", 0), 1e-9) / 1e9,
                   "fresh_output_file": {"seconds": fresh_dt, "colour_blocks_per_s": blocks / fresh_dt, "file_write_GB_per_s_while_writing": out_bytes / max(fresh.get("file_write_seconds", 0), 1e-9) / 1e9,
                                         "note": "first pass into a file that does not exist yet: every output page is allocated by the kernel on first touch (tmpfs), which is serialised inside the kernel; the headline figures are a long-lived server's steady state: spool files that exist and stay mapped from call to call"},
-                  "input_generation_seconds": gen_s, "first_block_equals_direct_kernels": ok, "host_cpus": os.cpu_count()}))
+                  "cpp_host": cpp, "input_generation_seconds": gen_s, "first_block_equals_direct_kernels": ok, "host_cpus": os.cpu_count()}))
