@@ -83,6 +83,7 @@ SIGNATURES = {
     "fhe_rgb_to_ycc_blocks": (_i, [_vp, _vp, _u64, _i, _i, _vp]),
     "fhe_fill_random": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "fhe_digest": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    "fhe_count_unreduced": (_i, [_vp, _vp, _u64, _vp, _vp]),
     # include/fhe_circuits.h
     "fhe_circuits_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "fhe_circuits_destroy": (_i, [_vp]),

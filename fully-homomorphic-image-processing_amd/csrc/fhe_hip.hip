@@ -264,8 +264,11 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
     // first entry point that multiplies ciphertexts (fhe_behz_ensure, call_once), so a DCT-only server neither pays for them
     // nor can fail on the auxiliary-prime search.  FHE_BEHZ_EAGER=1 restores construction at create time.
     if (env_on("FHE_BEHZ_EAGER") && (rc = fhe_behz_ensure(c))) { fhe_ctx_destroy(c); return rc; }
-    bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i)
+    // the second stream + events of the pipelined DCT mode exist only in contexts created with FHE_DCT_PIPELINE=1: an idle
+    // stream still takes a turn in the runtime's round-robin over its four hardware queues, and a host's own copy stream
+    // that lands on the compute stream's queue serialises with it (seal/server_jpeg_hip.cpp measured exactly that)
+    bool ok = !c->opt.dct_pipeline || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok && c->opt.dct_pipeline; ++i)
         ok = hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_cols[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { fhe_ctx_destroy(c); return fail(FHE_ERR_HIP, "stream/event creation failed"); }
@@ -1590,6 +1593,32 @@ extern "C" int fhe_digest(const fhe_ctx *, const uint64_t *data, uint64_t count,
     u64 blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     k_digest<<<(unsigned)blocks, 256, 0, st>>>((const u64 *)data, count, index0, (u64 *)d_out);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// residues at or above their modulus, counted: what seal::Ciphertext::load + is_valid_for reject one ciphertext at a time, for a
+// whole wave of a stream in one pass (the kernels assume canonical residues: the pseudo-Mersenne products take x < 2^62, the
+// FP64 path values below 2^52).  16 bytes per lane, one atomic per wave that saw a bad word.
+__global__ __launch_bounds__(256) void k_count_unreduced(const ulonglong2 *__restrict__ data, const Modulus *__restrict__ mods, u32 k, u32 half_n,
+                                                         u64 n_res_polys, u64 *out) {
+    u64 bad = 0;
+    for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
+        const u64 q = mods[rp % k].q;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < half_n; i += gridDim.x * blockDim.x) {
+            const ulonglong2 v = data[rp * half_n + i];
+            bad += (v.x >= q) + (v.y >= q);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
+}
+extern "C" int fhe_count_unreduced(const fhe_ctx *c, const uint64_t *ct, uint64_t n_polys, uint64_t *d_count, fhe_stream s) {
+    if (!c || !ct || !d_count) return fail(FHE_ERR_PARAM, "null argument");
+    const u64 nrp = n_polys * c->k;
+    if (!nrp) return FHE_OK;
+    dim3 grid((c->n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+    k_count_unreduced<<<grid, 256, 0, (hipStream_t)s>>>((const ulonglong2 *)ct, c->qb.d_mod, c->k, c->n / 2, nrp, (u64 *)d_count);
     KERNEL_CHECK();
     return FHE_OK;
 }

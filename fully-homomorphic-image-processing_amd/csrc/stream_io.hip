@@ -141,7 +141,7 @@ extern "C" int fhe_io_transfer(fhe_io_file *f, uint64_t first_record, uint64_t c
     if (!polys || !k || !n || k > FHE_MAX_K) return fail(FHE_ERR_PARAM, "bad record shape");
     if (!count) return FHE_OK;
     const size_t payload = (size_t)polys * k * n * 8, rec = kHeader + payload;
-    if ((first_record + count) * rec > f->size) return fail(FHE_ERR_PARAM, "ciphertext stream ended");
+    if (first_record > f->size / rec || count > f->size / rec - first_record) return fail(FHE_ERR_PARAM, "ciphertext stream ended");     // no u64 wrap for large record numbers
     if (!threads) threads = 1;
     if (threads > 64) threads = 64;
     if ((u64)threads > count) threads = (u32)count;

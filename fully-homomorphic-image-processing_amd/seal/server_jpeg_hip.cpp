@@ -69,6 +69,7 @@ struct Server {
     uint64_t *din[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint64_t *d_bad = nullptr;                      // residues at or above their modulus seen in the uploaded waves (fhe_count_unreduced)
     hipStream_t main = nullptr, h2d = nullptr, d2h = nullptr;
     std::vector<hipEvent_t> ev_copied, ev_landed;
     hipEvent_t ev_done[2], ev_drained[2];
@@ -102,6 +103,7 @@ struct Server {
             hcheck(hipEventCreateWithFlags(&ev_done[d], hipEventDisableTiming), "event");
             hcheck(hipEventCreateWithFlags(&ev_drained[d], hipEventDisableTiming), "event");
         }
+        check(fhe_dev_alloc(8, (void **)&d_bad), "fhe_dev_alloc");
         scratch_bytes = fhe_dct8x8_scratch_bytes(ctx, wave * 3);
         check(fhe_dev_alloc(scratch_bytes, &scratch), "fhe_dev_alloc(scratch)");
         // compute runs on the DEFAULT stream on purpose: the runtime spreads streams over four hardware queues, the context owns
@@ -153,6 +155,7 @@ struct Server {
             }
         });
         std::string err;
+        hcheck(hipMemsetAsync(d_bad, 0, 8, main), "memset");
         const double t0 = now();
         try {
             for (long w = 0; w < waves; ++w) {
@@ -167,6 +170,7 @@ struct Server {
                 free_in.put(InSlot{r.slot, ev_copied[r.slot], true});
                 hcheck(hipStreamWaitEvent(main, ev_copied[r.slot], 0), "wait");
                 if (drained_used[d]) hcheck(hipStreamWaitEvent(main, ev_drained[d], 0), "wait");   // dout[d] has been copied out
+                check(fhe_count_unreduced(ctx, din[d], nb * 3 * 64 * 2, d_bad, main), "fhe_count_unreduced");  // the payload is a client's: what Ciphertext::load would reject
                 check(fhe_rgb_to_ycc_blocks(ctx, din[d], nb, 100, 100, main), "fhe_rgb_to_ycc_blocks");      // in place: Y, Cb, Cr in the stream's block layout
                 check(fhe_dct8x8_quant(ctx, plan, din[d], dout[d], nb * 3, scratch, scratch_bytes, main), "fhe_dct8x8_quant");
                 hcheck(hipEventRecord(ev_done[d], main), "record");
@@ -194,6 +198,10 @@ struct Server {
         if (err.empty() && !writer_err.empty()) err = "writer: " + writer_err;
         if (err.empty() && !reader_err.empty()) err = "reader: " + reader_err;
         if (!err.empty()) throw Fail{err};
+        uint64_t bad = 0;
+        check(fhe_download(&bad, d_bad, 8, main), "fhe_download");
+        check(fhe_stream_sync(main), "fhe_stream_sync");
+        if (bad) throw Fail{"the input stream holds " + std::to_string(bad) + " residues that are not reduced modulo the coefficient moduli"};
         return dt;
     }
 };

@@ -106,6 +106,28 @@ class StreamFile:
             self.h = None
 
 
+class _ResidueCheck:
+    """fhe_count_unreduced on every uploaded wave: the streams' record headers are checked by the I/O layer, the payload here --
+    a residue at or above its modulus would otherwise be computed on silently (seal::Ciphertext::load rejects it, and so does
+    the facade's).  One u64 counter on the device, read once when the job is done."""
+
+    def __init__(self, ctx, enabled=True):
+        from . import _lib
+        self.ctx, self._lib, self.enabled = ctx, _lib, enabled
+        self.count = torch.zeros(1, dtype=torch.int64, device=ctx.device) if enabled else None
+
+    def add(self, t):
+        if self.enabled and t.numel():
+            self._lib.call("fhe_count_unreduced", self.ctx.h, C.c_void_p(t.data_ptr()), t.numel() // (self.ctx.k * self.ctx.n), C.c_void_p(self.count.data_ptr()),
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def verdict(self):
+        if self.enabled:
+            bad = int(self.count.item())
+            if bad:
+                raise ValueError("the input stream holds %d residues that are not reduced modulo the coefficient moduli" % bad)
+
+
 def _stop_pipeline(reader_thread, writer_thread, free_in, to_write):
     """Bring a streaming pipeline to rest before its mappings and staging buffers go away (normal end and error paths
     alike): both I/O threads get their end-of-work sentinel and are JOINED -- a thread may still be inside fhe_io_transfer,
@@ -119,7 +141,7 @@ def _stop_pipeline(reader_thread, writer_thread, free_in, to_write):
     torch.cuda.synchronize()
 
 
-def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None):
+def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_dct=True, io_threads=8, slots=3, stats=None, validate=True):
     """Process `n_blocks` colour blocks.  in_path / out_path: file names, or StreamFile objects a long-lived server keeps
     open (their mappings, and the page-table entries behind them, are then reused from call to call).  Input order per block: 64 R, 64 G, 64 B ciphertexts
     (homo/server_jpeg.cpp:115-124).  Output order per block: 64 Y, 64 Cb, 64 Cr
@@ -135,12 +157,15 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
       HBM -> pinned    its own HIP stream, `slots` page-locked output buffers
       pinned -> file   a writer thread: fhe_io_write_records
     Events order the hand-overs; the host never waits for the device except where a buffer is about to be reused.
-    stats (a dict), if given, receives wall seconds, device compute seconds and byte counts."""
+    stats (a dict), if given, receives wall seconds, device compute seconds and byte counts.
+    validate: every uploaded wave is checked for residues that are not below their modulus (fhe_count_unreduced; ValueError at
+    the end of the job -- what Ciphertext::load rejects per ciphertext, homo/server_jpeg.cpp:117-123)."""
     import queue
     import threading
     import time
     ev = Evaluator(ctx)
     plan = DctPlan(ctx, quant) if do_dct else None
+    residues = _ResidueCheck(ctx, validate)
     wave_blocks = max(1, min(wave_blocks, n_blocks))
     slots = max(2, slots)
     shape = (wave_blocks, 3, 64, 2, ctx.k, ctx.n)            # wave: block, channel, pixel, poly, prime, coeff
@@ -230,6 +255,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
             if stats is not None:
                 t_start.append(torch.cuda.Event(enable_timing=True))
                 t_start[-1].record(main)
+            residues.add(din[d][:nb])
             ev.rgb_to_ycc_blocks(din[d][:nb])                    # in place: Y, Cb, Cr in the stream's block layout
             if do_dct:
                 ev.dct8x8_quant(plan, din[d][:nb].view(nb * 3, 64, 2, ctx.k, ctx.n), out=dout[d][:nb].view(nb * 3, 64, 2, ctx.k, ctx.n))
@@ -258,6 +284,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         if errors:
             raise errors[0]
         torch.cuda.synchronize()
+        residues.verdict()
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
                          bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves),
@@ -325,7 +352,7 @@ def _row_windows(H, h, init_rows):
     return out
 
 
-def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None, rows=None):
+def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None, rows=None, validate=True):
     """homo/server_resize.cpp:127-146 + ResizeImage (homo/fhe_resize.h:308-392) on the GPU.
 
     Input stream: src_w * src_h pixels, row by row, three ciphertext records (R, G, B) per pixel
@@ -359,6 +386,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     from . import circuits
     ev = Evaluator(ctx)
     pc = circuits.PlainCache(ctx)
+    residues = _ResidueCheck(ctx, validate)
     init_rows = 4 if bicubic else 2
     out_size = 6 if bicubic else 4
     if dst_w < 2 or dst_h < 2 or src_h < init_rows or src_w < 1:
@@ -470,6 +498,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
                     s0 = (first + done_rows) % R
                     part = min(cnt - done_rows, R - s0)
                     ring[s0:s0 + part].copy_(hin[slot][done_rows:done_rows + part], non_blocking=True)
+                    residues.add(ring[s0:s0 + part])                 # on the copy stream, behind the copy
                     done_rows += part
                 copied = torch.cuda.Event()
                 copied.record(h2d)
@@ -520,6 +549,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         if errors:
             raise errors[0]
         torch.cuda.synchronize()
+        residues.verdict()
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
                          bytes_in=sum(c for _, c in reads) * src_w * 3 * rec_in, bytes_out=dst_w * (row1 - row0) * 3 * rec_out, steps=len(steps),
@@ -625,6 +655,9 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
         finally:
             os.close(fin)
         dev = host.to(ctx.device, non_blocking=True)
+        residues = _ResidueCheck(ctx)
+        residues.add(dev)
+        residues.verdict()
     first_run = [sum(pairs[:ch]) for ch in range(3)]
     res = []
     for ch, p0, p1 in pieces:

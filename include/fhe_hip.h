@@ -36,8 +36,8 @@
  *    them) are read ONCE, by fhe_ctx_create, and are fixed for the life of that context: no launch path
  *    reads the environment.  The defaults are the measured-best kernels; every alternative gives the same
  *    bits (the parity tests create a second context with the variable set).  Creating a context costs a few
- *    milliseconds and a few MB of device tables (twiddles of the coefficient base, one stream, four
- *    events); the ct x ct tables (twiddles for the k+1 auxiliary primes, base-conversion constants) are added
+ *    milliseconds and a few MB of device tables (twiddles of the coefficient base; one stream and four
+ *    events more in contexts created with FHE_DCT_PIPELINE=1); the ct x ct tables (twiddles for the k+1 auxiliary primes, base-conversion constants) are added
  *    by the first call that multiplies ciphertexts, so a DCT-only server neither pays for them nor can fail on
  *    the auxiliary-prime search (FHE_BEHZ_EAGER=1 builds them in fhe_ctx_create as before round 4).
  *  - "NTT form" buffers use a library-internal slot order; they are only meaningful to this
@@ -262,6 +262,13 @@ int fhe_fill_random(const fhe_ctx *ctx, uint64_t *ct, uint64_t n_polys, uint64_t
  * mod 2^64, written to *d_out (device u64). */
 int fhe_digest(const fhe_ctx *ctx, const uint64_t *data, uint64_t count, uint64_t index0,
                uint64_t *d_out, fhe_stream stream);
+
+/* Input validation for ciphertext STREAMS (include/fhe_stream.h checks record headers only): ADDS to *d_count (device u64,
+ * zeroed by the caller) the number of residues of the n_polys RNS polynomials at ct that are not below their modulus.
+ * Every kernel assumes canonical residues -- seal::Ciphertext::load rejects anything else, and so does the facade's load --
+ * so a server that takes streams from clients runs this on every wave it uploads (one HBM-bound pass, < 1 % of the PCIe
+ * time of that wave) and refuses the job when the count is not zero.  homo/server_jpeg.cpp:117-123 is the load it guards. */
+int fhe_count_unreduced(const fhe_ctx *ctx, const uint64_t *ct, uint64_t n_polys, uint64_t *d_count, fhe_stream stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,12 @@
  * gather I/O by several threads at once, payloads landing contiguously in (page-locked) staging memory that the GPU
  * copies from.  Host-only code (no device work): `threads` POSIX threads each issue preadv / pwritev calls that cover
  * many records per system call.  Blocking; callable from any thread (the Python host calls it with the GIL released).
+ *
+ * What is checked: every record HEADER (magic, polys, k, n) and the file bounds.  What is NOT: the payload -- residues that
+ * are not reduced modulo the coefficient moduli would be computed on silently (the kernels assume canonical inputs), so a
+ * server that reads streams it did not write validates each uploaded wave with fhe_count_unreduced (include/fhe_hip.h);
+ * server.server_jpeg / server_resize / server_decode and seal/server_jpeg_hip.cpp do.  A mapped stream that another process
+ * truncates while it is being read raises SIGBUS, like any mapping: spool files belong to the server.
  */
 #ifndef FHE_STREAM_H
 #define FHE_STREAM_H

@@ -336,3 +336,30 @@ def test_cpp_streaming_server_feeds_the_reference_client(fhe, tmp_path):
     out = run([client, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg"] + par)
     line = [ln for ln in out.splitlines() if ln.startswith("RMSError,")]
     assert line and line[0].split(",")[1] == "1.71767", out[-500:]
+
+
+def test_streaming_servers_reject_unreduced_residues(fhe, tmp_path):
+    """record headers are checked by the I/O layer, the payload by fhe_count_unreduced on every uploaded wave: one residue equal to
+    its modulus (what seal::Ciphertext::load would reject, homo/server_jpeg.cpp:117-123) fails the job in the Python server and in
+    the C++ one; the same stream with the word repaired passes"""
+    ctx = fhe.SEALContext.preset("P4096")
+    cts = fhe.to_host(ctx.random_ct(192, seed=3)).copy()
+    fin = tmp_path / "in.ct"
+
+    def write():
+        with open(fin, "wb") as f:
+            for c in cts:
+                fhe.server.write_ciphertext(f, c)
+    good = cts[100, 1, 2, 77]
+    cts[100, 1, 2, 77] = ctx.q[2]                                             # q_2 itself: not below the modulus
+    write()
+    with pytest.raises(ValueError, match="not reduced"):
+        fhe.server.server_jpeg(ctx, str(fin), str(tmp_path / "o.ct"), 1)
+    rc, err = _server_jpeg_hip(fin, tmp_path / "o2.ct", 1)
+    assert rc == 1 and "not reduced" in err
+    assert fhe.server.server_jpeg(ctx, str(fin), str(tmp_path / "o3.ct"), 1, validate=False) == 1      # the check can be waived for streams the server wrote itself
+    cts[100, 1, 2, 77] = good
+    write()
+    assert fhe.server.server_jpeg(ctx, str(fin), str(tmp_path / "o.ct"), 1) == 1
+    rc, res = _server_jpeg_hip(fin, tmp_path / "o2.ct", 1)
+    assert rc == 0 and open(tmp_path / "o.ct", "rb").read() == open(tmp_path / "o2.ct", "rb").read()
