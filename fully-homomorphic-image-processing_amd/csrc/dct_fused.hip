@@ -497,6 +497,61 @@ __global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_col
     else cols_body<L, LE, BIG, 0, PACK>(mid, out, consts, itw, wk, p, pinv, k, lds);
 }
 
+// EXPERIMENT (round 4, FHE_DCT_ONE_LAUNCH=D; off by default): rows and columns in ONE launch.  A unit is (prime, block,
+// polynomial): 16 row workgroups write its 1.25 MB packed intermediate, 16 column workgroups read it.  All 32 sit on one
+// XCD (blockIdx = 8 * sequence + xcd) and the XCD's sequence alternates [16 row workgroups of unit j + D][16 column
+// workgroups of unit j], so a unit's intermediate is consumed D units after it was produced -- while it is still in that
+// XCD's L2 / the Infinity Cache -- instead of a whole 256-block wave (3 GiB) later.  Workgroups are dispatched in blockIdx
+// order, so the rows a column workgroup waits for were dispatched before it and never wait themselves: no deadlock; the
+// wait is a bounded spin on a per-unit arrival counter (release: __threadfence + atomicAdd by every row workgroup;
+// acquire: atomic load + __threadfence), and a spin that runs out raises *err instead of hanging the device.
+template <int L, int LE>
+__global__ __launch_bounds__((Shape<L, LE>::TP), (Occ<L, LE>::W)) void k_dct_one_launch(const u64 *__restrict__ in, double *__restrict__ mid, u64 *__restrict__ out,
+                                                                        const double *__restrict__ consts, const double *__restrict__ tw_all,
+                                                                        const double *__restrict__ itw_all, const Modulus *__restrict__ mods, u32 k,
+                                                                        u32 n_blocks, u32 dist, u32 *__restrict__ arrived, u32 *__restrict__ err) {
+    __shared__ double lds[2 * Shape<L, LE>::LDS_WORDS];
+    const u32 xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, chunk = seq >> 5, r = seq & 31;
+    const bool is_row = r < 16;
+    const long j = is_row ? (long)chunk : (long)chunk - (long)(dist & 0xffffu);
+    const u32 n_units = n_blocks * 2 * k;
+    if (j < 0) return;
+    const u64 g = (u64)j * 8 + xcd;
+    if (g >= n_units) return;
+    Work wk;
+    wk.prime = (u32)(g / (n_blocks * 2));
+    const u32 rem = (u32)(g - (u64)wk.prime * n_blocks * 2);
+    wk.blk = rem >> 1;
+    wk.poly = rem & 1;
+    wk.line = (r & 15) >> 1;
+    wk.half = r & 1;
+    const double p = (double)mods[wk.prime].q, pinv = 1.0 / p;
+    if (is_row) {
+        const double *tw = tw_all + (size_t)wk.prime * Shape<L, LE>::N;
+        if (wk.half) rows_body<L, LE, false, 1, true, true>(in, mid, consts, tw, wk, p, pinv, k, lds);
+        else rows_body<L, LE, false, 0, true, true>(in, mid, consts, tw, wk, p, pinv, k, lds);
+        if (dist & 0x10000u) return;                       // timing-only switch of the experiment: no hand-over at all (results invalid)
+        __syncthreads();                                   // every thread's stores are issued ...
+        if (threadIdx.x == 0) {
+            __threadfence();                               // ... and visible device-wide before the unit counts this workgroup
+            atomicAdd(arrived + g, 1u);
+        }
+    } else {
+        if (!(dist & 0x10000u) && threadIdx.x == 0) {
+            u32 spins = 0;
+            while (__hip_atomic_load(arrived + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 16u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 24)) { atomicExch(err, 1u); break; }
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        const double *itw = itw_all + (size_t)wk.prime * Shape<L, LE>::N;
+        if (wk.half) cols_body<L, LE, false, 1, true>(mid, out, consts, itw, wk, p, pinv, k, lds);
+        else cols_body<L, LE, false, 0, true>(mid, out, consts, itw, wk, p, pinv, k, lds);
+    }
+}
+
 // Shoup-pair table in the u64 kernels' slot order (16 slots per thread) -> centred doubles in the
 // fused kernels' slot order: bit-reversed index j = (t << LE) + r lives at r * (n >> LE) + t.
 __global__ void k_consts_to_f64(const ulonglong2 *__restrict__ in, double *__restrict__ out, const Modulus *__restrict__ mods, u32 k, u32 n, u32 le, u32 total) {
@@ -725,6 +780,17 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
     const u64 grid = items * 2;
     if (grid > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many blocks for one launch");
     const bool big = c->max_prime_bits > 40;
+    if (c->opt.dct_one_launch && which == 3 && c->logn == 12 && dct_shape_le(c) == 3 && c->max_prime_bits <= 37 && c->opt.dct_pack && c->d_arrived) {
+        const u64 n_units = n_blocks * 2 * c->k;
+        if (n_units > c->arrived_cap) return fail(FHE_ERR_PARAM, "one-launch experiment: wave too large for the arrival counters");
+        HIP_TRY(hipMemsetAsync(c->d_arrived, 0, (n_units + 1) * sizeof(u32), st));
+        const u32 dist = c->opt.dct_one_launch;
+        const u64 chunks = (n_units + 7) / 8 + (dist & 0xffffu);
+        k_dct_one_launch<12, 3><<<(unsigned)(chunks * 32 * 8), Shape<12, 3>::TP, 0, st>>>(in, mid, out, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod,
+                                                                                       c->k, (u32)n_blocks, dist, c->d_arrived + 1, c->d_arrived);
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     switch (c->logn) {   // LE = 3 is only built for the headline size
         case 10: launch_pair<10, 4>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;
         case 11: launch_pair<11, 3>(c, plan, in, out, mid, (unsigned)grid, big, st, which); break;

@@ -232,6 +232,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.dct_pack = !off("FHE_DCT_PACK");
         o.dct_ldsc = !off("FHE_DCT_LDSC");
         o.dct_u64_fused = !off("FHE_DCT_U64_FUSED");
+        if (const char *e = getenv("FHE_DCT_ONE_LAUNCH")) o.dct_one_launch = (u32)atoi(e);
         o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
         o.ntt_single = env_on("FHE_NTT_SINGLE");
         o.ntt_nopm = env_on("FHE_NTT_NOPM");
@@ -264,6 +265,10 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
     // first entry point that multiplies ciphertexts (fhe_behz_ensure, call_once), so a DCT-only server neither pays for them
     // nor can fail on the auxiliary-prime search.  FHE_BEHZ_EAGER=1 restores construction at create time.
     if (env_on("FHE_BEHZ_EAGER") && (rc = fhe_behz_ensure(c))) { fhe_ctx_destroy(c); return rc; }
+    if (c->opt.dct_one_launch) {
+        c->arrived_cap = 1024 * 2 * (u64)k;
+        if (hipMalloc((void **)&c->d_arrived, (c->arrived_cap + 1) * sizeof(u32)) != hipSuccess) { fhe_ctx_destroy(c); return fail(FHE_ERR_HIP, "arrival counters"); }
+    }
     // the second stream + events of the pipelined DCT mode exist only in contexts created with FHE_DCT_PIPELINE=1: an idle
     // stream still takes a turn in the runtime's round-robin over its four hardware queues, and a host's own copy stream
     // that lands on the compute stream's queue serialises with it (seal/server_jpeg_hip.cpp measured exactly that)
@@ -279,6 +284,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
 extern "C" int fhe_ctx_destroy(fhe_ctx *c) {
     if (!c) return FHE_OK;
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->d_arrived) (void)hipFree(c->d_arrived);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
         if (c->ev_cols[i]) (void)hipEventDestroy(c->ev_cols[i]);

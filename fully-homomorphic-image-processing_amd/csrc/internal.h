@@ -51,6 +51,7 @@ struct FheOptions {
     bool dct_pack = true;            // FHE_DCT_PACK=0: FP64 intermediate instead of the packed one (primes <= 37 bits)
     bool dct_ldsc = true;            // FHE_DCT_LDSC=0: row-kernel constants through registers instead of LDS
     bool dct_u64_fused = true;       // FHE_DCT_U64_FUSED=0: three-launch general path instead of the fused u64 pair
+    u32 dct_one_launch = 0;          // FHE_DCT_ONE_LAUNCH=D (experiment): rows and columns of the FP64 pair in one launch, columns D units behind the rows
     bool ntt_nolazy = false;         // FHE_NTT_NOLAZY=1: Harvey butterflies with conditional subtractions everywhere
     bool ntt_single = false;         // FHE_NTT_SINGLE=1: one polynomial per workgroup at n >= 8192 as well
     bool ntt_nopm = false;           // FHE_NTT_NOPM=1: Shoup butterflies where the pseudo-Mersenne ones would run
@@ -84,6 +85,8 @@ struct fhe_ctx {
     std::string behz_err;
     // second stream + events for overlapping the column kernel of one wave of blocks with the row
     // kernel of the next (fhe_dct8x8_quant); created with the context
+    u32 *d_arrived = nullptr;        // one-launch experiment: [0] = error flag, [1 ...] per-unit arrival counters
+    u64 arrived_cap = 0;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
     // rgb_to_ycc_fhe constants (nine encoded factors + Delta*encode(128)), built on first use of each

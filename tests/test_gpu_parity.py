@@ -985,10 +985,11 @@ def test_fallback_kernels_give_the_same_bits(fhe, oracle_mod, switch):
     assert np.array_equal(fhe.to_host(m22)[3], orc.multiply(ha[3], hb[3]))
 
 
-@pytest.mark.parametrize("switches", [{"FHE_DCT_PIPELINE": 1, "FHE_DCT_WAVE_BLOCKS": 4}, {"FHE_DCT_PACK": 0}, {"FHE_DCT_LDSC": 0}, {"FHE_DCT_LE": 4}])
+@pytest.mark.parametrize("switches", [{"FHE_DCT_PIPELINE": 1, "FHE_DCT_WAVE_BLOCKS": 4}, {"FHE_DCT_PACK": 0}, {"FHE_DCT_LDSC": 0}, {"FHE_DCT_LE": 4}, {"FHE_DCT_ONE_LAUNCH": 2}])
 def test_dct_variants_give_the_same_bits(fhe, oracle_mod, switches):
-    """the two-stream pipelined mode (include/fhe_hip.h threading note), the FP64 intermediate, register-path constants
-    and the 16-coefficient shape of the fused FP64 pair against the default launch and the oracle (P4096, 10 blocks:
+    """the two-stream pipelined mode (include/fhe_hip.h threading note), the FP64 intermediate, register-path constants,
+    the 16-coefficient shape of the fused FP64 pair and the one-launch experiment (rows and columns in one grid, columns two
+    units behind the rows, arrival counters) against the default launch and the oracle (P4096, 10 blocks:
     ragged against the 2-block half waves of the pipelined mode)"""
     ctx, orc = _pair(fhe, oracle_mod, "P4096")
     alt = _variant(fhe, ctx, **switches)
