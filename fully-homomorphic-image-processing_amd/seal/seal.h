@@ -383,9 +383,14 @@ inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32
     uint32_t hdr[4] = {polys, k, n, 0};
     os.write(magic, 8);
     os.write((const char *)hdr, sizeof hdr);
-    std::vector<uint64_t> h(words);
-    if (words) check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
-    os.write((const char *)h.data(), (std::streamsize)(h.size() * 8));
+    // one staging buffer per thread, reused: a fresh 192 KiB vector per ciphertext is an mmap + page faults + munmap per call
+    static thread_local std::vector<uint64_t> h;
+    if (h.size() < words) h.resize(words);
+    if (words) {
+        check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
+        check(fhe_stream_sync(nullptr), "sync");
+    }
+    os.write((const char *)h.data(), (std::streamsize)(words * 8));
 }
 inline void save_words(std::ostream &os, const DevBuf &buf, uint32_t polys, uint32_t k, uint32_t n) { save_raw(os, buf.ptr(), buf.words(), polys, k, n); }
 #define FHE_FACADE_MAX_POLYS 64      /* the deepest reference circuit reaches size 22 (homo/fhe_decode.h:239) */
@@ -480,7 +485,7 @@ public:
     }
     void load(std::istream &is) {
         const double t0 = detail::now_s();
-        std::vector<uint64_t> h;
+        static thread_local std::vector<uint64_t> h;            // reused staging (see save_raw)
         uint32_t polys, k, n;
         detail::load_host(is, h, polys, k, n);
         shape(polys, k, n);
