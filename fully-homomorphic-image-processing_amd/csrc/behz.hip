@@ -670,55 +670,98 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_prepare_pm(const u6
     store_slots<L>(x[0], xb + (p * (K + 1) + j) * N, tid);
 }
 
+// steps 2(tail: times t) + 3 + 4 for PCPT coefficients (c0, c0 + stride) of ONE output polynomial: Dq -> its k residue polynomials
+// (coefficient form, any values the inverse transform leaves), Db -> its k + 1; res = the canonical residues of the product
 template <int K>
-__global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
-                                                            const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
-    const BehzPmDev &T = *Tp;     // wave-uniform: scalar loads at compile-time offsets
-    const u32 stride = gridDim.x * blockDim.x;             // n == PCPT * stride
-    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void floor_back_pm_at(const BehzPmDev &T, const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u32 n, u32 c0, u32 stride,
+                                                 u64 (&res)[PCPT][K]) {
     constexpr u32 MY = (1u << PM_SPLIT_Y) - 1, MZ = (1u << PM_SPLIT_Z) - 1;
-    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
-        u32 yl[PCPT][K], yh[PCPT][K], zl[PCPT][K], zh[PCPT][K];
-        u64 f[PCPT][K + 1];
+    u32 yl[PCPT][K], yh[PCPT][K], zl[PCPT][K], zh[PCPT][K];
+    u64 f[PCPT][K + 1];
 #pragma unroll
-        for (int i = 0; i < K; i++) {          // [t D]_q (q/q_i)^-1, canonical
-            const PmMod m = T.q[i];
-            const ulonglong2 w = T.t_inv_punct[i];
+    for (int i = 0; i < K; i++) {          // [t D]_q (q/q_i)^-1, canonical
+        const PmMod m = T.q[i];
+        const ulonglong2 w = T.t_inv_punct[i];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) {
+            const u64 y = canon_fold_pm(mul_pm(Dq[(size_t)i * n + c0 + e * stride], w, m), m);
+            yl[e][i] = (u32)y & MY;
+            yh[e][i] = (u32)(y >> PM_SPLIT_Y);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= K; j++) {         // fast floor: (t D - FastBConv([t D]_q)) q^-1 in Bsk, one two-column sum per prime
+        const PmMod m = T.b[j];
+        const ulonglong2 ft = T.flo_t_b[j];
+        PmAcc acc[PCPT];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) {
+            const u64 d = fold_pm(Db[(size_t)j * n + c0 + e * stride], m);       // any 64-bit value -> below (17/16) b_j
+            acc[e].A = 0; acc[e].B = 0;
+            f[e][j] = 0;
+            pm_mac(acc[e], (u32)d & MZ, (u32)(d >> PM_SPLIT_Z), ft);
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const ulonglong2 c = T.flo_q2b[i][j];
 #pragma unroll
             for (int e = 0; e < PCPT; e++) {
-                const u64 y = canon_fold_pm(mul_pm(Dq[(p * K + i) * n + c0 + e * stride], w, m), m);
-                yl[e][i] = (u32)y & MY;
-                yh[e][i] = (u32)(y >> PM_SPLIT_Y);
+                if (i > 0 && i % PM_GROUP_Y == 0) { f[e][j] += pm_acc_reduce(acc[e], m); acc[e].A = 0; acc[e].B = 0; }      // K > 4: a second group of columns
+                pm_mac(acc[e], yl[e][i], yh[e][i], c);
             }
         }
 #pragma unroll
-        for (int j = 0; j <= K; j++) {         // fast floor: (t D - FastBConv([t D]_q)) q^-1 in Bsk, one two-column sum per prime
+        for (int e = 0; e < PCPT; e++) f[e][j] += pm_acc_reduce(acc[e], m);              // below 1.5 b_j per group: 3 b_j
+    }
+    const PmMod mk = T.b[K];
+    u64 conv[PCPT];
+#pragma unroll
+    for (int e = 0; e < PCPT; e++) conv[e] = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < K; j0 += 2) {
+        PmAcc acc[PCPT];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) { acc[e].A = 0; acc[e].B = 0; }
+#pragma unroll
+        for (int j = j0; j < j0 + 2 && j < K; j++) {
             const PmMod m = T.b[j];
-            const ulonglong2 ft = T.flo_t_b[j];
-            PmAcc acc[PCPT];
+            const ulonglong2 w = T.inv_punct_B[j], cj = T.back_B2msk[j];
 #pragma unroll
             for (int e = 0; e < PCPT; e++) {
-                const u64 d = fold_pm(Db[(p * (K + 1) + j) * n + c0 + e * stride], m);       // any 64-bit value -> below (17/16) b_j
-                acc[e].A = 0; acc[e].B = 0;
-                f[e][j] = 0;
-                pm_mac(acc[e], (u32)d & MZ, (u32)(d >> PM_SPLIT_Z), ft);
+                const u64 z = canon_fold_pm(mul_pm(f[e][j], w, m), m);                   // canonical integer in [0, b_j)
+                zl[e][j] = (u32)z & MZ;
+                zh[e][j] = (u32)(z >> PM_SPLIT_Z);
+                pm_mac(acc[e], zl[e][j], zh[e][j], cj);
             }
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-                const ulonglong2 c = T.flo_q2b[i][j];
-#pragma unroll
-                for (int e = 0; e < PCPT; e++) {
-                    if (i > 0 && i % PM_GROUP_Y == 0) { f[e][j] += pm_acc_reduce(acc[e], m); acc[e].A = 0; acc[e].B = 0; }      // K > 4: a second group of columns
-                    pm_mac(acc[e], yl[e][i], yh[e][i], c);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < PCPT; e++) f[e][j] += pm_acc_reduce(acc[e], m);              // below 1.5 b_j per group: 3 b_j
         }
-        const PmMod mk = T.b[K];
-        u64 conv[PCPT];
 #pragma unroll
-        for (int e = 0; e < PCPT; e++) conv[e] = 0;
+        for (int e = 0; e < PCPT; e++) conv[e] += pm_acc_reduce(acc[e], mk);             // each below 1.5 m_sk
+    }
+    u32 al[PCPT], ah[PCPT];                // |alpha_sk| (at most k for a product; split like the z_j all the same)
+    bool neg[PCPT];
+    {
+        const ulonglong2 ib = T.inv_B_mod_msk;
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) {
+            const u64 alpha = canon_fold_pm(mul_pm(conv[e] + 4 * mk.q - f[e][K], ib, mk), mk);      // f_K below 3 m_sk, conv below 6 m_sk: below 2^62
+            neg[e] = alpha > (mk.q >> 1);
+            const u64 a_abs = neg[e] ? mk.q - alpha : alpha;
+            al[e] = (u32)a_abs & MZ;
+            ah[e] = (u32)(a_abs >> PM_SPLIT_Z);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const PmMod m = T.q[i];
+        const ulonglong2 bn = T.back_neg[i], bp = T.back_pos[i];
+        u64 tot[PCPT];
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) {
+            PmAcc a0;
+            a0.A = 0; a0.B = 0;
+            pm_mac(a0, al[e], ah[e], neg[e] ? bn : bp);
+            tot[e] = pm_acc_reduce(a0, m);
+        }
 #pragma unroll
         for (int j0 = 0; j0 < K; j0 += 2) {
             PmAcc acc[PCPT];
@@ -726,60 +769,76 @@ __global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restric
             for (int e = 0; e < PCPT; e++) { acc[e].A = 0; acc[e].B = 0; }
 #pragma unroll
             for (int j = j0; j < j0 + 2 && j < K; j++) {
-                const PmMod m = T.b[j];
-                const ulonglong2 w = T.inv_punct_B[j], cj = T.back_B2msk[j];
+                const ulonglong2 cji = T.back_B2q[j][i];
 #pragma unroll
-                for (int e = 0; e < PCPT; e++) {
-                    const u64 z = canon_fold_pm(mul_pm(f[e][j], w, m), m);                   // canonical integer in [0, b_j)
-                    zl[e][j] = (u32)z & MZ;
-                    zh[e][j] = (u32)(z >> PM_SPLIT_Z);
-                    pm_mac(acc[e], zl[e][j], zh[e][j], cj);
-                }
+                for (int e = 0; e < PCPT; e++) pm_mac(acc[e], zl[e][j], zh[e][j], cji);
             }
 #pragma unroll
-            for (int e = 0; e < PCPT; e++) conv[e] += pm_acc_reduce(acc[e], mk);             // each below 1.5 m_sk
-        }
-        u32 al[PCPT], ah[PCPT];                // |alpha_sk| (at most k for a product; split like the z_j all the same)
-        bool neg[PCPT];
-        {
-            const ulonglong2 ib = T.inv_B_mod_msk;
-#pragma unroll
-            for (int e = 0; e < PCPT; e++) {
-                const u64 alpha = canon_fold_pm(mul_pm(conv[e] + 4 * mk.q - f[e][K], ib, mk), mk);      // f_K below 3 m_sk, conv below 6 m_sk: below 2^62
-                neg[e] = alpha > (mk.q >> 1);
-                const u64 a_abs = neg[e] ? mk.q - alpha : alpha;
-                al[e] = (u32)a_abs & MZ;
-                ah[e] = (u32)(a_abs >> PM_SPLIT_Z);
-            }
+            for (int e = 0; e < PCPT; e++) tot[e] += pm_acc_reduce(acc[e], m);
         }
 #pragma unroll
-        for (int i = 0; i < K; i++) {
-            const PmMod m = T.q[i];
-            const ulonglong2 bn = T.back_neg[i], bp = T.back_pos[i];
-            u64 tot[PCPT];
+        for (int e = 0; e < PCPT; e++) res[e][i] = canon_fold_pm(tot[e], m);
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void k_behz_floor_back_pm(const u64 *__restrict__ Dq, const u64 *__restrict__ Db, u64 *__restrict__ out,
+                                                            const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzPmDev &T = *Tp;     // wave-uniform: scalar loads at compile-time offsets
+    const u32 stride = gridDim.x * blockDim.x;             // n == PCPT * stride
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        u64 res[PCPT][K];
+        floor_back_pm_at<K>(T, Dq + p * K * n, Db + p * (K + 1) * n, n, c0, stride, res);
 #pragma unroll
-            for (int e = 0; e < PCPT; e++) {
-                PmAcc a0;
-                a0.A = 0; a0.B = 0;
-                pm_mac(a0, al[e], ah[e], neg[e] ? bn : bp);
-                tot[e] = pm_acc_reduce(a0, m);
+        for (int i = 0; i < K; i++)
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) out[(p * K + i) * n + c0 + e * stride] = res[e][i];
+    }
+}
+
+// Cubic's tail fused into the floor / back conversion of its three products (homo/fhe_resize.h:176-188: a t3, b t2, c t, their sum
+// times encode(0.5) = x^-1, plus B): per output coefficient the three products' residues are formed, added, rotated by one
+// position (coefficient j takes S[j + 1], the last one -S[0]) and B is added -- the three size-so products never exist in memory
+// (per output polynomial 3 x k written + 3 x k read again + one launch less).  Da / Db / Dc: [count][size_ab | size_c][2k + 1 as
+// D_q then D_b per batch][n] as fhe_behz_tensor_shared leaves them; out through `mo`, B through `mB` (index maps of circuits.hip).
+template <int K>
+__global__ __launch_bounds__(256) void k_behz_floor3_combine_pm(const u64 *__restrict__ Aq, const u64 *__restrict__ Ab, const u64 *__restrict__ Bq2,
+                                                                const u64 *__restrict__ Bb2, const u64 *__restrict__ Cq, const u64 *__restrict__ Cb,
+                                                                u32 size_ab, u32 size_c, const u64 *__restrict__ Bct, CMap mB, u32 size_b,
+                                                                u64 *__restrict__ out, CMap mo, const BehzPmDev *__restrict__ Tp, u32 n, u64 n_polys) {
+    const BehzPmDev &T = *Tp;
+    const u32 stride = gridDim.x * blockDim.x;
+    const u32 c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 p = blockIdx.y; p < n_polys; p += gridDim.y) {
+        const u64 ct = p / size_ab;
+        const u32 poly = (u32)(p % size_ab);
+        u64 S[PCPT][K], r[PCPT][K];
+        floor_back_pm_at<K>(T, Aq + p * K * n, Ab + p * (K + 1) * n, n, c0, stride, S);
+        floor_back_pm_at<K>(T, Bq2 + p * K * n, Bb2 + p * (K + 1) * n, n, c0, stride, r);
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+            for (int e = 0; e < PCPT; e++) S[e][i] = addmod(S[e][i], r[e][i], T.q[i].q);
+        if (poly < size_c) {
+            const u64 pc = ct * size_c + poly;
+            floor_back_pm_at<K>(T, Cq + pc * K * n, Cb + pc * (K + 1) * n, n, c0, stride, r);
+#pragma unroll
+            for (int i = 0; i < K; i++)
+#pragma unroll
+                for (int e = 0; e < PCPT; e++) S[e][i] = addmod(S[e][i], r[e][i], T.q[i].q);
+        }
+        const u64 *pB = poly < size_b ? Bct + (mB(ct) * size_b + poly) * K * n : nullptr;
+        u64 *po = out + (mo(ct) * size_ab + poly) * K * n;
+#pragma unroll
+        for (int e = 0; e < PCPT; e++) {
+            const u32 c = c0 + e * stride, j = c ? c - 1 : n - 1;         // x^-1: coefficient c lands at c - 1, coefficient 0 at n - 1 negated
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u64 q = T.q[i].q;
+                u64 v = S[e][i];
+                if (!c) v = v ? q - v : 0;
+                po[(size_t)i * n + j] = pB ? addmod(v, pB[(size_t)i * n + j], q) : v;
             }
-#pragma unroll
-            for (int j0 = 0; j0 < K; j0 += 2) {
-                PmAcc acc[PCPT];
-#pragma unroll
-                for (int e = 0; e < PCPT; e++) { acc[e].A = 0; acc[e].B = 0; }
-#pragma unroll
-                for (int j = j0; j < j0 + 2 && j < K; j++) {
-                    const ulonglong2 cji = T.back_B2q[j][i];
-#pragma unroll
-                    for (int e = 0; e < PCPT; e++) pm_mac(acc[e], zl[e][j], zh[e][j], cji);
-                }
-#pragma unroll
-                for (int e = 0; e < PCPT; e++) tot[e] += pm_acc_reduce(acc[e], m);
-            }
-#pragma unroll
-            for (int e = 0; e < PCPT; e++) out[(p * K + i) * n + c0 + e * stride] = canon_fold_pm(tot[e], m);
         }
     }
 }
@@ -1352,6 +1411,41 @@ extern "C" int fhe_multiply_prepared_shared(const fhe_ctx *cc, const uint64_t *a
     const u64 *Bq = (const u64 *)bp, *Bb = Bq + b_count * sb * kn;
     u64 *Dq = p, *Db = Dq + count * so * kn;
     return behz_finish(c, Aq, Ab, sa, Bq, Bb, sb, (u64 *)out, count, Dq, Db, st, BMap{b_div, b_count, (b_first % b_count) * b_div});
+}
+
+bool fhe_behz_floor3_supported(const fhe_ctx *c) { return c && fhe_behz_ensure(c) == FHE_OK && c->behz->pm_dev && c->k <= 8 && !fhe_rgb_f64_supported(c); }
+size_t fhe_behz_d_words(const fhe_ctx *c, u32 so, u64 count) { return (size_t)count * so * (2 * (size_t)c->k + 1) * c->n; }
+static int tensor_both(const fhe_ctx *c, const u64 *Aq, const u64 *Ab, u32 sa, const u64 *Bq, const u64 *Bb, u32 sb, u64 count, u64 *Dq, u64 *Db, hipStream_t st, BMap bm) {
+    int rc;
+    if ((count * (u64)(c->k + 1) + 8) * (sa + sb - 1) > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    if ((rc = tensor_intt(c, Aq, Bq, Dq, c->qb.dev(), sa, sb, count, st, bm, c->max_prime_bits <= 58, c->qb.pm_class))) return rc;
+    return tensor_intt(c, Ab, Bb, Db, c->behz->aux.dev(), sa, sb, count, st, bm, c->behz->aux_bits <= 58, c->behz->aux.pm_class);
+}
+int fhe_behz_tensor_shared(const fhe_ctx *c, const u64 *a, u32 sa, const u64 *bp, u32 sb, u64 b_count, u64 b_div, u64 b_first, u64 *d, u64 count,
+                           u64 *scratch, hipStream_t st) {
+    if (int erc = fhe_behz_ensure(c)) return erc;
+    const u32 k = c->k, n = c->n, so = sa + sb - 1;
+    const size_t kn = (size_t)k * n;
+    u64 *xq = scratch, *xb = xq + count * sa * kn;
+    int rc;
+    if ((rc = behz_prepare(c, a, sa, count, xq, xb, st))) return rc;
+    const u64 *Bq = bp, *Bb = Bq + b_count * sb * kn;
+    return tensor_both(c, xq, xb, sa, Bq, Bb, sb, count, d, d + count * so * kn, st, BMap{b_div, b_count, (b_first % b_count) * b_div});
+}
+int fhe_behz_floor3_combine(const fhe_ctx *c, const u64 *da, const u64 *db, const u64 *dc, u32 size_ab, u32 size_c, const u64 *B, CMap mB, u32 size_b,
+                            u64 *out, CMap mo, u64 count, hipStream_t st) {
+    const u32 k = c->k, n = c->n;
+    const size_t kn = (size_t)k * n;
+    const u64 np = count * size_ab;
+    switch (k) {
+#define GO(KK) case KK: k_behz_floor3_combine_pm<KK><<<grid2(n / PCPT, np), 256, 0, st>>>(da, da + count * size_ab * kn, db, db + count * size_ab * kn, dc, dc + count * size_c * kn, \
+                                                                                   size_ab, size_c, B, mB, size_b, out, mo, c->behz->pm_dev, n, np); break;
+        GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+#undef GO
+        default: return fail(FHE_ERR_PARAM, "floor / back conversion is built for up to 8 coefficient moduli, not %u", k);
+    }
+    KERNEL_CHECK();
+    return FHE_OK;
 }
 
 extern "C" int fhe_multiply(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out,

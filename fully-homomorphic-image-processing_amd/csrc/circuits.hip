@@ -25,13 +25,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // kernels: index maps, gathers, unequal-size additions, Cubic's linear parts through index arrays
 // ------------------------------------------------------------------------------------------------
-// which ciphertext of a batch pair / output `c` refers to: an explicit index array, the periodic map
+// CMap (internal.h): which ciphertext of a batch pair / output `c` refers to -- an explicit index array, the periodic map
 // (off + c / div) % cnt, or c itself
-struct CMap {
-    const u32 *idx;
-    u64 div, cnt, off;
-    __device__ __forceinline__ u64 operator()(u64 c) const { return idx ? idx[c] : (cnt ? ((off + c / div) % cnt) : c); }
-};
 inline CMap ident() { return CMap{nullptr, 1, 0, 0}; }
 inline CMap by_index(const u32 *idx) { return CMap{idx, 1, 0, 0}; }
 inline CMap periodic(u64 div, u64 cnt, u64 off = 0) { return CMap{nullptr, div, cnt, off}; }
@@ -413,11 +408,28 @@ int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, cons
         TRY(R.add_general(true, cc, size, ident(), A.base, size, A.map, cc, size, count));   // c = C - A
     }
     const u32 so = size + 2;
+    if (count * so * R.k > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    if (R.cc->base2 && !tmap.idx && !c->opt.cubic_unfused && fhe_behz_floor3_supported(c)) {      // the same decision in the dry pass and the real one
+        const u64 t_cnt = tmap.cnt ? tmap.cnt : count, t_div = tmap.cnt ? tmap.div : 1, t_off = tmap.cnt ? tmap.off : 0;     // identity = period `count`
+        // the three products up to their inverse transforms, then ONE launch that floors, converts back, adds the three, applies
+        // encode(0.5) = x^-1 and adds B (behz.hip: k_behz_floor3_combine_pm): pa, pb, pc never exist in memory
+        u64 *da = R.alloc(fhe_behz_d_words(c, so, count)), *db = R.alloc(fhe_behz_d_words(c, so, count)), *dc = R.alloc(fhe_behz_d_words(c, so - 1, count));
+        const size_t m2 = R.mark();
+        u64 *prep = R.alloc(fhe_multiply_operand_words(c, size, count));
+        if (!R.dry) {
+            TRY(fhe_behz_tensor_shared(c, a, size, p2, 3, t_cnt, t_div, t_off, da, count, prep, R.st));     // a * t3 (t3 = t * t, :175)
+            TRY(fhe_behz_tensor_shared(c, b, size, p2, 3, t_cnt, t_div, t_off, db, count, prep, R.st));     // b * t2
+            TRY(fhe_behz_tensor_shared(c, cc, size, p1, 2, t_cnt, t_div, t_off, dc, count, prep, R.st));    // c * t
+            TRY(fhe_behz_floor3_combine(c, da, db, dc, so, so - 1, B.base, B.map, size, out, omap, count, R.st));    // :181-188
+        }
+        R.release(m2);
+        R.release(m);
+        return FHE_OK;
+    }
     u64 *pa = R.alloc(count * so * R.pw), *pb = R.alloc(count * so * R.pw), *pc = R.alloc(count * (so - 1) * R.pw);
     TRY(R.multiply(a, size, nullptr, p2, 3, tmap, pa, count));          // a * t3 (t3 = t * t, :175)
     TRY(R.multiply(b, size, nullptr, p2, 3, tmap, pb, count));          // b * t2
     TRY(R.multiply(cc, size, nullptr, p1, 2, tmap, pc, count));         // c * t
-    if (count * so * R.k > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
     if (R.cc->base2) {
         if (!R.dry) {
             k_cubic_combine_g<<<(unsigned)(count * so * R.k), 256, 0, R.st>>>(pa, pb, pc, so - 1, B.base, B.map, size, out, omap, c->qb.d_mod, R.k, R.n, so);

@@ -241,6 +241,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.behz_tensor_canon = env_on("FHE_BEHZ_TENSOR_CANON");
         o.behz_tensor_single = env_on("FHE_BEHZ_TENSOR_SINGLE");
         o.behz_fused_prepare = env_on("FHE_BEHZ_FUSED_PREPARE");
+        o.cubic_unfused = env_on("FHE_CUBIC_UNFUSED");
     }
     c->n = n;
     c->k = k;

@@ -59,6 +59,7 @@ struct FheOptions {
     bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
     bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions
     bool behz_tensor_single = false; // FHE_BEHZ_TENSOR_SINGLE=1: tensor + inverse transform one polynomial per workgroup
+    bool cubic_unfused = false;      // FHE_CUBIC_UNFUSED=1: Cubic's three products as three complete fhe_multiply calls + k_cubic_combine_g (before round 4's fused tail)
     bool behz_fused_prepare = false; // FHE_BEHZ_FUSED_PREPARE=1: base extension fused into the forward transforms (k_behz_prepare_pm: 25 % less HBM traffic per
                                      // product, 5 % slower -- the y_i are recomputed per auxiliary prime and the kernels are issue-bound; profiles/EXPERIMENTS.md)
 };
@@ -123,12 +124,29 @@ struct fhe_dct_plan {
         default: return fail(FHE_ERR_PARAM, "unsupported log2(n)=%u", logn);     \
     }
 
+// which ciphertext of a batch pair / output `c` refers to: an explicit index array, the periodic map (off + c / div) % cnt, or c itself
+// (the circuits' operands are taps into resident pixels, one offset per output column, one sine polynomial per harmonic, ...)
+struct CMap {
+    const u32 *idx;
+    u64 div, cnt, off;
+    __device__ __forceinline__ u64 operator()(u64 c) const { return idx ? idx[c] : (cnt ? ((off + c / div) % cnt) : c); }
+};
+
 // cross-TU internals
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
 int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
 void fhe_free_base(BaseTables &B);
 int fhe_behz_build(fhe_ctx *c);   // called once per context, through fhe_behz_ensure
-int fhe_behz_ensure(const fhe_ctx *c);   // thread-safe: builds the ct x ct tables on first use; later calls cost one atomic load
+int fhe_behz_ensure(const fhe_ctx *c);
+// Cubic's three products with their tail fused into the floor / back conversion (behz.hip: k_behz_floor3_combine_pm).
+// fhe_behz_tensor_shared = fhe_multiply_prepared_shared up to and including the inverse transforms: D_q [count][so][k][n] and
+// D_b [count][so][k+1][n] are left in `d` (fhe_behz_d_words); `scratch` holds the prepared form of `a` (fhe_multiply_operand_words).
+bool fhe_behz_floor3_supported(const fhe_ctx *c);
+size_t fhe_behz_d_words(const fhe_ctx *c, u32 so, u64 count);
+int fhe_behz_tensor_shared(const fhe_ctx *c, const u64 *a, u32 sa, const u64 *bp, u32 sb, u64 b_count, u64 b_div, u64 b_first, u64 *d, u64 count,
+                           u64 *scratch, hipStream_t st);
+int fhe_behz_floor3_combine(const fhe_ctx *c, const u64 *da, const u64 *db, const u64 *dc, u32 size_ab, u32 size_c, const u64 *B, CMap mB, u32 size_b,
+                            u64 *out, CMap mo, u64 count, hipStream_t st);   // thread-safe: builds the ct x ct tables on first use; later calls cost one atomic load
 void fhe_behz_free(fhe_ctx *c);
 // fused FP64 DCT path (dct_fused.hip)
 bool fhe_dct_f64_supported(const fhe_ctx *c);

@@ -524,6 +524,26 @@ def test_cubic_linear_vs_oracle(fhe, oracle_mod):
         assert np.array_equal(h(l2)[i], orc.linear(o1, o1, h(t)[i]))
 
 
+@pytest.mark.parametrize("preset", ["P8192", "SEAL23_4096"])
+def test_cubic_fused_tail_vs_three_products_and_oracle(fhe, oracle_mod, preset):
+    """Cubic on pseudo-Mersenne bases: the three products' floor / back conversion, their sum, encode(0.5) = x^-1 and + B in ONE
+    launch (k_behz_floor3_combine_pm) against FHE_CUBIC_UNFUSED=1 (three complete products + k_cubic_combine_g) and the oracle,
+    level 1 (size 2 -> 4) and level 2 (4 -> 6), a batch that is not a multiple of anything, operands at q - 1"""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    alt = _variant(fhe, ctx, FHE_CUBIC_UNFUSED=1)
+    h = fhe.to_host
+    t = ctx.random_ct(5, size=2, seed=410)
+    for size in (2, 4):
+        A, B, C, D = (ctx.random_ct(5, size=size, seed=400 + 10 * size + i) for i in range(4))
+        A[1] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=A.device).view(1, ctx.k, 1).expand(size, ctx.k, ctx.n)
+        got = fhe.circuits.cubic(fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), A, B, C, D, t)
+        want = fhe.circuits.cubic(fhe.Evaluator(alt), fhe.circuits.PlainCache(alt), A, B, C, D, t)
+        assert got.shape[-3] == size + 2 and torch.equal(got, want)
+        for i in (0, 1, 4):
+            assert np.array_equal(h(got)[i], orc.cubic(h(A)[i], h(B)[i], h(C)[i], h(D)[i], h(t)[i])), (size, i)
+
+
 def test_bicubic_resize_8x8_to_4x4(fhe, oracle_mod):
     """ResizeImage/SampleBicubic (homo/fhe_resize.h:254-392) on a small image, one channel:
     the product's batched sampler against per-pixel oracle Cubic calls, plus a decrypt known answer"""
