@@ -136,6 +136,24 @@ __global__ void k_add_plain_dev(u64 *ct, u64 stride_words, u64 count, const u64 
     }
 }
 
+
+// approximated_step's offset chain (homo/fhe_decode.h:228-229) in one launch: output ciphertext b = offset + the plaintexts
+// add_plain had added before step b (c_0 only; `chain` [count][k][len] holds those sums, Delta m' form, reduced mod q_i)
+__global__ __launch_bounds__(256) void k_offset_chain(const u64 *__restrict__ offset, const u64 *__restrict__ chain, u32 len, u64 *__restrict__ out,
+                                                      const Modulus *__restrict__ mods, u32 k, u32 n, u64 count) {
+    const u32 pp = blockIdx.y;                         // poly * k + prime of a size-2 ciphertext
+    const u32 prime = pp % k;
+    const u64 q = mods[prime].q;
+    for (u64 b = blockIdx.z; b < count; b += gridDim.z) {
+        const u64 *tab = chain + (b * k + prime) * len;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            u64 v = offset[(u64)pp * n + i];
+            if (pp < k && i < len) v = addmod(v, tab[i], q);
+            out[(b * 2 * k + pp) * n + i] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -753,11 +771,44 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
         std::vector<double> factor(degree);
         for (int j = 1; j <= degree; ++j) factor[j - 1] = ((float)j) * M_PI / ((double)order);      // :225
         u64 *cos_arg = R.alloc(nb * 2 * R.pw), *sin_arg = R.alloc((u64)degree * 2 * R.pw);
-        for (u32 i = 0; i < pos1; ++i)
-            for (int j = 0; j < degree; ++j) {
-                if (i >= pos0) TRY(R.copy(cos_arg + ((u64)j * np + (i - pos0)) * 2 * R.pw, offset, 2));   // :228 cos_arg(offset)
-                TRY(R.add_plain(offset, 2, 1, R.K((double)i)));                               // :229, inside the harmonic loop
+        // :228-229: cos_arg(offset), then add_plain(offset, encode(i)) INSIDE the harmonic loop -- the one serial chain of the
+        // circuit.  add_plain is an exact addition of Delta m' to c_0, so the value of `offset` at step (i, j) is offset + the sum
+        // of the plaintexts added before it: the sums are formed on the host (a few coefficients each: encode(i) has
+        // ceil(log2(i + 1)) of them) and ONE launch writes all np * degree arguments -- 2 np degree launches before round 4.
+        {
+            const fhe_ctx *c = R.c;
+            u32 len = 0;
+            for (u32 i = 0; i < pos1; ++i) {
+                const CircConst *kc = R.K((double)i);
+                if (!kc) return FHE_ERR_PARAM;
+                if (kc->plain.size() > len) len = (u32)kc->plain.size();
             }
+            if (!len) len = 1;
+            u64 *d_chain = R.alloc(nb * R.k * len);
+            if (!R.dry) {
+                std::vector<u64> run((size_t)R.k * len, 0), tab((size_t)nb * R.k * len);
+                for (u32 i = 0; i < pos1; ++i) {
+                    const CircConst *kc = R.K((double)i);
+                    for (int j = 0; j < degree; ++j) {
+                        if (i >= pos0) std::copy(run.begin(), run.end(), tab.begin() + ((size_t)j * np + (i - pos0)) * R.k * len);
+                        for (u32 pr = 0; pr < R.k; ++pr) {
+                            const u64 qi = c->qb.primes[pr];
+                            for (size_t x = 0; x < kc->plain.size(); ++x) {
+                                const u64 m = kc->plain[x];
+                                if (!m) continue;
+                                u64 v = hostmath::mulmod(c->delta_mod[pr], m % qi, qi);       // Delta m' as add_plain forms it (ensure_scaled)
+                                if (m >= c->upper_half_threshold) v = hostmath::addmod(v, c->upper_half_increment[pr], qi);
+                                run[(size_t)pr * len + x] = hostmath::addmod(run[(size_t)pr * len + x], v, qi);
+                            }
+                        }
+                    }
+                }
+                TRY(R.stage((const u32 *)tab.data(), tab.size() * 2, (u32 *)d_chain));
+                dim3 grid((R.n + 255) / 256, 2 * R.k, (unsigned)(nb < 16384 ? nb : 16384));
+                k_offset_chain<<<grid, 256, 0, R.st>>>(offset, d_chain, len, cos_arg, c->qb.d_mod, R.k, R.n, nb);
+                KERNEL_CHECK();
+            }
+        }
         for (int j = 0; j < degree; ++j) {
             u64 *ca = cos_arg + (u64)j * np * 2 * R.pw;
             TRY(R.mul_plain(ca, ca, (u64)np * 2, R.K(factor[j])));                            // :230
