@@ -19,6 +19,7 @@ for p in SEAL23_4096 SEAL3_8192 P8192; do python bench.py --preset $p --cpu-bloc
 python tools/bench_ops.py P4096 4096 > $O/bench_ops_P4096.txt 2>&1
 python tools/bench_ops.py P8192 2048 > $O/bench_ops_P8192.txt 2>&1
 FHE_BEHZ_FUSED_PREPARE=1 python tools/bench_ops.py P8192 2048 > $O/bench_ops_P8192_fused_prepare.txt 2>&1
+python tools/sweep_ctct_chunk.py P8192 1024 > $O/bench_ctct_chunks.txt 2>&1
 python bench_circuits.py resize --cpu-pixels 4 > $O/bench_circuits_resize.json 2> /dev/null
 python bench_circuits.py resize --shared --cpu-pixels 4 > $O/bench_circuits_resize_shared.json 2> /dev/null
 python bench_circuits.py decode --cpu-terms 2 > $O/bench_circuits_decode.json 2> /dev/null
