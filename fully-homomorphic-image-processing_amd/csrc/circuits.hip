@@ -58,6 +58,38 @@ __global__ __launch_bounds__(256) void k_add_general(const ulonglong2 *a, u32 si
     }
 }
 
+// the sum of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:113-118) in one pass: out[c][p] = zero[zmap(c)][p] (p < 2) +
+// sum over the five power terms i with p < size_i of term_i[tmap(c)][p], p < 11 -- modular additions of canonical residues, so
+// their order does not show in the result (seven launches of k_add_general before)
+struct TaylorTerms { const ulonglong2 *t[5]; u32 size[5]; };
+__global__ __launch_bounds__(256) void k_taylor_sum(const ulonglong2 *__restrict__ zero, CMap zmap, TaylorTerms T, CMap tmap, ulonglong2 *__restrict__ out,
+                                                    const Modulus *__restrict__ mods, u32 k, u32 half_n, u64 n_res_polys) {
+    for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
+        const u32 prime = (u32)(rp % k);
+        const u64 cp = rp / k;
+        const u32 poly = (u32)(cp % 11);
+        const u64 ct = cp / 11;
+        const u64 q = mods[prime].q;
+        const ulonglong2 *pz = poly < 2 ? zero + ((zmap(ct) * 2 + poly) * k + prime) * half_n : nullptr;
+        const u64 tc = tmap(ct);
+        const ulonglong2 *pt[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) pt[i] = poly < T.size[i] ? T.t[i] + ((tc * T.size[i] + poly) * k + prime) * half_n : nullptr;
+        ulonglong2 *po = out + rp * half_n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < half_n; i += gridDim.x * blockDim.x) {
+            ulonglong2 x = pz ? pz[i] : make_ulonglong2(0, 0);
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (pt[t]) {
+                    const ulonglong2 y = pt[t][i];
+                    x.x = addmod(x.x, y.x, q);
+                    x.y = addmod(x.y, y.y, q);
+                }
+            po[i] = x;
+        }
+    }
+}
+
 // x^e * P at coefficient j of a negacyclic polynomial: +-P[j - e]; returns the value to ADD
 __device__ __forceinline__ u64 rot_term(const u64 *__restrict__ p, int j, int e, int n, u64 q) {
     const int idx = j - e;
@@ -728,10 +760,15 @@ int taylor_terms(Run &R, const u64 *x, u64 count, const double *coeffs, u64 *ter
 // res = Enc(0) + constant, then the terms in the reference's order (:113-118); zero through zmap, term i of output c is
 // terms[i][tmap(c)] (the sine terms of approximated_step do not depend on the position)
 int taylor_sum(Run &R, const u64 *zero, CMap zmap, double constant, u64 *const terms[5], CMap tmap, u64 *res, u64 count) {
-    TRY(R.gather_pad(zero, 2, zmap, res, 11, count));
-    TRY(R.add_plain(res, 11, count, R.K(constant)));
-    for (int i = 0; i < 5; ++i) TRY(R.acc(res, 11, terms[i], kTermSize[i], tmap, count));
-    return FHE_OK;
+    if (!R.dry && count) {
+        TaylorTerms T;
+        for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)terms[i]; T.size[i] = kTermSize[i]; }
+        const u64 nrp = count * 11 * R.k;
+        dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+        k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)zero, zmap, T, tmap, (ulonglong2 *)res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
+        KERNEL_CHECK();
+    }
+    return R.add_plain(res, 11, count, R.K(constant));
 }
 
 int run_sincos(Run &R, int cosine, const u64 *x, const u64 *zero, u64 *out, u64 count) {
