@@ -374,6 +374,22 @@ struct Run {
         TRY(ensure_ntt(cc, kc, st));
         return fhe_multiply_plain(c, cu(in), mu(out), polys, cu(kc->d_ntt), st);
     }
+    // out[c][p] = addend[amap(c)][p] (p < addend_size) + sum_i src_i[c][p] * kc_i (p < size_i): fhe_multiply_plain_sum; the src_i are overwritten
+    int mul_plain_sum(int terms, u64 *const *src, const u32 *sizes, const CircConst *const *kc, const u64 *addend, CMap amap, u32 addend_size,
+                      u64 *out, u32 out_size, u64 count) {
+        for (int i = 0; i < terms; ++i) {
+            if (!kc[i]) return FHE_ERR_PARAM;
+            if (!kc[i]->nnz && !query) return fail(FHE_ERR_PARAM, "plain cannot be zero");
+        }
+        if (dry || !count) return FHE_OK;
+        PlainSumTerms T;
+        T.count = (u32)terms;
+        for (int i = 0; i < terms; ++i) {
+            TRY(ensure_ntt(cc, kc[i], st));
+            T.src[i] = src[i]; T.size[i] = sizes[i]; T.plain[i] = (const ulonglong2 *)kc[i]->d_ntt;
+        }
+        return fhe_multiply_plain_sum(c, T, addend, amap, addend_size, out, out_size, count, st);
+    }
     int add_plain(u64 *ct, u32 size, u64 count, const CircConst *kc, int sign = 1) {
         if (!kc) return FHE_ERR_PARAM;
         if (dry || !count || !kc->nnz) return FHE_OK;
@@ -732,52 +748,66 @@ const double kSinCoeffs[5] = {0.5, -1.0 / 24.0, 1.0 / 720.0, -1.0 / 40320.0, 1.0
 const double kCosCoeffs[5] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0};     // :146-192
 const u32 kTermSize[5] = {3, 5, 7, 9, 11};
 
-// the five power terms of homomorphic_sin / homomorphic_cos: even Taylor polynomial of degree 10 in (x - 3 pi / 2).
+// homomorphic_sin / homomorphic_cos: even Taylor polynomial of degree 10 in (x - 3 pi / 2).
 // The reference rebuilds every power from a fresh copy of the shifted argument (11 squares, 4 multiplies, :66-112); the
-// repeated squares are the same ring elements bit for bit, so each is formed once.  terms[i]: [count][kTermSize[i]]
-int taylor_terms(Run &R, const u64 *x, u64 count, const double *coeffs, u64 *terms[5]) {
-    for (int i = 0; i < 5; ++i) terms[i] = R.alloc(count * kTermSize[i] * R.pw);
+// repeated squares are the same ring elements bit for bit, so each is formed once.  x: [count_t] arguments; res: [count]
+// outputs of size 11, output c = Enc(0) zero[zmap(c)] + constant + sum_i coeff_i * power_i of argument tmap(c) (:113-118;
+// `broadcast`: count != count_t, the sine polynomials of approximated_step do not depend on the position).
+// The five multiply_plain calls and the sum are ONE launch where the context has the pseudo-Mersenne transforms
+// (fhe_multiply_plain_sum: one inverse transform per output polynomial); otherwise five multiply_plain calls + k_taylor_sum.
+int taylor_eval(Run &R, const u64 *x, u64 count_t, const double *coeffs, const u64 *zero, CMap zmap, double constant, CMap tmap, bool broadcast,
+                u64 *res, u64 count) {
     const size_t m = R.mark();
-    u64 *sx = R.alloc(count * 2 * R.pw), *s4 = R.alloc(count * 5 * R.pw), *psx = R.prepare_alloc(2, count), *tmp = R.alloc(count * 10 * R.pw);
-    TRY(R.copy(sx, x, count * 2));
-    TRY(R.add_plain(sx, 2, count, R.K(-3 * M_PI / 2.0)));               // :57 / :137
-    TRY(R.square(sx, 2, terms[0], count));                              // s2
-    TRY(R.square(terms[0], 3, s4, count));                              // s4
-    TRY(R.square(s4, 5, terms[3], count));                              // s8
-    TRY(R.prepare(sx, 2, count, psx));                                  // the four products below share this operand
-    TRY(R.multiply(s4, 5, nullptr, psx, 2, ident(), tmp, count));       // s5
-    TRY(R.multiply(tmp, 6, nullptr, psx, 2, ident(), terms[2], count)); // s6
-    TRY(R.multiply(terms[3], 9, nullptr, psx, 2, ident(), tmp, count)); // s9
-    TRY(R.multiply(tmp, 10, nullptr, psx, 2, ident(), terms[4], count));// s10
-    TRY(R.mul_plain(terms[0], terms[0], count * 3, R.K(coeffs[0])));
-    TRY(R.mul_plain(s4, terms[1], count * 5, R.K(coeffs[1])));
-    TRY(R.mul_plain(terms[2], terms[2], count * 7, R.K(coeffs[2])));
-    TRY(R.mul_plain(terms[3], terms[3], count * 9, R.K(coeffs[3])));
-    TRY(R.mul_plain(terms[4], terms[4], count * 11, R.K(coeffs[4])));
+    const u64 ct = count_t;
+    u64 *pwr[5];
+    for (int i = 0; i < 5; ++i) pwr[i] = R.alloc(ct * kTermSize[i] * R.pw);      // s2, s4, s6, s8, s10
+    {
+        const size_t m1 = R.mark();
+        u64 *sx = R.alloc(ct * 2 * R.pw), *psx = R.prepare_alloc(2, ct), *tmp = R.alloc(ct * 10 * R.pw);
+        TRY(R.copy(sx, x, ct * 2));
+        TRY(R.add_plain(sx, 2, ct, R.K(-3 * M_PI / 2.0)));               // :57 / :137
+        TRY(R.square(sx, 2, pwr[0], ct));                                // s2
+        TRY(R.square(pwr[0], 3, pwr[1], ct));                            // s4
+        TRY(R.square(pwr[1], 5, pwr[3], ct));                            // s8
+        TRY(R.prepare(sx, 2, ct, psx));                                  // the four products below share this operand
+        TRY(R.multiply(pwr[1], 5, nullptr, psx, 2, ident(), tmp, ct));   // s5
+        TRY(R.multiply(tmp, 6, nullptr, psx, 2, ident(), pwr[2], ct));   // s6
+        TRY(R.multiply(pwr[3], 9, nullptr, psx, 2, ident(), tmp, ct));   // s9
+        TRY(R.multiply(tmp, 10, nullptr, psx, 2, ident(), pwr[4], ct));  // s10
+        R.release(m1);
+    }
+    const CircConst *kc[5];
+    for (int i = 0; i < 5; ++i) {
+        kc[i] = R.K(coeffs[i]);
+        if (!kc[i]) return FHE_ERR_PARAM;
+    }
+    if (fhe_multiply_plain_sum_supported(R.c)) {
+        u64 *src[5] = {pwr[0], pwr[1], pwr[2], pwr[3], pwr[4]};
+        if (!broadcast) {
+            TRY(R.mul_plain_sum(5, src, kTermSize, kc, zero, zmap, 2, res, 11, count));
+        } else {
+            u64 *S = R.alloc(ct * 11 * R.pw);
+            TRY(R.mul_plain_sum(5, src, kTermSize, kc, nullptr, ident(), 0, S, 11, ct));
+            TRY(R.add_general(false, zero, 2, zmap, S, 11, tmap, res, 11, count));
+        }
+    } else {
+        for (int i = 0; i < 5; ++i) TRY(R.mul_plain(pwr[i], pwr[i], ct * kTermSize[i], kc[i]));       // every power is dead after its product
+        if (!R.dry && count) {
+            TaylorTerms T;
+            for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)pwr[i]; T.size[i] = kTermSize[i]; }
+            const u64 nrp = count * 11 * R.k;
+            dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+            k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)zero, zmap, T, tmap, (ulonglong2 *)res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
+            KERNEL_CHECK();
+        }
+    }
+    TRY(R.add_plain(res, 11, count, R.K(constant)));
     R.release(m);
     return FHE_OK;
-}
-// res = Enc(0) + constant, then the terms in the reference's order (:113-118); zero through zmap, term i of output c is
-// terms[i][tmap(c)] (the sine terms of approximated_step do not depend on the position)
-int taylor_sum(Run &R, const u64 *zero, CMap zmap, double constant, u64 *const terms[5], CMap tmap, u64 *res, u64 count) {
-    if (!R.dry && count) {
-        TaylorTerms T;
-        for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)terms[i]; T.size[i] = kTermSize[i]; }
-        const u64 nrp = count * 11 * R.k;
-        dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
-        k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)zero, zmap, T, tmap, (ulonglong2 *)res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
-        KERNEL_CHECK();
-    }
-    return R.add_plain(res, 11, count, R.K(constant));
 }
 
 int run_sincos(Run &R, int cosine, const u64 *x, const u64 *zero, u64 *out, u64 count) {
-    const size_t m = R.mark();
-    u64 *terms[5];
-    TRY(taylor_terms(R, x, count, cosine ? kCosCoeffs : kSinCoeffs, terms));
-    TRY(taylor_sum(R, zero, ident(), cosine ? 1.0 : -1.0, terms, ident(), out, count));
-    R.release(m);
-    return FHE_OK;
+    return taylor_eval(R, x, count, cosine ? kCosCoeffs : kSinCoeffs, zero, ident(), cosine ? 1.0 : -1.0, ident(), false, out, count);
 }
 
 // approximated_step (:202-242) for one run, output positions [pos0, pos1) of the npos = width * height the reference walks
@@ -862,22 +892,27 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
                 }
             TRY(R.stage(h.data(), h.size(), d_idx));
         }
-        {
-            const size_t m3 = R.mark();
-            u64 *terms[5];
-            TRY(taylor_terms(R, cos_arg, nb, kCosCoeffs, terms));
-            TRY(taylor_sum(R, zeros, by_index(d_idx + nb), 1.0, terms, ident(), co, nb));
-            R.release(m3);
-            TRY(taylor_terms(R, sin_arg, (u64)degree, kSinCoeffs, terms));
-            TRY(taylor_sum(R, zeros, by_index(d_idx), -1.0, terms, periodic(np, degree), si, nb));
-            R.release(m3);
-        }
+        TRY(taylor_eval(R, cos_arg, nb, kCosCoeffs, zeros, by_index(d_idx + nb), 1.0, ident(), false, co, nb));
+        TRY(taylor_eval(R, sin_arg, (u64)degree, kSinCoeffs, zeros, by_index(d_idx), -1.0, periodic(np, degree), true, si, nb));
         u64 *prod = R.alloc(nb * 21 * R.pw);
         TRY(R.multiply(si, 11, co, nullptr, 11, ident(), prod, nb));                           // :234-235
-        for (int j = 0; j < degree; ++j) {
-            u64 *pj = prod + (u64)j * np * 21 * R.pw;
-            TRY(R.mul_plain(pj, pj, (u64)np * 21, R.K(2.0 / (M_PI * ((float)(j + 1))))));      // :236
-            TRY(R.add(cacc, pj, cacc, (u64)np * 21));                                         // :237
+        if (fhe_multiply_plain_sum_supported(R.c) && degree <= FHE_PLAIN_SUM_MAX_TERMS) {       // :236-237 for every harmonic in one launch
+            u64 *src[FHE_PLAIN_SUM_MAX_TERMS];
+            const CircConst *kc[FHE_PLAIN_SUM_MAX_TERMS];
+            u32 sizes[FHE_PLAIN_SUM_MAX_TERMS];
+            for (int j = 0; j < degree; ++j) {
+                src[j] = prod + (u64)j * np * 21 * R.pw;
+                sizes[j] = 21;
+                kc[j] = R.K(2.0 / (M_PI * ((float)(j + 1))));
+                if (!kc[j]) return FHE_ERR_PARAM;
+            }
+            TRY(R.mul_plain_sum(degree, src, sizes, kc, cacc, ident(), 21, cacc, 21, np));
+        } else {
+            for (int j = 0; j < degree; ++j) {
+                u64 *pj = prod + (u64)j * np * 21 * R.pw;
+                TRY(R.mul_plain(pj, pj, (u64)np * 21, R.K(2.0 / (M_PI * ((float)(j + 1))))));      // :236
+                TRY(R.add(cacc, pj, cacc, (u64)np * 21));                                         // :237
+            }
         }
         R.release(m2);
     }

@@ -242,6 +242,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.behz_tensor_single = env_on("FHE_BEHZ_TENSOR_SINGLE");
         o.behz_fused_prepare = env_on("FHE_BEHZ_FUSED_PREPARE");
         o.cubic_unfused = env_on("FHE_CUBIC_UNFUSED");
+        o.plain_sum_unfused = env_on("FHE_PLAIN_SUM_UNFUSED");
     }
     c->n = n;
     c->k = k;
@@ -767,6 +768,98 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain_pm(const u64 *_
         for (int r = 0; r < 16; r++) x[j][r] = canon_rq_pm<C::RQ>(x[j][r], m);
         store_coeff<L>(x[j], out + ((M * g + j) * pair_stride + prime) * N, tid);
     }
+}
+
+// sum of plaintext products with ONE inverse transform: out[c][p] = addend[amap(c)][p] + sum over the terms i with p < size_i of
+// src_i[c][p] * plain_i.  multiply_plain is linear, so INTT(sum_i NTT(src_i) . plain_i) is the same ring element -- and the same
+// canonical residues -- as the sum of the separate multiply_plain results; per output polynomial the terms cost one forward
+// transform each and share the inverse one (the Taylor sums of homomorphic_sin / cos: 35 + 11 transforms per ciphertext instead
+// of 35 + 35; the harmonic sum of approximated_step: degree + 1 instead of 2 degree).  Two kernels: forward transform + slot
+// product IN PLACE over each term (values below RQ, slot order), then sum of the terms' slots + inverse transform + addend.
+// (One kernel that keeps the partial sums in registers across the terms' forward transforms was measured first: 223 spilled
+// VGPRs, slower than the separate calls.)
+template <int L, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain_fwd_pm(u64 *__restrict__ io, const ulonglong2 *__restrict__ plain, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const PmMod m = base.pm[prime];
+    u64 x[1][16];
+    load_coeff<L>(x[0], io + (size_t)blockIdx.x * N, tid);
+    ntt_fwd_regs_pm<L, 1, 16, C::LIM, C::CS>(x, base.tw_pm + (size_t)prime * N, m, lds, tid);
+    PM_FENCE();
+    const ulonglong2 *pl = plain + (size_t)prime * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[0][r] = mulvv_pm(fold_pm(x[0][r], m), pl[r * TP + tid].x, m);
+    store_slots<L>(x[0], io + (size_t)blockIdx.x * N, tid);
+}
+// the partial sums stay below 8 RQ + 17/16 q < 2^62 (folded every eighth term)
+template <int L, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_sum_inv_pm(const PlainSumTerms T, const u64 *__restrict__ addend, CMap amap, u32 addend_size,
+                                                                   u64 *__restrict__ out, u32 out_size, RnsBase base) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N;
+    const int tid = threadIdx.x;
+    const u32 prime = blockIdx.x % base.count;
+    const u64 cp = blockIdx.x / base.count;
+    const u32 poly = (u32)(cp % out_size);
+    const u64 ct = cp / out_size;
+    const PmMod m = base.pm[prime];
+    u64 y[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) y[0][r] = 0;
+    u32 pending = 0;
+    for (u32 i = 0; i < T.count; i++) {
+        if (poly >= T.size[i]) continue;
+        u64 x[16];
+        load_slots<L>(x, T.src[i] + ((ct * T.size[i] + poly) * base.count + prime) * N, tid);
+        if (++pending == 8) {
+            pending = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) y[0][r] = fold_pm(y[0][r], m);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[0][r] += x[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) y[0][r] = fold_pm(y[0][r], m);
+    ntt_inv_regs_pm<L, 1, C::RQ, C::XB, C::LIM, C::RQ>(y, base.itw_pm + (size_t)prime * N, m, lds, tid);
+    const u64 *pa = (addend && poly < addend_size) ? addend + ((amap(ct) * addend_size + poly) * base.count + prime) * N : nullptr;
+    u64 *po = out + (size_t)blockIdx.x * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        u64 v = canon_rq_pm<C::RQ>(y[0][r], m);
+        if (pa) v = addmod(v, pa[elem_index<L - 4>(tid, r)], m.q);
+        po[elem_index<L - 4>(tid, r)] = v;
+    }
+}
+bool fhe_multiply_plain_sum_supported(const fhe_ctx *c) {
+    return c && c->qb.pm_class && !c->opt.ntt_nopm && !(fhe_rgb_f64_supported(c) && !c->opt.force_u64) && !c->opt.plain_sum_unfused;
+}
+int fhe_multiply_plain_sum(const fhe_ctx *c, const PlainSumTerms &T, const u64 *addend, CMap amap, u32 addend_size, u64 *out, u32 out_size, u64 count,
+                           hipStream_t st) {
+    if (!fhe_multiply_plain_sum_supported(c)) return fail(FHE_ERR_PARAM, "multiply_plain sum: no pseudo-Mersenne transform for this context");
+    if (T.count < 1 || T.count > FHE_PLAIN_SUM_MAX_TERMS || !out || !out_size) return fail(FHE_ERR_PARAM, "multiply_plain sum: bad arguments");
+    const u64 nrp = count * out_size * c->k;
+    if (!nrp) return FHE_OK;
+    if (nrp > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
+    const RnsBase base = c->qb.dev();
+    for (u32 i = 0; i < T.count; i++) {
+        if (!T.src[i] || !T.plain[i] || T.size[i] > out_size) return fail(FHE_ERR_PARAM, "multiply_plain sum: bad term %u", i);
+        const u64 trp = count * T.size[i] * c->k;
+        if (!trp) continue;
+#define GO_PM(CC) DISPATCH_L(c->logn, (k_mulplain_fwd_pm<L, CC><<<(unsigned)trp, NttShape<L>::TP, 0, st>>>(T.src[i], T.plain[i], base)))
+        if (c->qb.pm_class == 1) { GO_PM(PmA); }
+        else { GO_PM(PmB); }
+#undef GO_PM
+    }
+#define GO_PM(CC) DISPATCH_L(c->logn, (k_sum_inv_pm<L, CC><<<(unsigned)nrp, NttShape<L>::TP, 0, st>>>(T, addend, amap, addend_size, out, out_size, base)))
+    if (c->qb.pm_class == 1) { GO_PM(PmA); }
+    else { GO_PM(PmB); }
+#undef GO_PM
+    KERNEL_CHECK();
+    return FHE_OK;
 }
 
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st) {

@@ -59,6 +59,7 @@ struct FheOptions {
     bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
     bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions
     bool behz_tensor_single = false; // FHE_BEHZ_TENSOR_SINGLE=1: tensor + inverse transform one polynomial per workgroup
+    bool plain_sum_unfused = false;  // FHE_PLAIN_SUM_UNFUSED=1: the Taylor / harmonic sums as separate multiply_plain calls and additions (before k_mulplain_sum_pm)
     bool cubic_unfused = false;      // FHE_CUBIC_UNFUSED=1: Cubic's three products as three complete fhe_multiply calls + k_cubic_combine_g (before round 4's fused tail)
     bool behz_fused_prepare = false; // FHE_BEHZ_FUSED_PREPARE=1: base extension fused into the forward transforms (k_behz_prepare_pm: 25 % less HBM traffic per
                                      // product, 5 % slower -- the y_i are recomputed per auxiliary prime and the kernels are issue-bound; profiles/EXPERIMENTS.md)
@@ -131,6 +132,19 @@ struct CMap {
     u64 div, cnt, off;
     __device__ __forceinline__ u64 operator()(u64 c) const { return idx ? idx[c] : (cnt ? ((off + c / div) % cnt) : c); }
 };
+
+// terms of fhe_multiply_plain_sum (fhe_hip.hip): src_i [count][size_i][k][n] -- OVERWRITTEN (left in NTT form) --, plain_i in NTT form
+// (fhe_plain_prepare)
+#define FHE_PLAIN_SUM_MAX_TERMS 16
+struct PlainSumTerms {
+    u32 count;
+    u32 size[FHE_PLAIN_SUM_MAX_TERMS];
+    u64 *src[FHE_PLAIN_SUM_MAX_TERMS];
+    const ulonglong2 *plain[FHE_PLAIN_SUM_MAX_TERMS];
+};
+bool fhe_multiply_plain_sum_supported(const fhe_ctx *c);
+int fhe_multiply_plain_sum(const fhe_ctx *c, const PlainSumTerms &T, const u64 *addend, CMap amap, u32 addend_size, u64 *out, u32 out_size, u64 count,
+                           hipStream_t st);
 
 // cross-TU internals
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);

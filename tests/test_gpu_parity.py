@@ -613,6 +613,35 @@ def test_approximated_step_vs_oracle(fhe, oracle_mod):
         assert np.array_equal(fhe.to_host(g)[0], r)
 
 
+@pytest.mark.parametrize("preset", ["P8192", "SEAL23_4096"])
+def test_plain_sums_with_one_inverse_transform_vs_separate_products(fhe, oracle_mod, preset):
+    """the Taylor sums of homomorphic_sin / cos and the harmonic sum of approximated_step on pseudo-Mersenne bases: forward
+    transform + slot product per term, ONE inverse transform per output polynomial (k_mulplain_fwd_pm + k_sum_inv_pm) against
+    FHE_PLAIN_SUM_UNFUSED=1 (one multiply_plain per term, then the additions) -- the same bits -- and against the oracle"""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    alt = _variant(fhe, ctx, FHE_PLAIN_SUM_UNFUSED=1)
+    x, z = ctx.random_ct(3, size=2, seed=810), ctx.random_ct(3, size=2, seed=811)
+    x[1] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=x.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
+    outs = []
+    for c in (ctx, alt):
+        ev, pc = fhe.Evaluator(c), fhe.circuits.PlainCache(c)
+        outs.append((fhe.circuits.homomorphic_sin(ev, pc, x, z), fhe.circuits.homomorphic_cos(ev, pc, x, z)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.array_equal(fhe.to_host(outs[0][0])[1], oracle_mod.oracle_homomorphic_sin(orc, fhe.to_host(x)[1], fhe.to_host(z)[1]))
+    assert np.array_equal(fhe.to_host(outs[0][1])[2], oracle_mod.oracle_homomorphic_cos(orc, fhe.to_host(x)[2], fhe.to_host(z)[2]))
+    amp, idx, cnt = (ctx.random_ct(1, size=2, seed=910 + i) for i in range(3))
+    zeros = ctx.random_ct(3 * 2 * 2, size=2, seed=920).reshape(3, 2, 2, 2, ctx.k, ctx.n)
+    runs = [fhe.circuits.approximated_step(fhe.Evaluator(c), fhe.circuits.PlainCache(c), amp, idx, cnt, order=64, degree=2, delta=0.5, width=3, height=1,
+                                           zeros=zeros) for c in (ctx, alt)]
+    for g, w in zip(*runs):
+        assert g.shape[-3] == 22 and torch.equal(g, w)
+    hz = fhe.to_host(zeros)
+    ref = oracle_mod.oracle_approximated_step(orc, fhe.to_host(amp)[0], fhe.to_host(idx)[0], fhe.to_host(cnt)[0], 64, 2, 0.5, 3, 1,
+                                              lambda i, j, which: hz[i, j - 1, int(which == "cos")])
+    assert np.array_equal(fhe.to_host(runs[0][2])[0], ref[2])
+
+
 # ---------------------------------------------------------------------------------------------
 # empty / ragged inputs and error behaviour of the C ABI
 # ---------------------------------------------------------------------------------------------
