@@ -418,6 +418,16 @@ struct Run {
         release(m);
         return rc;
     }
+    // both operands in prepared form (an operand that enters several products is prepared once)
+    int multiply_pp(const u64 *ap, u32 sa, const u64 *bp, u32 sb, u64 *out, u64 count) {
+        const size_t bytes = fhe_multiply_scratch_bytes(c, sa, sb, count);
+        const size_t m = mark();
+        void *scr = alloc((bytes + 7) / 8);
+        int rc = FHE_OK;
+        if (!dry && count) rc = fhe_multiply_prepared(c, nullptr, cu(ap), sa, nullptr, cu(bp), sb, mu(out), count, scr, bytes, st);
+        release(m);
+        return rc;
+    }
     int square(const u64 *a, u32 sa, u64 *out, u64 count) {
         const size_t bytes = fhe_multiply_scratch_bytes(c, sa, sa, count);
         const size_t m = mark();
@@ -763,14 +773,15 @@ int taylor_eval(Run &R, const u64 *x, u64 count_t, const double *coeffs, const u
     for (int i = 0; i < 5; ++i) pwr[i] = R.alloc(ct * kTermSize[i] * R.pw);      // s2, s4, s6, s8, s10
     {
         const size_t m1 = R.mark();
-        u64 *sx = R.alloc(ct * 2 * R.pw), *psx = R.prepare_alloc(2, ct), *tmp = R.alloc(ct * 10 * R.pw);
+        u64 *sx = R.alloc(ct * 2 * R.pw), *psx = R.prepare_alloc(2, ct), *ps4 = R.prepare_alloc(5, ct), *tmp = R.alloc(ct * 10 * R.pw);
         TRY(R.copy(sx, x, ct * 2));
         TRY(R.add_plain(sx, 2, ct, R.K(-3 * M_PI / 2.0)));               // :57 / :137
-        TRY(R.square(sx, 2, pwr[0], ct));                                // s2
+        TRY(R.prepare(sx, 2, ct, psx));                                  // enters five products
+        TRY(R.multiply_pp(psx, 2, psx, 2, pwr[0], ct));                  // s2
         TRY(R.square(pwr[0], 3, pwr[1], ct));                            // s4
-        TRY(R.square(pwr[1], 5, pwr[3], ct));                            // s8
-        TRY(R.prepare(sx, 2, ct, psx));                                  // the four products below share this operand
-        TRY(R.multiply(pwr[1], 5, nullptr, psx, 2, ident(), tmp, ct));   // s5
+        TRY(R.prepare(pwr[1], 5, ct, ps4));                              // enters two
+        TRY(R.multiply_pp(ps4, 5, ps4, 5, pwr[3], ct));                  // s8
+        TRY(R.multiply_pp(ps4, 5, psx, 2, tmp, ct));                     // s5
         TRY(R.multiply(tmp, 6, nullptr, psx, 2, ident(), pwr[2], ct));   // s6
         TRY(R.multiply(pwr[3], 9, nullptr, psx, 2, ident(), tmp, ct));   // s9
         TRY(R.multiply(tmp, 10, nullptr, psx, 2, ident(), pwr[4], ct));  // s10
