@@ -42,7 +42,9 @@ WORKLOADS = {
     "ops8192": ([PY, os.path.join(ROOT, "tools", "bench_ops.py"), "P8192", "1024"],
                 ["k_ntt_fwd", "k_ntt_inv", "k_mulplain", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_eltwise", "k_dyadic"]),
     "resize": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--max-pixels", "512"],
-               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_cubic_coeffs_g", "k_cubic_combine_g"]),
+               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_floor3_combine", "k_behz_to_bsk", "k_cubic_coeffs_g", "k_cubic_combine_g"]),
+    "decode": ([PY, os.path.join(ROOT, "bench_circuits.py"), "decode"],
+               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_mulplain_pm", "k_mulplain_fwd_pm", "k_sum_inv_pm"]),
     "seal23": ([PY, os.path.join(ROOT, "bench.py"), "--preset", "SEAL23_4096", "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
                ["k_dct_rows_u64", "k_dct_cols_u64"]),
 }
