@@ -49,7 +49,7 @@ report("ntt_inverse", timed(lambda: ev.ntt_inverse(a, out=out)), 2 * B * ct_byte
 report("dyadic_multiply", timed(lambda: ev.dyadic_multiply(a, b, out=out)), 3 * B * ct_bytes)
 Bm = max(1, B // 8)
 am, bm = a[:Bm].contiguous(), b[:Bm].contiguous()
-report("multiply 2x2->3", timed(lambda: ev.multiply(am, bm), 3), (2 + 2 + 3) * Bm * ct_bytes / 2, Bm)
+report("multiply 2x2->3", timed(lambda: ev.multiply(am, bm), 20), (2 + 2 + 3) * Bm * ct_bytes / 2, Bm)
 if preset == "P8192":      # counter traffic of the product's launches (tools/collect_traffic.py ctct), quoted only for the sources it was measured on
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_ctct.json")
@@ -60,8 +60,8 @@ if preset == "P8192":      # counter traffic of the product's launches (tools/co
         print(json.dumps({"preset": preset, "op": "multiply 2x2->3 traffic", "hbm_bytes_per_product": round(tj["hbm_bytes_per_product"]) if same else None,
                           "algorithmic_bytes_per_product": tj["algorithmic_bytes_per_product"], "ratio_to_algorithmic": round(tj["ratio_to_algorithmic"], 2) if same else None,
                           "note": None if same else "profiles/pmc_traffic_ctct.json was measured on other kernel sources; re-run tools/collect_traffic.py ctct"}), flush=True)
-report("square 2->3", timed(lambda: ev.square(am), 3), (2 + 3) * Bm * ct_bytes / 2, Bm)
+report("square 2->3", timed(lambda: ev.square(am), 20), (2 + 3) * Bm * ct_bytes / 2, Bm)
 dbc = 30
 evk = fhe.KeyGenerator(ctx, seed=3).generate_evaluation_keys(dbc)
 c3 = ctx.random_ct(Bm, size=3, seed=4)
-report("relinearize 3->2 (dbc 30)", timed(lambda: ev.relinearize(c3, evk, dbc), 3), (3 + 2) * Bm * ct_bytes / 2, Bm)
+report("relinearize 3->2 (dbc 30)", timed(lambda: ev.relinearize(c3, evk, dbc), 20), (3 + 2) * Bm * ct_bytes / 2, Bm)
