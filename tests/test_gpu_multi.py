@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(args, nproc=1):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench(args, nproc=1, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
@@ -52,3 +52,15 @@ def test_two_gpus_sharded_run_and_rccl_wave_gather():
     # 2 x 128 blocks generate the same bytes as 1 x 256 (global block index seeds the inputs)
     assert one["output_digest"] == two["output_digest"] == gathered["output_digest"]
     assert two["n_gpus"] == 2 and gathered["config"]["gather"] == "wave"
+
+
+def test_world2_path_of_bench_on_one_gpu_over_gloo():
+    """bench.py's world > 1 code path (global-index seeding per rank, barrier-bracketed timing, MAX / SUM all-reduces, all-gather of
+    the per-rank times, digest all-reduce) with two ranks that share device 0 and gloo for the collectives (FHE_BENCH_BACKEND=gloo):
+    what a one-GPU box can run of the launch the driver makes on 2/4/8 GPUs.  2 x 128 blocks == 1 x 256 blocks, by digest."""
+    one = _bench(["--blocks", "256", "--steps", "1", "--warmup", "0", "--cpu-blocks", "0"])
+    two = _bench(["--blocks", "128", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"], nproc=2, FHE_BENCH_BACKEND="gloo")
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and len(two["ms_per_step_per_rank"]) == 2
+    assert two["collective_backend"].startswith("gloo") and two["verified_bit_exact_vs_oracle"]
+    assert one["output_digest"] == two["output_digest"]
+    assert abs(two["value"] - 2 * 128 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
