@@ -34,12 +34,19 @@ def _dist_setup(args):
         raise SystemExit("bench_circuits.py needs a HIP device (no CPU path exists)")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    # FHE_BENCH_BACKEND=gloo (tests only, as in bench.py): ranks share the devices there are, collectives on host tensors
+    backend = os.environ.get("FHE_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local, dist
 
 
@@ -62,7 +69,7 @@ def _timed(fn, dist, reps=1):
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
     return res, wall / reps, e0.elapsed_time(e1) / reps

@@ -203,8 +203,8 @@ def test_server_decode_unit_shards_write_the_single_process_file(fhe, oracle_mod
 # ------------------------------------------------------------------------------------------------
 # RCCL: two devices
 # ------------------------------------------------------------------------------------------------
-def _bench_circuits(args, nproc):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench_circuits(args, nproc, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     script = os.path.join(ROOT, "bench_circuits.py")
     if nproc == 1:
         cmd = [sys.executable, script] + args
@@ -226,6 +226,16 @@ def test_bench_circuits_sharded_modes_on_one_gpu():
     assert a["n_gpus"] == 1 and a["roofline"]["bound"] == "hbm" and a["cpu_baseline"]["kind"] == "port" and a["output_digest"]
     b = _bench_circuits(["decode", "--preset", "P4096", "--positions", "4", "--degree", "2"], 1)
     assert b["n_gpus"] == 1 and b["output_digest"] and b["roofline"]["frac"] > 0
+
+
+def test_world2_paths_of_bench_circuits_on_one_gpu_over_gloo():
+    """the row-sharded resize (per-pixel and shared offsets) and the position-sharded decode as TWO processes on device 0, gloo for
+    the collectives (FHE_BENCH_BACKEND=gloo): the launch the driver would make on two GPUs, minus RCCL.  Same digests as one rank."""
+    for base in (["resize", "--preset", "P4096", "--src", "24", "--dst", "12", "--pixels", "48", "--shared"],
+                 ["resize", "--preset", "P4096", "--src", "24", "--dst", "12", "--pixels", "48"],
+                 ["decode", "--preset", "P4096", "--positions", "4", "--degree", "2"]):
+        one, two = _bench_circuits(base, 1), _bench_circuits(base, 2, FHE_BENCH_BACKEND="gloo")
+        assert two["n_gpus"] == 2 and one["output_digest"] == two["output_digest"], base
 
 
 def test_two_gpus_resize_rows_and_decode_units_over_rccl():
