@@ -42,6 +42,8 @@ SIGNATURES = {
     "fhe_default_coeff_modulus": (_i, [_u32, _i, C.POINTER(_u64)]),
     "fhe_dev_alloc": (_i, [_sz, C.POINTER(_vp)]),
     "fhe_dev_free": (_i, [_vp]),
+    "fhe_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "fhe_host_free": (_i, [_vp]),
     "fhe_upload": (_i, [_vp, _vp, _sz, _vp]),
     "fhe_download": (_i, [_vp, _vp, _sz, _vp]),
     "fhe_copy": (_i, [_vp, _vp, _sz, _vp]),

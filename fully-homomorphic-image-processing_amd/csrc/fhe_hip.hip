@@ -335,6 +335,14 @@ extern "C" int fhe_dev_alloc(size_t bytes, void **dptr) {
     return FHE_OK;
 }
 extern "C" int fhe_dev_free(void *p) { if (p) HIP_TRY(hipFree(p)); return FHE_OK; }
+extern "C" int fhe_host_alloc(size_t bytes, void **hptr) {
+    if (!hptr) return fail(FHE_ERR_PARAM, "null argument");
+    *hptr = nullptr;
+    if (!bytes) return FHE_OK;
+    HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return FHE_OK;
+}
+extern "C" int fhe_host_free(void *p) { if (p) HIP_TRY(hipHostFree(p)); return FHE_OK; }
 extern "C" int fhe_upload(void *d, const void *h, size_t bytes, fhe_stream s) {
     HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
     return FHE_OK;

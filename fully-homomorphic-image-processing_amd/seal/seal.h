@@ -378,13 +378,36 @@ private:
 // not pinned by anything in the reference -- SURVEY.md App. A.6): magic "FHEHIP1\0", u32 polys,
 // u32 k, u32 n, u32 reserved, then polys*k*n little-endian u64.
 namespace detail {
+// Staging buffer of Ciphertext::load / save, one per thread, grown on demand and kept: page-locked (fhe_host_alloc) so that the
+// transfer is one DMA, not a second staging copy inside the runtime; plain memory if the allocation is refused.  Never freed:
+// thread-local destructors may run after the device runtime has shut down.
+struct HostStage {
+    uint64_t *p = nullptr;
+    size_t cap = 0, n = 0;
+    bool locked = false;
+    void resize(size_t words) {
+        if (words > cap) {
+            if (p) { if (locked) (void)fhe_host_free(p); else std::free(p); }
+            p = nullptr; cap = 0;
+            void *q = nullptr;
+            locked = fhe_host_alloc(words * 8, &q) == FHE_OK && q;
+            if (!locked) q = std::malloc(words * 8);
+            if (!q) throw std::bad_alloc();
+            p = (uint64_t *)q; cap = words;
+        }
+        n = words;
+    }
+    uint64_t *data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+inline HostStage &host_stage() { static thread_local HostStage *s = new HostStage(); return *s; }
 inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32_t polys, uint32_t k, uint32_t n) {
     const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
     uint32_t hdr[4] = {polys, k, n, 0};
     os.write(magic, 8);
     os.write((const char *)hdr, sizeof hdr);
-    // one staging buffer per thread, reused: a fresh 192 KiB vector per ciphertext is an mmap + page faults + munmap per call
-    static thread_local std::vector<uint64_t> h;
+    HostStage &h = host_stage();
     if (h.size() < words) h.resize(words);
     if (words) {
         check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
@@ -395,7 +418,8 @@ inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32
 inline void save_words(std::ostream &os, const DevBuf &buf, uint32_t polys, uint32_t k, uint32_t n) { save_raw(os, buf.ptr(), buf.words(), polys, k, n); }
 #define FHE_FACADE_MAX_POLYS 64      /* the deepest reference circuit reaches size 22 (homo/fhe_decode.h:239) */
 // header + payload of one record into host memory, every field bounded and every residue checked (the stream is untrusted)
-inline void load_host(std::istream &is, std::vector<uint64_t> &h, uint32_t &polys, uint32_t &k, uint32_t &n, uint32_t want_polys = 0) {
+template <typename Buf>       // std::vector<uint64_t> or HostStage
+inline void load_host(std::istream &is, Buf &h, uint32_t &polys, uint32_t &k, uint32_t &n, uint32_t want_polys = 0) {
     char magic[8];
     uint32_t hdr[4];
     is.read(magic, 8);
@@ -485,7 +509,7 @@ public:
     }
     void load(std::istream &is) {
         const double t0 = detail::now_s();
-        static thread_local std::vector<uint64_t> h;            // reused staging (see save_raw)
+        detail::HostStage &h = detail::host_stage();
         uint32_t polys, k, n;
         detail::load_host(is, h, polys, k, n);
         shape(polys, k, n);

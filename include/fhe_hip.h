@@ -99,6 +99,10 @@ int fhe_upload(void *dst_dev, const void *src_host, size_t bytes, fhe_stream str
 int fhe_download(void *dst_host, const void *src_dev, size_t bytes, fhe_stream stream);
 int fhe_copy(void *dst_dev, const void *src_dev, size_t bytes, fhe_stream stream);
 int fhe_stream_sync(fhe_stream stream);
+/* page-locked host memory for staging buffers of hosts without their own allocator (the facade's Ciphertext::load / save go
+ * through one per thread: a transfer from or to pageable memory is staged a second time inside the runtime) */
+int fhe_host_alloc(size_t bytes, void **hptr);
+int fhe_host_free(void *hptr);
 /* `count` scattered device buffers (addresses in HOST memory, consumed before the call returns) of words_each u64 ->
  * dst[i * dst_stride_words ...], one launch per 256 sources, no staging copy.  The SEAL facade's lazy mode uses it to
  * run the reference's one-ciphertext-at-a-time Evaluator calls (homo/fhe_image.h:206-284) as batched launches.  16-byte

@@ -87,6 +87,8 @@ int fhe_dev_alloc(size_t bytes, void **p) {
     return *p ? FHE_OK : fail(FHE_ERR_NOMEM, "malloc(%zu)", bytes);
 }
 int fhe_dev_free(void *p) { free(p); return FHE_OK; }
+int fhe_host_alloc(size_t b, void **p) { if (!p) return FHE_ERR_PARAM; *p = b ? malloc(b) : NULL; return (b && !*p) ? FHE_ERR_HIP : FHE_OK; }
+int fhe_host_free(void *p) { free(p); return FHE_OK; }
 int fhe_upload(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
 int fhe_download(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
 int fhe_copy(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memmove(d, s, b); return FHE_OK; }
