@@ -872,10 +872,10 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
                         for (u32 pr = 0; pr < R.k; ++pr) {
                             const u64 qi = c->qb.primes[pr];
                             for (size_t x = 0; x < kc->plain.size(); ++x) {
-                                const u64 m = kc->plain[x];
-                                if (!m) continue;
-                                u64 v = hostmath::mulmod(c->delta_mod[pr], m % qi, qi);       // Delta m' as add_plain forms it (ensure_scaled)
-                                if (m >= c->upper_half_threshold) v = hostmath::addmod(v, c->upper_half_increment[pr], qi);
+                                const u64 coef = kc->plain[x];
+                                if (!coef) continue;
+                                u64 v = hostmath::mulmod(c->delta_mod[pr], coef % qi, qi);    // Delta m' as add_plain forms it (ensure_scaled)
+                                if (coef >= c->upper_half_threshold) v = hostmath::addmod(v, c->upper_half_increment[pr], qi);
                                 run[(size_t)pr * len + x] = hostmath::addmod(run[(size_t)pr * len + x], v, qi);
                             }
                         }

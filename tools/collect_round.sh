@@ -3,7 +3,6 @@
 # usage (via gpurun): tools/collect_round.sh r04        -- tools/isa_counts.py $1 must have been run before (no GPU needed)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
 # counters first: bench.py's issue_roofline and traffic fields read profiles/ (hash-matched to the running sources)
 python tools/collect_counters.py $1 > $O/collect_counters.log 2>&1
 cp gpurun_out/$1/counters.json profiles/${1}_counters.json 2>/dev/null; cp gpurun_out/$1/counters.txt $O/counters_summary.txt 2>/dev/null
@@ -12,6 +11,8 @@ python tools/collect_traffic.py > $O/collect_traffic.log 2>&1; cp gpurun_out/pmc
 python tools/collect_traffic.py ctct > $O/collect_traffic_ctct.log 2>&1; cp gpurun_out/pmc_traffic_ctct.json $O/pmc_traffic_ctct.json
 FHE_BEHZ_FUSED_PREPARE=1 python tools/collect_traffic.py ctct > $O/collect_traffic_ctct_fused.log 2>&1; cp gpurun_out/pmc_traffic_ctct.json $O/pmc_traffic_ctct_fused_prepare.json
 cp $O/pmc_traffic_ctct.json profiles/pmc_traffic_ctct.json
+cp $O/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --cpu-blocks 0 > $O/bench_default_with_traffic.json 2>/dev/null
 python bench.py --cpu-blocks 0 --blocks 8192 --steps 3 --warmup 1 > $O/bench_config4_share_8192.json 2>/dev/null
 python bench.py --cpu-blocks 0 --gather local --steps 3 --warmup 1 > $O/bench_gather_local.json 2>/dev/null
