@@ -819,6 +819,27 @@ def test_u64_lazy_ranges_at_boundary_prime_sizes(fhe, oracle_mod, bits, n):
         assert np.array_equal(out[0], orc.dct_quant(blk[0], fhe.YQT))
 
 
+def test_plain_sums_on_a_58_bit_q_base(fhe, oracle_mod):
+    """the PmB instantiation of k_mulplain_fwd_pm / k_sum_inv_pm (partial sums of eight terms below 1.5 q each on 58-bit primes):
+    homomorphic_sin / cos on a q-base of the largest 58- and 57-bit NTT primes, an operand at q - 1, against the separate
+    products and the oracle"""
+    import torch
+    n = 4096
+    q = [_largest_ntt_prime_below(58, n), _largest_ntt_prime_below(57, n)]
+    ctx, orc = fhe.SEALContext(n, q, 1 << 14), oracle_mod.Oracle(n, q, 1 << 14)
+    assert fhe._lib.load().fhe_arith_path(ctx.h) & 3 == 2
+    alt = _variant(fhe, ctx, FHE_PLAIN_SUM_UNFUSED=1)
+    x, z = ctx.random_ct(2, size=2, seed=830), ctx.random_ct(2, size=2, seed=831)
+    x[1] = torch.tensor([qi - 1 for qi in q], dtype=torch.int64, device=x.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
+    outs = []
+    for c in (ctx, alt):
+        ev, pc = fhe.Evaluator(c), fhe.circuits.PlainCache(c)
+        outs.append((fhe.circuits.homomorphic_sin(ev, pc, x, z), fhe.circuits.homomorphic_cos(ev, pc, x, z)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.array_equal(fhe.to_host(outs[0][0])[1], oracle_mod.oracle_homomorphic_sin(orc, fhe.to_host(x)[1], fhe.to_host(z)[1]))
+    assert np.array_equal(fhe.to_host(outs[0][1])[0], oracle_mod.oracle_homomorphic_cos(orc, fhe.to_host(x)[0], fhe.to_host(z)[0]))
+
+
 @pytest.mark.parametrize("bits,n", [(35, 8192), (34, 4096), (35, 16384)])
 def test_u64_forward_canonicalisation_at_the_smallest_lazy_primes(fhe, oracle_mod, monkeypatch, bits, n):
     """canon_below_64q (csrc/ntt_core.h) estimates the quotient of the lazy forward transform's outputs from their high
