@@ -86,9 +86,38 @@ def _cpu_name():
     return "unknown"
 
 
-def _roofline(alg_bytes, dev_ms, kernels):
+def _all_source_hash():
+    """every file of csrc/ (the hash tools/collect_traffic.py circuits ties its record to)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _traffic(workload, units):
+    """HBM bytes of one job from profiles/pmc_traffic_circuits.json (FETCH_SIZE + WRITE_SIZE of every launch of the circuit, per
+    output pixel / per run; tools/collect_traffic.py circuits), quoted only for the sources it was measured on"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_circuits.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_traffic_circuits.json is missing; run tools/collect_traffic.py circuits"
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("kernel_source_hash") != _all_source_hash():
+        return None, "profiles/pmc_traffic_circuits.json was measured on other kernel sources (%s); re-run tools/collect_traffic.py circuits" % tj.get("kernel_source_hash")
+    rec = tj.get(workload)
+    if not rec:
+        return None, "no record for %s" % workload
+    return rec["hbm_bytes_per_unit"] * units, tj.get("source")
+
+
+def _roofline(alg_bytes, dev_ms, kernels, workload=None, units=0):
     achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, src = _traffic(workload, units) if workload else (None, None)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": dev_ms, "kernel": kernels,
             "note": "a sequence of ct x ct launches (csrc/behz.hip), VALU-issue-bound: the per-kernel issue fractions and counter traffic are in profiles/*_issue_roofline.txt and profiles/pmc_traffic_ctct.json"}
 
@@ -169,7 +198,8 @@ def resize(args):
                "config": {"workload": "bicubic resize %dx%d -> %dx%d via the Cubic circuit, one channel, %s (n=%d, %d coeff moduli)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
                           "offsets": form, "batch_pixels": P, "sharding": "destination rows x%d, source rows +- halo per rank, no data-path collective" % world},
                "seconds": wall, "first_pass_seconds": first_pass, "cubic_calls_per_s": 5 * n_out / wall, "out_size": 6,
-               "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm, k_cubic_combine_g"),
+               "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm", "resize_shared" if args.shared else "resize", n_mine if args.preset == "P8192" else 0),
+               "job_executions": 4, "units_per_job": n_mine,
                "output_digest": "%016x" % digest}
         if args.cpu_pixels:
             from oracle import oracle as om
@@ -222,7 +252,8 @@ def decode(args):
                "config": {"workload": "approximated_step W*H=%d degree=%d, %s (n=%d, %d coeff moduli)" % (npos, degree, args.preset, ctx.n, ctx.k),
                           "sharding": "output positions x%d; run operands, offset chain and sine polynomials replicated; no data-path collective" % world},
                "seconds": wall, "steps_per_s": 1 / wall, "out_size": so, "outputs": npos,
-               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_add_general"),
+               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_sum_inv_pm", "decode", (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0),
+               "job_executions": 2, "units_per_job": p1 - p0,
                "output_digest": "%016x" % digest}
         if args.cpu_terms:
             from oracle import oracle as om

@@ -11,6 +11,7 @@ python tools/collect_traffic.py > $O/collect_traffic.log 2>&1; cp gpurun_out/pmc
 python tools/collect_traffic.py ctct > $O/collect_traffic_ctct.log 2>&1; cp gpurun_out/pmc_traffic_ctct.json $O/pmc_traffic_ctct.json
 FHE_BEHZ_FUSED_PREPARE=1 python tools/collect_traffic.py ctct > $O/collect_traffic_ctct_fused.log 2>&1; cp gpurun_out/pmc_traffic_ctct.json $O/pmc_traffic_ctct_fused_prepare.json
 cp $O/pmc_traffic_ctct.json profiles/pmc_traffic_ctct.json
+python tools/collect_traffic.py circuits > $O/collect_traffic_circuits.log 2>&1; cp gpurun_out/pmc_traffic_circuits.json $O/pmc_traffic_circuits.json
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --cpu-blocks 0 > $O/bench_default_with_traffic.json 2>/dev/null

@@ -126,6 +126,66 @@ def ctct(f_read, f_write):
     print(json.dumps(res))
 
 
+# ---- the circuits (bench_circuits.py): every launch of the library in one process, per output pixel / per run -------------
+CIRCUITS = {
+    "resize": ["resize", "--max-pixels", "1024"],
+    "resize_shared": ["resize", "--shared", "--max-pixels", "1024"],
+    "decode": ["decode"],
+}
+NOT_THE_CIRCUIT = ("k_fill_random", "k_digest", "at::native", "rocclr", "k_make_shoup")      # inputs, digests, torch's own kernels, table set-up
+
+
+def all_source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_pass_all(counter, tag, cmd):
+    out = os.path.join(ROOT, "gpurun_out", "traffic_" + tag)
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--pmc", counter, "--"] + cmd,
+                       check=True, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    tot = collections.defaultdict(float)
+    with open(os.path.join(out, "p_counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"]
+            if any(x in k for x in NOT_THE_CIRCUIT):
+                continue
+            tot[k.split("(")[0].split("<")[0].split("::")[-1].replace("void ", "")] += float(row["Counter_Value"])
+    return tot, line
+
+
+def circuits(f_read, f_write):
+    res = {"kernel_source_hash": all_source_hash(), "read_factor": f_read, "write_factor": f_write,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench_circuits.py at P8192, every launch of the library "
+                     "summed (inputs, digests and torch's own kernels left out), divided by the job executions of the process and the units of a job; "
+                     "factors as calibrated for pmc_traffic.json; tools/collect_traffic.py circuits"}
+    for name, argv in CIRCUITS.items():
+        cmd = [sys.executable, os.path.join(ROOT, "bench_circuits.py")] + argv
+        rd, line = run_pass_all("FETCH_SIZE", "circ_%s_fetch" % name, cmd)
+        wr, _ = run_pass_all("WRITE_SIZE", "circ_%s_write" % name, cmd)
+        jobs = line["job_executions"]
+        units = line["units_per_job"] if name != "decode" else 1           # per output pixel; per run
+        per_kernel = {k: {"read_bytes_per_unit": rd[k] * 1024 * f_read / jobs / units, "write_bytes_per_unit": wr.get(k, 0.0) * 1024 * f_write / jobs / units}
+                      for k in sorted(rd)}
+        total = sum(v["read_bytes_per_unit"] + v["write_bytes_per_unit"] for v in per_kernel.values())
+        alg = line["roofline"]["algorithmic_bytes_per_launch"] / units
+        res[name] = {"unit": "output pixel" if name != "decode" else "run", "hbm_bytes_per_unit": total, "algorithmic_bytes_per_unit": alg,
+                     "ratio_to_algorithmic": total / alg, "units_measured": line["units_per_job"], "job_executions": jobs, "per_kernel": per_kernel,
+                     "command": "bench_circuits.py " + " ".join(argv)}
+    for d in ("profiles", "gpurun_out"):
+        os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+        with open(os.path.join(ROOT, d, "pmc_traffic_circuits.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    print(json.dumps({k: (v if not isinstance(v, dict) else {x: v[x] for x in v if x != "per_kernel"}) for k, v in res.items()}))
+
+
 def main():
     cal_bytes = CAL_CTS * 2 * 3 * 4096 * 8
     crd, cnames = run_pass(["FETCH_SIZE"], "cal_fetch", CAL, ["k_poly_f64"])
@@ -134,6 +194,8 @@ def main():
     f_write = cal_bytes / (cwr["k_poly_f64"]["WRITE_SIZE"] * 1024)
     if "ctct" in sys.argv[1:]:
         return ctct(f_read, f_write)
+    if "circuits" in sys.argv[1:]:
+        return circuits(f_read, f_write)
     rd, names = run_pass(["FETCH_SIZE"], "fetch", CMD, ["k_dct_rows", "k_dct_cols"])
     wr, _ = run_pass(["WRITE_SIZE"], "write", CMD, ["k_dct_rows", "k_dct_cols"])
     per_kernel, total = {}, 0.0
