@@ -48,6 +48,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "fhe_hip.h"
@@ -283,7 +284,8 @@ struct CtxState {
     struct Stats {
         uint64_t recorded, computed, dropped, flushes, groups, launches, gathers;
         double flush_s;                // host time inside flush (launch overhead: the launches are asynchronous)
-        Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0), flush_s(0) {}
+        double create_s, destroy_s;    // fhe_ctx_create (device runtime start-up included when it is the process's first device call) / fhe_ctx_destroy
+        Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0), flush_s(0), create_s(0), destroy_s(0) {}
     } stats;
     CtxState() : h(nullptr), n(0), k(0), t(0), pending_words(0), eager(false), flushing(false) {
         const char *e = std::getenv("FHE_FACADE_EAGER");
@@ -291,15 +293,18 @@ struct CtxState {
     }
     ~CtxState() {
         pending.clear();
+        const double td = now_s();
         if (h) fhe_ctx_destroy(h);
+        stats.destroy_s = now_s() - td;
         // FHE_FACADE_STATS=1: one line on stderr when the context goes away; any other value: appended to the file of that name
         if (const char *e = std::getenv("FHE_FACADE_STATS")) {
             FILE *f = (e[0] == '1' && !e[1]) ? stderr : std::fopen(e, "a");
             if (f) {
-                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu save_ms=%llu\n",
+                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu save_ms=%llu ctx_create_ms=%llu ctx_destroy_ms=%llu\n",
                              eager ? "eager" : "lazy", (unsigned long long)stats.recorded, (unsigned long long)stats.computed, (unsigned long long)stats.dropped,
                              (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers,
-                             (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3));
+                             (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3),
+                             (unsigned long long)(stats.create_s * 1e3), (unsigned long long)(stats.destroy_s * 1e3));
                 if (f != stderr) std::fclose(f);
             }
         }
@@ -320,7 +325,9 @@ public:
         for (const auto &m : p.q_) s.q.push_back(m.value());
         int dev = 0;
         if (const char *e = std::getenv("FHE_DEVICE")) dev = std::atoi(e);
+        const double tc = detail::now_s();
         detail::check(fhe_ctx_create(s.n, s.q.data(), s.k, s.t, dev, &s.h), "SEALContext");
+        s.stats.create_s = detail::now_s() - tc;
         s.Q = detail::Big(1);
         for (uint64_t qi : s.q) s.Q.mul_small(qi);
         s.Qhalf = s.Q;
@@ -348,16 +355,42 @@ private:
     BigUInt total_;
 };
 
+// Coefficients of a plaintext.  A FractionalEncoder hands out the SAME immutable object for the same double every time (the
+// reference re-encodes a few dozen constants tens of thousands of times: homo/fhe_image.h:221-236,259,301,317-319), so a
+// Plaintext made by encode() costs a map lookup instead of an n-coefficient vector, and the Evaluator recognises it by address
+// instead of hashing and comparing n coefficients per call.  Writing through a Plaintext copies a shared object first.
+namespace detail {
+struct PlainData {
+    std::vector<uint64_t> c;
+    bool frozen = false;          // shared by an encoder's memo: never written again
+    mutable int len = -1;         // significant coefficients, computed once
+    int significant() const {
+        if (len < 0) { int n = (int)c.size(); while (n > 0 && c[n - 1] == 0) --n; len = n; }
+        return len;
+    }
+};
+}  // namespace detail
+
 class Plaintext {
 public:
     Plaintext() {}
-    explicit Plaintext(std::vector<uint64_t> c) : c_(std::move(c)) {}
-    int coeff_count() const { return (int)c_.size(); }
-    int significant_coeff_count() const { int n = (int)c_.size(); while (n > 0 && c_[n - 1] == 0) --n; return n; }
-    uint64_t operator[](int i) const { return c_[i]; }
-    const std::vector<uint64_t> &data() const { return c_; }
-    std::vector<uint64_t> &data() { return c_; }
+    explicit Plaintext(std::vector<uint64_t> c) : d_(std::make_shared<detail::PlainData>()) { d_->c = std::move(c); }
+    explicit Plaintext(std::shared_ptr<detail::PlainData> frozen) : d_(std::move(frozen)) {}
+    int coeff_count() const { return d_ ? (int)d_->c.size() : 0; }
+    int significant_coeff_count() const { return d_ ? d_->significant() : 0; }
+    uint64_t operator[](int i) const { return d_->c[i]; }
+    const std::vector<uint64_t> &data() const { static const std::vector<uint64_t> none; return d_ ? d_->c : none; }
+    std::vector<uint64_t> &data() {                      // mutable access: this handle's own copy, cached length dropped
+        if (!d_) d_ = std::make_shared<detail::PlainData>();
+        else if (d_->frozen || d_.use_count() > 1) { auto own = std::make_shared<detail::PlainData>(); own->c = d_->c; d_ = std::move(own); }
+        d_->len = -1;
+        return d_->c;
+    }
+    // facade internals: the immutable object behind a plaintext made by FractionalEncoder::encode (null otherwise)
+    const detail::PlainData *frozen_data() const { return d_ && d_->frozen ? d_.get() : nullptr; }
+    const std::shared_ptr<detail::PlainData> &shared_data() const { return d_; }
     std::string to_string() const {   // SEAL style: "7FFx^3 + 1x^1 + 2"
+        const std::vector<uint64_t> &c_ = data();
         std::ostringstream o;
         bool first = true;
         for (int i = (int)c_.size() - 1; i >= 0; --i) {
@@ -371,7 +404,7 @@ public:
         return o.str();
     }
 private:
-    std::vector<uint64_t> c_;
+    std::shared_ptr<detail::PlainData> d_;
 };
 
 // Wire format of save()/load() for ciphertexts and keys (self-consistent; SEAL 2.3's own format is
@@ -1045,9 +1078,19 @@ public:
         if (ic_ <= 0 || fc_ <= 0 || (uint32_t)(ic_ + fc_) > n_) throw std::invalid_argument("coefficient counts do not fit the polynomial");
     }
     Plaintext encode(double value) const {
-        std::vector<uint64_t> c(n_);
-        if (fhe_frac_encode(n_, t_, value, ic_, fc_, c.data()) < 0) throw std::invalid_argument(fhe_last_error());
-        return Plaintext(std::move(c));
+        uint64_t bits;
+        std::memcpy(&bits, &value, 8);
+        auto it = memo_.find(bits);
+        if (it != memo_.end()) return Plaintext(it->second);
+        std::shared_ptr<detail::PlainData> d = std::make_shared<detail::PlainData>();
+        d->c.resize(n_);
+        const int len = fhe_frac_encode(n_, t_, value, ic_, fc_, d->c.data());
+        if (len < 0) throw std::invalid_argument(fhe_last_error());
+        d->len = len;
+        d->frozen = true;
+        if (memo_.size() >= 4096) memo_.clear();          // plaintexts handed out keep their objects alive
+        memo_.emplace(bits, d);
+        return Plaintext(std::move(d));
     }
     double decode(const Plaintext &p) const {
         std::vector<uint64_t> c(p.data());
@@ -1064,6 +1107,7 @@ private:
     uint64_t t_;
     uint32_t n_;
     int ic_, fc_;
+    mutable std::unordered_map<uint64_t, std::shared_ptr<detail::PlainData>> memo_;      // by the bits of the double; single-threaded like the reference
 };
 
 class Evaluator {
@@ -1132,6 +1176,19 @@ private:
         if (len) record(sign > 0 ? detail::Node::ADDP : detail::Node::SUBP, a, nullptr, plain_entry(p, len), (uint32_t)a.size());
     }
     std::shared_ptr<detail::PlainEntry> plain_entry(const Plaintext &p, int len) {
+        const detail::PlainData *fz = p.frozen_data();                     // an encoder's immutable object: recognised by address
+        if (fz) {
+            auto it = by_object_.find(fz);
+            if (it != by_object_.end()) return it->second.second;
+        }
+        std::shared_ptr<detail::PlainEntry> e = plain_entry_by_value(p, len);
+        if (fz) {
+            if (by_object_.size() >= 4096) by_object_.clear();
+            by_object_.emplace(fz, std::make_pair(p.shared_data(), e));    // the object is kept alive, so its address cannot be reused
+        }
+        return e;
+    }
+    std::shared_ptr<detail::PlainEntry> plain_entry_by_value(const Plaintext &p, int len) {
         uint64_t h = 1469598103934665603ULL;                               // FNV-1a over the significant coefficients
         for (int i = 0; i < len; ++i) { h ^= p[i] + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1); h *= 1099511628211ULL; }
         auto range = plain_cache_.equal_range(h);
@@ -1149,6 +1206,7 @@ private:
     std::shared_ptr<detail::CtxState> st_;
     detail::DevBuf scratch_;
     std::multimap<uint64_t, std::shared_ptr<detail::PlainEntry>> plain_cache_;
+    std::unordered_map<const detail::PlainData *, std::pair<std::shared_ptr<detail::PlainData>, std::shared_ptr<detail::PlainEntry>>> by_object_;
 };
 
 // ---- throughput helpers: the fused/batched C ABI behind SEAL-typed arguments ---------------------
