@@ -111,6 +111,28 @@ int main(int argc, char **argv) {
         CHECK(s1.str() != s2.str() && dec(c1) == 1.0 && dec(c2) == 1.0, "encryption is randomised");
     }
 
+    // plaintext values: the encoder hands out one shared immutable object per distinct double; a write goes to a private copy
+    {
+        Plaintext p1 = encoder.encode(0.707106781), p2 = encoder.encode(0.707106781), p3 = encoder.encode(-0.707106781);
+        CHECK(p1.frozen_data() && p1.frozen_data() == p2.frozen_data() && p3.frozen_data() != p1.frozen_data(), "one object per distinct value");
+        const int len = p1.significant_coeff_count();
+        Plaintext q(p1);
+        q.data()[0] = 5;                                   // copy on write
+        CHECK(!q.frozen_data() && q[0] == 5 && p1[0] != 5 && p2[0] != 5 && p1.significant_coeff_count() == len, "a write must not reach the shared object");
+        CHECK(encoder.decode(p2) == encoder.decode(encoder.encode(0.707106781)), "the memo returns the same coefficients");
+        Plaintext r = q, u = q;
+        u.data()[1] = 7;
+        CHECK(r[1] != 7 && u[1] == 7, "two handles of one private plaintext separate on write");
+        Ciphertext c1(a), c2(a), c3(a);
+        evaluator.multiply_plain(c1, p1); evaluator.multiply_plain(c2, p2);
+        evaluator.multiply_plain(c3, Plaintext(std::vector<uint64_t>(p1.data())));   // the same coefficients through the by-value path
+        std::stringstream s1, s2, s3; c1.save(s1); c2.save(s2); c3.save(s3);
+        CHECK(s1.str() == s2.str() && s1.str() == s3.str(), "products by the shared object and by an equal private plaintext are the same bytes");
+        Plaintext z; CHECK(z.significant_coeff_count() == 0 && z.coeff_count() == 0 && z.to_string() == "0", "empty plaintext");
+        bool threw = false; try { Ciphertext c(a); evaluator.multiply_plain(c, encoder.encode(0.0)); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw, "multiply_plain by encode(0) must throw");
+    }
+
     // fused block circuit on one encrypted 8x8 block
     const std::vector<double> yqt = {16,11,10,16,24,40,51,61,12,12,14,19,26,58,60,55,14,13,16,24,40,57,69,56,14,17,22,29,51,87,80,62,
                                      18,22,37,56,68,109,103,77,24,35,55,64,81,104,113,92,49,64,78,87,103,121,120,101,72,92,95,98,112,100,103,99};
