@@ -249,7 +249,7 @@ struct PlainEntry {                    // one distinct plaintext an Evaluator ha
     DevBuf prepared;                   // fhe_plain_prepare form, built when the first dense product runs
     PlainEntry() : nnz(0) {}
 };
-inline double *io_seconds() { static double t[2] = {0, 0}; return t; }     // process-wide: host time in Ciphertext::load / save
+inline double *io_seconds() { static double t[4] = {0, 0, 0, 0}; return t; }     // process-wide: host time in Ciphertext::load / save, and the device transfers inside them
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct CtxState;
 struct Node {                          // an immutable ciphertext VALUE: materialised (st) or the recipe for it (op, a, b, plain)
@@ -300,11 +300,11 @@ struct CtxState {
         if (const char *e = std::getenv("FHE_FACADE_STATS")) {
             FILE *f = (e[0] == '1' && !e[1]) ? stderr : std::fopen(e, "a");
             if (f) {
-                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu save_ms=%llu ctx_create_ms=%llu ctx_destroy_ms=%llu\n",
+                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu (upload %llu) save_ms=%llu (download %llu) ctx_create_ms=%llu ctx_destroy_ms=%llu\n",
                              eager ? "eager" : "lazy", (unsigned long long)stats.recorded, (unsigned long long)stats.computed, (unsigned long long)stats.dropped,
                              (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers,
-                             (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3),
-                             (unsigned long long)(stats.create_s * 1e3), (unsigned long long)(stats.destroy_s * 1e3));
+                             (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[2] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3),
+                             (unsigned long long)(io_seconds()[3] * 1e3), (unsigned long long)(stats.create_s * 1e3), (unsigned long long)(stats.destroy_s * 1e3));
                 if (f != stderr) std::fclose(f);
             }
         }
@@ -443,8 +443,10 @@ inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32
     HostStage &h = host_stage();
     if (h.size() < words) h.resize(words);
     if (words) {
+        const double t0 = now_s();
         check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
         check(fhe_stream_sync(nullptr), "sync");
+        io_seconds()[3] += now_s() - t0;
     }
     os.write((const char *)h.data(), (std::streamsize)(words * 8));
 }
@@ -546,7 +548,9 @@ public:
         uint32_t polys, k, n;
         detail::load_host(is, h, polys, k, n);
         shape(polys, k, n);
+        const double t1 = detail::now_s();
         if (!h.empty()) buffer().upload(h.data(), h.size());
+        detail::io_seconds()[2] += detail::now_s() - t1;
         detail::io_seconds()[0] += detail::now_s() - t0;
     }
     // ---- facade internals --------------------------------------------------------------------------------------
