@@ -760,15 +760,27 @@ const u32 kTermSize[5] = {3, 5, 7, 9, 11};
 
 // homomorphic_sin / homomorphic_cos: even Taylor polynomial of degree 10 in (x - 3 pi / 2).
 // The reference rebuilds every power from a fresh copy of the shifted argument (11 squares, 4 multiplies, :66-112); the
-// repeated squares are the same ring elements bit for bit, so each is formed once.  x: [count_t] arguments; res: [count]
-// outputs of size 11, output c = Enc(0) zero[zmap(c)] + constant + sum_i coeff_i * power_i of argument tmap(c) (:113-118;
-// `broadcast`: count != count_t, the sine polynomials of approximated_step do not depend on the position).
-// The five multiply_plain calls and the sum are ONE launch where the context has the pseudo-Mersenne transforms
+// repeated squares are the same ring elements bit for bit, so each is formed once -- for ALL arguments of a call in one batch,
+// sines and cosines alike (the powers do not know which polynomial they will enter).  A segment [first, first + count_t) of the
+// arguments then gets its coefficients: res: [count] outputs of size 11, output c = Enc(0) zero[zmap(c)] + constant +
+// sum_i coeff_i * power_i of argument first + tmap(c) (:113-118; `broadcast`: count != count_t, the sine polynomials of
+// approximated_step do not depend on the position).
+// The five multiply_plain calls and the sum are two launches where the context has the pseudo-Mersenne transforms
 // (fhe_multiply_plain_sum: one inverse transform per output polynomial); otherwise five multiply_plain calls + k_taylor_sum.
-int taylor_eval(Run &R, const u64 *x, u64 count_t, const double *coeffs, const u64 *zero, CMap zmap, double constant, CMap tmap, bool broadcast,
-                u64 *res, u64 count) {
+struct TaylorSeg {
+    u64 first, count_t;
+    const double *coeffs;
+    const u64 *zero;
+    CMap zmap;
+    double constant;
+    CMap tmap;
+    bool broadcast;
+    u64 *res;
+    u64 count;
+};
+int taylor_eval(Run &R, const u64 *x, u64 count_all, const TaylorSeg *segs, int nsegs) {
     const size_t m = R.mark();
-    const u64 ct = count_t;
+    const u64 ct = count_all;
     u64 *pwr[5];
     for (int i = 0; i < 5; ++i) pwr[i] = R.alloc(ct * kTermSize[i] * R.pw);      // s2, s4, s6, s8, s10
     {
@@ -787,38 +799,45 @@ int taylor_eval(Run &R, const u64 *x, u64 count_t, const double *coeffs, const u
         TRY(R.multiply(tmp, 10, nullptr, psx, 2, ident(), pwr[4], ct));  // s10
         R.release(m1);
     }
-    const CircConst *kc[5];
-    for (int i = 0; i < 5; ++i) {
-        kc[i] = R.K(coeffs[i]);
-        if (!kc[i]) return FHE_ERR_PARAM;
-    }
-    if (fhe_multiply_plain_sum_supported(R.c)) {
-        u64 *src[5] = {pwr[0], pwr[1], pwr[2], pwr[3], pwr[4]};
-        if (!broadcast) {
-            TRY(R.mul_plain_sum(5, src, kTermSize, kc, zero, zmap, 2, res, 11, count));
+    for (int sg = 0; sg < nsegs; ++sg) {
+        const TaylorSeg &S = segs[sg];
+        const size_t ms = R.mark();
+        const CircConst *kc[5];
+        u64 *src[5];
+        for (int i = 0; i < 5; ++i) {
+            kc[i] = R.K(S.coeffs[i]);
+            if (!kc[i]) return FHE_ERR_PARAM;
+            src[i] = pwr[i] + S.first * kTermSize[i] * R.pw;
+        }
+        if (fhe_multiply_plain_sum_supported(R.c)) {
+            if (!S.broadcast) {
+                TRY(R.mul_plain_sum(5, src, kTermSize, kc, S.zero, S.zmap, 2, S.res, 11, S.count));
+            } else {
+                u64 *sum = R.alloc(S.count_t * 11 * R.pw);
+                TRY(R.mul_plain_sum(5, src, kTermSize, kc, nullptr, ident(), 0, sum, 11, S.count_t));
+                TRY(R.add_general(false, S.zero, 2, S.zmap, sum, 11, S.tmap, S.res, 11, S.count));
+            }
         } else {
-            u64 *S = R.alloc(ct * 11 * R.pw);
-            TRY(R.mul_plain_sum(5, src, kTermSize, kc, nullptr, ident(), 0, S, 11, ct));
-            TRY(R.add_general(false, zero, 2, zmap, S, 11, tmap, res, 11, count));
+            for (int i = 0; i < 5; ++i) TRY(R.mul_plain(src[i], src[i], S.count_t * kTermSize[i], kc[i]));   // every power is dead after its product
+            if (!R.dry && S.count) {
+                TaylorTerms T;
+                for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)src[i]; T.size[i] = kTermSize[i]; }
+                const u64 nrp = S.count * 11 * R.k;
+                dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+                k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)S.zero, S.zmap, T, S.tmap, (ulonglong2 *)S.res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
+                KERNEL_CHECK();
+            }
         }
-    } else {
-        for (int i = 0; i < 5; ++i) TRY(R.mul_plain(pwr[i], pwr[i], ct * kTermSize[i], kc[i]));       // every power is dead after its product
-        if (!R.dry && count) {
-            TaylorTerms T;
-            for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)pwr[i]; T.size[i] = kTermSize[i]; }
-            const u64 nrp = count * 11 * R.k;
-            dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
-            k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)zero, zmap, T, tmap, (ulonglong2 *)res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
-            KERNEL_CHECK();
-        }
+        TRY(R.add_plain(S.res, 11, S.count, R.K(S.constant)));
+        R.release(ms);
     }
-    TRY(R.add_plain(res, 11, count, R.K(constant)));
     R.release(m);
     return FHE_OK;
 }
 
 int run_sincos(Run &R, int cosine, const u64 *x, const u64 *zero, u64 *out, u64 count) {
-    return taylor_eval(R, x, count, cosine ? kCosCoeffs : kSinCoeffs, zero, ident(), cosine ? 1.0 : -1.0, ident(), false, out, count);
+    const TaylorSeg seg = {0, count, cosine ? kCosCoeffs : kSinCoeffs, zero, ident(), cosine ? 1.0 : -1.0, ident(), false, out, count};
+    return taylor_eval(R, x, count, &seg, 1);
 }
 
 // approximated_step (:202-242) for one run, output positions [pos0, pos1) of the npos = width * height the reference walks
@@ -848,7 +867,7 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
         const size_t m2 = R.mark();
         std::vector<double> factor(degree);
         for (int j = 1; j <= degree; ++j) factor[j - 1] = ((float)j) * M_PI / ((double)order);      // :225
-        u64 *cos_arg = R.alloc(nb * 2 * R.pw), *sin_arg = R.alloc((u64)degree * 2 * R.pw);
+        u64 *args = R.alloc((nb + (u64)degree) * 2 * R.pw), *cos_arg = args, *sin_arg = args + nb * 2 * R.pw;     // one batch of Taylor arguments
         // :228-229: cos_arg(offset), then add_plain(offset, encode(i)) INSIDE the harmonic loop -- the one serial chain of the
         // circuit.  add_plain is an exact addition of Delta m' to c_0, so the value of `offset` at step (i, j) is offset + the sum
         // of the plaintexts added before it: the sums are formed on the host (a few coefficients each: encode(i) has
@@ -903,8 +922,9 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
                 }
             TRY(R.stage(h.data(), h.size(), d_idx));
         }
-        TRY(taylor_eval(R, cos_arg, nb, kCosCoeffs, zeros, by_index(d_idx + nb), 1.0, ident(), false, co, nb));
-        TRY(taylor_eval(R, sin_arg, (u64)degree, kSinCoeffs, zeros, by_index(d_idx), -1.0, periodic(np, degree), true, si, nb));
+        const TaylorSeg segs[2] = {{0, nb, kCosCoeffs, zeros, by_index(d_idx + nb), 1.0, ident(), false, co, nb},
+                                   {nb, (u64)degree, kSinCoeffs, zeros, by_index(d_idx), -1.0, periodic(np, degree), true, si, nb}};
+        TRY(taylor_eval(R, args, nb + (u64)degree, segs, 2));
         u64 *prod = R.alloc(nb * 21 * R.pw);
         TRY(R.multiply(si, 11, co, nullptr, 11, ident(), prod, nb));                           // :234-235
         if (fhe_multiply_plain_sum_supported(R.c) && degree <= FHE_PLAIN_SUM_MAX_TERMS) {       // :236-237 for every harmonic in one launch
