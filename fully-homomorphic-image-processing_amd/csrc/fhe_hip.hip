@@ -804,8 +804,8 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_mulplain_fwd_pm(u64 *__r
 }
 // the partial sums stay below 8 RQ + 17/16 q < 2^62 (folded every eighth term)
 template <int L, typename C>
-__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_sum_inv_pm(const PlainSumTerms T, const u64 *__restrict__ addend, CMap amap, u32 addend_size,
-                                                                   u64 *__restrict__ out, u32 out_size, RnsBase base) {
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_sum_inv_pm(const PlainSumTerms T, const u64 *addend, CMap amap, u32 addend_size,
+                                                                   u64 *out, u32 out_size, RnsBase base) {      // out may be addend (the harmonic sum accumulates in place)
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;

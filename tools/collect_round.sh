@@ -44,4 +44,5 @@ tools/prof.sh ${1}_seal23 python $R/bench.py --preset SEAL23_4096 --cpu-blocks 0
 for d in bench resize resize_shared decode ops8192 seal23; do cp $R/gpurun_out/prof_${1}_$d/p_kernel_stats.csv $O/kernel_stats_$d.csv 2>/dev/null; done
 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1
 python tools/soak.py > $O/soak.txt 2>&1
+python tools/soak.py 320 P8192 >> $O/soak.txt 2>&1
 ls -la $O

@@ -37,6 +37,17 @@ taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
 xf, yf = ctx.random_ct(w * h, seed=32), ctx.random_ct(w * h, seed=33)
 half = (w * h) // 2
 ref_bic = [ctx.digest(fhe.circuits.sample_bicubic(ev, pc, pix, taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous()).view(-1)) for s, e in ((0, half), (half, w * h))]
+# approximated_step: the offset chain through the staging ring, the in-place forward transforms of the plaintext sums and the harmonic sum
+# that accumulates in place (k_mulplain_fwd_pm / k_sum_inv_pm on pseudo-Mersenne bases, the separate products elsewhere)
+s_amp, s_idx, s_cnt = (ctx.random_ct(1, size=2, seed=41 + i) for i in range(3))
+s_zeros = ctx.random_ct(3 * 3 * 2, size=2, seed=44).reshape(3, 3, 2, 2, ctx.k, ctx.n)
+
+
+def step_digest():
+    return ctx.digest(torch.cat(fhe.circuits.approximated_step(ev, pc, s_amp, s_idx, s_cnt, order=64, degree=3, delta=0.5, width=3, height=1, zeros=s_zeros)).view(-1))
+
+
+ref_step = step_digest()
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -63,5 +74,8 @@ for i in range(iters):
         if [ctx.digest(o1.view(-1)), ctx.digest(o2.view(-1))] != ref_bic:
             bad += 1
             print("sample_bicubic digest mismatch at iteration", i, flush=True)
+        if step_digest() != ref_step:
+            bad += 1
+            print("approximated_step digest mismatch at iteration", i, flush=True)
 print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
