@@ -22,8 +22,12 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     for name, argv in (("client --send", [cl, "--send", "-f", "image/in.jpg", "-c", "image/ct_in.txt", "--cmod", "4096"] + extra),
                        ("server_jpeg", [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt", "--cmod", "4096"] + extra),
                        ("client --recieve", [cl, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg", "--cmod", "4096"] + extra)):
+        # FHE_REF_SERVER_PREFIX="rocprofv3 --kernel-trace --stats -d <dir> -o p --": the server step under the profiler (its kernel
+        # statistics are the launches the reference's unchanged loop turns into; the wall time then includes the profiler)
+        if name == "server_jpeg" and os.environ.get("FHE_REF_SERVER_PREFIX"):
+            argv = os.environ["FHE_REF_SERVER_PREFIX"].split() + argv
         t0 = time.time()
-        r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=dict(os.environ, FHE_FACADE_STATS="1"))
+        r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=dict(os.environ, FHE_FACADE_STATS="1", TMPDIR="/tmp"))
         dt = time.time() - t0
         print(f"{name}: rc={r.returncode} {dt:.2f} s", flush=True)
         if r.returncode: print(r.stdout[-1500:], r.stderr[-1500:]); sys.exit(1)
