@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfhe_hip.so")
+LIB_PATH = os.environ.get("FHE_HIP_LIB") or os.path.join(_HERE, "libfhe_hip.so")      # FHE_HIP_LIB: another build of the same library (compiler-flag experiments)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h"), os.path.join(os.path.dirname(_HERE), "include", "fhe_stream.h")]
 
