@@ -364,7 +364,8 @@ def main():
         names = {1: ["k_dct_rows", "k_dct_cols"], 2: ["k_dct_rows_u64", "k_dct_cols_u64"]}.get(path)
         if names and ctx.n == 4096 and args.preset in ("P4096", "SEAL23_4096"):
             res["issue_roofline"] = issue_roofline(names, B, dev_ms_per_step)
-            res["roofline"]["limiter"] = "valu-issue (see issue_roofline); the HBM fraction is reported because BASELINE.json's metric asks for it"
+            res["roofline"]["limiter"] = ("valu-issue at the package power limit (see issue_roofline; 1.37 kW and sclk 2.13-2.20 GHz measured under this pair, "
+                                          "profiles/r04_power_clocks_headline.txt); the HBM fraction is reported because BASELINE.json's metric asks for it")
         if world == 1 and args.cpu_blocks > 0 and args.preset == "P4096":
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
             try:
