@@ -1050,9 +1050,15 @@ def test_fallback_kernels_give_the_same_bits(fhe, oracle_mod, switch):
     assert torch.equal(ev.multiply_plain(a, pp), ev2.multiply_plain(a, pp2))
     m22, m32, sq = ev2.multiply(a, b), ev2.multiply(c3, b), ev2.square(c3)
     assert torch.equal(m22, ev.multiply(a, b)) and torch.equal(m32, ev.multiply(c3, b)) and torch.equal(sq, ev.square(c3))
+    c5 = ctx.random_ct(3, size=5, seed=44)
+    sq2, sq5 = ev.square(a), ev.square(c5)                        # even and odd numbers of cross terms, an operand at q - 1
+    assert torch.equal(sq2, ev2.square(a)) and torch.equal(sq5, ev2.square(c5)) and torch.equal(sq2, ev.multiply(a, a.clone()))
     ha, hb = fhe.to_host(a), fhe.to_host(b)
     assert np.array_equal(fhe.to_host(m22)[0], orc.multiply(ha[0], hb[0]))
     assert np.array_equal(fhe.to_host(m22)[3], orc.multiply(ha[3], hb[3]))
+    assert np.array_equal(fhe.to_host(sq2)[0], orc.multiply(ha[0], ha[0]))
+    hc5 = fhe.to_host(c5)
+    assert np.array_equal(fhe.to_host(sq5)[2], orc.multiply(hc5[2], hc5[2]))
 
 
 @pytest.mark.parametrize("switches", [{"FHE_DCT_PIPELINE": 1, "FHE_DCT_WAVE_BLOCKS": 4}, {"FHE_DCT_PACK": 0}, {"FHE_DCT_LDSC": 0}, {"FHE_DCT_LE": 4}, {"FHE_DCT_ONE_LAUNCH": 2}])
