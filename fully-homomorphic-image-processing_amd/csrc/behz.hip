@@ -370,7 +370,10 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt2(const 
 // (M cc + h) per workgroup.  The products (mulvv_pm: seven multiply-adds, each below C::RQ / 16 q <= 6q) are summed as
 // integers (at most 12 terms: 72 q < 2^62 on a 55-bit base, 18 q on a 58-bit one), one fold_pm brings a sum below (17/16) q, and the transform leaves its outputs below C::RQ / 16 q: k_behz_floor_back<.., WIDE_CHUNK> takes them
 // as they are (its Shoup products accept any 64-bit value, its 128-bit sums a start value below 4 b_j).
-template <int L, int M, typename C>
+// SQ: the product of a batch with itself (A == Bm, equal sizes, identity map): a_i a_j and a_j a_i are the same integer, so each
+// cross term is formed once and added twice -- the same integer sum, half of a square's slot products and operand loads.  A
+// separate instantiation: as a run-time flag the branch cost every product its operand prefetch (profiles/EXPERIMENTS.md).
+template <int L, int M, typename C, bool SQ>
 __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(const u64 *__restrict__ A, const u64 *__restrict__ Bm, u64 *__restrict__ D,
                                                                              RnsBase base, u32 sa, u32 sb, u64 groups, BMap bm) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
@@ -385,17 +388,18 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
     const u64 cc = g / nb;
     const PmMod m = base.pm[j];
     u64 acc[M][16];
-    const u32 lo = o >= sb ? o - sb + 1 : 0, hi = o < sa ? o : sa - 1;
+    const u32 lo = o >= sb ? o - sb + 1 : 0;
+    const u32 hi = SQ ? (o + 1) / 2 : (o < sa ? o + 1 : sa);       // one past the last term; SQ: the cross terms ja < o - ja
 #pragma unroll
     for (int h = 0; h < M; h++) {
-        const u64 c = M * cc + h, cb = bm(c);
+        const u64 c = M * cc + h, cb = SQ ? c : bm(c);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[h][r] = 0;
-        for (u32 ja = lo; ja <= hi; ja++) {
+        // all 32 operand loads of a term in flight before its first product (M = 1: 32 accumulator + 64 operand VGPRs);
+        // left to itself hipcc keeps two or three in flight and every pair of slots waits out a memory round trip
+        constexpr int G = M == 1 ? 16 : 8;
+        for (u32 ja = lo; ja < hi; ja++) {
             const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
-            // all 32 operand loads of a term in flight before its first product (M = 1: 32 accumulator + 64 operand VGPRs);
-            // left to itself hipcc keeps two or three in flight and every pair of slots waits out a memory round trip
-            constexpr int G = M == 1 ? 16 : 8;
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += G) {
                 u64 xa[G], xb[G];
@@ -404,6 +408,22 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
                 PM_FENCE();
 #pragma unroll
                 for (int r = 0; r < G; r++) acc[h][r0 + r] += mulvv_pm(xa[r], xb[r], m);      // canonical operands; below C::RQ / 16 q
+            }
+        }
+        if constexpr (SQ) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[h][r] += acc[h][r];                               // every cross term counts twice
+            if (!(o & 1)) {                                                                    // the middle term a_(o/2)^2, once
+                const u64 *pa = A + ((c * sa + o / 2) * nb + j) * N + tid;
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += G) {
+                    u64 xa[G];
+#pragma unroll
+                    for (int r = 0; r < G; r++) xa[r] = pa[(r0 + r) * TP];
+                    PM_FENCE();
+#pragma unroll
+                    for (int r = 0; r < G; r++) acc[h][r0 + r] += mulvv_pm(xa[r], xa[r], m);
+                }
             }
         }
 #pragma unroll
@@ -1282,8 +1302,11 @@ static int tensor_intt(const fhe_ctx *c, const u64 *A, const u64 *Bm, u64 *D, co
         if (pmc) {
             const unsigned grid = (unsigned)(((rest * nb + 7) / 8) * 8 * so);
             DISPATCH_L(c->logn, {
-                if (pmc == 1) k_behz_tensor_intt_pm<L, 1, PmA><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
-                else k_behz_tensor_intt_pm<L, 1, PmB><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+                const bool square = A2 == B2 && sa == sb && !bm.cnt && !c->opt.behz_square_full;
+                if (pmc == 1 && square) k_behz_tensor_intt_pm<L, 1, PmA, true><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+                else if (pmc == 1) k_behz_tensor_intt_pm<L, 1, PmA, false><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+                else if (square) k_behz_tensor_intt_pm<L, 1, PmB, true><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
+                else k_behz_tensor_intt_pm<L, 1, PmB, false><<<grid, NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm);
             });
         } else if (wide) { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, true><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }
         else { DISPATCH_L(c->logn, (k_behz_tensor_intt<L, false><<<(unsigned)(((rest * nb + 7) / 8) * 8 * so), NttShape<L>::TP, 0, st>>>(A2, B2, D2, base, sa, sb, rest * nb, bm))); }

@@ -243,6 +243,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.behz_fused_prepare = env_on("FHE_BEHZ_FUSED_PREPARE");
         o.cubic_unfused = env_on("FHE_CUBIC_UNFUSED");
         o.plain_sum_unfused = env_on("FHE_PLAIN_SUM_UNFUSED");
+        o.behz_square_full = env_on("FHE_BEHZ_SQUARE_FULL");
     }
     c->n = n;
     c->k = k;

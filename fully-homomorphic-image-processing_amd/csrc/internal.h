@@ -59,6 +59,7 @@ struct FheOptions {
     bool behz_chunk3 = false;        // FHE_BEHZ_CHUNK3=1: base conversions reduce every three terms (the 61-bit schedule)
     bool behz_tensor_canon = false;  // FHE_BEHZ_TENSOR_CANON=1: tensor step with canonical Barrett products and modular additions
     bool behz_tensor_single = false; // FHE_BEHZ_TENSOR_SINGLE=1: tensor + inverse transform one polynomial per workgroup
+    bool behz_square_full = false;   // FHE_BEHZ_SQUARE_FULL=1: squares form a_i a_j and a_j a_i separately (the general tensor kernel)
     bool plain_sum_unfused = false;  // FHE_PLAIN_SUM_UNFUSED=1: the Taylor / harmonic sums as separate multiply_plain calls and additions (before k_mulplain_sum_pm)
     bool cubic_unfused = false;      // FHE_CUBIC_UNFUSED=1: Cubic's three products as three complete fhe_multiply calls + k_cubic_combine_g (before round 4's fused tail)
     bool behz_fused_prepare = false; // FHE_BEHZ_FUSED_PREPARE=1: base extension fused into the forward transforms (k_behz_prepare_pm: 25 % less HBM traffic per

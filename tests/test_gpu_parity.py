@@ -1029,13 +1029,14 @@ def test_presets_run_the_arithmetic_the_parity_tests_assume(fhe):
 
 @pytest.mark.parametrize("switch", ["FHE_NTT_NOPM", "FHE_BEHZ_AUX61", "FHE_BEHZ_CHUNK3", "FHE_NTT_NOPM+FHE_BEHZ_AUX61", "FHE_NTT_NOPM+FHE_BEHZ_CHUNK3",
                                     "FHE_NTT_NOPM+FHE_NTT_NOLAZY", "FHE_NTT_NOPM+FHE_NTT_SINGLE", "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_CANON",
-                                    "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_SINGLE", "FHE_BEHZ_FUSED_PREPARE"])
+                                    "FHE_NTT_NOPM+FHE_BEHZ_TENSOR_SINGLE", "FHE_BEHZ_FUSED_PREPARE", "FHE_BEHZ_SQUARE_FULL"])
 def test_fallback_kernels_give_the_same_bits(fhe, oracle_mod, switch):
     """Shoup butterflies where the pseudo-Mersenne ones run by default (FHE_NTT_NOPM), and under them the 61-bit
     auxiliary base, the three-term dot-product schedule, Harvey butterflies with conditional subtractions, one polynomial
     per workgroup, the canonical tensor sum; the 61-bit auxiliary base and the three-term schedule also beside the
     pseudo-Mersenne q-base kernels; FHE_BEHZ_FUSED_PREPARE: the base extension fused into the forward transforms (k_behz_prepare_pm) where the default runs it as its own launch (k_behz_to_bsk_pm + two transform
-    launches).  Each is selected for a second context (the switches are read in fhe_ctx_create) and is
+    launches); FHE_BEHZ_SQUARE_FULL: squares through the general tensor kernel (a_i a_j and a_j a_i both formed) where the default
+    runs the symmetric instantiation (each cross term once, doubled).  Each is selected for a second context (the switches are read in fhe_ctx_create) and is
     bit-equal to the default kernels and to the oracle on transforms, multiply_plain and ct x ct products of sizes 2x2, 3x2
     and a square, at n = 8192 with 54/55-bit primes (where all of them differ from the default)."""
     import torch
