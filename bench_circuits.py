@@ -14,6 +14,11 @@ generates / loads its source rows +- the sampler's halo), decode shards the outp
 jobs, so the scaling is "strong".  Rank 0 prints ONE JSON line with `roofline` (HBM on algorithmic bytes: inputs read once,
 outputs written once) and, when asked for (--cpu-pixels / --cpu-terms), `cpu_baseline` (the oracle on one host core, on a
 bounded sample).  `output_digest` is the position-dependent digest of everything produced: equal for every GPU count.
+
+  --relin DBC   the RELINEARISED mode (include/fhe_circuits.h fhe_circuits_create_relin): the same
+                Evaluator call sequences with evaluator.relinearize after every multiply / square, decomposition bit count DBC
+                (the reference's unused DBC is 30, homo/fhe_image.h:28).  NOT the reference's ciphertext bits: outputs have 2
+                polynomials instead of 6 / 22; `config.mode` says so and the digests differ from the default lines' by design.
 """
 import argparse
 import json
@@ -122,6 +127,19 @@ def _roofline(alg_bytes, dev_ms, kernels, workload=None, units=0):
             "note": "a sequence of ct x ct launches (csrc/behz.hip), VALU-issue-bound: the per-kernel issue fractions and counter traffic are in profiles/*_issue_roofline.txt and profiles/pmc_traffic_ctct.json"}
 
 
+def _relin(args, fhe, ctx):
+    """(evk, dbc) for --relin: keys of a seeded key pair (the inputs are random residues, so any well-formed keys do)"""
+    if not args.relin:
+        return None
+    return (fhe.KeyGenerator(ctx, seed=1).generate_evaluation_keys(args.relin).contiguous(), args.relin)
+
+
+def _mode(args):
+    if args.relin:
+        return "relinearised after every multiply / square, dbc = %d (NOT the reference's bits: the reference never relinearises)" % args.relin
+    return "reference (no relinearisation: homo/fhe_resize.h:174-179, homo/fhe_decode.h:67-98,235,239)"
+
+
 def resize(args):
     import numpy as np
     import torch
@@ -130,6 +148,8 @@ def resize(args):
     ctx = fhe.SEALContext.preset(args.preset, device=local)
     ev = fhe.Evaluator(ctx)
     pc = fhe.circuits.PlainCache(ctx)
+    relin = _relin(args, fhe, ctx)
+    so = fhe.circuits.circuits_of(pc, relin).out_size(fhe.circuits.SAMPLE_BICUBIC)
     W = H = args.src
     w = h = args.dst
     ctw = 2 * ctx.k * ctx.n                                     # words of a ct(2)
@@ -148,7 +168,7 @@ def resize(args):
     n_mine = (y1 - y0) * w
     n_out = n_mine if args.max_pixels else w * h
     P = min(args.pixels, n_mine)
-    words = 6 * ctx.k * ctx.n
+    words = so * ctx.k * ctx.n
     if args.shared:
         # SURVEY.md 8(d) configs[2] input convention: one offset ciphertext per distinct fractional value, i.e. per output column / row
         xc = ctx.random_ct(w, size=2, seed=11)
@@ -163,7 +183,7 @@ def resize(args):
         def job(digest=False):          # the timed passes hand the bands to a no-op consumer; one untimed pass digests them
             acc.zero_()
             fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=consume if digest else (lambda first_px, t: None),
-                                               rows=(y0, y1), src_rows=(first, count))
+                                               rows=(y0, y1), src_rows=(first, count), relin=relin)
             return None
         alg = (W * (H if not args.max_pixels else count) + w + h) * ctw * 8 + n_out * words * 8
         form = "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"
@@ -177,7 +197,7 @@ def resize(args):
             acc.zero_()
             for s in range(0, n_mine, P):
                 e = min(s + P, n_mine)
-                out = fhe.circuits.sample_bicubic(ev, pc, pixels, my_taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous())
+                out = fhe.circuits.sample_bicubic(ev, pc, pixels, my_taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous(), relin=relin)
                 if digest:
                     part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
                     ctx.digest_into(out, part, index0=(y0 * w + s) * words)
@@ -196,9 +216,10 @@ def resize(args):
                "steps": 1, "warmup": 2, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "bicubic resize %dx%d -> %dx%d via the Cubic circuit, one channel, %s (n=%d, %d coeff moduli)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
-                          "offsets": form, "batch_pixels": P, "sharding": "destination rows x%d, source rows +- halo per rank, no data-path collective" % world},
-               "seconds": wall, "first_pass_seconds": first_pass, "cubic_calls_per_s": 5 * n_out / wall, "out_size": 6,
-               "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm", "resize_shared" if args.shared else "resize", n_mine if args.preset == "P8192" else 0),
+                          "mode": _mode(args), "offsets": form, "batch_pixels": P, "sharding": "destination rows x%d, source rows +- halo per rank, no data-path collective" % world},
+               "seconds": wall, "first_pass_seconds": first_pass, "cubic_calls_per_s": 5 * n_out / wall, "out_size": so,
+               "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm" + (", k_relin_*_pm" if relin else ""),
+                                     ("resize_shared" if args.shared else "resize") + ("_relin%d" % args.relin if relin else ""), n_mine if args.preset == "P8192" else 0),
                "job_executions": 4, "units_per_job": n_mine,
                "output_digest": "%016x" % digest}
         if args.cpu_pixels:
@@ -228,6 +249,7 @@ def decode(args):
     ctx = fhe.SEALContext.preset(args.preset, device=local)
     ev = fhe.Evaluator(ctx)
     pc = fhe.circuits.PlainCache(ctx)
+    relin = _relin(args, fhe, ctx)
     npos, degree = args.positions, args.degree
     p0, p1 = fhe.parallel.block_range(rank, world, npos)
     if p1 == p0:
@@ -236,10 +258,11 @@ def decode(args):
     ctw = 2 * ctx.k * ctx.n
     # the Enc(0) accumulators are inputs: [position][harmonic][sin, cos], seeded by the global position
     zeros = ctx.random_ct((p1 - p0) * degree * 2, size=2, seed=1000, first_index=p0 * degree * 2 * ctw).reshape(p1 - p0, degree, 2, 2, ctx.k, ctx.n) if degree else None
-    so = int(fhe._lib.load().fhe_approximated_step_out_size(degree))
+    so = fhe.circuits.circuits_of(pc, relin).out_size(fhe.circuits.STEP, degree)
 
     def job():
-        return fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, positions=(p0, p1))
+        return fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, positions=(p0, p1),
+                                              relin=relin)
     job()                                                       # warm-up at full size: scratch buffers and the allocator cache reach their steady state
     run, wall, dev_ms = _timed(job, dist)
     out = torch.cat(run)
@@ -250,9 +273,10 @@ def decode(args):
                "steps": 1, "warmup": 1, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "approximated_step W*H=%d degree=%d, %s (n=%d, %d coeff moduli)" % (npos, degree, args.preset, ctx.n, ctx.k),
-                          "sharding": "output positions x%d; run operands, offset chain and sine polynomials replicated; no data-path collective" % world},
+                          "mode": _mode(args), "sharding": "output positions x%d; run operands, offset chain and sine polynomials replicated; no data-path collective" % world},
                "seconds": wall, "steps_per_s": 1 / wall, "out_size": so, "outputs": npos,
-               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_sum_inv_pm", "decode", (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0),
+               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_sum_inv_pm" + (", k_relin_*_pm" if relin else ""), "decode" + ("_relin%d" % args.relin if relin else ""),
+                                     (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0),
                "job_executions": 2, "units_per_job": p1 - p0,
                "output_digest": "%016x" % digest}
         if args.cpu_terms:
@@ -286,5 +310,6 @@ if __name__ == "__main__":
     ap.add_argument("--shared", action="store_true", help="resize: one offset ciphertext per output column / row (SURVEY.md 8d) instead of one pair per pixel")
     ap.add_argument("--degree", type=int, default=12)
     ap.add_argument("--positions", type=int, default=16)
+    ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="relinearised mode with this decomposition bit count (0 = the reference's mode)")
     a = ap.parse_args()
     (resize if a.workload == "resize" else decode)(a)

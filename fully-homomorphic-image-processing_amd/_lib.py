@@ -12,6 +12,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h"), os.path.join(os.path.dirname(_HERE), "include", "fhe_stream.h")]
 
 FHE_OK = 0
+ABI_VERSION = 2      # FHE_ABI_VERSION of the include/fhe_hip.h this table was written against
 
 
 class FheError(RuntimeError):
@@ -75,6 +76,7 @@ SIGNATURES = {
     "fhe_evk_digits": (_u32, [_vp, _u32]),
     "fhe_relinearize": (_i, [_vp, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_relinearize_scratch_bytes": (_sz, [_vp, _u32, _u64]),
+    "fhe_relinearize_to": (_i, [_vp, _vp, _u64, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_dct_plan_create": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(_vp)]),
     "fhe_dct_plan_destroy": (_i, [_vp]),
     "fhe_dct8x8_scratch_bytes": (_sz, [_vp, _u64]),
@@ -89,6 +91,9 @@ SIGNATURES = {
     # include/fhe_circuits.h
     "fhe_circuits_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "fhe_circuits_destroy": (_i, [_vp]),
+    "fhe_circuits_create_relin": (_i, [_vp, _i, _i, _vp, _u32, C.POINTER(_vp)]),
+    "fhe_circuits_relin_dbc": (_u32, [_vp]),
+    "fhe_circuits_out_size": (_u32, [_vp, _i, _u32]),
     "fhe_resize_sample_plan": (_i, [_u32, _u32, _u32, _u32, _i, _vp, _vp, _vp]),
     "fhe_cubic_scratch_bytes": (_sz, [_vp, _u32, _u64]),
     "fhe_cubic": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp, _sz, _vp]),
@@ -142,6 +147,9 @@ def load():
         fn = getattr(L, name)  # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
+    got = L.fhe_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("%s reports ABI version %d, this binding was written against %d: rebuild the library (make -C csrc)" % (LIB_PATH, got, ABI_VERSION))
     _lib = L
     return L
 

@@ -59,15 +59,29 @@ def rgb_to_ycc(ev, pc, r, g, b):
 # ------------------------------------------------------------------------------------------------
 # the circuits handle and scratch
 # ------------------------------------------------------------------------------------------------
-class Circuits:
-    """fhe_circuits: the constants of the resize / decode circuits for one context and encoder."""
+CUBIC, LINEAR, SAMPLE_BICUBIC, SAMPLE_LINEAR, SINCOS, STEP, DECODE = range(7)      # FHE_CIRC_* of include/fhe_circuits.h
 
-    def __init__(self, ctx, int_coeffs=100, frac_coeffs=100):
+
+class Circuits:
+    """fhe_circuits: the constants of the resize / decode circuits for one context and encoder.
+    relin=(evk_ntt, dbc): the RELINEARISED mode (fhe_circuits_create_relin; SURVEY.md section 8(f) #4, not what the
+    reference does): evaluator.relinearize after every multiply / square, so every ciphertext of every circuit has two
+    polynomials.  evk_ntt as KeyGenerator.generate_evaluation_keys(dbc) returns it; the handle keeps it alive."""
+
+    def __init__(self, ctx, int_coeffs=100, frac_coeffs=100, relin=None):
         self.ctx = ctx
         h = C.c_void_p()
-        _lib.call("fhe_circuits_create", ctx.h, int_coeffs, frac_coeffs, C.byref(h))
+        if relin is None:
+            _lib.call("fhe_circuits_create", ctx.h, int_coeffs, frac_coeffs, C.byref(h))
+        else:
+            self._evk, dbc = relin
+            assert self._evk.is_contiguous() and self._evk.dtype == torch.int64
+            _lib.call("fhe_circuits_create_relin", ctx.h, int_coeffs, frac_coeffs, _ptr(self._evk), int(dbc), C.byref(h))
         self.h = h
         self._scratch = None
+
+    def out_size(self, circuit, arg=0):
+        return int(_lib.load().fhe_circuits_out_size(self.h, circuit, arg))
 
     def __del__(self):
         h = getattr(self, "h", None)
@@ -87,8 +101,15 @@ class Circuits:
         return self._scratch
 
 
-def circuits_of(pc):
-    """the fhe_circuits handle that goes with a PlainCache (same context and encoder), created on first use"""
+def circuits_of(pc, relin=None):
+    """the fhe_circuits handle that goes with a PlainCache (same context and encoder), created on first use;
+    relin=(evk_ntt, dbc): the relinearising handle for those keys"""
+    if relin is not None:
+        cache = pc.__dict__.setdefault("_circuits_relin", {})
+        key = (relin[0].data_ptr(), int(relin[1]))
+        if key not in cache:
+            cache[key] = Circuits(pc.ctx, pc.enc.int_coeffs, pc.enc.frac_coeffs, relin=relin)
+        return cache[key]
     h = getattr(pc, "_circuits", None)
     if h is None:
         h = pc._circuits = Circuits(pc.ctx, pc.enc.int_coeffs, pc.enc.frac_coeffs)
@@ -152,27 +173,26 @@ def cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin=None):
 
 def cubic(ev, pc, A, B, C, D, t, relin=None):
     """Cubic(result, A,B,C,D,t): homo/fhe_resize.h:143-189 for a batch (fhe_cubic).  Note t3 = t*t exactly as the
-    reference computes it (:175).  relin=(evk_ntt, dbc) selects the relinearised mode (cubic_evaluator_calls)."""
-    if relin is not None:
-        return cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin)
-    cc = circuits_of(pc)
+    reference computes it (:175).  relin=(evk_ntt, dbc) selects the relinearised mode of the library (every product
+    relinearised: result of size 2); cubic_evaluator_calls(..., relin) is the same thing one Evaluator call at a time."""
+    cc = circuits_of(pc, relin)
     size = A.shape[-3]
     count = _count(A, size)
     assert A.shape == B.shape == C.shape == D.shape and _count(t, 2) == count
-    out = ev.ctx.empty(*A.shape[:-3], size=size + 2)
+    out = ev.ctx.empty(*A.shape[:-3], size=cc.out_size(CUBIC, size))
     nbytes = _lib.load().fhe_cubic_scratch_bytes(cc.h, size, count)
     scr = cc.scratch(nbytes)
     _lib.call("fhe_cubic", cc.h, _ptr(A), _ptr(B), _ptr(C), _ptr(D), size, _ptr(t), _ptr(out), count, _ptr(scr), nbytes, _stream())
     return out
 
 
-def linear(ev, pc, A, B, t):
+def linear(ev, pc, A, B, t, relin=None):
     """Linear(result, A,B,t): homo/fhe_resize.h:191-204: (1 - t) A + t B (fhe_linear)."""
-    cc = circuits_of(pc)
+    cc = circuits_of(pc, relin)
     size = A.shape[-3]
     count = _count(A, size)
     assert A.shape == B.shape and _count(t, 2) == count
-    out = ev.ctx.empty(*A.shape[:-3], size=size + 1)
+    out = ev.ctx.empty(*A.shape[:-3], size=cc.out_size(LINEAR, size))
     nbytes = _lib.load().fhe_linear_scratch_bytes(cc.h, size, count)
     scr = cc.scratch(nbytes)
     _lib.call("fhe_linear", cc.h, _ptr(A), _ptr(B), size, _ptr(t), _ptr(out), count, _ptr(scr), nbytes, _stream())
@@ -193,8 +213,9 @@ def resize_sample_plan(src_w, src_h, dst_w, dst_h, bicubic=True):
     return taps, [float(v) for v in fx], [float(v) for v in fy]
 
 
-def _sample(name, width, out_size, ev, pc, pixels, taps, xfract, yfract):
-    cc = circuits_of(pc)
+def _sample(name, width, kind, ev, pc, pixels, taps, xfract, yfract, relin=None):
+    cc = circuits_of(pc, relin)
+    out_size = cc.out_size(kind)
     taps = _taps_array(taps, width)
     count = taps.shape[0]
     n_pixels = _count(pixels, 2)
@@ -208,16 +229,16 @@ def _sample(name, width, out_size, ev, pc, pixels, taps, xfract, yfract):
     return out
 
 
-def sample_bicubic(ev, pc, pixels, taps, xfract, yfract):
+def sample_bicubic(ev, pc, pixels, taps, xfract, yfract, relin=None):
     """SampleBicubic for a batch of output pixels and one colour channel (homo/fhe_resize.h:254-305;
     fhe_sample_bicubic).  pixels: [src_pixels, 2, k, n]; taps: [B][16] source indices; xfract/yfract: [B, 2, k, n]
-    ciphertexts of the fractional offsets.  Returns [B, 6, k, n]."""
-    return _sample("fhe_sample_bicubic", 16, 6, ev, pc, pixels, taps, xfract, yfract)
+    ciphertexts of the fractional offsets.  Returns [B, 6, k, n] ([B, 2, k, n] with relin=(evk_ntt, dbc))."""
+    return _sample("fhe_sample_bicubic", 16, SAMPLE_BICUBIC, ev, pc, pixels, taps, xfract, yfract, relin)
 
 
-def sample_linear(ev, pc, pixels, taps, xfract, yfract):
-    """SampleLinear for one channel (homo/fhe_resize.h:222-252; fhe_sample_linear).  Returns [B, 4, k, n]."""
-    return _sample("fhe_sample_linear", 4, 4, ev, pc, pixels, taps, xfract, yfract)
+def sample_linear(ev, pc, pixels, taps, xfract, yfract, relin=None):
+    """SampleLinear for one channel (homo/fhe_resize.h:222-252; fhe_sample_linear).  Returns [B, 4, k, n] ([B, 2, k, n] relinearised)."""
+    return _sample("fhe_sample_linear", 4, SAMPLE_LINEAR, ev, pc, pixels, taps, xfract, yfract, relin)
 
 
 BAND_CONSUMER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -231,7 +252,8 @@ def resize_source_rows(src_h, dst_h, row0, row1, bicubic=True):
     return int(first.value), int(count.value)
 
 
-def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None, rows=None, src_rows=None):
+def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yfract, batch=256, band_rows=4, consume=None, rows=None, src_rows=None,
+                          relin=None):
     """ResizeImage with SampleBicubic (homo/fhe_resize.h:254-392) for one colour channel when the fractional
     offsets arrive as ONE ciphertext per output column (xfract [dst_w, 2, k, n]) and ONE per output row
     (yfract [dst_h, 2, k, n]) -- SURVEY.md section 8(d), config 3: "xfract/yfract ciphertexts are inputs generated
@@ -255,26 +277,29 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
     shard's rows +- the halo), yfract the offsets of rows [y0, y1) only, and the result the pixels of those rows -- each
     bit-identical to the whole-image call's.
 
+    relin=(evk_ntt, dbc): the relinearised mode (every product relinearised; outputs of size 2 instead of 6).
+
     Returns [dst_h * dst_w, 6, k, n] (row-major; [(y1 - y0) * dst_w, ...] for a shard), or None when
     `consume(first_pixel, tensor)` takes the bands (first_pixel is the global index y * dst_w; the tensor is a view of a
     buffer the library reuses: clone what must outlive the callback)."""
-    cc = circuits_of(pc)
+    cc = circuits_of(pc, relin)
+    so = cc.out_size(SAMPLE_BICUBIC)
     ctx = ev.ctx
     y0, y1 = rows if rows is not None else (0, dst_h)
     s0, sc = src_rows if src_rows is not None else ((0, src_h) if rows is None else resize_source_rows(src_h, dst_h, y0, y1))
     assert _count(pixels, 2) == src_w * sc and _count(xfract, 2) == dst_w and _count(yfract, 2) == y1 - y0, (pixels.shape, sc, yfract.shape, rows)
     L = _lib.load()
-    out = None if consume is not None else ctx.empty(dst_w * (y1 - y0), size=6)
+    out = None if consume is not None else ctx.empty(dst_w * (y1 - y0), size=so)
     nbytes = L.fhe_resize_bicubic_shared_rows_scratch_bytes(cc.h, src_w, src_h, dst_w, dst_h, y0, y1, s0, sc, batch, band_rows, int(out is not None))
     scr = cc.scratch(nbytes)
-    words = 6 * ctx.k * ctx.n
+    words = so * ctx.k * ctx.n
     err = []
 
     def on_band(_user, first, d_band, npx, _stream_):
         try:
             off = d_band - scr.data_ptr()                              # the band buffer lies inside the scratch tensor
             assert 0 <= off and off + npx * words * 8 <= scr.numel() and off % 8 == 0
-            consume(int(first), scr[off:off + npx * words * 8].view(torch.int64).view(npx, 6, ctx.k, ctx.n))
+            consume(int(first), scr[off:off + npx * words * 8].view(torch.int64).view(npx, so, ctx.k, ctx.n))
             return 0
         except BaseException as e:                                     # must not propagate through the C frame
             err.append(e)
@@ -294,26 +319,27 @@ def resize_bicubic_shared(ev, pc, pixels, src_w, src_h, dst_w, dst_h, xfract, yf
 # ------------------------------------------------------------------------------------------------
 # decode path
 # ------------------------------------------------------------------------------------------------
-def _sincos(cosine, ev, pc, x, zero):
-    cc = circuits_of(pc)
+def _sincos(cosine, ev, pc, x, zero, relin=None):
+    cc = circuits_of(pc, relin)
     count = _count(x, 2)
     assert _count(zero, 2) == count
-    out = ev.ctx.empty(*x.shape[:-3], size=11)
+    out = ev.ctx.empty(*x.shape[:-3], size=cc.out_size(SINCOS))
     nbytes = _lib.load().fhe_homomorphic_sincos_scratch_bytes(cc.h, count)
     scr = cc.scratch(nbytes)
     _lib.call("fhe_homomorphic_sincos", cc.h, cosine, _ptr(x), _ptr(zero), _ptr(out), count, _ptr(scr), nbytes, _stream())
     return out
 
 
-def homomorphic_sin(ev, pc, x, zero):
-    """homo/fhe_decode.h:48-120; `zero` plays the role of encrypt(encode(0.0)) (:54)."""
-    return _sincos(0, ev, pc, x, zero)
+def homomorphic_sin(ev, pc, x, zero, relin=None):
+    """homo/fhe_decode.h:48-120; `zero` plays the role of encrypt(encode(0.0)) (:54).  relin=(evk_ntt, dbc): every power
+    relinearised where it is formed (result of size 2 instead of 11)."""
+    return _sincos(0, ev, pc, x, zero, relin)
 
 
-def homomorphic_cos(ev, pc, x, zero):
+def homomorphic_cos(ev, pc, x, zero, relin=None):
     """homo/fhe_decode.h:128-200 (the reference shifts by -3pi/2 here too, :137, and falls off the end
     without a return statement, :200; the value it leaves in `res` is what is returned here)."""
-    return _sincos(1, ev, pc, x, zero)
+    return _sincos(1, ev, pc, x, zero, relin)
 
 
 def stack_zeros(zeros, npos, degree, pos0=0):
@@ -322,7 +348,7 @@ def stack_zeros(zeros, npos, degree, pos0=0):
     return torch.cat([zeros(i, j, w) for i in range(pos0, pos0 + npos) for j in range(1, degree + 1) for w in ("sin", "cos")]).contiguous()
 
 
-def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros, positions=None):
+def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, width, height, zeros, positions=None, relin=None):
     """The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run
     (fhe_approximated_step).  amplitude/index/count: [1, 2, k, n].  zeros: a tensor [npos, degree, 2, 2, k, n]
     (stack_zeros order) or a callable (i, j, which) -> [1, 2, k, n] encryption of zero for position i, harmonic j,
@@ -339,14 +365,18 @@ def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, wid
 
     positions=(p0, p1) evaluates a SHARD of the output positions (fhe_approximated_step_range; the multi-GPU partition of
     the position loop, :224): zeros (tensor form) and the result then hold positions [p0, p1) only, each bit-identical
-    to the whole-run call's."""
-    cc = circuits_of(pc)
+    to the whole-run call's.
+
+    relin=(evk_ntt, dbc): the relinearised mode -- every power of the Taylor polynomials, the sin x cos product and the
+    final product by the amplitude are relinearised, so the 11 x 11 -> 21 product of the reference's evaluation is a 2 x 2
+    one and the results have 2 polynomials instead of 22."""
+    cc = circuits_of(pc, relin)
     npos = width * height
     p0, p1 = positions if positions is not None else (0, npos)
     if callable(zeros):
         zeros = stack_zeros(zeros, p1 - p0, degree, p0) if degree > 0 else None
     L = _lib.load()
-    so = L.fhe_approximated_step_out_size(degree)
+    so = cc.out_size(STEP, degree)
     out = ev.ctx.empty(p1 - p0, size=so)
     nbytes = L.fhe_approximated_step_range_scratch_bytes(cc.h, degree, npos, p0, p1)
     scr = cc.scratch(nbytes)
@@ -355,7 +385,7 @@ def approximated_step(ev, pc, amplitude, index, count, order, degree, delta, wid
     return [out[i:i + 1] for i in range(p1 - p0)]
 
 
-def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=None):
+def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=None, relin=None):
     """One colour channel of the server_decode driver loop (homo/server_decode.cpp:120-137; fhe_decode_channel).
     runs: [pairs, 2, 2, k, n] (elem, count per run); index: [1, 2, k, n] or [2, k, n], UPDATED IN PLACE (index += count
     per run, :137); acc0: [npos, 2, k, n], the channel's Enc(0) accumulators (:126); zeros: [pairs, npos, degree, 2, 2, k, n].
@@ -363,13 +393,13 @@ def decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width
 
     positions=(p0, p1): a SHARD of the channel's positions (fhe_decode_channel_range); acc0, zeros and the result hold
     positions [p0, p1) only, and `index` is this shard's own copy of the chain (it ends at the same value on every shard)."""
-    cc = circuits_of(pc)
+    cc = circuits_of(pc, relin)
     npos = width * height
     p0, p1 = positions if positions is not None else (0, npos)
     pairs = int(runs.shape[0]) if runs is not None else 0
     assert _count(acc0, 2) == p1 - p0 and index.is_contiguous()
     L = _lib.load()
-    so = L.fhe_approximated_step_out_size(degree) if pairs else 2
+    so = cc.out_size(DECODE, degree) if pairs else 2
     out = ev.ctx.empty(p1 - p0, size=so)
     nbytes = L.fhe_decode_channel_range_scratch_bytes(cc.h, degree, npos, p0, p1, pairs)
     scr = cc.scratch(nbytes)

@@ -905,16 +905,18 @@ __global__ __launch_bounds__(256) void k_relin_accum(const u64 *__restrict__ dig
         }
     }
 }
-__global__ __launch_bounds__(256) void k_relin_add(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, const BehzDev *__restrict__ Tp, u32 n, u64 count) {
+// dst may be the ciphertext itself (in place) or a compact size-2 batch (fhe_relinearize_to)
+__global__ __launch_bounds__(256) void k_relin_add(const u64 *ct, u64 stride, u64 *out, u64 out_stride, const u64 *__restrict__ acc, const BehzDev *__restrict__ Tp, u32 n, u64 count) {
     const BehzDev &T = *Tp;
     const u32 k = T.k;
     for (u64 u = blockIdx.y; u < count * 2 * k; u += gridDim.y) {
         const u32 ii = (u32)(u % k);
         const u32 pp = (u32)((u / k) & 1);
         const u64 c = u / (2 * k);
-        u64 *dst = ct + c * stride + ((u64)pp * k + ii) * n;
+        const u64 *src = ct + c * stride + ((u64)pp * k + ii) * n;
+        u64 *dst = out + c * out_stride + ((u64)pp * k + ii) * n;
         for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
-            dst[s] = addmod(dst[s], acc[u * n + s], T.q[ii].q);
+            dst[s] = addmod(src[s], acc[u * n + s], T.q[ii].q);
     }
 }
 
@@ -969,9 +971,9 @@ __global__ __launch_bounds__(256) void k_relin_accum_pm(const u64 *__restrict__ 
         }
     }
 }
-// (3) inverse transform of acc and the addition into c0 / c1 in one kernel
+// (3) inverse transform of acc and the addition into c0 / c1 in one kernel; the sum goes back in place or to a compact size-2 batch
 template <int L, typename C>
-__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_inv_add_pm(u64 *__restrict__ ct, u64 stride, const u64 *__restrict__ acc, RnsBase base) {
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_inv_add_pm(const u64 *ct, u64 stride, u64 *out, u64 out_stride, const u64 *__restrict__ acc, RnsBase base) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;
@@ -979,9 +981,9 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_inv_add_pm(u64 *__
     const u64 c = blockIdx.x / (2 * k);
     const PmMod m = base.pm[ii];
     u64 x[1][16], y[16];
-    u64 *dst = ct + c * stride + ((u64)pp * k + ii) * N;
+    u64 *dst = out + c * out_stride + ((u64)pp * k + ii) * N;
     load_slots<L>(x[0], acc + (u64)blockIdx.x * N, tid);
-    load_coeff<L>(y, dst, tid);
+    load_coeff<L>(y, ct + c * stride + ((u64)pp * k + ii) * N, tid);
     ntt_inv_regs_pm<L, 1, PM_FOLDED, C::XB, C::LIM, C::RQ>(x, base.itw_pm + (size_t)ii * N, m, lds, tid);
 #pragma unroll
     for (int r = 0; r < 16; r++) y[r] = addmod(y[r], canon_rq_pm<C::RQ>(x[0][r], m), m.q);
@@ -1493,13 +1495,18 @@ extern "C" size_t fhe_relinearize_scratch_bytes(const fhe_ctx *c, uint32_t dbc, 
 }
 extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride, uint64_t count, const uint64_t *evk, uint32_t dbc,
                                void *scratch, size_t scratch_bytes, fhe_stream s) {
-    if (!cc || !ct3 || !evk) return fail(FHE_ERR_PARAM, "null argument");
+    return fhe_relinearize_to(cc, ct3, stride, ct3, stride, count, evk, dbc, scratch, scratch_bytes, s);
+}
+extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
+                                  const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!cc || !ct3 || !evk || !out2) return fail(FHE_ERR_PARAM, "null argument");
     if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
     int rc;
     if (int erc = fhe_behz_ensure(c)) return erc;
     if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
+    if (out_stride < (u64)2 * c->k * c->n) return fail(FHE_ERR_PARAM, "output stride smaller than a size-2 ciphertext");
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
     hipStream_t st = (hipStream_t)s;
     const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
@@ -1512,7 +1519,7 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     DISPATCH_L(c->logn, {                                                                                                                  \
         k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc);      \
         k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                           \
-        k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((u64 *)ct3, stride, acc, base);                      \
+        k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, base); \
     })
         if (c->qb.pm_class == 1) { GO_PM(PmA); } else { GO_PM(PmB); }
 #undef GO_PM
@@ -1523,7 +1530,7 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
     if ((rc = qbase_ntt(false, c, dig, dig, count * k * nd, st))) return rc;
     k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);
     if ((rc = qbase_ntt(true, c, acc, acc, count * 2, st))) return rc;
-    k_relin_add<<<grid2(n, count * 2 * k), 256, 0, st>>>((u64 *)ct3, stride, acc, T, n, count);
+    k_relin_add<<<grid2(n, count * 2 * k), 256, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, T, n, count);
     KERNEL_CHECK();
     return FHE_OK;
 }

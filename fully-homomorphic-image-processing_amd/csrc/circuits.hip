@@ -59,16 +59,16 @@ __global__ __launch_bounds__(256) void k_add_general(const ulonglong2 *a, u32 si
 }
 
 // the sum of homomorphic_sin / homomorphic_cos (homo/fhe_decode.h:113-118) in one pass: out[c][p] = zero[zmap(c)][p] (p < 2) +
-// sum over the five power terms i with p < size_i of term_i[tmap(c)][p], p < 11 -- modular additions of canonical residues, so
+// sum over the five power terms i with p < size_i of term_i[tmap(c)][p], p < size_out (11; 2 in the relinearised mode) -- modular additions of canonical residues, so
 // their order does not show in the result (seven launches of k_add_general before)
 struct TaylorTerms { const ulonglong2 *t[5]; u32 size[5]; };
 __global__ __launch_bounds__(256) void k_taylor_sum(const ulonglong2 *__restrict__ zero, CMap zmap, TaylorTerms T, CMap tmap, ulonglong2 *__restrict__ out,
-                                                    const Modulus *__restrict__ mods, u32 k, u32 half_n, u64 n_res_polys) {
+                                                    const Modulus *__restrict__ mods, u32 k, u32 half_n, u64 n_res_polys, u32 size_out) {
     for (u64 rp = blockIdx.y; rp < n_res_polys; rp += gridDim.y) {
         const u32 prime = (u32)(rp % k);
         const u64 cp = rp / k;
-        const u32 poly = (u32)(cp % 11);
-        const u64 ct = cp / 11;
+        const u32 poly = (u32)(cp % size_out);
+        const u64 ct = cp / size_out;
         const u64 q = mods[prime].q;
         const ulonglong2 *pz = poly < 2 ? zero + ((zmap(ct) * 2 + poly) * k + prime) * half_n : nullptr;
         const u64 tc = tmap(ct);
@@ -203,6 +203,8 @@ struct fhe_circuits {
     const fhe_ctx *c = nullptr;
     int ic = 0, fc = 0;
     bool base2 = false;         // the encoder writes Cubic's constants as the fused passes assume
+    const u64 *evk = nullptr;   // relinearised mode (fhe_circuits_create_relin): evaluation keys for s^2, NTT form, caller-owned
+    u32 dbc = 0;                // its decomposition bit count; 0 = the reference's mode (no relinearisation)
     mutable std::mutex mu;
     mutable std::map<u64, std::unique_ptr<CircConst>> consts;     // keyed by the bits of the double
     // pinned staging ring for index arrays: host memcpy + stream-ordered copy, the host never waits for the device
@@ -308,14 +310,18 @@ struct Run {
     hipStream_t st;
     bool dry;
     bool query = false;                    // a *_scratch_bytes query: placeholder scalars, so constants are neither required to fit the encoder nor to be non-zero
+    bool relin;                            // the handle relinearises after every multiply / square: every ciphertext has two polynomials
     uintptr_t base = 0;
     size_t cap = 0, top = 0, high = 0;     // bytes
     u32 k, n;
     size_t pw;                             // words of one RNS polynomial
 
     Run(const fhe_circuits *circ, void *scratch, size_t bytes, fhe_stream s, bool dry_run)
-        : cc(circ), c(circ->c), st((hipStream_t)s), dry(dry_run), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
+        : cc(circ), c(circ->c), st((hipStream_t)s), dry(dry_run), relin(circ->dbc != 0), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
           pw((size_t)circ->c->k * circ->c->n) {}
+
+    // polynomials of a ciphertext that has `ref` of them in the reference's evaluation
+    u32 S(u32 ref) const { return relin && ref > 2 ? 2 : ref; }
 
     // 256-byte aligned bump allocation; in a dry run only the high-water mark is real
     u64 *alloc(size_t words) {
@@ -404,8 +410,39 @@ struct Run {
     // ct x ct products; the BEHZ scratch comes from the arena and is released again
     u64 *prepare_alloc(u32 size, u64 count) { return alloc(fhe_multiply_operand_words(c, size, count)); }
     int prepare(const u64 *a, u32 size, u64 count, u64 *prepared) { return dry ? FHE_OK : fhe_multiply_prepare(c, cu(a), size, count, mu(prepared), st); }
-    // a (plain ciphertexts) x b; exactly one of b / bp (prepared) is given; bmap.cnt != 0: bp is a shared batch
+    // evaluator.relinearize after a product (relinearised mode only): prod [count][3] -> out [count][2]
+    int relin_to(const u64 *prod, u64 *out, u64 count) {
+        const size_t bytes = fhe_relinearize_scratch_bytes(c, cc->dbc, count);
+        const size_t m = mark();
+        void *scr = alloc((bytes + 7) / 8);
+        int rc = FHE_OK;
+        if (!dry && count) rc = fhe_relinearize_to(c, cu(prod), 3 * pw, mu(out), 2 * pw, count, cu(cc->evk), cc->dbc, scr, bytes, st);
+        release(m);
+        return rc;
+    }
+    // a product of the circuit: `raw` forms it; in the relinearised mode it lands in a temporary and is relinearised into `out`
+    template <typename F>
+    int product(u32 sa, u32 sb, u64 *out, u64 count, F &&raw) {
+        if (!relin) return raw(out);
+        if (sa != 2 || sb != 2) return fail(FHE_ERR_PARAM, "relinearised mode: products are 2 x 2 (got %u x %u)", sa, sb);
+        const size_t m = mark();
+        u64 *tmp = alloc(count * 3 * pw);
+        int rc = raw(tmp);
+        if (!rc) rc = relin_to(tmp, out, count);
+        release(m);
+        return rc;
+    }
     int multiply(const u64 *a, u32 sa, const u64 *b, const u64 *bp, u32 sb, CMap bmap, u64 *out, u64 count) {
+        return product(sa, sb, out, count, [&](u64 *o) { return multiply_raw(a, sa, b, bp, sb, bmap, o, count); });
+    }
+    int multiply_pp(const u64 *ap, u32 sa, const u64 *bp, u32 sb, u64 *out, u64 count) {
+        return product(sa, sb, out, count, [&](u64 *o) { return multiply_pp_raw(ap, sa, bp, sb, o, count); });
+    }
+    int square(const u64 *a, u32 sa, u64 *out, u64 count) {
+        return product(sa, sa, out, count, [&](u64 *o) { return square_raw(a, sa, o, count); });
+    }
+    // a (plain ciphertexts) x b; exactly one of b / bp (prepared) is given; bmap.cnt != 0: bp is a shared batch
+    int multiply_raw(const u64 *a, u32 sa, const u64 *b, const u64 *bp, u32 sb, CMap bmap, u64 *out, u64 count) {
         const size_t bytes = fhe_multiply_scratch_bytes(c, sa, sb, count);
         const size_t m = mark();
         void *scr = alloc((bytes + 7) / 8);
@@ -419,7 +456,7 @@ struct Run {
         return rc;
     }
     // both operands in prepared form (an operand that enters several products is prepared once)
-    int multiply_pp(const u64 *ap, u32 sa, const u64 *bp, u32 sb, u64 *out, u64 count) {
+    int multiply_pp_raw(const u64 *ap, u32 sa, const u64 *bp, u32 sb, u64 *out, u64 count) {
         const size_t bytes = fhe_multiply_scratch_bytes(c, sa, sb, count);
         const size_t m = mark();
         void *scr = alloc((bytes + 7) / 8);
@@ -428,7 +465,7 @@ struct Run {
         release(m);
         return rc;
     }
-    int square(const u64 *a, u32 sa, u64 *out, u64 count) {
+    int square_raw(const u64 *a, u32 sa, u64 *out, u64 count) {
         const size_t bytes = fhe_multiply_scratch_bytes(c, sa, sa, count);
         const size_t m = mark();
         void *scr = alloc((bytes + 7) / 8);
@@ -448,7 +485,9 @@ struct Src {
 // ------------------------------------------------------------------------------------------------
 // Cubic (homo/fhe_resize.h:143-189)
 // ------------------------------------------------------------------------------------------------
-// p2 / p1: prepared t^2 (size 3) and t (size 2), indexed by the pair number through `tmap` (identity map: `count` entries)
+// p2 / p1: prepared t^2 (size 3; 2 in the relinearised mode) and t (size 2), indexed by the pair number through `tmap` (identity
+// map: `count` entries).  Relinearised mode: size == 2, and the three products come back as size-2 ciphertexts (each relinearised
+// on its own, as evaluator.relinearize after :176-178 would), so the output has 2 polynomials instead of size + 2.
 int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, const u64 *p1, CMap tmap, u64 *out, CMap omap, u64 count) {
     if (!count) return FHE_OK;
     const fhe_ctx *c = R.c;
@@ -483,9 +522,10 @@ int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, cons
         TRY(R.gather_pad(C.base, size, C.map, cc, size, count));
         TRY(R.add_general(true, cc, size, ident(), A.base, size, A.map, cc, size, count));   // c = C - A
     }
-    const u32 so = size + 2;
+    if (R.relin && size != 2) return fail(FHE_ERR_PARAM, "relinearised mode: Cubic takes size-2 ciphertexts");
+    const u32 so = R.S(size + 2), sc = R.S(size + 1), s2 = R.S(3);      // a t^2 and b t^2, c t, t^2
     if (count * so * R.k > 0x7fffffffULL) return fail(FHE_ERR_PARAM, "too many polynomials for one launch");
-    if (R.cc->base2 && !tmap.idx && !c->opt.cubic_unfused && fhe_behz_floor3_supported(c)) {      // the same decision in the dry pass and the real one
+    if (!R.relin && R.cc->base2 && !tmap.idx && !c->opt.cubic_unfused && fhe_behz_floor3_supported(c)) {      // the same decision in the dry pass and the real one
         const u64 t_cnt = tmap.cnt ? tmap.cnt : count, t_div = tmap.cnt ? tmap.div : 1, t_off = tmap.cnt ? tmap.off : 0;     // identity = period `count`
         // the three products up to their inverse transforms, then ONE launch that floors, converts back, adds the three, applies
         // encode(0.5) = x^-1 and adds B (behz.hip: k_behz_floor3_combine_pm): pa, pb, pc never exist in memory
@@ -502,18 +542,18 @@ int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, cons
         R.release(m);
         return FHE_OK;
     }
-    u64 *pa = R.alloc(count * so * R.pw), *pb = R.alloc(count * so * R.pw), *pc = R.alloc(count * (so - 1) * R.pw);
-    TRY(R.multiply(a, size, nullptr, p2, 3, tmap, pa, count));          // a * t3 (t3 = t * t, :175)
-    TRY(R.multiply(b, size, nullptr, p2, 3, tmap, pb, count));          // b * t2
+    u64 *pa = R.alloc(count * so * R.pw), *pb = R.alloc(count * so * R.pw), *pc = R.alloc(count * sc * R.pw);
+    TRY(R.multiply(a, size, nullptr, p2, s2, tmap, pa, count));         // a * t3 (t3 = t * t, :175)
+    TRY(R.multiply(b, size, nullptr, p2, s2, tmap, pb, count));         // b * t2
     TRY(R.multiply(cc, size, nullptr, p1, 2, tmap, pc, count));         // c * t
     if (R.cc->base2) {
         if (!R.dry) {
-            k_cubic_combine_g<<<(unsigned)(count * so * R.k), 256, 0, R.st>>>(pa, pb, pc, so - 1, B.base, B.map, size, out, omap, c->qb.d_mod, R.k, R.n, so);
+            k_cubic_combine_g<<<(unsigned)(count * so * R.k), 256, 0, R.st>>>(pa, pb, pc, sc, B.base, B.map, size, out, omap, c->qb.d_mod, R.k, R.n, so);
             KERNEL_CHECK();
         }
     } else {
         TRY(R.add(pa, pb, pa, count * so));                                                  // :181-184
-        TRY(R.acc(pa, so, pc, so - 1, ident(), count));
+        TRY(R.acc(pa, so, pc, sc, ident(), count));
         TRY(R.mul_plain(pa, pa, count * so, R.K(0.5)));
         if (omap.idx || omap.cnt) return fail(FHE_ERR_PARAM, "output maps need the base-2 encoder");
         TRY(R.add_general(false, pa, so, ident(), B.base, size, B.map, out, so, count));                     // :187
@@ -524,12 +564,13 @@ int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, cons
 
 // t [count][2] -> prepared t^2 and t in the arena (not released: the caller's mark does that)
 int cubic_powers(Run &R, const u64 *t, u64 count, u64 **p2, u64 **p1) {
-    *p2 = R.prepare_alloc(3, count);
+    const u32 s2 = R.S(3);
+    *p2 = R.prepare_alloc(s2, count);
     *p1 = R.prepare_alloc(2, count);
     const size_t m = R.mark();
-    u64 *t2 = R.alloc(count * 3 * R.pw);
-    TRY(R.square(t, 2, t2, count));                                     // t2 = square(t) = t3 (:174-175)
-    TRY(R.prepare(t2, 3, count, *p2));
+    u64 *t2 = R.alloc(count * s2 * R.pw);
+    TRY(R.square(t, 2, t2, count));                                     // t2 = square(t) = t3 (:174-175); relinearised in that mode
+    TRY(R.prepare(t2, s2, count, *p2));
     TRY(R.prepare(t, 2, count, *p1));
     R.release(m);
     return FHE_OK;
@@ -546,11 +587,13 @@ int run_cubic(Run &R, const u64 *A, const u64 *B, const u64 *C, const u64 *D, u3
 // ------------------------------------------------------------------------------------------------
 // pomt / pt: prepared (1 - t) and t, indexed through tmap; A, B contiguous [count][size]
 int linear_core(Run &R, const u64 *A, const u64 *B, u32 size, const u64 *pomt, const u64 *pt, CMap tmap, u64 *out, u64 count) {
+    if (R.relin && size != 2) return fail(FHE_ERR_PARAM, "relinearised mode: Linear takes size-2 ciphertexts");
     const size_t m = R.mark();
-    u64 *tmp = R.alloc(count * (size + 1) * R.pw);
+    const u32 so = R.S(size + 1);
+    u64 *tmp = R.alloc(count * so * R.pw);
     TRY(R.multiply(A, size, nullptr, pomt, 2, tmap, out, count));       // boaz1 = (1 - t) * A
     TRY(R.multiply(B, size, nullptr, pt, 2, tmap, tmp, count));         // boaz2 = B * t
-    TRY(R.add(out, tmp, out, count * (size + 1)));
+    TRY(R.add(out, tmp, out, count * so));
     R.release(m);
     return FHE_OK;
 }
@@ -592,14 +635,15 @@ int run_sample_bicubic(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps,
     }
     u64 *px2, *px1;
     TRY(cubic_powers(R, xfract, count, &px2, &px1));
-    u64 *cols = R.alloc(rows * 4 * R.pw);                               // [4][count][4][k][n]
+    const u32 sr = R.S(4);                                              // size of a row Cubic's result
+    u64 *cols = R.alloc(rows * sr * R.pw);                              // [4][count][sr][k][n]
     const CMap xm = periodic(1, count);                                 // pair r * count + c multiplies xfract[c]
     TRY(cubic_core(R, Src{pixels, by_index(d_idx)}, Src{pixels, by_index(d_idx + rows)}, Src{pixels, by_index(d_idx + 2 * rows)},
                    Src{pixels, by_index(d_idx + 3 * rows)}, 2, px2, px1, xm, cols, ident(), rows));
     u64 *py2, *py1;
     TRY(cubic_powers(R, yfract, count, &py2, &py1));
-    const size_t cw = count * 4 * R.pw;
-    return cubic_core(R, Src{cols, ident()}, Src{cols + cw, ident()}, Src{cols + 2 * cw, ident()}, Src{cols + 3 * cw, ident()}, 4, py2, py1,
+    const size_t cw = count * sr * R.pw;
+    return cubic_core(R, Src{cols, ident()}, Src{cols + cw, ident()}, Src{cols + 2 * cw, ident()}, Src{cols + 3 * cw, ident()}, sr, py2, py1,
                       ident(), out, ident(), count);
 }
 
@@ -621,11 +665,12 @@ int run_sample_linear(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps, 
     TRY(R.gather_pad(pixels, 2, by_index(d_idx + rows), B, 2, rows));
     u64 *pomx, *ptx;
     TRY(linear_operands(R, xfract, count, &pomx, &ptx));
-    u64 *cols = R.alloc(rows * 3 * R.pw);                               // [2][count][3][k][n]
+    const u32 sr = R.S(3);
+    u64 *cols = R.alloc(rows * sr * R.pw);                              // [2][count][sr][k][n]
     TRY(linear_core(R, A, B, 2, pomx, ptx, periodic(1, count), cols, rows));
     u64 *pomy, *pty;
     TRY(linear_operands(R, yfract, count, &pomy, &pty));
-    return linear_core(R, cols, cols + count * 3 * R.pw, 3, pomy, pty, ident(), out, count);
+    return linear_core(R, cols, cols + count * sr * R.pw, sr, pomy, pty, ident(), out, count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -692,11 +737,12 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
             band_need.push_back(need);
         }
     }
-    const size_t slot_words = (size_t)dst_w * 4 * R.pw;
+    const u32 sr = R.S(4), sout = R.S(6);                               // polynomials of a row Cubic's result and of an output pixel
+    const size_t slot_words = (size_t)dst_w * sr * R.pw;
     u64 *cache = R.alloc((size_t)max_live * slot_words);
     const u32 call_px = rows_per_call * dst_w;
     u32 *d_idx = R.alloc_u32((size_t)5 * call_px);                      // four tap arrays + the output slots of one call
-    u64 *band = out ? nullptr : R.alloc((size_t)call_px * 6 * R.pw);
+    u64 *band = out ? nullptr : R.alloc((size_t)call_px * sout * R.pw);
     std::map<u32, u32> slot_of;                                         // live source row -> slot
     std::vector<u32> free_slots;
     for (u32 s = max_live; s-- > 0;) free_slots.push_back(s);
@@ -738,10 +784,10 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
                 for (u32 x = 0; x < dst_w; ++x)
                     for (u32 j = 0; j < 4; ++j) h[(size_t)j * cnt + i * dst_w + x] = slot_of[ix.rows_of[(ya + i) * 4 + j]] * dst_w + x;
             TRY(R.stage(h.data(), (size_t)4 * cnt, d_idx));
-            u64 *dst = out ? out + (size_t)(ya - sh.row0) * dst_w * 6 * R.pw : band;
+            u64 *dst = out ? out + (size_t)(ya - sh.row0) * dst_w * sout * R.pw : band;
             // pixel c of the call sits in output row ya + c / dst_w: entry ya - row0 + c / dst_w of the prepared yfract batches
             TRY(cubic_core(R, Src{cache, by_index(d_idx)}, Src{cache, by_index(d_idx + cnt)}, Src{cache, by_index(d_idx + 2 * (size_t)cnt)},
-                           Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, 4, py2, py1, periodic(dst_w, n_rows, ya - sh.row0), dst, ident(), cnt));
+                           Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, sr, py2, py1, periodic(dst_w, n_rows, ya - sh.row0), dst, ident(), cnt));
             if (consume && !R.dry) {
                 const int rc = consume(user, (u64)ya * dst_w, cu(dst), cnt, (fhe_stream)R.st);
                 if (rc) return fail(rc < 0 ? rc : FHE_ERR_PARAM, "band consumer failed");
@@ -782,21 +828,24 @@ int taylor_eval(Run &R, const u64 *x, u64 count_all, const TaylorSeg *segs, int 
     const size_t m = R.mark();
     const u64 ct = count_all;
     u64 *pwr[5];
-    for (int i = 0; i < 5; ++i) pwr[i] = R.alloc(ct * kTermSize[i] * R.pw);      // s2, s4, s6, s8, s10
+    u32 tsz[5];                                                          // 3, 5, 7, 9, 11; all 2 in the relinearised mode (every power is relinearised where it is formed)
+    for (int i = 0; i < 5; ++i) tsz[i] = R.S(kTermSize[i]);
+    const u32 sres = R.S(11);
+    for (int i = 0; i < 5; ++i) pwr[i] = R.alloc(ct * tsz[i] * R.pw);             // s2, s4, s6, s8, s10
     {
         const size_t m1 = R.mark();
-        u64 *sx = R.alloc(ct * 2 * R.pw), *psx = R.prepare_alloc(2, ct), *ps4 = R.prepare_alloc(5, ct), *tmp = R.alloc(ct * 10 * R.pw);
+        u64 *sx = R.alloc(ct * 2 * R.pw), *psx = R.prepare_alloc(2, ct), *ps4 = R.prepare_alloc(tsz[1], ct), *tmp = R.alloc(ct * R.S(10) * R.pw);
         TRY(R.copy(sx, x, ct * 2));
         TRY(R.add_plain(sx, 2, ct, R.K(-3 * M_PI / 2.0)));               // :57 / :137
         TRY(R.prepare(sx, 2, ct, psx));                                  // enters five products
         TRY(R.multiply_pp(psx, 2, psx, 2, pwr[0], ct));                  // s2
-        TRY(R.square(pwr[0], 3, pwr[1], ct));                            // s4
-        TRY(R.prepare(pwr[1], 5, ct, ps4));                              // enters two
-        TRY(R.multiply_pp(ps4, 5, ps4, 5, pwr[3], ct));                  // s8
-        TRY(R.multiply_pp(ps4, 5, psx, 2, tmp, ct));                     // s5
-        TRY(R.multiply(tmp, 6, nullptr, psx, 2, ident(), pwr[2], ct));   // s6
-        TRY(R.multiply(pwr[3], 9, nullptr, psx, 2, ident(), tmp, ct));   // s9
-        TRY(R.multiply(tmp, 10, nullptr, psx, 2, ident(), pwr[4], ct));  // s10
+        TRY(R.square(pwr[0], tsz[0], pwr[1], ct));                       // s4
+        TRY(R.prepare(pwr[1], tsz[1], ct, ps4));                         // enters two
+        TRY(R.multiply_pp(ps4, tsz[1], ps4, tsz[1], pwr[3], ct));        // s8
+        TRY(R.multiply_pp(ps4, tsz[1], psx, 2, tmp, ct));                // s5
+        TRY(R.multiply(tmp, R.S(6), nullptr, psx, 2, ident(), pwr[2], ct));      // s6
+        TRY(R.multiply(pwr[3], tsz[3], nullptr, psx, 2, ident(), tmp, ct));      // s9
+        TRY(R.multiply(tmp, R.S(10), nullptr, psx, 2, ident(), pwr[4], ct));     // s10
         R.release(m1);
     }
     for (int sg = 0; sg < nsegs; ++sg) {
@@ -807,28 +856,28 @@ int taylor_eval(Run &R, const u64 *x, u64 count_all, const TaylorSeg *segs, int 
         for (int i = 0; i < 5; ++i) {
             kc[i] = R.K(S.coeffs[i]);
             if (!kc[i]) return FHE_ERR_PARAM;
-            src[i] = pwr[i] + S.first * kTermSize[i] * R.pw;
+            src[i] = pwr[i] + S.first * tsz[i] * R.pw;
         }
         if (fhe_multiply_plain_sum_supported(R.c)) {
             if (!S.broadcast) {
-                TRY(R.mul_plain_sum(5, src, kTermSize, kc, S.zero, S.zmap, 2, S.res, 11, S.count));
+                TRY(R.mul_plain_sum(5, src, tsz, kc, S.zero, S.zmap, 2, S.res, sres, S.count));
             } else {
-                u64 *sum = R.alloc(S.count_t * 11 * R.pw);
-                TRY(R.mul_plain_sum(5, src, kTermSize, kc, nullptr, ident(), 0, sum, 11, S.count_t));
-                TRY(R.add_general(false, S.zero, 2, S.zmap, sum, 11, S.tmap, S.res, 11, S.count));
+                u64 *sum = R.alloc(S.count_t * sres * R.pw);
+                TRY(R.mul_plain_sum(5, src, tsz, kc, nullptr, ident(), 0, sum, sres, S.count_t));
+                TRY(R.add_general(false, S.zero, 2, S.zmap, sum, sres, S.tmap, S.res, sres, S.count));
             }
         } else {
-            for (int i = 0; i < 5; ++i) TRY(R.mul_plain(src[i], src[i], S.count_t * kTermSize[i], kc[i]));   // every power is dead after its product
+            for (int i = 0; i < 5; ++i) TRY(R.mul_plain(src[i], src[i], S.count_t * tsz[i], kc[i]));   // every power is dead after its product
             if (!R.dry && S.count) {
                 TaylorTerms T;
-                for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)src[i]; T.size[i] = kTermSize[i]; }
-                const u64 nrp = S.count * 11 * R.k;
+                for (int i = 0; i < 5; ++i) { T.t[i] = (const ulonglong2 *)src[i]; T.size[i] = tsz[i]; }
+                const u64 nrp = S.count * sres * R.k;
                 dim3 grid((R.n / 2 + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
-                k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)S.zero, S.zmap, T, S.tmap, (ulonglong2 *)S.res, R.c->qb.d_mod, R.k, R.n / 2, nrp);
+                k_taylor_sum<<<grid, 256, 0, R.st>>>((const ulonglong2 *)S.zero, S.zmap, T, S.tmap, (ulonglong2 *)S.res, R.c->qb.d_mod, R.k, R.n / 2, nrp, sres);
                 KERNEL_CHECK();
             }
         }
-        TRY(R.add_plain(S.res, 11, S.count, R.K(S.constant)));
+        TRY(R.add_plain(S.res, sres, S.count, R.K(S.constant)));
         R.release(ms);
     }
     R.release(m);
@@ -844,7 +893,7 @@ int run_sincos(Run &R, int cosine, const u64 *x, const u64 *zero, u64 *out, u64 
 // (the whole run: pos0 = 0, pos1 = npos; a shard of the positions is the multi-GPU partition of the loop at :224).  Batch
 // index of the cosine polynomials = (j - 1) * np + (i - pos0), np = pos1 - pos0; only the cheap offset chain (:228-229) is
 // walked serially -- from position 0, so a shard replays the add_plain steps of the positions before it -- and the sine
-// polynomial is evaluated once per harmonic.  zeros: [np][degree][2][2][k][n], out: [np][so][k][n]
+// polynomial is evaluated once per harmonic.  zeros: [np][degree][2][2][k][n], out: [np][so + 1][k][n] (relinearised mode: [np][2][k][n])
 int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct, int order, int degree, double delta, u32 pos0, u32 pos1,
              const u64 *zeros, u64 *out) {
     const size_t m = R.mark();
@@ -856,7 +905,7 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
     TRY(R.add_plain(offset, 2, 1, R.K(-0.5)));                          // :218
     TRY(R.neg(offset, offset, 2));                                      // :219
     TRY(R.add_plain(b, 2, 1, R.K(delta - 0.5)));                        // :220
-    const u32 so = degree >= 1 ? 21 : 2;
+    const u32 so = degree >= 1 ? R.S(21) : 2, sty = R.S(11);            // the harmonic sum; a Taylor polynomial
     u64 *cacc = R.alloc((u64)np * so * R.pw);
     {
         u64 *c0 = R.alloc(2 * R.pw);
@@ -911,7 +960,7 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
             TRY(R.mul_plain(ca, ca, (u64)np * 2, R.K(factor[j])));                            // :230
             TRY(R.mul_plain(b, sin_arg + (u64)j * 2 * R.pw, 2, R.K(factor[j])));              // :226-227
         }
-        u64 *co = R.alloc(nb * 11 * R.pw), *si = R.alloc(nb * 11 * R.pw);
+        u64 *co = R.alloc(nb * sty * R.pw), *si = R.alloc(nb * sty * R.pw);
         u32 *d_idx = R.alloc_u32(2 * nb);
         if (!R.dry) {
             std::vector<u32> h(2 * nb);                                 // Enc(0) of (position i, harmonic j): sin at 2 (i * degree + j), cos next to it
@@ -925,24 +974,24 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
         const TaylorSeg segs[2] = {{0, nb, kCosCoeffs, zeros, by_index(d_idx + nb), 1.0, ident(), false, co, nb},
                                    {nb, (u64)degree, kSinCoeffs, zeros, by_index(d_idx), -1.0, periodic(np, degree), true, si, nb}};
         TRY(taylor_eval(R, args, nb + (u64)degree, segs, 2));
-        u64 *prod = R.alloc(nb * 21 * R.pw);
-        TRY(R.multiply(si, 11, co, nullptr, 11, ident(), prod, nb));                           // :234-235
+        u64 *prod = R.alloc(nb * so * R.pw);
+        TRY(R.multiply(si, sty, co, nullptr, sty, ident(), prod, nb));                           // :234-235
         if (fhe_multiply_plain_sum_supported(R.c) && degree <= FHE_PLAIN_SUM_MAX_TERMS) {       // :236-237 for every harmonic in one launch
             u64 *src[FHE_PLAIN_SUM_MAX_TERMS];
             const CircConst *kc[FHE_PLAIN_SUM_MAX_TERMS];
             u32 sizes[FHE_PLAIN_SUM_MAX_TERMS];
             for (int j = 0; j < degree; ++j) {
-                src[j] = prod + (u64)j * np * 21 * R.pw;
-                sizes[j] = 21;
+                src[j] = prod + (u64)j * np * so * R.pw;
+                sizes[j] = so;
                 kc[j] = R.K(2.0 / (M_PI * ((float)(j + 1))));
                 if (!kc[j]) return FHE_ERR_PARAM;
             }
-            TRY(R.mul_plain_sum(degree, src, sizes, kc, cacc, ident(), 21, cacc, 21, np));
+            TRY(R.mul_plain_sum(degree, src, sizes, kc, cacc, ident(), so, cacc, so, np));
         } else {
             for (int j = 0; j < degree; ++j) {
-                u64 *pj = prod + (u64)j * np * 21 * R.pw;
-                TRY(R.mul_plain(pj, pj, (u64)np * 21, R.K(2.0 / (M_PI * ((float)(j + 1))))));      // :236
-                TRY(R.add(cacc, pj, cacc, (u64)np * 21));                                         // :237
+                u64 *pj = prod + (u64)j * np * so * R.pw;
+                TRY(R.mul_plain(pj, pj, (u64)np * so, R.K(2.0 / (M_PI * ((float)(j + 1))))));      // :236
+                TRY(R.add(cacc, pj, cacc, (u64)np * so));                                         // :237
             }
         }
         R.release(m2);
@@ -959,7 +1008,7 @@ int run_step(Run &R, const u64 *amplitude, const u64 *index, const u64 *count_ct
 int run_decode_channel(Run &R, const u64 *runs, u32 pairs, u64 *index, const u64 *acc0, const u64 *zeros, int order, int degree, double delta,
                        u32 pos0, u32 pos1, u64 *out) {
     const u32 np = pos1 - pos0;
-    const u32 so = pairs ? fhe_approximated_step_out_size(degree) : 2;
+    const u32 so = pairs ? R.S(fhe_approximated_step_out_size(degree)) : 2;
     TRY(R.gather_pad(acc0, 2, ident(), out, so, np));                   // the channel's Enc(0) accumulators (server_decode.cpp:124-128)
     if (!pairs) return FHE_OK;
     const size_t m = R.mark();
@@ -1007,12 +1056,34 @@ int real_run(const fhe_circuits *cc, void *scratch, size_t bytes, fhe_stream s, 
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int fhe_circuits_create(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, fhe_circuits **out) {
+    return fhe_circuits_create_relin(ctx, int_coeffs, frac_coeffs, nullptr, 0, out);
+}
+extern "C" uint32_t fhe_circuits_relin_dbc(const fhe_circuits *cc) { return cc ? cc->dbc : 0; }
+extern "C" uint32_t fhe_circuits_out_size(const fhe_circuits *cc, int circuit, uint32_t arg) {
+    if (!cc) return 0;
+    u32 ref;
+    switch (circuit) {
+        case FHE_CIRC_CUBIC: ref = arg + 2; break;
+        case FHE_CIRC_LINEAR: ref = arg + 1; break;
+        case FHE_CIRC_SAMPLE_BICUBIC: ref = 6; break;
+        case FHE_CIRC_SAMPLE_LINEAR: ref = 4; break;
+        case FHE_CIRC_SINCOS: ref = 11; break;
+        case FHE_CIRC_STEP: case FHE_CIRC_DECODE: ref = fhe_approximated_step_out_size((int)arg); break;
+        default: return 0;
+    }
+    return cc->dbc && ref > 2 ? 2 : ref;
+}
+extern "C" int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc, fhe_circuits **out) {
     if (!ctx || !out) return fail(FHE_ERR_PARAM, "null argument");
     *out = nullptr;
+    if ((d_evk_ntt != nullptr) != (dbc != 0)) return fail(FHE_ERR_PARAM, "evaluation keys and a decomposition bit count come together");
+    if (dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (int_coeffs < 1 || frac_coeffs < 0 || (u32)(int_coeffs + frac_coeffs) > ctx->n) return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");
     if (int erc = fhe_behz_ensure(ctx)) return erc;                     // a circuits handle is a statement of intent to multiply ciphertexts
     std::unique_ptr<fhe_circuits> cc(new fhe_circuits);
     cc->c = ctx;
+    cc->evk = (const u64 *)d_evk_ntt;
+    cc->dbc = dbc;
     cc->ic = int_coeffs;
     cc->fc = frac_coeffs;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -29,7 +29,7 @@ int fhe_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *fhe_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t fhe_abi_version(void) { return 1; }
+extern "C" uint32_t fhe_abi_version(void) { return FHE_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
 // context

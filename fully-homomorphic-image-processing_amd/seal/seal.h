@@ -325,6 +325,9 @@ public:
         for (const auto &m : p.q_) s.q.push_back(m.value());
         int dev = 0;
         if (const char *e = std::getenv("FHE_DEVICE")) dev = std::atoi(e);
+        if (fhe_abi_version() != FHE_ABI_VERSION)
+            throw std::runtime_error("libfhe_hip reports ABI version " + std::to_string(fhe_abi_version()) + ", this facade was compiled against " +
+                                     std::to_string(FHE_ABI_VERSION) + " (include/fhe_hip.h): rebuild one of them");
         const double tc = detail::now_s();
         detail::check(fhe_ctx_create(s.n, s.q.data(), s.k, s.t, dev, &s.h), "SEALContext");
         s.stats.create_s = detail::now_s() - tc;

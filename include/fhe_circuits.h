@@ -35,6 +35,34 @@ typedef struct fhe_circuits fhe_circuits;
 int fhe_circuits_create(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, fhe_circuits **out);
 int fhe_circuits_destroy(fhe_circuits *circ);
 
+/* ---- the relinearised mode ---------------------------------------------------
+ * The reference multiplies ciphertexts without ever relinearising (homo/fhe_resize.h:174-179, homo/fhe_decode.h:67-98,
+ * 235,239): sizes reach 6 in SampleBicubic and 22 in approximated_step.  It does carry the decomposition bit count it
+ * would need (`dbc`, homo/client_resize.cpp:26,47,72, homo/client_decode.cpp:26, DBC = 30 homo/fhe_image.h:28) and never
+ * uses it.  A handle made by fhe_circuits_create_relin evaluates the SAME Evaluator call sequences with
+ * evaluator.relinearize(x, evk) after every multiply / square -- each product 2 x 2 -> 3 -> 2 -- so every ciphertext
+ * of every circuit has TWO polynomials: all `out` arrays below then hold [..][2][k][n] (fhe_circuits_out_size tells),
+ * and the `size` argument of fhe_cubic / fhe_linear must be 2.  These are NOT the reference's ciphertext bits (key
+ * switching adds its own noise term); they decrypt to the same values with a larger remaining noise budget, and they are
+ * bit-identical to the oracle's op-by-op composition multiply -> relinearize (oracle/oracle.py RelinOracle).
+ * d_evk_ntt: evaluation keys for s^2 as fhe_relinearize takes them ([k][fhe_evk_digits(dbc)][2][k][n], device memory,
+ * NTT form); they must outlive the handle.  Everything else is as for fhe_circuits_create. */
+int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc,
+                              fhe_circuits **out);
+/* the decomposition bit count of a relinearising handle, 0 for a handle in the reference's mode */
+uint32_t fhe_circuits_relin_dbc(const fhe_circuits *circ);
+/* polynomials per output ciphertext of a circuit for this handle.  `arg`: FHE_CIRC_CUBIC / FHE_CIRC_LINEAR the operand
+ * size, FHE_CIRC_STEP / FHE_CIRC_DECODE the degree (FHE_CIRC_DECODE: of a channel with at least one run), else ignored.
+ * Reference mode: size + 2, size + 1, 6, 4, 11, 22 (3 for degree 0), the same; relinearised mode: 2 throughout. */
+#define FHE_CIRC_CUBIC 0
+#define FHE_CIRC_LINEAR 1
+#define FHE_CIRC_SAMPLE_BICUBIC 2
+#define FHE_CIRC_SAMPLE_LINEAR 3
+#define FHE_CIRC_SINCOS 4
+#define FHE_CIRC_STEP 5
+#define FHE_CIRC_DECODE 6
+uint32_t fhe_circuits_out_size(const fhe_circuits *circ, int circuit, uint32_t arg);
+
 /* ---- resize path ---------------------------------------------------------------------------------------
  * Index arithmetic of ResizeImage / SampleBicubic / SampleLinear / GetPixelClamped in the reference's float
  * arithmetic (homo/fhe_resize.h:350-351,381-382,260-290,215-220): per output pixel (row-major) the clamped
@@ -45,13 +73,14 @@ int fhe_resize_sample_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint3
                            uint32_t *taps, double *xfract, double *yfract);
 
 /* Cubic(result, A, B, C, D, t) (homo/fhe_resize.h:143-189) for `count` independent 5-tuples: A..D of `size`
- * polynomials, t of size 2, out of size + 2.  t2 = square(t) and t3 = multiply(t, t) (:174-175, the
- * reference's t^3 IS t^2) are one ring element, formed once. */
+ * polynomials, t of size 2, out of size + 2 (relinearised mode: size must be 2, out has 2).  t2 = square(t) and
+ * t3 = multiply(t, t) (:174-175, the reference's t^3 IS t^2) are one ring element, formed once. */
 size_t fhe_cubic_scratch_bytes(const fhe_circuits *circ, uint32_t size, uint64_t count);
 int fhe_cubic(const fhe_circuits *circ, const uint64_t *A, const uint64_t *B, const uint64_t *C, const uint64_t *D,
               uint32_t size, const uint64_t *t, uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes,
               fhe_stream stream);
-/* Linear(result, A, B, t) = (1 - t) A + t B (homo/fhe_resize.h:191-204); out has size + 1 polynomials. */
+/* Linear(result, A, B, t) = (1 - t) A + t B (homo/fhe_resize.h:191-204); out has size + 1 polynomials (relinearised
+ * mode: size must be 2, out has 2). */
 size_t fhe_linear_scratch_bytes(const fhe_circuits *circ, uint32_t size, uint64_t count);
 int fhe_linear(const fhe_circuits *circ, const uint64_t *A, const uint64_t *B, uint32_t size, const uint64_t *t,
                uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream stream);
@@ -59,13 +88,13 @@ int fhe_linear(const fhe_circuits *circ, const uint64_t *A, const uint64_t *B, u
 /* SampleBicubic (homo/fhe_resize.h:254-305) for `count` output pixels of one colour channel.
  * pixels: [n_pixels][2][k][n] (the resident source window); taps: host, [count][16] indices into `pixels`
  * (fhe_resize_sample_plan order); xfract, yfract: [count][2][k][n] encryptions of the offsets (:262,266);
- * out: [count][6][k][n].  Five Cubic evaluations per pixel; xfract^2 and the prepared forms of xfract,
+ * out: [count][6][k][n] ([count][2][k][n] in the relinearised mode).  Five Cubic evaluations per pixel; xfract^2 and the prepared forms of xfract,
  * xfract^2 are shared by the four row Cubics. */
 size_t fhe_sample_bicubic_scratch_bytes(const fhe_circuits *circ, uint64_t count);
 int fhe_sample_bicubic(const fhe_circuits *circ, const uint64_t *pixels, uint64_t n_pixels, const uint32_t *taps,
                        const uint64_t *xfract, const uint64_t *yfract, uint64_t *out, uint64_t count, void *scratch,
                        size_t scratch_bytes, fhe_stream stream);
-/* SampleLinear (homo/fhe_resize.h:222-252): taps [count][4]; out [count][4][k][n]. */
+/* SampleLinear (homo/fhe_resize.h:222-252): taps [count][4]; out [count][4][k][n] (relinearised mode: [count][2][k][n]). */
 size_t fhe_sample_linear_scratch_bytes(const fhe_circuits *circ, uint64_t count);
 int fhe_sample_linear(const fhe_circuits *circ, const uint64_t *pixels, uint64_t n_pixels, const uint32_t *taps,
                       const uint64_t *xfract, const uint64_t *yfract, uint64_t *out, uint64_t count, void *scratch,
@@ -77,7 +106,8 @@ int fhe_sample_linear(const fhe_circuits *circ, const uint64_t *pixels, uint64_t
  * only and frac(v) on the row only (:351,382).  Every repeated ring element is formed once (row Cubics of
  * overlapping 4-row windows, squares and prepared operands per column / row); each output equals
  * fhe_sample_bicubic with xfract[x], yfract[y] bit for bit.  Output pixels are produced in bands of
- * `band_rows` destination rows, row-major: written to out ([dst_w * dst_h][6][k][n]) when out != NULL, and /
+ * `band_rows` destination rows, row-major: written to out ([dst_w * dst_h][S][k][n], S = fhe_circuits_out_size(circ,
+ * FHE_CIRC_SAMPLE_BICUBIC, 0) = 6, or 2 in the relinearised mode) when out != NULL, and /
  * or handed to `consume` (may be NULL) as consume(user, first_pixel, d_band, n_pixels, stream), which must
  * enqueue its reads of d_band on `stream` (the band buffer is reused).  `batch` bounds the Cubics per launch
  * sequence (rounded to whole rows of dst_w). */
@@ -116,7 +146,7 @@ int fhe_resize_bicubic_shared_rows(const fhe_circuits *circ, const uint64_t *pix
 /* ---- decode path ---------------------------------------------------------------------------------------
  * homomorphic_sin (cosine = 0, homo/fhe_decode.h:48-120) / homomorphic_cos (cosine = 1, :128-200; the value
  * the reference leaves in `res` before falling off the end without a return statement) for `count`
- * arguments: x, zero (the Enc(0) of :54 / :134): [count][2][k][n]; out: [count][11][k][n]. */
+ * arguments: x, zero (the Enc(0) of :54 / :134): [count][2][k][n]; out: [count][11][k][n] (relinearised mode: [count][2][k][n]). */
 size_t fhe_homomorphic_sincos_scratch_bytes(const fhe_circuits *circ, uint64_t count);
 int fhe_homomorphic_sincos(const fhe_circuits *circ, int cosine, const uint64_t *x, const uint64_t *zero,
                            uint64_t *out, uint64_t count, void *scratch, size_t scratch_bytes, fhe_stream stream);
@@ -124,7 +154,8 @@ int fhe_homomorphic_sincos(const fhe_circuits *circ, int cosine, const uint64_t 
 /* The homomorphic overload of approximated_step (homo/fhe_decode.h:202-242) for ONE run (amplitude, index,
  * count_ct: [2][k][n]) over npos = width * height positions.  zeros: [npos][degree][2][2][k][n], the Enc(0)
  * accumulators in the reference's call order (position i, harmonic j = 1..degree, sin then cos).
- * out: [npos][fhe_approximated_step_out_size(degree)][k][n] (22 polynomials for degree >= 1).
+ * out: [npos][fhe_approximated_step_out_size(degree)][k][n] (22 polynomials for degree >= 1; a relinearising handle
+ * writes [npos][2][k][n]: fhe_circuits_out_size(circ, FHE_CIRC_STEP, degree)).
  * `offset` advances by add_plain(offset, encode(i)) inside the harmonic loop (:229), as the reference does. */
 uint32_t fhe_approximated_step_out_size(int degree);
 size_t fhe_approximated_step_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos);
@@ -150,7 +181,8 @@ int fhe_approximated_step_range(const fhe_circuits *circ, const uint64_t *amplit
  * (runs: [pairs][2][2][k][n] = elem, count as loaded at :131-132) approximated_step is evaluated with the
  * running `index` ([2][k][n], in/out: :121 and :137 `index += count`), and its npos results are added to the
  * accumulators (:134-136).  zeros: [pairs][npos][degree][2][2][k][n].
- * out: [npos][S][k][n] with S = fhe_approximated_step_out_size(degree) if pairs > 0, else 2. */
+ * out: [npos][S][k][n] with S = fhe_circuits_out_size(circ, FHE_CIRC_DECODE, degree) (= fhe_approximated_step_out_size(degree)
+ * in the reference's mode) if pairs > 0, else 2. */
 size_t fhe_decode_channel_scratch_bytes(const fhe_circuits *circ, int degree, uint32_t npos, uint32_t pairs);
 int fhe_decode_channel(const fhe_circuits *circ, const uint64_t *runs, uint32_t pairs, uint64_t *index,
                        const uint64_t *acc0, const uint64_t *zeros, int order, int degree, double delta,

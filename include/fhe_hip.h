@@ -65,7 +65,16 @@ typedef struct fhe_dct_plan fhe_dct_plan;
 typedef void *fhe_stream;
 
 const char *fhe_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change and whenever entry points are added or a contract changes.
+ *   1: rounds 1-3.
+ *   2: + fhe_gather, fhe_host_alloc / fhe_host_free, fhe_stream_create / destroy, fhe_ctx_bind_thread / fhe_ctx_device,
+ *      fhe_count_unreduced, the *_range / *_rows circuit shards, fhe_relinearize_to, the relinearised mode of the circuits
+ *      (fhe_circuits_create_relin, fhe_circuits_out_size); fhe_ctx_create no longer builds or validates the ct x ct tables
+ *      (auxiliary-prime failures surface at the first multiply or at fhe_circuits_create), fhe_arith_path builds them as
+ *      a side effect, and the context's second stream exists only with FHE_DCT_PIPELINE=1.
+ * A host compiled against this header compares fhe_abi_version() with FHE_ABI_VERSION before anything else (the Python
+ * binding and seal/seal.h do). */
+#define FHE_ABI_VERSION 2
 uint32_t fhe_abi_version(void);
 
 /* ---- context: replaces seal::EncryptionParameters + seal::SEALContext -------------------------
@@ -225,6 +234,13 @@ int fhe_relinearize(const fhe_ctx *ctx, uint64_t *ct3, uint64_t ct_stride_words,
                     const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch, size_t scratch_bytes,
                     fhe_stream stream);
 size_t fhe_relinearize_scratch_bytes(const fhe_ctx *ctx, uint32_t dbc, uint64_t count);
+/* The same with the result written elsewhere: out2[c * out_stride_words ...] = the relinearised size-2 ciphertext of
+ * ct3[c * ct_stride_words ...] (a batch of products becomes a compact [count][2][k][n] batch without a copy of its own;
+ * the relinearised mode of the circuits, include/fhe_circuits.h, is built on it).  out2 == ct3 with equal strides is
+ * fhe_relinearize.  Same scratch. */
+int fhe_relinearize_to(const fhe_ctx *ctx, const uint64_t *ct3, uint64_t ct_stride_words, uint64_t *out2,
+                       uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,
+                       size_t scratch_bytes, fhe_stream stream);
 
 /* ---- fused block circuit: encrypted_dct (homo/fhe_image.h:196-288) followed by quantize_fhe
  * (homo/fhe_image.h:294-305) on n_blocks independent 8x8 blocks.  in/out: [n_blocks][64][2][k][n].

@@ -41,7 +41,7 @@ struct fhe_dct_plan {
 };
 
 const char *fhe_last_error(void) { return g_err; }
-uint32_t fhe_abi_version(void) { return 1; }
+uint32_t fhe_abi_version(void) { return FHE_ABI_VERSION; }
 
 int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out) {
     /* the same published SEAL prime tables the product restates */
@@ -277,6 +277,19 @@ int fhe_relinearize(const fhe_ctx *c, uint64_t *ct3, uint64_t stride, uint64_t c
                     uint32_t dbc, void *scr, size_t sbytes, fhe_stream s) {
     (void)scr; (void)sbytes; (void)s;
     for (uint64_t i = 0; i < count; i++) fo_relinearize3(c->o, ct3 + i * stride, evk, dbc);
+    return FHE_OK;
+}
+int fhe_relinearize_to(const fhe_ctx *c, const uint64_t *ct3, uint64_t stride, uint64_t *out2, uint64_t out_stride,
+                       uint64_t count, const uint64_t *evk, uint32_t dbc, void *scr, size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    uint64_t *tmp = (uint64_t *)malloc(3 * pw(c) * 8);
+    if (!tmp) return fail(FHE_ERR_NOMEM, "out of memory");
+    for (uint64_t i = 0; i < count; i++) {
+        memcpy(tmp, ct3 + i * stride, 3 * pw(c) * 8);
+        fo_relinearize3(c->o, tmp, evk, dbc);
+        memcpy(out2 + i * out_stride, tmp, 2 * pw(c) * 8);
+    }
+    free(tmp);
     return FHE_OK;
 }
 

@@ -392,3 +392,76 @@ def oracle_approximated_step(orc, amplitude, index, count, order, degree, delta,
             c = orc.add(c, term)                                      # :237
         run.append(orc.multiply(c, amplitude))                       # :239-240
     return run
+
+
+# ---------------------------------------------------------------------------------------------
+# The RELINEARISED mode (include/fhe_circuits.h fhe_circuits_create_relin): the reference's own
+# Evaluator call sequences with evaluator.relinearize(x, evk) after every multiply / square.  The reference never
+# relinearises (homo/fhe_resize.h:174-179, homo/fhe_decode.h:67-98,235,239) although it carries the decomposition bit
+# count it would need (homo/client_resize.cpp:26,47,72; DBC = 30, homo/fhe_image.h:28): these are the checker's
+# definitions of that mode, plain compositions of fo_multiply / fo_square + fo_relinearize3, written op by op.
+# ---------------------------------------------------------------------------------------------
+class RelinOracle:
+    """An Oracle whose multiply / square relinearise their result: every ciphertext keeps two polynomials.
+    evk: the oracle's own evaluation keys (Oracle.evk_gen), dbc their decomposition bit count."""
+
+    def __init__(self, orc, evk, dbc):
+        self.orc, self.evk, self.dbc = orc, evk, int(dbc)
+
+    def __getattr__(self, name):                 # every other operation is the plain oracle's
+        return getattr(self.orc, name)
+
+    def _rl(self, p):
+        assert p.shape[0] <= 3, "relinearised mode: operands have two polynomials"
+        return self.orc.relinearize(p, self.evk, self.dbc) if p.shape[0] == 3 else p
+
+    def multiply(self, a, b):
+        return self._rl(self.orc.multiply(a, b))
+
+    def square(self, a):
+        return self._rl(self.orc.square(a))
+
+
+def oracle_cubic_calls(orc, A, B, Cc, D, t):
+    """Cubic (homo/fhe_resize.h:143-189) one Evaluator call per line -- fo_cubic restates the same sequence in C; this form
+    takes any oracle-shaped object, so oracle_cubic_calls(RelinOracle(...), ...) is the relinearised Cubic."""
+    E = orc.encode
+    a = orc.multiply_plain(B, E(3))                     # :150
+    a = orc.sub(a, A)                                   # :151
+    a = orc.sub(a, orc.multiply_plain(Cc, E(3)))        # :152-153
+    a = orc.add(a, D)                                   # :154-155
+    b = orc.multiply_plain(A, E(2))                     # :158
+    b = orc.sub(b, orc.multiply_plain(B, E(5)))         # :159-160
+    b = orc.add(b, orc.multiply_plain(Cc, E(4)))        # :161-162
+    b = orc.sub(b, D)                                   # :163-164
+    c = orc.sub(Cc, A)                                  # :167-169
+    t2 = orc.square(t)                                  # :174
+    t3 = orc.multiply(t, t)                             # :175 (t3 IS t * t)
+    a = orc.multiply(a, t3)                             # :177
+    b = orc.multiply(b, t2)                             # :178
+    c = orc.multiply(c, t)                              # :179
+    a = orc.add(a, b)                                   # :181
+    a = orc.add(a, c)                                   # :182
+    a = orc.multiply_plain(a, E(0.5))                   # :183
+    return orc.add(a, B)                                # :184 (d = B)
+
+
+def oracle_linear_calls(orc, A, B, t):
+    """Linear (homo/fhe_resize.h:191-204) one Evaluator call per line."""
+    omt = orc.add_plain(orc.negate(t), orc.encode(1.0))     # :196
+    x = orc.multiply(omt, A)                                # :197
+    y = orc.multiply(B, t)                                  # :198
+    return orc.add(x, y)                                    # :199
+
+
+def oracle_sample_bicubic_calls(orc, p, xfract, yfract):
+    """SampleBicubic (homo/fhe_resize.h:293-303): p = the sixteen clamped taps, row-major 4 x 4"""
+    cols = [oracle_cubic_calls(orc, p[4 * r], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract) for r in range(4)]
+    return oracle_cubic_calls(orc, cols[0], cols[1], cols[2], cols[3], yfract)
+
+
+def oracle_sample_linear_calls(orc, p, xfract, yfract):
+    """SampleLinear (homo/fhe_resize.h:237-248): p = p00, p10, p01, p11"""
+    c0 = oracle_linear_calls(orc, p[0], p[1], xfract)
+    c1 = oracle_linear_calls(orc, p[2], p[3], xfract)
+    return oracle_linear_calls(orc, c0, c1, yfract)

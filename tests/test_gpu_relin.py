@@ -1,0 +1,234 @@
+"""GPU: the RELINEARISED mode of the circuits (include/fhe_circuits.h fhe_circuits_create_relin).
+
+The reference multiplies without ever relinearising (homo/fhe_resize.h:174-179, homo/fhe_decode.h:67-98,235,239) but carries
+the decomposition bit count it would need (homo/client_resize.cpp:26,47,72; DBC = 30, homo/fhe_image.h:28).  The mode is the
+reference's Evaluator call sequence with evaluator.relinearize after every multiply / square; the checker is the oracle's
+op-by-op composition fo_multiply -> fo_relinearize3 (oracle/oracle.py RelinOracle), compared bit for bit (integer work:
+array_equal, no tolerance), plus decrypt known answers with the remaining noise budget printed beside the reference mode's.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(n=1024, q=[0xFFFFEE001, 0xFFFFC4001], t=1 << 14)
+
+
+def _setup(fhe, om, name, dbc, key_seed=77):
+    """context + oracle + ONE set of evaluation keys in both libraries' NTT slot orders"""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    p = SMALL if name == "SMALL" else om.PRESETS[name]
+    ctx, orc = fhe.SEALContext(p["n"], p["q"], p["t"]), om.Oracle(p["n"], p["q"], p["t"])
+    sk, pk = orc.keygen(key_seed)
+    evk = orc.evk_gen(sk, dbc=dbc)                       # oracle NTT form [k][nd][2][k][n]
+    coeff = np.zeros_like(evk)
+    for idx in np.ndindex(evk.shape[:3]):
+        for i in range(ctx.k):
+            coeff[idx + (i,)] = orc.ntt_inv(evk[idx + (i,)], i)
+    evk_dev = fhe.Evaluator(ctx).ntt_forward(fhe.to_device(coeff)).contiguous()      # library slot order
+    return ctx, orc, om.RelinOracle(orc, evk, dbc), (evk_dev, dbc), sk, pk
+
+
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30), ("SEAL23_4096", 30), ("P8192", 60)])
+def test_cubic_and_linear_relin_vs_oracle(fhe, oracle_mod, preset, dbc):
+    """Cubic / Linear with every product relinearised: level 1 on random size-2 ciphertexts, level 2 on level-1 results
+    (what SampleBicubic / SampleLinear feed their column evaluation), a batch that is not a multiple of anything, one
+    operand at q - 1 everywhere; fhe_cubic (library) == cubic_evaluator_calls (one C-ABI call per Evaluator call) == oracle"""
+    import torch
+    ctx, orc, rorc, relin, _, _ = _setup(fhe, oracle_mod, preset, dbc)
+    ev, pc, h = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), fhe.to_host
+    A, B, C, D = (ctx.random_ct(3, size=2, seed=400 + i) for i in range(4))
+    t = ctx.random_ct(3, size=2, seed=410)
+    A[1] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=A.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
+    r1 = fhe.circuits.cubic(ev, pc, A, B, C, D, t, relin=relin)
+    assert r1.shape[-3] == 2
+    assert torch.equal(r1, fhe.circuits.cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin))
+    want1 = [oracle_mod.oracle_cubic_calls(rorc, h(A)[i], h(B)[i], h(C)[i], h(D)[i], h(t)[i]) for i in range(3)]
+    for i in range(3):
+        assert np.array_equal(h(r1)[i], want1[i]), i
+    # level 2: the column Cubic of SampleBicubic takes four row results
+    r2 = fhe.circuits.cubic(ev, pc, r1, B, r1, D, t, relin=relin)
+    assert r2.shape[-3] == 2
+    assert np.array_equal(h(r2)[2], oracle_mod.oracle_cubic_calls(rorc, want1[2], h(B)[2], want1[2], h(D)[2], h(t)[2]))
+    l1 = fhe.circuits.linear(ev, pc, A, B, t, relin=relin)
+    l2 = fhe.circuits.linear(ev, pc, l1, r1, t, relin=relin)
+    assert l1.shape[-3] == 2 and l2.shape[-3] == 2
+    for i in (0, 1):
+        o1 = oracle_mod.oracle_linear_calls(rorc, h(A)[i], h(B)[i], h(t)[i])
+        assert np.array_equal(h(l1)[i], o1)
+        assert np.array_equal(h(l2)[i], oracle_mod.oracle_linear_calls(rorc, o1, want1[i], h(t)[i]))
+    # the reference's mode on the same handle family is untouched by the existence of a relinearising handle
+    assert fhe.circuits.cubic(ev, pc, A, B, C, D, t).shape[-3] == 4
+    # argument errors: the relinearised Cubic takes size-2 operands only
+    A4 = ctx.random_ct(3, size=4, seed=1)
+    with pytest.raises(fhe._lib.FheError):
+        fhe.circuits.cubic(ev, pc, A4, A4, A4, A4, t, relin=relin)
+
+
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30)])
+def test_samplers_relin_vs_oracle_and_decrypt(fhe, oracle_mod, preset, dbc):
+    """SampleBicubic / SampleLinear / the shared-offset ResizeImage in the relinearised mode on an 8x8 -> 4x4 image of real
+    encryptions: library == oracle composition bit for bit on sampled pixels, every output decrypts to the closed form, and
+    the remaining noise budget is reported beside the reference mode's"""
+    ctx, orc, rorc, relin, sk, pk = _setup(fhe, oracle_mod, preset, dbc, key_seed=21)
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    W = H = 8
+    w = h_ = 4
+    vals = [float((29 * x + 53 * y) % 256) for y in range(H) for x in range(W)]
+    pix = np.stack([orc.encrypt(pk, orc.encode(v), seed=500 + i) for i, v in enumerate(vals)])
+    d_pix = fhe.to_device(pix)
+
+    def plain_cubic(A, B, C, D, t):     # closed form of homo/fhe_resize.h:149-185 with t3 = t*t
+        a, b, c = -A + 3 * B - 3 * C + D, 2 * A - 5 * B + 4 * C - D, C - A
+        return 0.5 * (a * t * t + b * t * t + c * t) + B
+
+    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=True)
+    xf = np.stack([orc.encrypt(pk, orc.encode(f), seed=600 + i) for i, f in enumerate(fx)])
+    yf = np.stack([orc.encrypt(pk, orc.encode(f), seed=700 + i) for i, f in enumerate(fy)])
+    out = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, fhe.to_device(xf), fhe.to_device(yf), relin=relin))
+    ref_mode = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, fhe.to_device(xf), fhe.to_device(yf)))
+    assert out.shape == (w * h_, 2, ctx.k, ctx.n) and ref_mode.shape[1] == 6
+    picks = (0, 5, 15) if preset == "SMALL" else (5,)
+    for o in picks:
+        assert np.array_equal(out[o], oracle_mod.oracle_sample_bicubic_calls(rorc, [pix[i] for i in taps[o]], xf[o], yf[o])), o
+    budgets = []
+    decrypts = preset != "SMALL"           # n = 1024 with a 72-bit q has no noise budget for two levels of products: bits only there
+    for o in range(w * h_ if decrypts else 0):
+        v = [vals[i] for i in taps[o]]
+        cols = [plain_cubic(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3], fx[o]) for r in range(4)]
+        expect = plain_cubic(cols[0], cols[1], cols[2], cols[3], fy[o])
+        plain, budget = orc.decrypt(sk, out[o])
+        p_ref, b_ref = orc.decrypt(sk, ref_mode[o])
+        assert budget > 0 and abs(orc.decode(plain) - expect) < 1e-6 and abs(orc.decode(p_ref) - expect) < 1e-6
+        budgets.append((budget, b_ref))
+    if decrypts:
+        print("\n[relin %s dbc=%d] SampleBicubic noise budget left: relinearised min %d bits, reference mode min %d bits"
+              % (preset, dbc, min(b for b, _ in budgets), min(b for _, b in budgets)))
+    # shared offsets (one ciphertext per output column / row): every output equals the per-pixel sampler with xfract[x], yfract[y]
+    import torch
+    xs, ys = fhe.to_device(xf[:w].copy()), fhe.to_device(yf[::w].copy())
+    shared = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix, W, H, w, h_, xs, ys, batch=8, band_rows=2, relin=relin)
+    per_px = fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, xs.repeat(h_, 1, 1, 1).contiguous(), ys.repeat_interleave(w, dim=0).contiguous(), relin=relin)
+    assert shared.shape[-3] == 2 and torch.equal(shared, per_px)
+    # a shard of the destination rows == the same rows of the whole image
+    first, cnt = fhe.circuits.resize_source_rows(H, h_, 1, 3)
+    part = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix[first * W:(first + cnt) * W].contiguous(), W, H, w, h_, xs, ys[1:3].contiguous(), batch=8, band_rows=2,
+                                              rows=(1, 3), src_rows=(first, cnt), relin=relin)
+    assert torch.equal(part, shared[w:3 * w])
+    # bilinear
+    taps4, fx4, fy4 = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=False)
+    xf4 = np.stack([orc.encrypt(pk, orc.encode(f), seed=800 + i) for i, f in enumerate(fx4)])
+    yf4 = np.stack([orc.encrypt(pk, orc.encode(f), seed=900 + i) for i, f in enumerate(fy4)])
+    lin = fhe.to_host(fhe.circuits.sample_linear(ev, pc, d_pix, taps4, fhe.to_device(xf4), fhe.to_device(yf4), relin=relin))
+    assert lin.shape[1] == 2
+    for o in picks:
+        assert np.array_equal(lin[o], oracle_mod.oracle_sample_linear_calls(rorc, [pix[i] for i in taps4[o]], xf4[o], yf4[o])), o
+    for o in range(w * h_ if decrypts else 0):
+        v = [vals[i] for i in taps4[o]]
+        c0, c1 = (1 - fx4[o]) * v[0] + fx4[o] * v[1], (1 - fx4[o]) * v[2] + fx4[o] * v[3]
+        plain, budget = orc.decrypt(sk, lin[o])
+        assert budget > 0 and abs(orc.decode(plain) - ((1 - fy4[o]) * c0 + fy4[o] * c1)) < 1e-6
+
+
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30), ("SEAL23_4096", 30)])
+def test_sincos_relin_vs_oracle(fhe, oracle_mod, preset, dbc):
+    """homomorphic_sin / cos with every power relinearised where it is formed: sizes stay 2 (11 in the reference's mode)"""
+    ctx, orc, rorc, relin, _, _ = _setup(fhe, oracle_mod, preset, dbc)
+    ev, pc, h = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), fhe.to_host
+    x, z = ctx.random_ct(3, size=2, seed=800), ctx.random_ct(3, size=2, seed=801)
+    s = fhe.circuits.homomorphic_sin(ev, pc, x, z, relin=relin)
+    c = fhe.circuits.homomorphic_cos(ev, pc, x, z, relin=relin)
+    assert s.shape[-3] == 2 and c.shape[-3] == 2
+    for i in ((0, 2) if preset != "SMALL" else (0, 1, 2)):
+        assert np.array_equal(h(s)[i], oracle_mod.oracle_homomorphic_sin(rorc, h(x)[i], h(z)[i])), i
+        assert np.array_equal(h(c)[i], oracle_mod.oracle_homomorphic_cos(rorc, h(x)[i], h(z)[i])), i
+
+
+@pytest.mark.parametrize("preset,dbc,npos,degree", [("SMALL", 16, 3, 2), ("P8192", 30, 2, 2)])
+def test_approximated_step_and_decode_channel_relin_vs_oracle(fhe, oracle_mod, preset, dbc, npos, degree):
+    """approximated_step in the relinearised mode (the sin x cos product is 2 x 2 instead of 11 x 11, results have 2 polynomials
+    instead of 22) against the oracle; a shard of the positions == the whole run; decode_channel over two runs == the
+    composition of its steps; degree 0 (no harmonics) as well"""
+    import torch
+    ctx, orc, rorc, relin, _, _ = _setup(fhe, oracle_mod, preset, dbc)
+    ev, pc, h = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), fhe.to_host
+    amp, idx, cnt = (ctx.random_ct(1, size=2, seed=900 + i) for i in range(3))
+    zeros = ctx.random_ct(npos * degree * 2, size=2, seed=920).reshape(npos, degree, 2, 2, ctx.k, ctx.n)
+    hz = h(zeros)
+    run = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, relin=relin)
+    ref = oracle_mod.oracle_approximated_step(rorc, h(amp)[0], h(idx)[0], h(cnt)[0], 64, degree, 0.5, npos, 1,
+                                              lambda i, j, wh: hz[i, j - 1, int(wh == "cos")])
+    assert len(run) == npos
+    for g, r in zip(run, ref):
+        assert g.shape[-3] == 2 and np.array_equal(h(g)[0], r)
+    part = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1,
+                                          zeros=zeros[1:].contiguous(), positions=(1, npos), relin=relin)
+    for g, w in zip(part, run[1:]):
+        assert torch.equal(g, w)
+    flat = fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=0, delta=0.5, width=npos, height=1, zeros=None, relin=relin)
+    ref0 = oracle_mod.oracle_approximated_step(rorc, h(amp)[0], h(idx)[0], h(cnt)[0], 64, 0, 0.5, npos, 1, None)
+    assert flat[0].shape[-3] == 2 and np.array_equal(h(flat[0])[0], ref0[0])
+    # the driver loop of homo/server_decode.cpp:120-137 over two runs
+    runs = torch.stack([torch.cat([amp, cnt]), torch.cat([ctx.random_ct(1, size=2, seed=930), ctx.random_ct(1, size=2, seed=931)])]).contiguous()
+    acc0 = ctx.random_ct(npos, size=2, seed=940)
+    z2 = torch.stack([zeros, ctx.random_ct(npos * degree * 2, size=2, seed=950).reshape(npos, degree, 2, 2, ctx.k, ctx.n)]).contiguous()
+    index = idx.clone()
+    got = fhe.circuits.decode_channel(ev, pc, runs, index, acc0, z2, 64, degree, 0.5, npos, 1, relin=relin)
+    assert got.shape[-3] == 2
+    want, index2 = acc0.clone(), idx.clone()
+    for p in range(2):
+        step = fhe.circuits.approximated_step(ev, pc, runs[p, 0:1].contiguous(), index2, runs[p, 1:2].contiguous(), 64, degree, 0.5, npos, 1, z2[p], relin=relin)
+        want = ev.add(want, torch.cat(step))
+        index2 = ev.add(index2, runs[p, 1:2].contiguous())
+    assert torch.equal(got, want) and torch.equal(index, index2)
+
+
+def _ring_mul(a, b, t):
+    """exact product in Z_t[x] / (x^n + 1) (coefficients < 2^14 and n <= 8192: every partial sum stays below 2^41)"""
+    n = len(a)
+    c = np.convolve(a.astype(np.int64), b.astype(np.int64))
+    r = c[:n].copy()
+    r[:n - 1] -= c[n:]
+    return r % t
+
+
+def test_homomorphic_sin_known_answers_with_noise_budgets(fhe, oracle_mod):
+    """the reference's own check (tests/test_decode.cpp:39-48: x in {1..7}, n = 8192, print the remaining noise budget and the
+    decoded value beside sin x) in both modes.  The known answer is the PLAINTEXT polynomial: a correct BFV evaluation decrypts
+    to exactly the product / sum of the encoded polynomials in Z_t[x]/(x^n + 1) whenever its noise budget is positive (for
+    x = 1, 2, 3 the coefficients of the tenth power wrap modulo t = 2^14 and the decoded number is not sin x -- in the reference
+    too; that is the encoder's limit, not the evaluation's).  Budgets of the two modes are printed side by side."""
+    ctx, orc, rorc, relin, sk, pk = _setup(fhe, oracle_mod, "P8192", 30, key_seed=5)
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    t = ctx.t
+    xs = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+    x = fhe.to_device(np.stack([orc.encrypt(pk, orc.encode(v), seed=40 + i) for i, v in enumerate(xs)]))
+    z = fhe.to_device(np.stack([orc.encrypt(pk, orc.encode(0.0), seed=60 + i) for i in range(len(xs))]))
+    ref = fhe.to_host(fhe.circuits.homomorphic_sin(ev, pc, x, z))
+    rel = fhe.to_host(fhe.circuits.homomorphic_sin(ev, pc, x, z, relin=relin))
+    assert ref.shape[1] == 11 and rel.shape[1] == 2
+    E = lambda v: orc.encode(v).astype(np.int64)
+    print()
+    ok_rel = 0
+    for i, v in enumerate(xs):
+        s = (E(v) + E(-3 * math.pi / 2)) % t                      # homo/fhe_decode.h:57
+        s2 = _ring_mul(s, s, t)
+        s4 = _ring_mul(s2, s2, t)
+        s8 = _ring_mul(s4, s4, t)
+        s6 = _ring_mul(_ring_mul(s4, s, t), s, t)
+        s10 = _ring_mul(_ring_mul(s8, s, t), s, t)
+        want = E(-1.0)
+        for pw, cf in ((s2, 0.5), (s4, -1.0 / 24.0), (s6, 1.0 / 720.0), (s8, -1.0 / 40320.0), (s10, 1.0 / 3628800.0)):      # :66-118
+            want = (want + _ring_mul(pw, E(cf), t)) % t
+        p_ref, b_ref = orc.decrypt(sk, ref[i])
+        p_rel, b_rel = orc.decrypt(sk, rel[i])
+        print("[relin P8192 dbc=30] homomorphic_sin(%g): plaintext model decodes to %.9f (sin = %.9f); noise budget left: reference mode %d bits, relinearised %d bits"
+              % (v, orc.decode(want.astype(np.uint64)), math.sin(v), b_ref, b_rel))
+        if b_ref > 0:
+            assert np.array_equal(p_ref.astype(np.int64), want), ("reference mode", v)
+        if b_rel > 0:
+            assert np.array_equal(p_rel.astype(np.int64), want), ("relinearised mode", v)
+            ok_rel += 1
+    assert ok_rel == len(xs), "the relinearised evaluation must keep a positive noise budget at n = 8192"
