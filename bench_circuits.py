@@ -6,6 +6,7 @@
   python bench_circuits.py decode [--gpus N]             approximated_step (homo/fhe_decode.h:202-242), W*H=16,
                                                          degree 12, n=8192: one run
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench_circuits.py <workload> --gpus N ...
+  (`python bench_circuits.py <workload> --gpus N` without a launcher starts the N ranks itself: bench.ensure_world)
 
 Inputs are synthetic random-residue ciphertexts; the server-side encryptions of the reference's circuits (fractional
 offsets, Enc(0)) are inputs.  Multi-GPU (one process per GPU, RCCL for the barrier, the
@@ -37,7 +38,7 @@ def _dist_setup(args):
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench_circuits.py needs a HIP device (no CPU path exists)")
-    if world != args.gpus:
+    if world != args.gpus:            # bench.ensure_world has started the ranks or refused already; this guards direct calls of resize() / decode()
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     # FHE_BENCH_BACKEND=gloo (tests only, as in bench.py): ranks share the devices there are, collectives on host tensors
     backend = os.environ.get("FHE_BENCH_BACKEND", "nccl")
@@ -119,12 +120,18 @@ def _traffic(workload, units):
     return rec["hbm_bytes_per_unit"] * units, tj.get("source")
 
 
-def _roofline(alg_bytes, dev_ms, kernels, workload=None, units=0):
+def _roofline(alg_bytes, dev_ms, kernels, workload=None, units=0, issue=None):
+    """HBM roofline on algorithmic bytes (the figure BASELINE.json's metric asks for) -- `bound` says what the counters say binds
+    the launch sequence (the issue-side object `issue`, bench.issue_roofline_workload) when they say something else"""
     achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
     traffic, src = _traffic(workload, units) if workload else (None, None)
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": dev_ms, "kernel": kernels,
-            "note": "a sequence of ct x ct launches (csrc/behz.hip), VALU-issue-bound: the per-kernel issue fractions and counter traffic are in profiles/*_issue_roofline.txt and profiles/pmc_traffic_ctct.json"}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+           "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": dev_ms, "kernel": kernels}
+    if issue and issue.get("frac") and issue["frac"] > out["frac"]:
+        out["bound"] = "valu-issue"
+        out["frac_of"] = ("hbm peak (the metric's roofline); the launch sequence is bound by VALU issue: launch-time-weighted issue fraction %.2f at the clock the "
+                          "counters saw, %.2f at the nominal %.1f GHz (issue_roofline)" % (issue["frac"], issue["frac_at_nominal_clock"], issue["nominal_clock_ghz"]))
+    return out
 
 
 def _relin(args, fhe, ctx):
@@ -212,14 +219,18 @@ def resize(args):
     torch.cuda.synchronize()
     digest = fhe.parallel.combine_digests(int(acc.cpu().numpy().view(np.uint64)[0]))
     if rank == 0:
+        from bench import issue_roofline_workload
+        wl = ("resize_shared" if args.shared else "resize") + ("_relin%d" % args.relin if relin else "")
+        issue = issue_roofline_workload(wl) if args.preset == "P8192" else None
         res = {"metric": "bicubic-resized output pixels/sec (one colour channel)", "value": n_out / wall, "unit": "pixels/s", "n_gpus": world,
                "steps": 1, "warmup": 2, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "bicubic resize %dx%d -> %dx%d via the Cubic circuit, one channel, %s (n=%d, %d coeff moduli)" % (W, H, w, h, args.preset, ctx.n, ctx.k),
                           "mode": _mode(args), "offsets": form, "batch_pixels": P, "sharding": "destination rows x%d, source rows +- halo per rank, no data-path collective" % world},
                "seconds": wall, "first_pass_seconds": first_pass, "cubic_calls_per_s": 5 * n_out / wall, "out_size": so,
+               "issue_roofline": issue,
                "roofline": _roofline(alg // world, dev_ms, "k_cubic_coeffs_g, k_behz_*_pm, k_ntt_fwd_pm" + (", k_relin_*_pm" if relin else ""),
-                                     ("resize_shared" if args.shared else "resize") + ("_relin%d" % args.relin if relin else ""), n_mine if args.preset == "P8192" else 0),
+                                     wl, n_mine if args.preset == "P8192" else 0, issue),
                "job_executions": 4, "units_per_job": n_mine,
                "output_digest": "%016x" % digest}
         if args.cpu_pixels:
@@ -268,6 +279,9 @@ def decode(args):
     out = torch.cat(run)
     digest = fhe.parallel.combine_digests(ctx.digest(out, index0=p0 * so * ctx.k * ctx.n))
     if rank == 0:
+        from bench import issue_roofline_workload
+        wl = "decode" + ("_relin%d" % args.relin if relin else "")
+        issue = issue_roofline_workload(wl) if (args.preset == "P8192" and degree == 12) else None
         alg = (3 + npos * degree * 2) * ctw * 8 + npos * so * ctx.k * ctx.n * 8
         res = {"metric": "approximated_step runs/sec (all W*H output positions of one run)", "value": 1 / wall, "unit": "runs/s", "n_gpus": world,
                "steps": 1, "warmup": 1, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -275,8 +289,9 @@ def decode(args):
                "config": {"workload": "approximated_step W*H=%d degree=%d, %s (n=%d, %d coeff moduli)" % (npos, degree, args.preset, ctx.n, ctx.k),
                           "mode": _mode(args), "sharding": "output positions x%d; run operands, offset chain and sine polynomials replicated; no data-path collective" % world},
                "seconds": wall, "steps_per_s": 1 / wall, "out_size": so, "outputs": npos,
-               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_sum_inv_pm" + (", k_relin_*_pm" if relin else ""), "decode" + ("_relin%d" % args.relin if relin else ""),
-                                     (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0),
+               "issue_roofline": issue,
+               "roofline": _roofline(alg // world, dev_ms, "k_behz_*_pm, k_ntt_fwd_pm, k_mulplain*, k_sum_inv_pm" + (", k_relin_*_pm" if relin else ""), wl,
+                                     (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0, issue),
                "job_executions": 2, "units_per_job": p1 - p0,
                "output_digest": "%016x" % digest}
         if args.cpu_terms:
@@ -312,4 +327,6 @@ if __name__ == "__main__":
     ap.add_argument("--positions", type=int, default=16)
     ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="relinearised mode with this decomposition bit count (0 = the reference's mode)")
     a = ap.parse_args()
+    from bench import ensure_world
+    ensure_world(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # `python bench_circuits.py <workload> --gpus N` starts its N ranks itself
     (resize if a.workload == "resize" else decode)(a)

@@ -789,6 +789,15 @@ int fhe_dct_f64_launch(const fhe_ctx *c, const fhe_dct_plan *plan, const u64 *in
         k_dct_one_launch<12, 3><<<(unsigned)(chunks * 32 * 8), Shape<12, 3>::TP, 0, st>>>(in, mid, out, plan->d_consts_f64, c->qb.d_tw_f64, c->qb.d_itw_f64, c->qb.d_mod,
                                                                                        c->k, (u32)n_blocks, dist, c->d_arrived + 1, c->d_arrived);
         KERNEL_CHECK();
+        // EXPERIMENT path (FHE_DCT_ONE_LAUNCH; profiles/EXPERIMENTS.md section 1; never a default, never in a parity path other than its
+        // own test): a column workgroup that gives up waiting for its rows sets d_arrived[0] and goes on with an incomplete
+        // intermediate, so the flag is read back before the call reports success.  That makes this path synchronous -- acceptable
+        // for a measurement switch, and the only way the caller cannot receive a silently wrong result.  (The no-deadlock argument
+        // also rests on workgroups being dispatched in blockIdx order, which HIP does not promise: one more reason it stays off.)
+        u32 timed_out = 0;
+        HIP_TRY(hipMemcpyAsync(&timed_out, c->d_arrived, sizeof(u32), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (timed_out) return fail(FHE_ERR_HIP, "one-launch experiment: a column workgroup timed out waiting for its row transforms; the output is incomplete");
         return FHE_OK;
     }
     switch (c->logn) {   // LE = 3 is only built for the headline size

@@ -1,7 +1,15 @@
 // stream_io.hip -- include/fhe_stream.h: fixed-size ciphertext records between a file and contiguous staging memory,
 // by positional scatter / gather I/O from several threads (host code only; built with the library's other units).
-#include "internal.h"
+// Nothing here needs the HIP headers: the unit also compiles as plain C++ (g++ -x c++), which is how the sanitizer / fuzz
+// build of oracle/Makefile (target `asan`, oracle/stream_fuzz_main.cpp) takes it.
 #include "../../include/fhe_stream.h"
+
+#include <string>
+#include <vector>
+typedef unsigned long long u64;      // as in modarith.h
+typedef unsigned int u32;
+int fhe_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));      // fhe_hip.hip: sets fhe_last_error()
+#define fail fhe_fail
 
 #include <errno.h>
 #include <fcntl.h>

@@ -10,7 +10,7 @@
 // Each method is one library call: the taps are index arrays, every temporary lives in the handle's scratch buffer, no
 // per-ciphertext work happens on the host.  Results are bit-identical to the reference's functions of the same names
 // (homo/fhe_resize.h:143-392, homo/fhe_decode.h:48-242, homo/server_decode.cpp:120-137) called one ciphertext at a
-// time through seal::Evaluator with the same server-side encryptions (seal/circuits_test.cpp checks exactly that).
+// time through seal::Evaluator with the same server-side encryptions (oracle/ref_vs_batched_main.cpp checks exactly that).
 #ifndef FHE_SEAL_HIP_CIRCUITS_H
 #define FHE_SEAL_HIP_CIRCUITS_H
 

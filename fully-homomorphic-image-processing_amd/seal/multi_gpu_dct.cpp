@@ -81,28 +81,39 @@ uint64_t *dalloc(uint64_t words) {
     return (uint64_t *)p;
 }
 
-uint64_t digest_of(const fhe_ctx *ctx, const uint64_t *d, uint64_t words, uint64_t index0, uint64_t *d_slot, fhe_stream st) {
-    uint64_t h = 0;
+// digest of one wave into ITS OWN device slot, asynchronously on `st`: no host round trip inside the wave loop (the slots are
+// brought back and summed once, after the loop).  Round 4 synchronised the stream here -- once per peer per wave on the root,
+// so the receives of wave w + 1 could not be posted before seven digests of wave w had each gone to the host and back: fine
+// for a verifier, wrong for the thing the first real multi-GPU run is going to time.
+void digest_into(const fhe_ctx *ctx, const uint64_t *d, uint64_t words, uint64_t index0, uint64_t *d_slot, fhe_stream st) {
     check(fhe_digest(ctx, d, words, index0, d_slot, st), "fhe_digest");
-    check(fhe_download(&h, d_slot, 8, st), "fhe_download");
-    check(fhe_stream_sync(st), "fhe_stream_sync");
-    return h;
+}
+uint64_t sum_slots(const uint64_t *d_slots, uint64_t count, fhe_stream st) {
+    std::vector<uint64_t> h(count, 0);
+    if (count) {
+        check(fhe_download(h.data(), d_slots, count * 8, st), "fhe_download");
+        check(fhe_stream_sync(st), "fhe_stream_sync");
+    }
+    uint64_t s = 0;
+    for (uint64_t v : h) s += v;
+    return s;
 }
 
 void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
     fhe_ctx *ctx = nullptr;
     fhe_dct_plan *plan = nullptr;
-    fhe_stream st = nullptr, st_comm = nullptr;
+    fhe_stream st = nullptr, st_comm = nullptr, st_dig = nullptr;
     try {
         hcheck(hipSetDevice(R.device), "hipSetDevice");
         check(fhe_ctx_create(J.n, J.q, J.k, J.t, R.device, &ctx), "fhe_ctx_create");     // one context per rank: nothing is shared between ranks
         check(fhe_ctx_bind_thread(ctx), "fhe_ctx_bind_thread");
         check(fhe_stream_create(&st), "fhe_stream_create");
         check(fhe_stream_create(&st_comm), "fhe_stream_create");
+        check(fhe_stream_create(&st_dig), "fhe_stream_create");                            // the root digests received waves here, beside the next wave's receives
         check(fhe_dct_plan_create(ctx, YQT, 100, 100, st, &plan), "fhe_dct_plan_create");
         const uint64_t wpb = J.words_per_block, mine = R.end - R.start;
         const uint64_t n_waves = (mine + J.wave - 1) / J.wave;
-        uint64_t *in = dalloc(J.wave * wpb), *out[2] = {dalloc(J.wave * wpb), dalloc(J.wave * wpb)}, *d_slot = dalloc(1);
+        uint64_t *in = dalloc(J.wave * wpb), *out[2] = {dalloc(J.wave * wpb), dalloc(J.wave * wpb)};
         const size_t scr_bytes = fhe_dct8x8_scratch_bytes(ctx, J.wave);
         void *scr = nullptr;
         check(fhe_dev_alloc(scr_bytes, &scr), "fhe_dev_alloc(scratch)");
@@ -111,8 +122,13 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
             hcheck(hipEventCreateWithFlags(&computed[i], hipEventDisableTiming), "event");
             hcheck(hipEventCreateWithFlags(&sent[i], hipEventDisableTiming), "event");
         }
-        // the root's receive buffers: one wave per peer
-        std::vector<uint64_t *> rx;
+        // the root's receive buffers: TWO waves per peer, so that wave w + 1 arrives while wave w is being digested
+        std::vector<uint64_t *> rx[2];
+        hipEvent_t received[2], digested[2];
+        for (int i = 0; i < 2; ++i) {
+            hcheck(hipEventCreateWithFlags(&received[i], hipEventDisableTiming), "event");
+            hcheck(hipEventCreateWithFlags(&digested[i], hipEventDisableTiming), "event");
+        }
         // every rank has the same number of waves up to one: the root posts receives for the longest peer shard, peers send
         // zero-length nothing for a missing last wave (wave counts are computed from the same split on both sides)
         std::vector<uint64_t> peer_blocks(J.world, 0);
@@ -125,7 +141,14 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
             if (w > max_waves) max_waves = w;
         }
         if (J.gather && R.rank == 0)
-            for (int r = 1; r < J.world; ++r) rx.push_back(dalloc(J.wave * wpb));
+            for (int b = 0; b < 2; ++b)
+                for (int r = 1; r < J.world; ++r) rx[b].push_back(dalloc(J.wave * wpb));
+        // digest slots: one per own wave, one per (wave, peer) on the root; zeroed once, summed once after the loop
+        const uint64_t n_own = max_waves, n_rx = (J.gather && R.rank == 0) ? max_waves * (uint64_t)(J.world - 1) : 0;
+        uint64_t *d_own = dalloc(n_own + 1), *d_rx = dalloc(n_rx + 1);
+        hcheck(hipMemsetAsync(d_own, 0, (n_own + 1) * 8, (hipStream_t)st), "memset");
+        hcheck(hipMemsetAsync(d_rx, 0, (n_rx + 1) * 8, (hipStream_t)st), "memset");
+        check(fhe_stream_sync(st), "sync");
         arrived.fetch_add(1);
         while (arrived.load() < J.world) std::this_thread::yield();                      // every rank is set up: start the clock together
         const double t0 = now();
@@ -136,7 +159,7 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
                 if (w >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st, sent[slot], 0), "wait(sent)");      // out[slot] has left for the root
                 check(fhe_fill_random(ctx, in, nb * 64 * 2, SEED, b0 * wpb, st), "fhe_fill_random");       // block g = splitmix64(seed ^ global index)
                 check(fhe_dct8x8_quant(ctx, plan, in, out[slot], nb, scr, scr_bytes, st), "fhe_dct8x8_quant");
-                R.digest += digest_of(ctx, out[slot], nb * wpb, b0 * wpb, d_slot, st);
+                digest_into(ctx, out[slot], nb * wpb, b0 * wpb, d_own + w, st);
                 hcheck(hipEventRecord(computed[slot], (hipStream_t)st), "record");
             }
             if (!J.gather) continue;
@@ -149,25 +172,32 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
             } else {
                 // wave w of every peer that has one, as ONE group: the transfers arrive concurrently, each over its peer's own link
                 std::vector<std::pair<int, uint64_t>> got;
+                if (w >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st_comm, digested[slot], 0), "wait(digested)");     // rx[slot] has been read
                 ncheck(ncclGroupStart(), "ncclGroupStart");
                 for (int r = 1; r < J.world; ++r) {
                     const uint64_t done = w * J.wave;
                     if (done >= peer_blocks[r]) continue;
                     const uint64_t cnt = peer_blocks[r] - done < J.wave ? peer_blocks[r] - done : J.wave;
-                    ncheck(ncclRecv(rx[r - 1], cnt * wpb, ncclUint64, r, J.comms[0], (hipStream_t)st_comm), "ncclRecv");
+                    ncheck(ncclRecv(rx[slot][r - 1], cnt * wpb, ncclUint64, r, J.comms[0], (hipStream_t)st_comm), "ncclRecv");
                     got.push_back({r, cnt});
                 }
                 ncheck(ncclGroupEnd(), "ncclGroupEnd");
+                hcheck(hipEventRecord(received[slot], (hipStream_t)st_comm), "record");
+                hcheck(hipStreamWaitEvent((hipStream_t)st_dig, received[slot], 0), "wait(received)");
                 for (auto &g : got) {
                     uint64_t s, e;
                     block_range(g.first, J.world, J.total, s, e);
-                    R.received_digest += digest_of(ctx, rx[g.first - 1], g.second * wpb, (s + w * J.wave) * wpb, d_slot, st_comm);
+                    digest_into(ctx, rx[slot][g.first - 1], g.second * wpb, (s + w * J.wave) * wpb, d_rx + w * (uint64_t)(J.world - 1) + (g.first - 1), st_dig);
                 }
+                hcheck(hipEventRecord(digested[slot], (hipStream_t)st_dig), "record");
             }
         }
         check(fhe_stream_sync(st), "sync");
         check(fhe_stream_sync(st_comm), "sync");
-        R.seconds = now() - t0;
+        check(fhe_stream_sync(st_dig), "sync");
+        R.seconds = now() - t0;                                                           // the ONE host synchronisation of the loop
+        R.digest = sum_slots(d_own, n_own, st);
+        R.received_digest = sum_slots(d_rx, n_rx, st);
     } catch (const Fail &f) {
         R.error = f.what;
         arrived.fetch_add(J.world);                                                       // release the others' start barrier
@@ -175,6 +205,7 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
     if (plan) fhe_dct_plan_destroy(plan);
     if (st) fhe_stream_destroy(st);
     if (st_comm) fhe_stream_destroy(st_comm);
+    if (st_dig) fhe_stream_destroy(st_dig);
     if (ctx) fhe_ctx_destroy(ctx);                                                        // device buffers die with the process
 }
 }  // namespace

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -41,6 +42,7 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <random>
 #include <sys/random.h>
@@ -84,7 +86,7 @@ struct Big {                                  // fixed 768-bit unsigned integer 
 // Ciphertext around every Evaluator call (homo/fhe_image.h:207 `Ciphertext boaz1(data[i])`), and
 // hipMalloc/hipFree synchronise the device; recycling buffers keeps the op-at-a-time mode asynchronous.
 // All facade work runs on the default stream, so a recycled buffer is only touched after the work
-// that used it before.  Single-threaded like the reference.
+// that used it before.  The free lists are mutex-guarded: several host threads may create and destroy ciphertexts at once.
 class Pool {
 public:
     static Pool &instance() { static Pool p; return p; }
@@ -96,8 +98,11 @@ public:
         return c;
     }
     uint64_t *get(size_t words) {
-        auto &fl = free_[words];
-        if (!fl.empty()) { uint64_t *p = fl.back(); fl.pop_back(); return p; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto &fl = free_[words];
+            if (!fl.empty()) { uint64_t *p = fl.back(); fl.pop_back(); return p; }
+        }
         void *q = nullptr;
         check(fhe_dev_alloc((words + (guard() ? 2 : 0)) * 8, &q), "device alloc");
         if (guard()) {                                       // FHE_FACADE_GUARD=1 (debugging): a canary behind every buffer, checked when it comes back
@@ -116,6 +121,7 @@ public:
                 std::abort();
             }
         }
+        std::lock_guard<std::mutex> lk(mu_);
         free_[words].push_back(p);
     }
     // buffers are returned to the driver at process exit (the HIP runtime may already be gone when
@@ -123,6 +129,7 @@ public:
 private:
     static bool guard() { static const bool g = [] { const char *e = std::getenv("FHE_FACADE_GUARD"); return e && *e == '1'; }(); return g; }
     static constexpr uint64_t kCanary = 0x5AFE5AFE5AFE5AFEULL;
+    std::mutex mu_;
     std::map<size_t, std::vector<uint64_t *>> free_;
 };
 
@@ -232,7 +239,10 @@ namespace detail {
 // fully reduced -- every kernel assumes canonical inputs (the FP64 path needs values below 2^52, the
 // lazy Shoup bounds values below q_i) -- where SEAL's load + is_valid_for checks would reject them.
 struct KnownModuli { uint32_t k, n; std::vector<uint64_t> q; };
-inline std::vector<KnownModuli> &known_moduli() { static std::vector<KnownModuli> v; return v; }
+inline std::vector<KnownModuli> &known_moduli_unlocked() { static std::vector<KnownModuli> v; return v; }
+inline std::mutex &known_moduli_mu() { static std::mutex m; return m; }
+// a snapshot: contexts may be created by other threads while a stream is being loaded
+inline std::vector<KnownModuli> known_moduli() { std::lock_guard<std::mutex> lk(known_moduli_mu()); return known_moduli_unlocked(); }
 
 // ---- the expression graph of the lazy mode ---------------------------------------------------------------------------
 struct Storage {                       // a refcounted device allocation; a batched launch's results are slices of one
@@ -260,12 +270,15 @@ struct Node {                          // an immutable ciphertext VALUE: materia
     std::shared_ptr<PlainEntry> plain;
     std::shared_ptr<Storage> st;
     size_t off;
-    CtxState *ctx;
-    int handles;                       // Ciphertext objects holding this value
+    std::weak_ptr<CtxState> ctx;       // the context whose graph holds the recipe; a value that outlives it can no longer be computed (materialize throws)
+    std::atomic<int> handles;          // Ciphertext objects holding this value (copied and destroyed from any thread)
     int level;
     bool needed;
-    Node() : op(VALUE), size(0), k(0), n(0), off(0), ctx(nullptr), handles(0), level(0), needed(false) {}
-    bool done() const { return (bool)st; }
+    bool failed;                       // the flush that should have computed it threw: every later use throws instead of dereferencing nothing
+    std::atomic<bool> ready;           // st / off are set: published with release, so a thread that sees it may read the value without the graph's mutex
+    Node() : op(VALUE), size(0), k(0), n(0), off(0), handles(0), level(0), needed(false), failed(false), ready(false) {}
+    bool done() const { return ready.load(std::memory_order_acquire); }
+    void set_storage(std::shared_ptr<Storage> s, size_t o) { st = std::move(s); off = o; ready.store(true, std::memory_order_release); }
     uint64_t *ptr() const { return st->p + off; }
     size_t words() const { return (size_t)size * k * n; }
 };
@@ -278,6 +291,10 @@ struct CtxState {
     std::vector<Big> punct;            // Q / q_i
     std::vector<uint64_t> inv_punct;   // (Q/q_i)^-1 mod q_i
     // lazy mode: values recorded and not yet computed, in creation order (operands before consumers)
+    // Threads: SEAL's Evaluator may be shared by threads working on distinct ciphertexts; here every Evaluator call appends to
+    // this one graph and any observation flushes all of it, so recording, flushing and materialising hold `mu` (recursive: a
+    // flush inside record).  A value another thread recorded may be computed by this thread's flush -- same bytes either way.
+    std::recursive_mutex mu;
     std::vector<std::shared_ptr<Node>> pending;
     size_t pending_words;
     bool eager, flushing;
@@ -342,9 +359,12 @@ public:
             s.punct.push_back(pi);
         }
         total_ = BigUInt(s.Q.bits());
-        bool known = false;
-        for (const auto &m : detail::known_moduli()) known |= (m.k == s.k && m.n == s.n && m.q == s.q);
-        if (!known) detail::known_moduli().push_back(detail::KnownModuli{s.k, s.n, s.q});
+        {
+            std::lock_guard<std::mutex> lk(detail::known_moduli_mu());
+            bool known = false;
+            for (const auto &m : detail::known_moduli_unlocked()) known |= (m.k == s.k && m.n == s.n && m.q == s.q);
+            if (!known) detail::known_moduli_unlocked().push_back(detail::KnownModuli{s.k, s.n, s.q});
+        }
     }
     const SmallModulus &plain_modulus() const { return plain_; }
     const BigPoly &poly_modulus() const { return poly_; }
@@ -467,16 +487,17 @@ inline void load_host(std::istream &is, Buf &h, uint32_t &polys, uint32_t &k, ui
     if (hdr[0] < 1 || hdr[0] > FHE_FACADE_MAX_POLYS || hdr[1] < 1 || hdr[1] > FHE_MAX_K || hdr[2] < 1024 || hdr[2] > 16384 ||
         (hdr[2] & (hdr[2] - 1)) || (want_polys && hdr[0] != want_polys))
         throw std::invalid_argument("ciphertext/key header out of range");
+    const std::vector<KnownModuli> known = known_moduli();
     const KnownModuli *km = nullptr;
-    for (const auto &m : known_moduli()) if (m.k == hdr[1] && m.n == hdr[2]) km = &m;
-    if (!known_moduli().empty() && !km) throw std::invalid_argument("ciphertext/key does not match any context of this process");
+    for (const auto &m : known) if (m.k == hdr[1] && m.n == hdr[2]) km = &m;
+    if (!known.empty() && !km) throw std::invalid_argument("ciphertext/key does not match any context of this process");
     polys = hdr[0]; k = hdr[1]; n = hdr[2];
     h.resize((size_t)polys * k * n);
     is.read((char *)h.data(), (std::streamsize)(h.size() * 8));
     if (!is) throw std::invalid_argument("truncated ciphertext/key stream");
     if (km) {
         bool ok = false;                       // several contexts may share (k, n): accept if one of them fits
-        for (const auto &m : known_moduli()) {
+        for (const auto &m : known) {
             if (m.k != k || m.n != n) continue;
             bool fits = true;
             for (size_t p = 0; p < (size_t)polys * k && fits; ++p) {
@@ -561,7 +582,7 @@ public:
     void shape(uint32_t size, uint32_t k, uint32_t n) {
         std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
         v->size = size; v->k = k; v->n = n;
-        v->st = std::make_shared<detail::Storage>(v->words());
+        v->set_storage(std::make_shared<detail::Storage>(v->words()), 0);
         set_node(std::move(v));
     }
     // mutable access: the value is computed, and copied first if another handle shares it (copy on write)
@@ -571,7 +592,7 @@ public:
         if (h_.p->handles > 1 || h_.p.use_count() > 1) {
             std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
             v->size = h_.p->size; v->k = h_.p->k; v->n = h_.p->n;
-            v->st = std::make_shared<detail::Storage>(v->words());
+            v->set_storage(std::make_shared<detail::Storage>(v->words()), 0);
             detail::check(fhe_copy(v->ptr(), h_.p->ptr(), v->words() * 8, nullptr), "device copy");
             set_node(std::move(v));
         }
@@ -586,8 +607,8 @@ public:
     void set_node(std::shared_ptr<detail::Node> v) { release(); h_.p = std::move(v); retain(); }
     void materialize() const {
         if (!h_.p || h_.p->done()) return;
-        if (h_.p->ctx) detail::flush(*h_.p->ctx);
-        if (!h_.p->done()) throw std::runtime_error("ciphertext value was never computed (an earlier evaluation failed)");
+        if (std::shared_ptr<detail::CtxState> c = h_.p->ctx.lock()) detail::flush(*c);
+        if (!h_.p->done()) throw std::runtime_error("ciphertext value was never computed (an earlier evaluation failed, or its SEALContext is gone)");
     }
 private:
     void retain() { if (h_.p) ++h_.p->handles; }
@@ -625,7 +646,14 @@ inline const uint64_t *batch_operand(CtxState &s, const std::vector<Node *> &g, 
     s.stats.gathers += (hi - lo + 255) / 256;
     return into;
 }
+#ifdef FHE_FACADE_TEST_HOOKS
+// TEST BUILDS ONLY (seal/facade_threads.cpp): the number of launch groups that still run before one throws; < 0 = never
+inline int &fail_groups_after() { static int v = -1; return v; }
+#endif
 inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size_t hi) {
+#ifdef FHE_FACADE_TEST_HOOKS
+    if (fail_groups_after() >= 0 && fail_groups_after()-- == 0) throw std::runtime_error("facade test hook: injected launch failure");
+#endif
     const Node &f = *g[lo];
     const size_t pw = s.poly_words(), cnt = hi - lo;
     const uint32_t sa = f.a->size, sb = f.b ? f.b->size : 0, so = f.size;
@@ -694,14 +722,14 @@ inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size
     }
     for (size_t i = lo; i < hi; ++i) {
         Node &n = *g[i];
-        n.st = out;
-        n.off = (i - lo) * so * pw;
         n.a.reset(); n.b.reset(); n.plain.reset();          // operands may go once nobody else needs them
         n.op = Node::VALUE;
+        n.set_storage(out, (i - lo) * so * pw);
     }
     s.stats.computed += cnt;
 }
 inline void flush(CtxState &s) {
+    std::lock_guard<std::recursive_mutex> lk(s.mu);
     if (s.flushing || s.pending.empty()) return;
     s.flushing = true;
     const double t_flush = now_s();
@@ -750,6 +778,10 @@ inline void flush(CtxState &s) {
             }
         }
     } catch (...) {
+        // the values this flush did not reach are gone from `pending` and will never be computed: mark them, so that a later
+        // Evaluator call that takes one as an operand (or a save / decrypt of it) throws instead of reading a null Storage
+        for (auto &sp : work)
+            if (!sp->done()) { sp->failed = true; sp->a.reset(); sp->b.reset(); sp->plain.reset(); }
         s.flushing = false;
         throw;
     }
@@ -1087,6 +1119,7 @@ public:
     Plaintext encode(double value) const {
         uint64_t bits;
         std::memcpy(&bits, &value, 8);
+        std::lock_guard<std::mutex> lk(memo_mu_);
         auto it = memo_.find(bits);
         if (it != memo_.end()) return Plaintext(it->second);
         std::shared_ptr<detail::PlainData> d = std::make_shared<detail::PlainData>();
@@ -1114,7 +1147,8 @@ private:
     uint64_t t_;
     uint32_t n_;
     int ic_, fc_;
-    mutable std::unordered_map<uint64_t, std::shared_ptr<detail::PlainData>> memo_;      // by the bits of the double; single-threaded like the reference
+    mutable std::mutex memo_mu_;
+    mutable std::unordered_map<uint64_t, std::shared_ptr<detail::PlainData>> memo_;      // by the bits of the double
 };
 
 class Evaluator {
@@ -1146,12 +1180,12 @@ public:
         if (a.size() > 3) throw std::invalid_argument("relinearize: only size-3 ciphertexts are supported (keys for s^2)");
         if (a.size() < 3) return;
         const size_t bytes = fhe_relinearize_scratch_bytes(st_->h, evk.dbc, 1);
-        scratch_.resize((bytes + 7) / 8);
+        detail::DevBuf scratch_((bytes + 7) / 8);                              // per call: an Evaluator may be shared by threads
         const size_t pw = st_->poly_words();
         const uint64_t *src = static_cast<const Ciphertext &>(a).ptr();        // computes the value; no copy-on-write
         std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
         v->size = 2; v->k = st_->k; v->n = st_->n;
-        v->st = std::make_shared<detail::Storage>(3 * pw);                     // the key switch works in place on three polynomials
+        v->set_storage(std::make_shared<detail::Storage>(3 * pw), 0);          // the key switch works in place on three polynomials
         detail::check(fhe_copy(v->ptr(), src, 3 * pw * 8, nullptr), "copy");
         detail::check(fhe_relinearize(st_->h, v->ptr(), 3 * pw, 1, evk.buf.ptr(), evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
         a.set_node(std::move(v));
@@ -1165,8 +1199,16 @@ private:
     // a <- op(a, b): a new value; a's old value stays what it was for every other handle
     void record(detail::Node::Op op, Ciphertext &a, const Ciphertext *b, std::shared_ptr<detail::PlainEntry> plain, uint32_t size) {
         detail::CtxState &s = *st_;
+        std::lock_guard<std::recursive_mutex> lk(s.mu);
+        // an operand must be a computed value or a recipe THIS context still holds: one whose flush failed, or that belongs to
+        // a context that is gone or to another one, can never be computed
+        for (const Ciphertext *c : {static_cast<const Ciphertext *>(&a), b}) {
+            if (!c || c->node()->done()) continue;
+            if (c->node()->failed) throw std::runtime_error("operand was never computed: an earlier evaluation failed");
+            if (c->node()->ctx.lock() != st_) throw std::invalid_argument("operand is a pending value of another SEALContext");
+        }
         std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
-        v->op = op; v->size = size; v->k = s.k; v->n = s.n; v->ctx = &s;
+        v->op = op; v->size = size; v->k = s.k; v->n = s.n; v->ctx = st_;
         v->a = a.node();
         if (b) v->b = b->node();
         v->plain = std::move(plain);
@@ -1183,6 +1225,7 @@ private:
         if (len) record(sign > 0 ? detail::Node::ADDP : detail::Node::SUBP, a, nullptr, plain_entry(p, len), (uint32_t)a.size());
     }
     std::shared_ptr<detail::PlainEntry> plain_entry(const Plaintext &p, int len) {
+        std::lock_guard<std::mutex> lk(cache_mu_);
         const detail::PlainData *fz = p.frozen_data();                     // an encoder's immutable object: recognised by address
         if (fz) {
             auto it = by_object_.find(fz);
@@ -1211,7 +1254,7 @@ private:
         return e;
     }
     std::shared_ptr<detail::CtxState> st_;
-    detail::DevBuf scratch_;
+    std::mutex cache_mu_;                                                   // the two plaintext caches below
     std::multimap<uint64_t, std::shared_ptr<detail::PlainEntry>> plain_cache_;
     std::unordered_map<const detail::PlainData *, std::pair<std::shared_ptr<detail::PlainData>, std::shared_ptr<detail::PlainEntry>>> by_object_;
 };

@@ -23,6 +23,8 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -245,5 +247,8 @@ int main(int argc, char **argv) {
     }
     if (fin) fhe_io_close(fin);
     if (fout) fhe_io_close(fout);
+    // a failed job (an input residue that is not reduced, a foreign record, an I/O error) must not leave a complete-looking output
+    // stream behind: what was written was computed on input the server refuses
+    if (rc && fout && truncate(out_path, 0) != 0) std::fprintf(stderr, "server_jpeg_hip: could not truncate %s\n", out_path);
     return rc;
 }

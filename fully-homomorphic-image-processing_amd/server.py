@@ -109,23 +109,50 @@ class StreamFile:
 class _ResidueCheck:
     """fhe_count_unreduced on every uploaded wave: the streams' record headers are checked by the I/O layer, the payload here --
     a residue at or above its modulus would otherwise be computed on silently (seal::Ciphertext::load rejects it, and so does
-    the facade's).  One u64 counter on the device, read once when the job is done."""
+    the facade's).  One u64 counter on the device, read once when the job is done.  The counter is zeroed on the stream that
+    is current at construction; every count waits for that event on ITS stream first (the servers count on their copy
+    streams, which are non-blocking: without the wait the zero fill and the first atomic add would be unordered)."""
 
     def __init__(self, ctx, enabled=True):
         from . import _lib
         self.ctx, self._lib, self.enabled = ctx, _lib, enabled
         self.count = torch.zeros(1, dtype=torch.int64, device=ctx.device) if enabled else None
+        self._zeroed = None
+        if enabled:
+            self._zeroed = torch.cuda.Event()
+            self._zeroed.record(torch.cuda.current_stream())
 
     def add(self, t):
         if self.enabled and t.numel():
+            st = torch.cuda.current_stream()
+            st.wait_event(self._zeroed)
             self._lib.call("fhe_count_unreduced", self.ctx.h, C.c_void_p(t.data_ptr()), t.numel() // (self.ctx.k * self.ctx.n), C.c_void_p(self.count.data_ptr()),
-                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                           C.c_void_p(st.cuda_stream))
 
-    def verdict(self):
+    def verdict(self, refuse_output=None):
+        """raises ValueError when a residue was not reduced; `refuse_output()` runs first (the servers have written their
+        whole output stream by then: it must not be left behind looking complete)"""
         if self.enabled:
             bad = int(self.count.item())
             if bad:
-                raise ValueError("the input stream holds %d residues that are not reduced modulo the coefficient moduli" % bad)
+                if refuse_output is not None:
+                    refuse_output()
+                raise ValueError("the input stream holds %d residues that are not reduced modulo the coefficient moduli; the output was computed on them and has been "
+                                 "discarded (an output mapping kept open by the caller is NOT truncated: discard its contents)" % bad)
+
+
+def _refuser(own_out, fout, out_path):
+    """what a server does with its output stream when the input turns out to be invalid: a file it opened itself is closed and
+    truncated to zero bytes (any reader then fails on the first record); a StreamFile the caller keeps open (a reused spool
+    mapping) cannot be truncated under its mapping -- the ValueError tells the caller to discard it"""
+    def refuse():
+        if own_out:
+            fout.close()
+            try:
+                os.truncate(out_path, 0)
+            except OSError:
+                pass
+    return refuse
 
 
 def _stop_pipeline(reader_thread, writer_thread, free_in, to_write):
@@ -284,7 +311,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         if errors:
             raise errors[0]
         torch.cuda.synchronize()
-        residues.verdict()
+        residues.verdict(_refuser(own_out, fout, out_path))
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
                          bytes_in=n_blocks * 192 * rec, bytes_out=n_blocks * 192 * rec, waves=len(waves),
@@ -549,7 +576,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         if errors:
             raise errors[0]
         torch.cuda.synchronize()
-        residues.verdict()
+        residues.verdict(_refuser(own_out, fout, out_path))
         if stats is not None:
             stats.update(seconds=time.perf_counter() - t0, device_compute_seconds=sum(a.elapsed_time(b) for a, b in zip(t_start, t_stop)) / 1e3,
                          bytes_in=sum(c for _, c in reads) * src_w * 3 * rec_in, bytes_out=dst_w * (row1 - row0) * 3 * rec_out, steps=len(steps),

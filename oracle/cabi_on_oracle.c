@@ -12,6 +12,7 @@
  * Plaintext / key material in "NTT form" uses the oracle's own slot order; it is opaque to callers,
  * exactly like the product's (include/fhe_hip.h, layout note).
  */
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -103,12 +104,17 @@ int fhe_gather(const uint64_t *const *src, uint64_t count, uint64_t words, uint6
 static fo_ctx *codec_ctx(uint32_t n, uint64_t t) {
     static struct { uint32_t n; uint64_t t; fo_ctx *o; } cache[16];
     static int used;
-    for (int i = 0; i < used; i++)
-        if (cache[i].n == n && cache[i].t == t) return cache[i].o;
-    uint64_t q[FHE_MAX_K];
-    if (fhe_default_coeff_modulus(8192, 1, q) <= 0) return NULL;          /* 0x7fffffff380001 = 1 mod 2^19 */
-    fo_ctx *o = fo_ctx_create(n, q, 1, t);
-    if (o && used < 16) { cache[used].n = n; cache[used].t = t; cache[used].o = o; used++; }
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;       /* the facade's thread test encodes from several threads */
+    pthread_mutex_lock(&mu);
+    fo_ctx *o = NULL;
+    for (int i = 0; i < used && !o; i++)
+        if (cache[i].n == n && cache[i].t == t) o = cache[i].o;
+    if (!o) {
+        uint64_t q[FHE_MAX_K];
+        if (fhe_default_coeff_modulus(8192, 1, q) > 0) o = fo_ctx_create(n, q, 1, t);      /* 0x7fffffff380001 = 1 mod 2^19 */
+        if (o && used < 16) { cache[used].n = n; cache[used].t = t; cache[used].o = o; used++; }
+    }
+    pthread_mutex_unlock(&mu);
     return o;
 }
 int fhe_frac_encode(uint32_t n, uint64_t t, double v, int ic, int fc, uint64_t *plain) {

@@ -60,15 +60,14 @@ for _n in (2048, 4096, 8192, 16384):
             PUBLISHED_RESIZE[("bicubic", _n, _t)] = "113.692"
 
 
-def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17, decoded=None):
+def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17, decoded=None, variant=None, env=None):
     """client_resize --send / server_resize / client_resize --recieve exactly as benchmark/benchmark.py:18-29
     runs them; returns (RMSError string, seconds, the reference's own per-call timer values of the server).
     `decoded`: a list that receives the doubles FractionalEncoder::decode returned to the receiving client, in
     call order (oracle/ref_hook.cpp, FHE_DECODE_LOG_FILE): the samples before the client's int / clamp / uint8_t
     conversion."""
-    sfx = "" if gpu else "_cpu"
-    cl = os.path.join(ROOT, "oracle", "_ref", "ref_client_resize" + sfx)
-    sv = os.path.join(ROOT, "oracle", "_ref", "ref_server_resize" + sfx)
+    cl, sv = _bins(("ref_client_resize", "ref_server_resize"), gpu, variant)
+    extra_env = env or {}
     image = image or os.path.join(ROOT, "tests", "golden", "boazbarak.jpg")
     t0 = time.time()
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
@@ -79,12 +78,12 @@ def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17, deco
         for argv in ([cl, "--send", "-f", "image/in.jpg", "-o", "image/ct_in.txt"] + par,
                      [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt"] + par + (["--bicubic"] if inter == "bicubic" else []),
                      [cl, "--recieve", "-f", "image/in.jpg", "-c", "image/ct_out.txt", "-o", "image/out.png"] + par):
-            env = dict(os.environ)
+            env = dict(os.environ, **extra_env)
             if decoded is not None and "--recieve" in argv:
                 env["FHE_DECODE_LOG_FILE"] = d + "/decoded.f64"
             r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=env)
             if r.returncode:
-                raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-1000:])
+                raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-3000:])
             if argv[0] == sv:
                 timers = [float(x) for ln in r.stdout.splitlines() if ln.startswith(("Linear,", "Cubic,")) for x in ln.split(",")[1:] if x.strip()]
         rms = [ln.split(",")[1] for ln in r.stdout.splitlines() if ln.startswith("RMSError,")]
@@ -95,10 +94,17 @@ def run_resize_set(inter, n, t, gpu=False, image=None, width=17, height=17, deco
     return rms[0] if rms else None, time.time() - t0, timers
 
 
-def run_set(n, t, gpu=False, image=None):
-    sfx = "" if gpu else "_cpu"
-    cl = os.path.join(ROOT, "oracle", "_ref", "ref_client_jpeg" + sfx)
-    sv = os.path.join(ROOT, "oracle", "_ref", "ref_server_jpeg" + sfx)
+def _bins(names, gpu, variant):
+    """oracle/_ref/<name>[_cpu]; variant="asan": the SERVER is the AddressSanitizer / UBSan build oracle/_san/<name>_cpu_asan
+    (the clients stay the plain CPU builds: oracle/Makefile says why)"""
+    out = [os.path.join(ROOT, "oracle", "_ref", nm + ("" if gpu else "_cpu")) for nm in names]
+    if variant:
+        out = [os.path.join(ROOT, "oracle", "_san", nm + "_cpu_" + variant) if "server" in nm else p for nm, p in zip(names, out)]
+    return out
+
+
+def run_set(n, t, gpu=False, image=None, variant=None, env=None):
+    cl, sv = _bins(("ref_client_jpeg", "ref_server_jpeg"), gpu, variant)
     image = image or os.path.join(ROOT, "tests", "golden", "boazbarak.jpg")
     t0 = time.time()
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
@@ -108,9 +114,9 @@ def run_set(n, t, gpu=False, image=None):
         for argv in ([cl, "--send", "-f", "image/in.jpg", "-c", "image/ct_in.txt"] + par,
                      [sv, "-f", "image/ct_in.txt", "-o", "image/ct_out.txt"] + par,
                      [cl, "--recieve", "-f", "image/in.jpg", "-i", "image/ct_out.txt", "-o", "image/out.jpg"] + par):
-            r = subprocess.run(argv, cwd=d, capture_output=True, text=True)
+            r = subprocess.run(argv, cwd=d, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
             if r.returncode:
-                raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-1000:])
+                raise RuntimeError(" ".join(argv) + "\n" + r.stdout[-1000:] + r.stderr[-3000:])
         rms = [ln.split(",")[1] for ln in r.stdout.splitlines() if ln.startswith("RMSError,")]
     return rms[0] if rms else None, time.time() - t0
 

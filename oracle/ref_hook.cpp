@@ -22,8 +22,9 @@ struct HookInstaller {
         FILE *f = std::fopen(path, "rb");
         if (!f) { std::fprintf(stderr, "ref_hook: cannot open %s\n", path); std::exit(2); }
         seal::detail::encrypt_hook() = [f](const seal::Plaintext &, seal::Ciphertext &out) -> bool {
-            if (seal::detail::known_moduli().empty()) { std::fprintf(stderr, "ref_hook: encrypt before any context\n"); std::exit(2); }
-            const seal::detail::KnownModuli &m = seal::detail::known_moduli().back();
+            const std::vector<seal::detail::KnownModuli> known = seal::detail::known_moduli();      // a snapshot (by value)
+            if (known.empty()) { std::fprintf(stderr, "ref_hook: encrypt before any context\n"); std::exit(2); }
+            const seal::detail::KnownModuli &m = known.back();
             const size_t words = (size_t)2 * m.k * m.n;
             std::vector<uint64_t> buf(words);
             if (std::fread(buf.data(), 8, words, f) != words) { std::fprintf(stderr, "ref_hook: hook file exhausted\n"); std::exit(2); }

@@ -13,7 +13,13 @@ HDR = struct.Struct("<8sIIII")                      # seal/seal.h save_words: ma
 
 
 def ref_bin(name, gpu):
-    path = os.path.join(REF_DIR, name + ("" if gpu else "_cpu"))
+    """oracle/_ref/<name>[_cpu]; FHE_REF_VARIANT=asan (tests/test_sanitizers.py) selects the AddressSanitizer / UBSan build
+    oracle/_san/<name>_cpu_asan of the CPU variants"""
+    variant = os.environ.get("FHE_REF_VARIANT")
+    if variant and not gpu:
+        path = os.path.join(ROOT, "oracle", "_san", name + "_cpu_" + variant)
+    else:
+        path = os.path.join(REF_DIR, name + ("" if gpu else "_cpu"))
     return path if os.path.exists(path) else None
 
 

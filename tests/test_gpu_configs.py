@@ -16,6 +16,29 @@ from refrun import oracle_sample, ref_bin, run_decode_circuit, sample_origins
 
 pytestmark = pytest.mark.gpu
 
+# configs[2]: the sixteen output pixels (x, y) of the 64 x 64 result that are compared with the ORACLE (about 0.6 s of host time each):
+# the four corners (both taps clamped), one pixel on each edge away from the corners (one tap clamped: rows only / columns only),
+# and eight interior pixels -- among them both sides of a source-window slide (output rows 31 | 32 read source rows 61..64 | 63..66,
+# output columns 31 | 32 likewise) and the rows next to the clamped borders
+PICKS_XY = [(0, 0), (63, 0), (0, 63), (63, 63),
+            (20, 0), (41, 63), (0, 25), (63, 40),
+            (17, 31), (17, 32), (31, 45), (32, 45), (40, 10), (5, 50), (62, 1), (1, 62)]
+
+
+def _oracle_pixel(fhe, orc, pixels, W, H, origin, xf_ct, yf_ct, cache):
+    """one output pixel of ResizeImage / SampleBicubic (homo/fhe_resize.h:254-305) through the oracle's Cubic, from the device image"""
+    xi, yi = origin
+    need = sorted({min(max(yi + dy, 0), H - 1) * W + min(max(xi + dx, 0), W - 1) for dx in (-1, 0, 1, 2) for dy in (-1, 0, 1, 2)})
+    for i in need:
+        if i not in cache:
+            cache[i] = fhe.to_host(pixels[i:i + 1])[0]
+    pix = {i: cache[i][None] for i in need}                                    # oracle_sample indexes pix[idx, ch]
+
+    class View:
+        def __getitem__(self, key):
+            return pix[key[0]][key[1]]
+    return oracle_sample(orc, View(), W, H, xi, yi, 0, xf_ct, yf_ct, True)
+
 
 def test_config2_bicubic_128_to_64_at_n8192(fhe, oracle_mod):
     import torch
@@ -29,7 +52,7 @@ def test_config2_bicubic_128_to_64_at_n8192(fhe, oracle_mod):
     n_out = w * h
     xf_all, yf_all = ctx.random_ct(n_out, size=2, seed=11), ctx.random_ct(n_out, size=2, seed=12)
     origins = sample_origins(W, H, w, h)
-    picks = {0: None, 63: None, 64 * 31 + 17: None, n_out - 1: None}           # corners (clamped taps) and an interior pixel
+    picks = {y * w + x: None for x, y in PICKS_XY}                            # corners, edges, interior incl. both sides of a window slide
 
     def run(batch):
         total = 0
@@ -49,27 +72,20 @@ def test_config2_bicubic_128_to_64_at_n8192(fhe, oracle_mod):
     d192 = run(192)                                                            # other chunk boundaries, other batch shapes
     assert d256 == d192
     hp = {}
+    assert len(picks) == 16 and origins[31 * w + 17][1] + 2 == origins[32 * w + 17][1]      # rows 31 | 32 sit on either side of a slide of the 4-row window
     for o, got in picks.items():
-        xi, yi = origins[o]
-        need = sorted({min(max(yi + dy, 0), H - 1) * W + min(max(xi + dx, 0), W - 1) for dx in (-1, 0, 1, 2) for dy in (-1, 0, 1, 2)})
-        for i in need:
-            if i not in hp:
-                hp[i] = fhe.to_host(pixels[i:i + 1])[0]
-        pix = {i: hp[i][None] for i in need}                                   # oracle_sample indexes pix[idx, ch]
-
-        class View:
-            def __getitem__(self, key):
-                return pix[key[0]][key[1]]
-        ref = oracle_sample(orc, View(), W, H, xi, yi, 0, fhe.to_host(xf_all[o:o + 1])[0], fhe.to_host(yf_all[o:o + 1])[0], True)
-        assert np.array_equal(got, ref), o
+        ref = _oracle_pixel(fhe, orc, pixels, W, H, origins[o], fhe.to_host(xf_all[o:o + 1])[0], fhe.to_host(yf_all[o:o + 1])[0], hp)
+        assert np.array_equal(got, ref), (o % w, o // w)
 
 
-def test_config2_shared_offsets_full_size_equals_per_pixel_sampling(fhe):
+def test_config2_shared_offsets_full_size_equals_per_pixel_sampling(fhe, oracle_mod):
     """configs[2] at its stated size and parameters with one offset ciphertext per output column / row:
     the shared-row evaluation (12,288 Cubics) and the per-pixel evaluation (20,480 Cubics) give the same 4096 size-6
-    ciphertexts -- compared through the position-dependent digest of all 6 GiB and on sampled pixels."""
+    ciphertexts -- compared through the position-dependent digest of all 6 GiB, and sixteen pixels of the shared-offset
+    evaluation (corners, edges, both sides of a window slide) against the ORACLE directly, not only against sample_bicubic."""
     import torch
     ctx = fhe.SEALContext.preset("P8192")
+    orc = oracle_mod.Oracle.preset("P8192")
     ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
     W = H = 128
     w = h = 64
@@ -80,7 +96,7 @@ def test_config2_shared_offsets_full_size_equals_per_pixel_sampling(fhe):
 
     def consume(first, t):
         acc[0] = (acc[0] + ctx.digest(t, index0=first * words)) % (1 << 64)
-        for o in (0, 63, 64 * 31 + 17, w * h - 1):
+        for o in [y * w + x for x, y in PICKS_XY]:
             if first <= o < first + t.shape[0]:
                 keep[o] = t[o - first].clone()
     assert fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xf, yf, consume=consume) is None
@@ -95,7 +111,12 @@ def test_config2_shared_offsets_full_size_equals_per_pixel_sampling(fhe):
         for o, t in keep.items():
             if s <= o < e:
                 assert torch.equal(out[o - s], t), o
-    assert len(keep) == 4 and total == acc[0]
+    assert len(keep) == 16 and total == acc[0]
+    origins, hp = sample_origins(W, H, w, h), {}
+    hx, hy = fhe.to_host(xf), fhe.to_host(yf)
+    for o, t in keep.items():
+        ref = _oracle_pixel(fhe, orc, pixels, W, H, origins[o], hx[o % w], hy[o // w], hp)
+        assert np.array_equal(fhe.to_host(t[None])[0], ref), (o % w, o // w)
 
 
 @pytest.mark.parametrize("preset,W,H,w,h,band,batch", [("SMALL", 16, 12, 8, 7, 3, 16), ("SMALL", 9, 9, 17, 17, 4, 64), ("P8192", 24, 24, 12, 12, 4, 48)])

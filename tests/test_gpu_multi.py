@@ -1,6 +1,6 @@
 """GPU: the N > 1 path with the HIP evaluator as the per-shard compute.  Needs two devices for the RCCL run
-(skipped on a one-GPU box; the driver's multi-GPU bench exercises it there); the single-device checks of the
-gather mode run everywhere."""
+(skipped on a one-GPU box -- no box this repository has run on had two, so NO RCCL transfer has executed yet); the
+single-device checks of the gather mode and the world-2 code paths over gloo run everywhere."""
 import json
 import os
 import socket
@@ -64,3 +64,36 @@ def test_world2_path_of_bench_on_one_gpu_over_gloo():
     assert two["collective_backend"].startswith("gloo") and two["verified_bit_exact_vs_oracle"]
     assert one["output_digest"] == two["output_digest"]
     assert abs(two["value"] - 2 * 128 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
+
+
+def _direct(script, args, **extra_env):
+    """the launch the driver makes: `python <script> --gpus N ...`, no launcher around it"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+
+
+def test_bench_gpus_2_is_the_whole_launch():
+    """`python bench.py --gpus 2` by itself starts two ranks (bench.ensure_world re-executes under torch.distributed.run); on a
+    one-GPU box the ranks share the device over gloo.  n_gpus == rccl_ranks == 2 and 2 x 128 blocks == 1 x 256 blocks by digest."""
+    one = _bench(["--blocks", "256", "--steps", "1", "--warmup", "0", "--cpu-blocks", "0"])
+    r = _direct("bench.py", ["--gpus", "2", "--blocks", "128", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"], FHE_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and len(two["ms_per_step_per_rank"]) == 2
+    assert two["output_digest"] == one["output_digest"] and two["verified_bit_exact_vs_oracle"]
+
+
+def test_bench_gpus_more_than_devices_fails_loudly():
+    """--gpus 8 on a box with fewer devices must not print an N = 1 line labelled as 8: non-zero exit with the device count in the
+    message; and a launcher whose WORLD_SIZE disagrees with --gpus is refused the same way"""
+    import torch
+    have = torch.cuda.device_count()
+    for script, extra in (("bench.py", []), ("bench_circuits.py", ["decode"])):
+        r = _direct(script, extra + ["--gpus", str(have + 7)])
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert "exposes %d HIP device" % have in r.stderr, r.stderr[-500:]
+        r = _direct(script, extra + ["--gpus", "2"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+        assert r.returncode != 0 and "WORLD_SIZE is 1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

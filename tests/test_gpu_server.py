@@ -355,8 +355,9 @@ def test_streaming_servers_reject_unreduced_residues(fhe, tmp_path):
     write()
     with pytest.raises(ValueError, match="not reduced"):
         fhe.server.server_jpeg(ctx, str(fin), str(tmp_path / "o.ct"), 1)
+    assert os.path.getsize(tmp_path / "o.ct") == 0                            # no complete-looking output stream is left behind
     rc, err = _server_jpeg_hip(fin, tmp_path / "o2.ct", 1)
-    assert rc == 1 and "not reduced" in err
+    assert rc == 1 and "not reduced" in err and os.path.getsize(tmp_path / "o2.ct") == 0
     assert fhe.server.server_jpeg(ctx, str(fin), str(tmp_path / "o3.ct"), 1, validate=False) == 1      # the check can be waived for streams the server wrote itself
     cts[100, 1, 2, 77] = good
     write()

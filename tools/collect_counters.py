@@ -42,9 +42,13 @@ WORKLOADS = {
     "ops8192": ([PY, os.path.join(ROOT, "tools", "bench_ops.py"), "P8192", "1024"],
                 ["k_ntt_fwd", "k_ntt_inv", "k_mulplain", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_eltwise", "k_dyadic"]),
     "resize": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--max-pixels", "512"],
-               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_floor3_combine", "k_behz_to_bsk", "k_cubic_coeffs_g", "k_cubic_combine_g"]),
+               ["k_"]),
     "decode": ([PY, os.path.join(ROOT, "bench_circuits.py"), "decode"],
-               ["k_ntt_fwd", "k_behz_tensor_intt", "k_behz_floor_back", "k_behz_to_bsk", "k_mulplain_pm", "k_mulplain_fwd_pm", "k_sum_inv_pm"]),
+               ["k_"]),
+    # every kernel of the circuits' launch sequences (bench_circuits.py carries the launch-time-weighted issue fraction of these)
+    "resize_shared": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--shared", "--max-pixels", "1024"], ["k_"]),
+    "decode_relin30": ([PY, os.path.join(ROOT, "bench_circuits.py"), "decode", "--relin", "30"], ["k_"]),
+    "resize_relin30": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--relin", "30", "--max-pixels", "512"], ["k_"]),
     "seal23": ([PY, os.path.join(ROOT, "bench.py"), "--preset", "SEAL23_4096", "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
                ["k_dct_rows_u64", "k_dct_cols_u64"]),
 }
