@@ -399,7 +399,14 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
         // left to itself hipcc keeps two or three in flight and every pair of slots waits out a memory round trip
         constexpr int G = M == 1 ? 16 : 8;
         for (u32 ja = lo; ja < hi; ja++) {
+#ifdef BEHZ_EXP_TENSOR_SAME_OPERAND
+            // MEASUREMENT BUILD ONLY (profiles/EXPERIMENTS.md, round 5: never in the shipped library; results are WRONG): every term reads
+            // the SAME two operand polynomials, so all but the first reads of a workgroup hit the cache -- the upper bound of what sharing
+            // operand loads between the output polynomials of a (pair, prime) could buy
+            const u64 *pa = A + ((c * sa + 0) * nb + j) * N + tid, *pb = Bm + ((cb * sb + 0) * nb + j) * N + tid;
+#else
             const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
+#endif
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += G) {
                 u64 xa[G], xb[G];

@@ -359,8 +359,11 @@ extern "C" int fhe_copy(void *dst, const void *src, size_t bytes, fhe_stream s) 
 }
 extern "C" int fhe_stream_sync(fhe_stream s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return FHE_OK; }
 
-// fhe_gather: `count` scattered device buffers of words_each u64 -> one strided batch, ONE launch per 256 sources.  The
-// source addresses travel in the kernel arguments (2 KB), so the call needs no staging copy and no host synchronisation.
+// fhe_gather: `count` scattered device buffers of words_each u64 -> one strided batch.  Up to 256 sources travel in the
+// kernel arguments (2 KB): no staging copy, no host synchronisation, one launch.  More sources go through a pointer table in
+// device memory that lives exactly as long as the launch needs it (stream-ordered allocation, a staged copy of the host
+// array, ONE launch, stream-ordered release) -- round 4 issued one launch per 256 sources, which was more than half of the
+// launches of the reference's server_jpeg through the lazy facade (6,912 operands per level: 27 launches per gather).
 // This is what turns the facade's one-ciphertext-at-a-time calls into batched launches (seal/seal.h, lazy evaluation).
 namespace {
 constexpr int GATHER_PTRS = 256;
@@ -370,24 +373,76 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a, ulonglong2 *__rest
     ulonglong2 *__restrict__ d = dst + (u64)blockIdx.y * dst_stride_pairs;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < pairs_each; i += (u64)gridDim.x * blockDim.x) d[i] = s[i];
 }
+__global__ __launch_bounds__(256) void k_gather_table(const ulonglong2 *const *__restrict__ table, u64 count, ulonglong2 *__restrict__ dst, u64 pairs_each,
+                                                      u64 dst_stride_pairs) {
+    for (u64 c = blockIdx.y; c < count; c += gridDim.y) {
+        const ulonglong2 *__restrict__ s = table[c];
+        ulonglong2 *__restrict__ d = dst + c * dst_stride_pairs;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < pairs_each; i += (u64)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
 }  // namespace
 extern "C" int fhe_gather(const uint64_t *const *src_host, uint64_t count, uint64_t words_each, uint64_t *dst, uint64_t dst_stride_words, fhe_stream s) {
     if (!count || !words_each) return FHE_OK;
     if (!src_host || !dst) return fail(FHE_ERR_PARAM, "null argument");
     if ((words_each & 1) || (dst_stride_words & 1) || dst_stride_words < words_each || ((uintptr_t)dst & 15))
         return fail(FHE_ERR_PARAM, "gather moves 16-byte units: even word counts and 16-byte aligned buffers");
+    for (u64 i = 0; i < count; ++i)
+        if (!src_host[i] || ((uintptr_t)src_host[i] & 15)) return fail(FHE_ERR_PARAM, "gather source %llu is null or not 16-byte aligned", (unsigned long long)i);
     const u64 pairs = words_each / 2;
     const unsigned bx = (unsigned)std::min<u64>((pairs + 255) / 256, 64);
-    for (u64 done = 0; done < count; done += GATHER_PTRS) {
-        const unsigned part = (unsigned)std::min<u64>(GATHER_PTRS, count - done);
+    hipStream_t st = (hipStream_t)s;
+    if (count <= GATHER_PTRS) {
         GatherArgs a;
-        for (unsigned i = 0; i < part; ++i) {
-            if (!src_host[done + i] || ((uintptr_t)src_host[done + i] & 15)) return fail(FHE_ERR_PARAM, "gather source %llu is null or not 16-byte aligned", (unsigned long long)(done + i));
-            a.src[i] = (const ulonglong2 *)src_host[done + i];
-        }
-        for (unsigned i = part; i < GATHER_PTRS; ++i) a.src[i] = nullptr;
-        k_gather<<<dim3(bx, part), 256, 0, (hipStream_t)s>>>(a, (ulonglong2 *)(dst + done * dst_stride_words), pairs, dst_stride_words / 2);
+        for (unsigned i = 0; i < (unsigned)count; ++i) a.src[i] = (const ulonglong2 *)src_host[i];
+        for (unsigned i = (unsigned)count; i < GATHER_PTRS; ++i) a.src[i] = nullptr;
+        k_gather<<<dim3(bx, (unsigned)count), 256, 0, st>>>(a, (ulonglong2 *)dst, pairs, dst_stride_words / 2);
         KERNEL_CHECK();
+        return FHE_OK;
+    }
+    // pointer tables go through a process-wide page-locked ring (the caller's array is pageable: handing it to hipMemcpyAsync would
+    // make the call wait for the stream); a slot is reused only after the copy that read it has run (one event per slot)
+    struct PtrRing {
+        enum : size_t { kSlots = 8, kSlotPtrs = 32768 };            // 256 KiB per slot
+        std::mutex mu;
+        void **pinned = nullptr;
+        hipEvent_t ev[kSlots] = {};
+        bool used[kSlots] = {};
+        int next = 0;
+    };
+    static PtrRing *ring = new PtrRing();                            // never freed: static destructors may run after the runtime is gone
+    for (u64 done = 0; done < count; done += PtrRing::kSlotPtrs) {
+        const u64 part = std::min<u64>(PtrRing::kSlotPtrs, count - done);
+        void *table = nullptr;
+        HIP_TRY(hipMallocAsync(&table, part * sizeof(void *), st));
+        hipError_t e = hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(ring->mu);
+            if (!ring->pinned) {
+                e = hipHostMalloc((void **)&ring->pinned, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *), hipHostMallocDefault);
+                for (int i = 0; i < (int)PtrRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
+                if (e != hipSuccess) ring->pinned = nullptr;
+            }
+            if (e == hipSuccess) {
+                const int slot = ring->next;
+                ring->next = (slot + 1) % (int)PtrRing::kSlots;
+                if (ring->used[slot]) e = hipEventSynchronize(ring->ev[slot]);
+                void **p = ring->pinned + (size_t)slot * PtrRing::kSlotPtrs;
+                if (e == hipSuccess) {
+                    memcpy(p, src_host + done, part * sizeof(void *));
+                    e = hipMemcpyAsync(table, p, part * sizeof(void *), hipMemcpyHostToDevice, st);
+                }
+                if (e == hipSuccess) e = hipEventRecord(ring->ev[slot], st);
+                ring->used[slot] = e == hipSuccess;
+            }
+        }
+        if (e == hipSuccess) {
+            k_gather_table<<<dim3(bx, (unsigned)part), 256, 0, st>>>((const ulonglong2 *const *)table, part, (ulonglong2 *)(dst + done * dst_stride_words), pairs,
+                                                                    dst_stride_words / 2);
+            e = hipGetLastError();
+        }
+        (void)hipFreeAsync(table, st);
+        if (e != hipSuccess) return fail(FHE_ERR_HIP, "gather: %s", hipGetErrorString(e));
     }
     return FHE_OK;
 }

@@ -218,13 +218,35 @@ __device__ __forceinline__ void ntt_inv_pass4t(u64 (&x)[16], const ulonglong2 *_
     }
 }
 
+// A transpose between passes with register bits at [LO, LO + 4) regroups elements inside aligned blocks of 2^(max LO + 4)
+// coefficients, i.e. among 2^(max LO) consecutive threads.  For max LO <= 6 that is (part of) ONE wavefront: every element a
+// lane reads was written by a lane of its own wave, to a region of the buffer no other wave touches in this transpose -- and
+// the wave's own earlier reads of that region (the previous transpose) are ordered before by the in-order LDS queue.  So the
+// exchange needs no workgroup barrier at all, only that the compiler keeps the writes before the reads (wave-level fences):
+// n = 8192 keeps 2 of its 6 s_barriers per transform (the first, 512-thread-wide transpose), n = 4096 2 of 4.  (Round 5; before,
+// every transpose was bracketed by two __syncthreads.  NTT_WAVE_LOCAL_TRANSPOSE 0 restores that for A/B measurements.)
+#ifndef NTT_WAVE_LOCAL_TRANSPOSE
+#define NTT_WAVE_LOCAL_TRANSPOSE 1
+#endif
 template <int LO_FROM, int LO_TO>
 __device__ __forceinline__ void ntt_transpose(u64 (&x)[16], u64 *lds, int tid) {
     constexpr int PL = imin(LO_FROM, LO_TO);
-    __syncthreads();   // earlier readers of this buffer are done
+    constexpr bool wave_local = NTT_WAVE_LOCAL_TRANSPOSE && (LO_FROM <= 6) && (LO_TO <= 6);
+    if constexpr (wave_local) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();   // earlier readers of this buffer are done
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) lds[lds_pad<PL>(elem_index<LO_FROM>(tid, r))] = x[r];
-    __syncthreads();
+    if constexpr (wave_local) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = lds[lds_pad<PL>(elem_index<LO_TO>(tid, r))];
 }

@@ -66,14 +66,25 @@ int main(int argc, char **argv) {
     { Ciphertext c(a); evaluator.add_plain(c, encoder.encode(0.75)); CHECK(dec(c) == 38.0, "add_plain -> %g", dec(c)); }
     { Ciphertext c(a); evaluator.sub_plain(c, encoder.encode(128.0)); CHECK(dec(c) == 37.25 - 128.0, "sub_plain -> %g", dec(c)); }
     { Ciphertext c(a); evaluator.multiply_plain(c, encoder.encode(0.541196100)); CHECK(std::fabs(dec(c) - 37.25 * 0.541196100) < 1e-9, "multiply_plain -> %.12g", dec(c)); }
+    if (!std::getenv("FHE_FACADE_RELIN"))
     { Ciphertext c(a); evaluator.multiply(c, b); CHECK(c.size() == 3 && dec(c) == 37.25 * -2.5, "multiply -> size %d value %g", c.size(), dec(c));
       Ciphertext d(c); evaluator.add(d, a); CHECK(d.size() == 3 && dec(d) == 37.25 * -2.5 + 37.25, "add 3+2 -> %g", dec(d));
       Ciphertext e(a); evaluator.sub(e, c); CHECK(e.size() == 3 && dec(e) == 37.25 - 37.25 * -2.5, "sub 2-3 -> %g", dec(e));
       EvaluationKeys evk; keygen.generate_evaluation_keys(30, evk);
       evaluator.relinearize(c, evk); CHECK(c.size() == 2 && dec(c) == 37.25 * -2.5, "relinearize -> size %d value %g", c.size(), dec(c));
       CHECK(decryptor.invariant_noise_budget(c) > 0, "budget after relinearize"); }
-    { Ciphertext c(b); evaluator.square(c); CHECK(c.size() == 3 && dec(c) == 6.25, "square -> %g", dec(c));
+    const bool auto_relin = std::getenv("FHE_FACADE_RELIN") != nullptr;       // every product comes back with two polynomials
+    { Ciphertext c(b); evaluator.square(c); CHECK(c.size() == (auto_relin ? 2 : 3) && dec(c) == 6.25, "square -> size %d value %g", c.size(), dec(c));
       Ciphertext d(b); evaluator.multiply(d, b); CHECK(dec(d) == 6.25, "multiply(x,x) -> %g", dec(d)); }
+    if (auto_relin) {      // FHE_FACADE_RELIN=<dbc>: a chain of products stays at size 2 and decrypts (keys derived from the secret key the Decryptor was given)
+        Ciphertext c(a);
+        evaluator.multiply(c, b);
+        CHECK(c.size() == 2, "auto-relinearised product has size %d", c.size());
+        evaluator.multiply(c, b);
+        evaluator.add(c, a);
+        CHECK(c.size() == 2 && dec(c) == 37.25 * 6.25 + 37.25, "two relinearised products + add -> size %d value %g", c.size(), dec(c));
+        CHECK(decryptor.invariant_noise_budget(c) > 0, "budget after two relinearised products");
+    }
     { std::stringstream ss; a.save(ss); b.save(ss); Ciphertext c, d; c.load(ss); d.load(ss);
       CHECK(dec(c) == 37.25 && dec(d) == -2.5, "save/load stream of two ciphertexts");
       std::stringstream ks; pk.save(ks); sk.save(ks); PublicKey pk2; SecretKey sk2; pk2.load(ks); sk2.load(ks);

@@ -259,11 +259,12 @@ struct PlainEntry {                    // one distinct plaintext an Evaluator ha
     DevBuf prepared;                   // fhe_plain_prepare form, built when the first dense product runs
     PlainEntry() : nnz(0) {}
 };
+inline unsigned long long *io_counts() { static unsigned long long c[3] = {0, 0, 0}; return c; }      // saves served from a host window, window transfers, per-record downloads
 inline double *io_seconds() { static double t[4] = {0, 0, 0, 0}; return t; }     // process-wide: host time in Ciphertext::load / save, and the device transfers inside them
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct CtxState;
 struct Node {                          // an immutable ciphertext VALUE: materialised (st) or the recipe for it (op, a, b, plain)
-    enum Op { VALUE, ADD, SUB, NEG, ADDP, SUBP, MULP, MUL, SQR };
+    enum Op { VALUE, ADD, SUB, NEG, ADDP, SUBP, MULP, MUL, SQR, RELIN };
     Op op;
     uint32_t size, k, n;
     std::shared_ptr<Node> a, b;
@@ -298,15 +299,27 @@ struct CtxState {
     std::vector<std::shared_ptr<Node>> pending;
     size_t pending_words;
     bool eager, flushing;
+    // FHE_FACADE_RELIN=<dbc> (NOT what the reference does): every multiply / square is followed by a
+    // relinearisation with this decomposition bit count, so the reference's UNCHANGED circuits (homo/fhe_resize.h:174-179,
+    // homo/fhe_decode.h:67-98,235,239) run with ciphertexts of size 2 throughout.  The keys for s^2 are derived from the
+    // secret key the first time one is seen on this context (the reference's servers load it and build a Decryptor:
+    // homo/server_resize.cpp:103-116, homo/server_decode.cpp:109-121); a product before that throws.
+    uint32_t relin_dbc, relin_digits;
+    DevBuf relin_evk;                  // [k][digits][2][k][n], NTT form
     struct Stats {
         uint64_t recorded, computed, dropped, flushes, groups, launches, gathers;
         double flush_s;                // host time inside flush (launch overhead: the launches are asynchronous)
         double create_s, destroy_s;    // fhe_ctx_create (device runtime start-up included when it is the process's first device call) / fhe_ctx_destroy
         Stats() : recorded(0), computed(0), dropped(0), flushes(0), groups(0), launches(0), gathers(0), flush_s(0), create_s(0), destroy_s(0) {}
     } stats;
-    CtxState() : h(nullptr), n(0), k(0), t(0), pending_words(0), eager(false), flushing(false) {
+    CtxState() : h(nullptr), n(0), k(0), t(0), pending_words(0), eager(false), flushing(false), relin_dbc(0), relin_digits(0) {
         const char *e = std::getenv("FHE_FACADE_EAGER");
         eager = e && *e == '1';
+        if (const char *r = std::getenv("FHE_FACADE_RELIN")) {
+            const int v = std::atoi(r);
+            if (v < 1 || v > 60) throw std::invalid_argument("FHE_FACADE_RELIN must be a decomposition bit count in 1..60");
+            relin_dbc = (uint32_t)v;
+        }
     }
     ~CtxState() {
         pending.clear();
@@ -317,11 +330,12 @@ struct CtxState {
         if (const char *e = std::getenv("FHE_FACADE_STATS")) {
             FILE *f = (e[0] == '1' && !e[1]) ? stderr : std::fopen(e, "a");
             if (f) {
-                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu (upload %llu) save_ms=%llu (download %llu) ctx_create_ms=%llu ctx_destroy_ms=%llu\n",
+                std::fprintf(f, "[seal facade] mode=%s recorded=%llu computed=%llu dropped=%llu flushes=%llu groups=%llu launches=%llu gathers=%llu flush_ms=%llu load_ms=%llu (upload %llu) save_ms=%llu (download %llu; %llu saves from %llu window transfers, %llu single) ctx_create_ms=%llu ctx_destroy_ms=%llu\n",
                              eager ? "eager" : "lazy", (unsigned long long)stats.recorded, (unsigned long long)stats.computed, (unsigned long long)stats.dropped,
                              (unsigned long long)stats.flushes, (unsigned long long)stats.groups, (unsigned long long)stats.launches, (unsigned long long)stats.gathers,
                              (unsigned long long)(stats.flush_s * 1e3), (unsigned long long)(io_seconds()[0] * 1e3), (unsigned long long)(io_seconds()[2] * 1e3), (unsigned long long)(io_seconds()[1] * 1e3),
-                             (unsigned long long)(io_seconds()[3] * 1e3), (unsigned long long)(stats.create_s * 1e3), (unsigned long long)(stats.destroy_s * 1e3));
+                             (unsigned long long)(io_seconds()[3] * 1e3), io_counts()[0], io_counts()[1], io_counts()[2], (unsigned long long)(stats.create_s * 1e3),
+                             (unsigned long long)(stats.destroy_s * 1e3));
                 if (f != stderr) std::fclose(f);
             }
         }
@@ -458,6 +472,81 @@ struct HostStage {
     bool empty() const { return n == 0; }
 };
 inline HostStage &host_stage() { static thread_local HostStage *s = new HostStage(); return *s; }
+
+// Ciphertext::load: consecutive records land in ONE page-locked ring and go to the device as ASYNCHRONOUS copies -- the host
+// reads record i + 1 from the stream while record i is on the wire (round 4: one synchronous transfer per ciphertext, 6,912 x
+// 13 us of the reference's server_jpeg).  The copies are enqueued on the DEFAULT stream, like every launch of the facade: a
+// recycled device buffer (Pool) is overwritten only after the kernels that still read it, and the launches that consume a
+// loaded value run after its copy -- no cross-stream hazard exists (a separate upload stream, tried first, overwrote recycled
+// buffers under kernels still queued on the default stream: the lazy server_resize differed from the eager one).  The host
+// side of the ring wraps after ONE stream synchronisation per 64 MiB.  Process-wide, mutex-guarded.  Never freed (static
+// destructors may run after the device runtime has shut down).
+struct UploadRing {
+    std::mutex mu;
+    HostStage buf;
+    size_t off = 0;
+    enum : size_t { kWords = (size_t)8 << 20 };                     // 64 MiB
+    static UploadRing &instance() { static UploadRing *r = new UploadRing(); return *r; }
+    // room for `words` (the caller fills it, then calls send); the lock is held from reserve to send
+    uint64_t *reserve(size_t words) {
+        const size_t cap = words > kWords ? words : kWords;
+        if (buf.cap < cap) { wait(); buf.resize(cap); off = 0; }
+        if (off + words > buf.cap) { wait(); off = 0; }
+        return buf.p + off;
+    }
+    void send(uint64_t *dev, size_t words) {
+        check(fhe_upload(dev, buf.p + off, words * 8, nullptr), "upload");
+        off += words;
+    }
+    void wait() { check(fhe_stream_sync(nullptr), "sync"); }
+};
+// Ciphertext::save: the results of a batched launch are slices of ONE device allocation, and the reference saves them one
+// after the other (homo/server_jpeg.cpp:146-153).  The first save of a slice brings its whole allocation to the host in ONE
+// transfer (allocations up to 32 MiB: the per-block result groups of server_jpeg hold 8-64 ciphertexts each) or a 16 MiB
+// window of it starting at the slice (larger allocations, saved front to back); the following saves of that allocation are
+// served from the host copy.  Copies live in one page-locked 128 MiB arena that is simply restarted when full.  An
+// allocation whose windows are replaced twice without having served a second save is read one record at a time from then on.
+// Process-wide, mutex-guarded; values are immutable, and Ciphertext::ptr() (the one mutable access) drops every copy.
+struct DownloadWindow {
+    struct Entry { std::shared_ptr<Storage> st; size_t lo, hi, at, hits; };        // [lo, hi) of st (words) sits at arena word `at`
+    std::mutex mu;
+    HostStage arena;
+    size_t used = 0;
+    std::vector<Entry> entries;
+    std::vector<std::pair<const Storage *, int>> strikes;                           // allocations whose windows did not pay
+    enum : size_t { kArenaWords = (size_t)16 << 20, kWholeWords = (size_t)4 << 20, kWindowWords = (size_t)2 << 20 };      // enumerators: no ODR-use in C++11
+    static DownloadWindow &instance() { static DownloadWindow *w = new DownloadWindow(); return *w; }
+    // host copy of [off, off + words) of the allocation, or nullptr: read that record directly
+    const uint64_t *get(const std::shared_ptr<Storage> &st, size_t off, size_t words, double &transfer_s) {
+        for (Entry &e : entries)
+            if (e.st == st && off >= e.lo && off + words <= e.hi) { ++e.hits; ++io_counts()[0]; return arena.p + e.at + (off - e.lo); }
+        for (auto &sk : strikes) if (sk.first == st.get() && sk.second >= 2) return nullptr;
+        for (size_t i = 0; i < entries.size(); ++i)
+            if (entries[i].st == st) {                              // a window of this allocation is being replaced: did it pay?
+                if (entries[i].hits < 1) {
+                    bool found = false;
+                    for (auto &sk : strikes) if (sk.first == st.get()) { ++sk.second; found = true; }
+                    if (!found) strikes.push_back({st.get(), 1});
+                }
+                entries.erase(entries.begin() + (long)i);
+                break;
+            }
+        const size_t take = st->words <= kWholeWords ? st->words : std::min<size_t>(st->words - off, std::max<size_t>(kWindowWords, words));
+        const size_t lo = st->words <= kWholeWords ? 0 : off;
+        if (take > kArenaWords) return nullptr;
+        if (arena.cap < kArenaWords) arena.resize(kArenaWords);
+        if (used + take > kArenaWords) { entries.clear(); strikes.clear(); used = 0; }
+        const double t0 = now_s();
+        check(fhe_download(arena.p + used, st->p + lo, take * 8, nullptr), "download");
+        check(fhe_stream_sync(nullptr), "sync");
+        transfer_s += now_s() - t0;
+        ++io_counts()[1];
+        entries.push_back(Entry{st, lo, lo + take, used, 0});
+        used += take;
+        return arena.p + entries.back().at + (off - lo);
+    }
+    void forget() { std::lock_guard<std::mutex> lk(mu); entries.clear(); strikes.clear(); used = 0; }
+};
 inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32_t polys, uint32_t k, uint32_t n) {
     const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
     uint32_t hdr[4] = {polys, k, n, 0};
@@ -563,17 +652,48 @@ public:
         if (!h_.p) { detail::save_raw(os, nullptr, 0, 0, 0, 0); return; }
         materialize();
         const double t0 = detail::now_s();
-        detail::save_raw(os, h_.p->ptr(), h_.p->words(), h_.p->size, h_.p->k, h_.p->n);
+        const detail::Node &nd = *h_.p;
+        if (nd.st->words >= 2 * nd.words()) {
+            // a slice of a batched launch's results: served from the host window of that allocation (one transfer per window)
+            const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
+            const uint32_t hdr[4] = {nd.size, nd.k, nd.n, 0};
+            os.write(magic, 8);
+            os.write((const char *)hdr, sizeof hdr);
+            detail::DownloadWindow &W = detail::DownloadWindow::instance();
+            std::lock_guard<std::mutex> lk(W.mu);
+            const uint64_t *h = W.get(nd.st, nd.off, nd.words(), detail::io_seconds()[3]);
+            if (h) os.write((const char *)h, (std::streamsize)(nd.words() * 8));
+            else {                                            // saves that jump around a large allocation: one record at a time
+                detail::HostStage &hs = detail::host_stage();
+                if (hs.size() < nd.words()) hs.resize(nd.words());
+                const double t1 = detail::now_s();
+                detail::check(fhe_download(hs.data(), nd.ptr(), nd.words() * 8, nullptr), "download");
+                detail::check(fhe_stream_sync(nullptr), "sync");
+                detail::io_seconds()[3] += detail::now_s() - t1;
+                ++detail::io_counts()[2];
+                os.write((const char *)hs.data(), (std::streamsize)(nd.words() * 8));
+            }
+        } else {
+            ++detail::io_counts()[2];
+            detail::save_raw(os, nd.ptr(), nd.words(), nd.size, nd.k, nd.n);
+        }
         detail::io_seconds()[1] += detail::now_s() - t0;
     }
     void load(std::istream &is) {
         const double t0 = detail::now_s();
-        detail::HostStage &h = detail::host_stage();
+        detail::UploadRing &R = detail::UploadRing::instance();
+        std::lock_guard<std::mutex> lk(R.mu);
+        struct Slot {                      // load_host's buffer interface over the ring: the record is validated in place
+            detail::UploadRing &r; uint64_t *p; size_t n;
+            void resize(size_t w) { p = r.reserve(w); n = w; }
+            uint64_t *data() { return p; }
+            size_t size() const { return n; }
+        } h{R, nullptr, 0};
         uint32_t polys, k, n;
         detail::load_host(is, h, polys, k, n);
         shape(polys, k, n);
         const double t1 = detail::now_s();
-        if (!h.empty()) buffer().upload(h.data(), h.size());
+        if (h.n) R.send(h_.p->ptr(), h.n);          // asynchronous, stream-ordered with everything that uses the value
         detail::io_seconds()[2] += detail::now_s() - t1;
         detail::io_seconds()[0] += detail::now_s() - t0;
     }
@@ -589,6 +709,7 @@ public:
     uint64_t *ptr() {
         if (!h_.p) return nullptr;
         materialize();
+        detail::DownloadWindow::instance().forget();          // the caller may write through this pointer: no host copy of the allocation stays valid
         if (h_.p->handles > 1 || h_.p.use_count() > 1) {
             std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
             v->size = h_.p->size; v->k = h_.p->k; v->n = h_.p->n;
@@ -642,8 +763,8 @@ inline const uint64_t *batch_operand(CtxState &s, const std::vector<Node *> &g, 
     std::vector<const uint64_t *> src(hi - lo);
     for (size_t i = lo; i < hi; ++i) src[i - lo] = (second ? g[i]->b : g[i]->a)->ptr();
     check(fhe_gather(src.data(), hi - lo, w, into, w, nullptr), "gather");
-    s.stats.launches += (hi - lo + 255) / 256;
-    s.stats.gathers += (hi - lo + 255) / 256;
+    s.stats.launches += (hi - lo + 32767) / 32768;           // fhe_gather: one launch per 32,768 sources (a device pointer table above 256)
+    s.stats.gathers += (hi - lo + 32767) / 32768;
     return into;
 }
 #ifdef FHE_FACADE_TEST_HOOKS
@@ -716,6 +837,14 @@ inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size
                 check(fhe_multiply(s.h, A, sa, B, sb, o, cnt, scratch.p, bytes, nullptr), "multiply");
             }
             s.stats.launches += f.op == Node::SQR ? 5 : 8;
+            break;
+        }
+        case Node::RELIN: {                // FHE_FACADE_RELIN: the size-3 products of the level, relinearised into compact size-2 results
+            const uint64_t *A = batch_operand(s, g, lo, hi, false, nullptr, ta);
+            const size_t bytes = fhe_relinearize_scratch_bytes(s.h, s.relin_dbc, cnt);
+            Storage scratch((bytes + 7) / 8);
+            check(fhe_relinearize_to(s.h, A, 3 * pw, o, 2 * pw, cnt, s.relin_evk.ptr(), s.relin_dbc, scratch.p, bytes, nullptr), "relinearize");
+            s.stats.launches += 2;
             break;
         }
         default: throw std::logic_error("facade: unknown pending operation");
@@ -922,6 +1051,49 @@ inline void ring_mul(const CtxState &s, const DevBuf &a, size_t a_polys, const D
         check(fhe_dyadic_multiply(s.h, out.ptr() + p * s.poly_words(), b_ntt.ptr(), out.ptr() + p * s.poly_words(), 1, nullptr), "dyadic");
     check(fhe_ntt_inverse(s.h, out.ptr(), out.ptr(), a_polys, nullptr), "intt");
 }
+// evaluation keys for s^2 (SEAL 2.3 generate_evaluation_keys(dbc, keys)): evk[i][d] = (-(a s + e) + 2^(dbc d) s^2 E_i, a),
+// [k][digits][2][k][n], NTT form.  sk: [k][n] coefficient form, sk_ntt its transform.
+inline void make_evk(const CtxState &s, const DevBuf &sk, const DevBuf &sk_ntt, int decomposition_bit_count, DevBuf &out, uint32_t &digits) {
+    if (decomposition_bit_count < 1 || decomposition_bit_count > 60) throw std::invalid_argument("decomposition_bit_count");
+    Sampler smp(s);
+    const size_t pw = s.poly_words();
+    const uint32_t nd = fhe_evk_digits(s.h, (uint32_t)decomposition_bit_count);
+    digits = nd;
+    out.resize((size_t)s.k * nd * 2 * pw);
+    DevBuf s2;
+    ring_mul(s, sk, 1, sk_ntt, s2);
+    std::vector<uint64_t> hs2(pw);
+    s2.download(hs2.data(), pw);
+    for (uint32_t i = 0; i < s.k; ++i)
+        for (uint32_t d = 0; d < nd; ++d) {
+            std::vector<uint64_t> a = smp.uniform(), e = smp.noise();
+            DevBuf da(pw), de(pw), as;
+            da.upload(a.data(), pw);
+            de.upload(e.data(), pw);
+            ring_mul(s, da, 1, sk_ntt, as);
+            check(fhe_add(s.h, as.ptr(), de.ptr(), as.ptr(), 1, nullptr), "add");
+            check(fhe_negate(s.h, as.ptr(), as.ptr(), 1, nullptr), "negate");
+            std::vector<uint64_t> k0(pw);
+            as.download(k0.data(), pw);
+            const uint64_t qi = s.q[i], wd = powmod(2, (uint64_t)decomposition_bit_count * d, qi);
+            for (uint32_t c = 0; c < s.n; ++c) {        // + w^d s^2 in RNS component i only
+                uint64_t &x = k0[(size_t)i * s.n + c];
+                x = (uint64_t)(((u128)x + mulmod(hs2[(size_t)i * s.n + c], wd, qi)) % qi);
+            }
+            uint64_t *dst = out.ptr() + (((size_t)i * nd + d) * 2) * pw;
+            check(fhe_upload(dst, k0.data(), pw * 8, nullptr), "upload");
+            check(fhe_upload(dst + pw, a.data(), pw * 8, nullptr), "upload");
+            check(fhe_stream_sync(nullptr), "sync");
+        }
+    check(fhe_ntt_forward(s.h, out.ptr(), out.ptr(), (uint64_t)s.k * nd * 2, nullptr), "ntt");
+    check(fhe_stream_sync(nullptr), "sync");
+}
+// FHE_FACADE_RELIN: the context's own keys for s^2, made once from the first secret key seen on it
+inline void ensure_relin_keys(CtxState &s, const DevBuf &sk, const DevBuf &sk_ntt) {
+    std::lock_guard<std::recursive_mutex> lk(s.mu);
+    if (!s.relin_dbc || s.relin_evk.words()) return;
+    make_evk(s, sk, sk_ntt, (int)s.relin_dbc, s.relin_evk, s.relin_digits);
+}
 }  // namespace detail
 
 class KeyGenerator {
@@ -946,46 +1118,14 @@ public:
         detail::check(fhe_negate(s.h, as.ptr(), pk_.buf.ptr(), 1, nullptr), "negate");     // -(a s + e)
         detail::check(fhe_copy(pk_.buf.ptr() + pw, da.ptr(), pw * 8, nullptr), "copy");      // a
         detail::check(fhe_stream_sync(nullptr), "sync");
+        detail::ensure_relin_keys(*st_, sk_.buf, sk_ntt_);
     }
     const PublicKey &public_key() const { return pk_; }
     const SecretKey &secret_key() const { return sk_; }
     // evaluation keys for s^2 (SEAL 2.3 generate_evaluation_keys(dbc, keys))
     void generate_evaluation_keys(int decomposition_bit_count, EvaluationKeys &evk) {
-        const detail::CtxState &s = *st_;
-        if (decomposition_bit_count < 1 || decomposition_bit_count > 60) throw std::invalid_argument("decomposition_bit_count");
-        detail::Sampler smp(s);
-        const size_t pw = s.poly_words();
-        const uint32_t nd = fhe_evk_digits(s.h, (uint32_t)decomposition_bit_count);
+        detail::make_evk(*st_, sk_.buf, sk_ntt_, decomposition_bit_count, evk.buf, evk.digits);
         evk.dbc = (uint32_t)decomposition_bit_count;
-        evk.digits = nd;
-        evk.buf.resize((size_t)s.k * nd * 2 * pw);
-        detail::DevBuf s2;
-        detail::ring_mul(s, sk_.buf, 1, sk_ntt_, s2);
-        std::vector<uint64_t> hs2(pw);
-        s2.download(hs2.data(), pw);
-        for (uint32_t i = 0; i < s.k; ++i)
-            for (uint32_t d = 0; d < nd; ++d) {
-                std::vector<uint64_t> a = smp.uniform(), e = smp.noise();
-                detail::DevBuf da(pw), de(pw), as;
-                da.upload(a.data(), pw);
-                de.upload(e.data(), pw);
-                detail::ring_mul(s, da, 1, sk_ntt_, as);
-                detail::check(fhe_add(s.h, as.ptr(), de.ptr(), as.ptr(), 1, nullptr), "add");
-                detail::check(fhe_negate(s.h, as.ptr(), as.ptr(), 1, nullptr), "negate");
-                std::vector<uint64_t> k0(pw);
-                as.download(k0.data(), pw);
-                const uint64_t qi = s.q[i], wd = detail::powmod(2, (uint64_t)decomposition_bit_count * d, qi);
-                for (uint32_t c = 0; c < s.n; ++c) {        // + w^d s^2 in RNS component i only
-                    uint64_t &x = k0[(size_t)i * s.n + c];
-                    x = (uint64_t)(((detail::u128)x + detail::mulmod(hs2[(size_t)i * s.n + c], wd, qi)) % qi);
-                }
-                uint64_t *dst = evk.buf.ptr() + (((size_t)i * nd + d) * 2) * pw;
-                detail::check(fhe_upload(dst, k0.data(), pw * 8, nullptr), "upload");
-                detail::check(fhe_upload(dst + pw, a.data(), pw * 8, nullptr), "upload");
-                detail::check(fhe_stream_sync(nullptr), "sync");
-            }
-        detail::check(fhe_ntt_forward(s.h, evk.buf.ptr(), evk.buf.ptr(), (uint64_t)s.k * nd * 2, nullptr), "ntt");
-        detail::check(fhe_stream_sync(nullptr), "sync");
     }
 private:
     std::shared_ptr<detail::CtxState> st_;
@@ -1047,6 +1187,7 @@ public:
         if (sk.buf.words() != s.poly_words()) throw std::invalid_argument("secret key does not match the context");
         sk_ntt_.resize(s.poly_words());
         detail::check(fhe_ntt_forward(s.h, sk.buf.ptr(), sk_ntt_.ptr(), 1, nullptr), "ntt");
+        detail::ensure_relin_keys(*st_, sk.buf, sk_ntt_);       // FHE_FACADE_RELIN: this is where a server that loaded the secret key hands it over
     }
     void decrypt(const Ciphertext &ct, Plaintext &out) { int budget; run(ct, &out, budget); }
     int invariant_noise_budget(const Ciphertext &ct) { int budget; run(ct, nullptr, budget); return budget; }
@@ -1172,8 +1313,9 @@ public:
         need(a); need(b);
         if (&a == &b || a.node() == b.node()) { square(a); return; }           // one value: the product of a ciphertext with itself
         record(detail::Node::MUL, a, &b, nullptr, (uint32_t)(a.size() + b.size() - 1));
+        auto_relin(a);
     }
-    void square(Ciphertext &a) { need(a); record(detail::Node::SQR, a, nullptr, nullptr, (uint32_t)(2 * a.size() - 1)); }
+    void square(Ciphertext &a) { need(a); record(detail::Node::SQR, a, nullptr, nullptr, (uint32_t)(2 * a.size() - 1)); auto_relin(a); }
     // repeated until size 2, as SEAL does.  Not deferred (the reference never calls it; the keys are the caller's object).
     void relinearize(Ciphertext &a, const EvaluationKeys &evk) {
         need(a);
@@ -1193,6 +1335,15 @@ public:
     // compute everything recorded so far (observing a value does this implicitly)
     void flush() { detail::flush(*st_); }
 private:
+    // FHE_FACADE_RELIN=<dbc>: evaluator.relinearize(a, keys of this context) after every product, recorded like any other call
+    void auto_relin(Ciphertext &a) {
+        detail::CtxState &s = *st_;
+        if (!s.relin_dbc || a.size() < 3) return;
+        if (a.size() != 3) throw std::runtime_error("FHE_FACADE_RELIN: a product of size " + std::to_string(a.size()) + " (operands must have two polynomials)");
+        if (!s.relin_evk.words())
+            throw std::runtime_error("FHE_FACADE_RELIN needs the secret key to derive its evaluation keys: construct a Decryptor or a KeyGenerator on this context before the first product");
+        record(detail::Node::RELIN, a, nullptr, nullptr, 2);
+    }
     void need(const Ciphertext &c) const {
         if (c.size() < 1 || c.k() != st_->k || c.n() != st_->n) throw std::invalid_argument("ciphertext is empty or does not match the context");
     }

@@ -94,6 +94,9 @@ int fhe_upload(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memc
 int fhe_download(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memcpy(d, s, b); return FHE_OK; }
 int fhe_copy(void *d, const void *s, size_t b, fhe_stream st) { (void)st; memmove(d, s, b); return FHE_OK; }
 int fhe_stream_sync(fhe_stream st) { (void)st; return FHE_OK; }
+/* every "stream" of the CPU backend is the calling thread: transfers and operations complete before they return */
+int fhe_stream_create(fhe_stream *out) { if (!out) return FHE_ERR_PARAM; *out = (fhe_stream)(uintptr_t)1; return FHE_OK; }
+int fhe_stream_destroy(fhe_stream st) { (void)st; return FHE_OK; }
 int fhe_gather(const uint64_t *const *src, uint64_t count, uint64_t words, uint64_t *dst, uint64_t stride, fhe_stream st) {
     (void)st;
     for (uint64_t i = 0; i < count; i++) memmove(dst + i * stride, src[i], words * 8);

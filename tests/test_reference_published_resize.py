@@ -54,9 +54,14 @@ def test_oracle_reproduces_published_bilinear_rms_on_cpu():
     if not _have("_cpu"):
         pytest.skip("oracle/_ref/ref_*_resize_cpu not built (needs /root/reference at build time)")
     sets = [11, 31, 101]
-    with ThreadPoolExecutor(len(sets)) as ex:
-        got = list(ex.map(lambda t: run_resize_set("bilinear", 2048, t)[0], sets))
-    assert got == [PUBLISHED_RESIZE[("bilinear", 2048, t)] for t in sets]
+    # + the RELINEARISED mode through the facade switch FHE_FACADE_RELIN=<dbc>: the reference's unchanged
+    # server_resize, every product followed by a relinearisation with keys the facade derives from the secret key the server
+    # loads (homo/server_resize.cpp:103-116) -- size-2 ciphertexts throughout, the same decrypted samples, the same RMSError
+    # (dbc = 16: at n = 2048 the 54-bit modulus has no room for the key-switch noise of 30-bit digits)
+    jobs = [(t, {}) for t in sets] + [(11, {"FHE_FACADE_RELIN": "16"})]
+    with ThreadPoolExecutor(len(jobs)) as ex:
+        got = list(ex.map(lambda j: run_resize_set("bilinear", 2048, j[0], env=j[1])[0], jobs))
+    assert got == [PUBLISHED_RESIZE[("bilinear", 2048, t)] for t, _ in jobs]
 
 
 @pytest.mark.gpu
@@ -72,6 +77,23 @@ def test_product_reproduces_published_resize_rms_on_gpu(inter, n, sets):
     with ThreadPoolExecutor(3) as ex:
         got = list(ex.map(lambda t: run_resize_set(inter, n, t, gpu=True)[0], sets))
     assert got == [PUBLISHED_RESIZE[(inter, n, t)] for t in sets]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inter,n,t,dbc", [("bicubic", 4096, 101, 30), ("bilinear", 4096, 1009, 30), ("bicubic", 8192, 3001, 60)])
+def test_reference_server_resize_in_the_relinearised_mode_on_gpu(inter, n, t, dbc, tmp_path):
+    """FHE_FACADE_RELIN=<dbc>: the reference's UNCHANGED server_resize (homo/fhe_resize.h Cubic / Linear through seal::Evaluator)
+    with every product relinearised by the facade (keys derived from the secret key the server loads); the client decrypts
+    size-2 ciphertexts to the same samples: the published RMSError.  The facade's statistics show the relinearisations."""
+    if not _have(""):
+        pytest.skip("oracle/_ref/ref_*_resize not built (needs /root/reference at build time)")
+    sf = str(tmp_path / "stats.txt")
+    rms = run_resize_set(inter, n, t, gpu=True, env={"FHE_FACADE_RELIN": str(dbc), "FHE_FACADE_STATS": sf})[0]
+    assert rms == PUBLISHED_RESIZE[(inter, n, t)]
+    recorded = max(int(m) for m in re.findall(r"recorded=(\d+)", open(sf).read()))
+    products = 867 * (25 if inter == "bicubic" else 6)                # 17 x 17 x 3 samples; Cubic: 5 products x 5 calls, Linear: 2 x 3
+    plain = {"bicubic": 867 * 5 * 20, "bilinear": 867 * 3 * 5}[inter]  # the Evaluator calls of the reference's mode ...
+    assert recorded >= plain + products                                # ... plus one relinearisation per product
 
 
 # Bicubic at t = 11: plaintext coefficients wrap modulo t and 23 of the 867 decoded samples leave [0, 255]
