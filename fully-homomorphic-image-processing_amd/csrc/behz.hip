@@ -399,14 +399,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_behz_tensor_intt_pm(cons
         // left to itself hipcc keeps two or three in flight and every pair of slots waits out a memory round trip
         constexpr int G = M == 1 ? 16 : 8;
         for (u32 ja = lo; ja < hi; ja++) {
-#ifdef BEHZ_EXP_TENSOR_SAME_OPERAND
-            // MEASUREMENT BUILD ONLY (profiles/EXPERIMENTS.md, round 5: never in the shipped library; results are WRONG): every term reads
-            // the SAME two operand polynomials, so all but the first reads of a workgroup hit the cache -- the upper bound of what sharing
-            // operand loads between the output polynomials of a (pair, prime) could buy
-            const u64 *pa = A + ((c * sa + 0) * nb + j) * N + tid, *pb = Bm + ((cb * sb + 0) * nb + j) * N + tid;
-#else
             const u64 *pa = A + ((c * sa + ja) * nb + j) * N + tid, *pb = Bm + ((cb * sb + (o - ja)) * nb + j) * N + tid;
-#endif
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += G) {
                 u64 xa[G], xb[G];
@@ -997,6 +990,43 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_inv_add_pm(const u
     store_coeff<L>(y, dst, tid);
 }
 
+// (2) + (3) in one launch (round 5, opt-in FHE_RELIN_FUSED=1: measured 1-3 % slower than the two launches at dbc = 30, level at dbc = 60): workgroup (c, pp, ii) forms acc[c][pp][ii] = sum_{i,d} dig * evk slot by slot in registers -- all
+// 32 operand loads of a term in flight before its first product, like the tensor step --, folds once, runs the inverse transform
+// and adds c_pp on the way out.  The accumulators never exist in memory (2 polynomials written and read back per ciphertext and
+// prime before) and one launch per relinearisation goes away; the digits are read once per pp instead of once (8 more polynomial
+// reads per (c, ii), out of L2 for the second reader).  Same integer sums, same fold, same transform: the same bits.
+template <int L, typename C>
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_accum_inv_add_pm(const u64 *ct, u64 stride, u64 *out, u64 out_stride, const u64 *__restrict__ dig,
+                                                                                const u64 *__restrict__ evk, RnsBase base, u32 nd) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u32 k = base.count, ii = blockIdx.x % k, pp = (blockIdx.x / k) & 1;
+    const u64 c = blockIdx.x / (2 * k);
+    const PmMod m = base.pm[ii];
+    u64 acc[1][16], y[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][r] = 0;
+    const u32 terms = k * nd;                            // (i, d) pairs, at most 20: 20 x 6q < 2^62 on a 55-bit base
+    for (u32 t = 0; t < terms; t++) {
+        const u64 *pa = dig + ((c * terms + t) * k + ii) * N + tid, *pb = evk + (((u64)t * 2 + pp) * k + ii) * N + tid;
+        u64 xa[16], xb[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { xa[r] = pa[r * TP]; xb[r] = pb[r * TP]; }
+        PM_FENCE();
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][r] += mulvv_pm(xa[r], xb[r], m);
+    }
+    u64 *dst = out + c * out_stride + ((u64)pp * k + ii) * N;
+    load_coeff<L>(y, ct + c * stride + ((u64)pp * k + ii) * N, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][r] = fold_pm(acc[0][r], m);
+    ntt_inv_regs_pm<L, 1, PM_FOLDED, C::XB, C::LIM, C::RQ>(acc, base.itw_pm + (size_t)ii * N, m, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; r++) y[r] = addmod(y[r], canon_rq_pm<C::RQ>(acc[0][r], m), m.q);
+    store_coeff<L>(y, dst, tid);
+}
+
 inline dim3 grid2(u32 n, u64 rows) { return dim3((n + 255) / 256, (unsigned)(rows < 32768 ? (rows ? rows : 1) : 32768)); }
 
 }  // namespace
@@ -1525,8 +1555,13 @@ extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64
 #define GO_PM(CC)                                                                                                                          \
     DISPATCH_L(c->logn, {                                                                                                                  \
         k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc);      \
-        k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                           \
-        k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, base); \
+        if (!c->opt.relin_fused) {                                                                                                        \
+            k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                       \
+            k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, base); \
+        } else {                                                                                                                           \
+            k_relin_accum_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, dig, \
+                                                                                                  (const u64 *)evk, base, nd);           \
+        }                                                                                                                                  \
     })
         if (c->qb.pm_class == 1) { GO_PM(PmA); } else { GO_PM(PmB); }
 #undef GO_PM

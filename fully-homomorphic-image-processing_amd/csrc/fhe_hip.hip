@@ -233,6 +233,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.dct_ldsc = !off("FHE_DCT_LDSC");
         o.dct_u64_fused = !off("FHE_DCT_U64_FUSED");
         if (const char *e = getenv("FHE_DCT_ONE_LAUNCH")) o.dct_one_launch = (u32)atoi(e);
+        o.relin_fused = env_on("FHE_RELIN_FUSED");
         o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
         o.ntt_single = env_on("FHE_NTT_SINGLE");
         o.ntt_nopm = env_on("FHE_NTT_NOPM");

@@ -491,6 +491,16 @@ def test_relinearize(fhe, oracle_mod, preset, dbc):
     got = fhe.to_host(ev.relinearize(fhe.to_device(prod), evk_dev, dbc))
     for i in range(2):
         assert np.array_equal(got[i], orc.relinearize(prod[i], evk, dbc=dbc))
+    # FHE_RELIN_FUSED=1: the key-switch sums formed inside the inverse-transform kernel (k_relin_accum_inv_add_pm) where the default runs
+    # the accumulation and the inverse transform + addition as two launches (k_relin_accum_pm + k_relin_inv_add_pm): same bits;
+    # and a batch that is not a multiple of anything, out of place (fhe_relinearize_to) with an operand at q - 1
+    alt = _variant(fhe, ctx, FHE_RELIN_FUSED=1)
+    big = np.concatenate([prod, prod[::-1], prod[:1]])
+    for i, q in enumerate(ctx.q):
+        big[4, :, i, :] = q - 1
+    g1 = fhe.to_host(ev.relinearize(fhe.to_device(big), evk_dev, dbc))
+    g2 = fhe.to_host(fhe.Evaluator(alt).relinearize(fhe.to_device(big), evk_dev, dbc))
+    assert np.array_equal(g1, g2) and np.array_equal(g1[:2], got) and np.array_equal(g1[4], orc.relinearize(big[4], evk, dbc=dbc))
     assert orc.decode(orc.decrypt(sk, got[0])[0]) == 3.5 * -2.25
     assert orc.decode(orc.decrypt(sk, got[1])[0]) == 3.5 * 3.5
 

@@ -25,6 +25,12 @@ python tools/sweep_ctct_chunk.py P8192 1024 > $O/bench_ctct_chunks.txt 2>&1
 python bench_circuits.py resize --cpu-pixels 4 > $O/bench_circuits_resize.json 2> /dev/null
 python bench_circuits.py resize --shared --cpu-pixels 4 > $O/bench_circuits_resize_shared.json 2> /dev/null
 python bench_circuits.py decode --cpu-terms 2 > $O/bench_circuits_decode.json 2> /dev/null
+# the relinearised mode: the same workloads with evaluator.relinearize after every product, dbc 30 (the reference's unused DBC) and 60
+for dbc in 30 60; do
+  python bench_circuits.py resize --relin $dbc > $O/bench_circuits_resize_relin$dbc.json 2> /dev/null
+  python bench_circuits.py resize --shared --relin $dbc > $O/bench_circuits_resize_shared_relin$dbc.json 2> /dev/null
+  python bench_circuits.py decode --relin $dbc > $O/bench_circuits_decode_relin$dbc.json 2> /dev/null
+done
 python tools/bench_rgb.py > $O/bench_rgb.txt 2>&1
 python tools/bench_server.py > $O/bench_server.txt 2>&1
 python tools/bench_server_resize.py > $O/bench_server_resize.txt 2>&1
@@ -35,13 +41,16 @@ python tools/run_ref_cli.py 48 48 --golden --pmod 3001 > $O/ref_cli_config0_lazy
 FHE_FACADE_EAGER=1 python tools/run_ref_cli.py 48 48 --golden --pmod 3001 > $O/ref_cli_config0_eager.txt 2>&1
 python tools/run_ref_resize.py bicubic 4096 101 > $O/ref_cli_resize.txt 2>&1
 python tools/run_ref_resize.py bilinear 4096 101 >> $O/ref_cli_resize.txt 2>&1
+FHE_FACADE_RELIN=30 python tools/run_ref_resize.py bicubic 4096 101 > $O/ref_cli_resize_relin30.txt 2>&1
 tools/prof.sh ${1}_bench python $R/bench.py --cpu-blocks 0 --no-verify > $O/kernel_stats_bench_default.txt 2>&1
 tools/prof.sh ${1}_resize python $R/bench_circuits.py resize > $O/kernel_stats_resize.txt 2>&1
 tools/prof.sh ${1}_resize_shared python $R/bench_circuits.py resize --shared > $O/kernel_stats_resize_shared.txt 2>&1
 tools/prof.sh ${1}_decode python $R/bench_circuits.py decode > $O/kernel_stats_decode.txt 2>&1
+tools/prof.sh ${1}_decode_relin30 python $R/bench_circuits.py decode --relin 30 > $O/kernel_stats_decode_relin30.txt 2>&1
+tools/prof.sh ${1}_resize_shared_relin30 python $R/bench_circuits.py resize --shared --relin 30 > $O/kernel_stats_resize_shared_relin30.txt 2>&1
 tools/prof.sh ${1}_ops8192 python $R/tools/bench_ops.py P8192 2048 > $O/kernel_stats_ops_P8192.txt 2>&1
 tools/prof.sh ${1}_seal23 python $R/bench.py --preset SEAL23_4096 --cpu-blocks 0 --no-verify --blocks 512 > $O/kernel_stats_bench_SEAL23_4096.txt 2>&1
-for d in bench resize resize_shared decode ops8192 seal23; do cp $R/gpurun_out/prof_${1}_$d/p_kernel_stats.csv $O/kernel_stats_$d.csv 2>/dev/null; done
+for d in bench resize resize_shared decode decode_relin30 resize_shared_relin30 ops8192 seal23; do cp $R/gpurun_out/prof_${1}_$d/p_kernel_stats.csv $O/kernel_stats_$d.csv 2>/dev/null; done
 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1
 python tools/soak.py > $O/soak.txt 2>&1
 python tools/soak.py 320 P8192 >> $O/soak.txt 2>&1

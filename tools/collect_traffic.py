@@ -131,6 +131,10 @@ CIRCUITS = {
     "resize": ["resize", "--max-pixels", "1024"],
     "resize_shared": ["resize", "--shared", "--max-pixels", "1024"],
     "decode": ["decode"],
+    # the relinearised mode (include/fhe_circuits.h fhe_circuits_create_relin), decomposition bit count 30
+    "resize_relin30": ["resize", "--relin", "30", "--max-pixels", "1024"],
+    "resize_shared_relin30": ["resize", "--shared", "--relin", "30", "--max-pixels", "1024"],
+    "decode_relin30": ["decode", "--relin", "30"],
 }
 NOT_THE_CIRCUIT = ("k_fill_random", "k_digest", "at::native", "rocclr", "k_make_shoup")      # inputs, digests, torch's own kernels, table set-up
 
@@ -171,12 +175,12 @@ def circuits(f_read, f_write):
         rd, line = run_pass_all("FETCH_SIZE", "circ_%s_fetch" % name, cmd)
         wr, _ = run_pass_all("WRITE_SIZE", "circ_%s_write" % name, cmd)
         jobs = line["job_executions"]
-        units = line["units_per_job"] if name != "decode" else 1           # per output pixel; per run
+        units = line["units_per_job"] if not name.startswith("decode") else 1           # per output pixel; per run
         per_kernel = {k: {"read_bytes_per_unit": rd[k] * 1024 * f_read / jobs / units, "write_bytes_per_unit": wr.get(k, 0.0) * 1024 * f_write / jobs / units}
                       for k in sorted(rd)}
         total = sum(v["read_bytes_per_unit"] + v["write_bytes_per_unit"] for v in per_kernel.values())
         alg = line["roofline"]["algorithmic_bytes_per_launch"] / units
-        res[name] = {"unit": "output pixel" if name != "decode" else "run", "hbm_bytes_per_unit": total, "algorithmic_bytes_per_unit": alg,
+        res[name] = {"unit": "output pixel" if not name.startswith("decode") else "run", "hbm_bytes_per_unit": total, "algorithmic_bytes_per_unit": alg,
                      "ratio_to_algorithmic": total / alg, "units_measured": line["units_per_job"], "job_executions": jobs, "per_kernel": per_kernel,
                      "command": "bench_circuits.py " + " ".join(argv)}
     for d in ("profiles", "gpurun_out"):
