@@ -267,7 +267,9 @@ def main():
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    # FHE_BENCH_FORCE_DIST=1: a process group even for ONE rank -- the RCCL initialisation, barrier, all-reduce and all-gather of the
+    # multi-GPU path execute (trivially) on a one-GPU box; tests/test_gpu_multi.py uses it so that the collective code has run on RCCL
+    if world > 1 or os.environ.get("FHE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -437,7 +439,7 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if path == 1 else "u64", "data": "synthetic",
-            "rccl_ranks": rccl_ranks, "collective_backend": ("rccl" if backend == "nccl" else backend + " (test mode: ranks share devices)") if world > 1 else None,
+            "rccl_ranks": rccl_ranks, "collective_backend": ("rccl" if backend == "nccl" else backend + " (test mode: ranks share devices)") if dist is not None else None,
             "ms_per_step_per_rank": rank_ms,
             "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=%d, %d coeff moduli, t=2^14" % (B, ctx.n, ctx.k),
                        "blocks_per_gpu": B, "poly_modulus_degree": ctx.n, "coeff_moduli": [hex(x) for x in ctx.q],

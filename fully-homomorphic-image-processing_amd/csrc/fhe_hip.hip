@@ -401,49 +401,51 @@ extern "C" int fhe_gather(const uint64_t *const *src_host, uint64_t count, uint6
         KERNEL_CHECK();
         return FHE_OK;
     }
-    // pointer tables go through a process-wide page-locked ring (the caller's array is pageable: handing it to hipMemcpyAsync would
-    // make the call wait for the stream); a slot is reused only after the copy that read it has run (one event per slot)
+    // Pointer tables go through a process-wide ring of page-locked host slots, each with its own device slot (allocated once): the
+    // caller's array is pageable (handing it to hipMemcpyAsync would make the call wait for the stream), and a slot pair is reused
+    // only after the gather KERNEL that read its device half has run (one event per slot, recorded behind the kernel).  A first
+    // version took the device table from hipMallocAsync / hipFreeAsync around every launch: on the default stream the kernel
+    // then read zeroed table entries now and then (memory access faults at addresses near 0 in the reference's server_resize
+    // through the lazy facade; tests/test_reference_published_resize.py) -- the stream-ordered pool is not used any more.
     struct PtrRing {
         enum : size_t { kSlots = 8, kSlotPtrs = 32768 };            // 256 KiB per slot
         std::mutex mu;
-        void **pinned = nullptr;
+        void **pinned = nullptr, **device = nullptr;
         hipEvent_t ev[kSlots] = {};
         bool used[kSlots] = {};
         int next = 0;
     };
-    static PtrRing *ring = new PtrRing();                            // never freed: static destructors may run after the runtime is gone
+    static PtrRing *rings[32] = {};                                  // one per device, never freed: static destructors may run after the runtime is gone
+    static std::mutex rings_mu;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));                                     // launches act on the calling thread's current device (include/fhe_hip.h)
+    if (dev < 0 || dev >= 32) return fail(FHE_ERR_PARAM, "gather: device %d out of range", dev);
+    PtrRing *ring;
+    {
+        std::lock_guard<std::mutex> lk0(rings_mu);
+        if (!rings[dev]) rings[dev] = new PtrRing();
+        ring = rings[dev];
+    }
+    std::lock_guard<std::mutex> lk(ring->mu);
+    if (!ring->pinned) {
+        hipError_t e = hipHostMalloc((void **)&ring->pinned, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&ring->device, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *));
+        for (int i = 0; i < (int)PtrRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) { ring->pinned = nullptr; return fail(FHE_ERR_HIP, "gather: pointer ring: %s", hipGetErrorString(e)); }
+    }
     for (u64 done = 0; done < count; done += PtrRing::kSlotPtrs) {
         const u64 part = std::min<u64>(PtrRing::kSlotPtrs, count - done);
-        void *table = nullptr;
-        HIP_TRY(hipMallocAsync(&table, part * sizeof(void *), st));
-        hipError_t e = hipSuccess;
-        {
-            std::lock_guard<std::mutex> lk(ring->mu);
-            if (!ring->pinned) {
-                e = hipHostMalloc((void **)&ring->pinned, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *), hipHostMallocDefault);
-                for (int i = 0; i < (int)PtrRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
-                if (e != hipSuccess) ring->pinned = nullptr;
-            }
-            if (e == hipSuccess) {
-                const int slot = ring->next;
-                ring->next = (slot + 1) % (int)PtrRing::kSlots;
-                if (ring->used[slot]) e = hipEventSynchronize(ring->ev[slot]);
-                void **p = ring->pinned + (size_t)slot * PtrRing::kSlotPtrs;
-                if (e == hipSuccess) {
-                    memcpy(p, src_host + done, part * sizeof(void *));
-                    e = hipMemcpyAsync(table, p, part * sizeof(void *), hipMemcpyHostToDevice, st);
-                }
-                if (e == hipSuccess) e = hipEventRecord(ring->ev[slot], st);
-                ring->used[slot] = e == hipSuccess;
-            }
-        }
-        if (e == hipSuccess) {
-            k_gather_table<<<dim3(bx, (unsigned)part), 256, 0, st>>>((const ulonglong2 *const *)table, part, (ulonglong2 *)(dst + done * dst_stride_words), pairs,
-                                                                    dst_stride_words / 2);
-            e = hipGetLastError();
-        }
-        (void)hipFreeAsync(table, st);
-        if (e != hipSuccess) return fail(FHE_ERR_HIP, "gather: %s", hipGetErrorString(e));
+        const int slot = ring->next;
+        ring->next = (slot + 1) % (int)PtrRing::kSlots;
+        if (ring->used[slot]) HIP_TRY(hipEventSynchronize(ring->ev[slot]));
+        void **hp = ring->pinned + (size_t)slot * PtrRing::kSlotPtrs, **dp = ring->device + (size_t)slot * PtrRing::kSlotPtrs;
+        memcpy(hp, src_host + done, part * sizeof(void *));
+        HIP_TRY(hipMemcpyAsync(dp, hp, part * sizeof(void *), hipMemcpyHostToDevice, st));
+        k_gather_table<<<dim3(bx, (unsigned)part), 256, 0, st>>>((const ulonglong2 *const *)dp, part, (ulonglong2 *)(dst + done * dst_stride_words), pairs,
+                                                                dst_stride_words / 2);
+        KERNEL_CHECK();
+        HIP_TRY(hipEventRecord(ring->ev[slot], st));
+        ring->used[slot] = true;
     }
     return FHE_OK;
 }

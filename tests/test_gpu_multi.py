@@ -97,3 +97,24 @@ def test_bench_gpus_more_than_devices_fails_loudly():
         assert "exposes %d HIP device" % have in r.stderr, r.stderr[-500:]
         r = _direct(script, extra + ["--gpus", "2"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
         assert r.returncode != 0 and "WORLD_SIZE is 1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_one_rank_process_group_runs_the_collectives_on_rccl():
+    """no box this repository has seen exposes two devices, so the multi-rank RCCL transfers have never run; what CAN run is the
+    collective code of bench.py on a ONE-rank RCCL communicator (FHE_BENCH_FORCE_DIST=1 under the launcher with one process):
+    communicator initialisation on the device, barrier, MAX / SUM all-reduces and the all-gather on device tensors, the digest
+    all-reduce (parallel.combine_digests) -- RCCL's kernels execute, and the line equals the plain one-process run"""
+    plain = _bench(["--blocks", "128", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FHE_BENCH_FORCE_DIST="1")
+    env.pop("FHE_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "128", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert one["collective_backend"] == "rccl" and one["rccl_ranks"] == 1 and one["n_gpus"] == 1 and len(one["ms_per_step_per_rank"]) == 1
+    assert one["output_digest"] == plain["output_digest"] and one["verified_bit_exact_vs_oracle"]

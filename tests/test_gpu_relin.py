@@ -232,3 +232,26 @@ def test_homomorphic_sin_known_answers_with_noise_budgets(fhe, oracle_mod):
             assert np.array_equal(p_rel.astype(np.int64), want), ("relinearised mode", v)
             ok_rel += 1
     assert ok_rel == len(xs), "the relinearised evaluation must keep a positive noise budget at n = 8192"
+
+
+def test_relin_handle_argument_errors(fhe, oracle_mod):
+    """fhe_circuits_create_relin: keys and bit count come together, dbc in 1..60; the handle reports its mode and its output sizes"""
+    import ctypes as C
+    ctx, orc, rorc, relin, _, _ = _setup(fhe, oracle_mod, "SMALL", 16)
+    L = fhe._lib.load()
+    h = C.c_void_p()
+    evk = C.c_void_p(relin[0].data_ptr())
+    assert L.fhe_circuits_create_relin(ctx.h, 100, 100, None, 30, C.byref(h)) < 0 and b"come together" in L.fhe_last_error()
+    assert L.fhe_circuits_create_relin(ctx.h, 100, 100, evk, 0, C.byref(h)) < 0
+    assert L.fhe_circuits_create_relin(ctx.h, 100, 100, evk, 61, C.byref(h)) < 0 and b"out of range" in L.fhe_last_error()
+    assert L.fhe_circuits_create_relin(ctx.h, 100, 100, evk, 16, C.byref(h)) == 0
+    K = fhe.circuits
+    assert L.fhe_circuits_relin_dbc(h) == 16
+    assert [L.fhe_circuits_out_size(h, c, a) for c, a in ((K.CUBIC, 2), (K.LINEAR, 2), (K.SAMPLE_BICUBIC, 0), (K.SAMPLE_LINEAR, 0), (K.SINCOS, 0), (K.STEP, 12), (K.STEP, 0),
+                                                        (K.DECODE, 3))] == [2] * 8
+    assert L.fhe_circuits_out_size(h, 99, 0) == 0
+    L.fhe_circuits_destroy(h)
+    plain = K.circuits_of(K.PlainCache(ctx))
+    assert L.fhe_circuits_relin_dbc(plain.h) == 0
+    assert [plain.out_size(c, a) for c, a in ((K.CUBIC, 2), (K.CUBIC, 4), (K.LINEAR, 3), (K.SAMPLE_BICUBIC, 0), (K.SAMPLE_LINEAR, 0), (K.SINCOS, 0), (K.STEP, 12), (K.STEP, 0))] \
+        == [4, 6, 4, 6, 4, 11, 22, 3]
