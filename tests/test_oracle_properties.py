@@ -152,3 +152,45 @@ def test_transform_constant_product_equals_plain_mulmod(oracle_mod):
         cases += [(rng.getrandbits(64), rng.randrange(q)) for _ in range(2000)]
         for a, w in cases:
             assert L.fo_mulmod_const_check(a, w, q) == (a * w) % q, (a, w, q)
+
+
+def test_relinearised_compositions_decrypt_to_the_closed_forms(oracle_mod):
+    """the checker of the relinearised mode (oracle.RelinOracle + the op-by-op restatements of Cubic / Linear / the samplers) pinned
+    on the CPU: fo_cubic == oracle_cubic_calls on the plain oracle (the C restatement and the Python one agree bit for bit), and
+    under RelinOracle every product comes back with two polynomials and the results decrypt to the closed forms with budget to
+    spare (n = 4096, three 36/37-bit moduli, dbc 30 and 60; at this small q the key switch costs a few bits against the reference's
+    size-4 result -- 30 against 33 at dbc 30 -- where at n = 8192 it gains them: tests/test_gpu_relin.py prints both)"""
+    om = oracle_mod
+    orc = om.Oracle(4096, Q3, T)
+    sk, pk = orc.keygen(5)
+    enc = lambda v, s: orc.encrypt(pk, orc.encode(v), seed=s)
+    A, B, C_, D, t = 10.0, 50.0, 90.0, 40.0, 0.25
+    cA, cB, cC, cD, ct = (enc(v, 20 + i) for i, v in enumerate((A, B, C_, D, t)))
+    ref = orc.cubic(cA, cB, cC, cD, ct)
+    assert np.array_equal(ref, om.oracle_cubic_calls(orc, cA, cB, cC, cD, ct)) and ref.shape[0] == 4
+    assert np.array_equal(orc.linear(cA, cB, ct), om.oracle_linear_calls(orc, cA, cB, ct))
+    a, b, c = -A + 3 * B - 3 * C_ + D, 2 * A - 5 * B + 4 * C_ - D, C_ - A
+    cubic = lambda A_, B_, C__, D_, t_: 0.5 * ((-A_ + 3 * B_ - 3 * C__ + D_) * t_ * t_ + (2 * A_ - 5 * B_ + 4 * C__ - D_) * t_ * t_ + (C__ - A_) * t_) + B_
+    expect = 0.5 * (a * t * t + b * t * t + c * t) + B
+    p_ref, b_ref = orc.decrypt(sk, ref)
+    assert orc.decode(p_ref) == expect
+    for dbc in (30, 60):
+        rorc = om.RelinOracle(orc, orc.evk_gen(sk, dbc=dbc), dbc)
+        rel = om.oracle_cubic_calls(rorc, cA, cB, cC, cD, ct)
+        assert rel.shape[0] == 2
+        p_rel, b_rel = orc.decrypt(sk, rel)
+        assert orc.decode(p_rel) == expect and b_rel > 0 and b_ref > 0, (dbc, b_rel, b_ref)
+        lin = om.oracle_linear_calls(rorc, cA, cB, ct)
+        assert lin.shape[0] == 2 and orc.decode(orc.decrypt(sk, lin)[0]) == (1 - t) * A + t * B
+    # level 2 -- a column Cubic over four row results, as SampleBicubic composes them -- needs the room of n = 8192 (218-bit q)
+    orc = om.Oracle.preset("P8192")
+    sk, pk = orc.keygen(6)
+    cA, cB, cC, cD, ct = (orc.encrypt(pk, orc.encode(v), seed=40 + i) for i, v in enumerate((A, B, C_, D, t)))
+    rorc = om.RelinOracle(orc, orc.evk_gen(sk, dbc=30), 30)
+    rows = [om.oracle_cubic_calls(rorc, cA, cB, cC, cD, ct), om.oracle_cubic_calls(rorc, cB, cC, cD, cA, ct),
+            om.oracle_cubic_calls(rorc, cC, cD, cA, cB, ct), om.oracle_cubic_calls(rorc, cD, cA, cB, cC, ct)]
+    col = om.oracle_sample_bicubic_calls(rorc, [cA, cB, cC, cD, cB, cC, cD, cA, cC, cD, cA, cB, cD, cA, cB, cC], ct, ct)
+    assert np.array_equal(col, om.oracle_cubic_calls(rorc, rows[0], rows[1], rows[2], rows[3], ct))
+    vals = [cubic(A, B, C_, D, t), cubic(B, C_, D, A, t), cubic(C_, D, A, B, t), cubic(D, A, B, C_, t)]
+    plain, budget = orc.decrypt(sk, col)
+    assert col.shape[0] == 2 and budget > 0 and abs(orc.decode(plain) - cubic(vals[0], vals[1], vals[2], vals[3], t)) < 1e-9

@@ -119,11 +119,13 @@ def test_plain_ring_model_reproduces_every_published_conversion():
     import subprocess
     import sys
     tool = os.path.join(ROOT, "tools", "plain_ring_model.py")
-    run = lambda *a: subprocess.run([sys.executable, tool] + list(a), capture_output=True, text=True, check=True).stdout.strip()
-    assert run("11").endswith("RMSError 17.9597")
-    assert run("11", "wrap").endswith("RMSError 17.9597")                 # no sample leaves [0, 255]: the clamp is invisible
-    assert run("11", "bicubic").endswith("RMSError " + BICUBIC_T11_CLAMPED)
-    assert run("11", "bicubic", "wrap").endswith("RMSError " + PUBLISHED_RESIZE[("bicubic", 4096, 11)])
+    run = lambda a: subprocess.run([sys.executable, tool] + list(a), capture_output=True, text=True, check=True).stdout.strip()
+    with ThreadPoolExecutor(4) as ex:                                     # four independent processes
+        r = list(ex.map(run, [("11",), ("11", "wrap"), ("11", "bicubic"), ("11", "bicubic", "wrap")]))
+    assert r[0].endswith("RMSError 17.9597")
+    assert r[1].endswith("RMSError 17.9597")                              # no sample leaves [0, 255]: the clamp is invisible
+    assert r[2].endswith("RMSError " + BICUBIC_T11_CLAMPED)
+    assert r[3].endswith("RMSError " + PUBLISHED_RESIZE[("bicubic", 4096, 11)])
     assert PUBLISHED_RESIZE[("bicubic", 4096, 11)] == "34.4"
 
 
