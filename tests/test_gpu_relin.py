@@ -194,13 +194,14 @@ def _ring_mul(a, b, t):
     return r % t
 
 
-def test_homomorphic_sin_known_answers_with_noise_budgets(fhe, oracle_mod):
+@pytest.mark.parametrize("dbc", [30, 60])
+def test_homomorphic_sin_known_answers_with_noise_budgets(fhe, oracle_mod, dbc):
     """the reference's own check (tests/test_decode.cpp:39-48: x in {1..7}, n = 8192, print the remaining noise budget and the
     decoded value beside sin x) in both modes.  The known answer is the PLAINTEXT polynomial: a correct BFV evaluation decrypts
     to exactly the product / sum of the encoded polynomials in Z_t[x]/(x^n + 1) whenever its noise budget is positive (for
     x = 1, 2, 3 the coefficients of the tenth power wrap modulo t = 2^14 and the decoded number is not sin x -- in the reference
     too; that is the encoder's limit, not the evaluation's).  Budgets of the two modes are printed side by side."""
-    ctx, orc, rorc, relin, sk, pk = _setup(fhe, oracle_mod, "P8192", 30, key_seed=5)
+    ctx, orc, rorc, relin, sk, pk = _setup(fhe, oracle_mod, "P8192", dbc, key_seed=5)
     ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
     t = ctx.t
     xs = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
@@ -224,8 +225,8 @@ def test_homomorphic_sin_known_answers_with_noise_budgets(fhe, oracle_mod):
             want = (want + _ring_mul(pw, E(cf), t)) % t
         p_ref, b_ref = orc.decrypt(sk, ref[i])
         p_rel, b_rel = orc.decrypt(sk, rel[i])
-        print("[relin P8192 dbc=30] homomorphic_sin(%g): plaintext model decodes to %.9f (sin = %.9f); noise budget left: reference mode %d bits, relinearised %d bits"
-              % (v, orc.decode(want.astype(np.uint64)), math.sin(v), b_ref, b_rel))
+        print("[relin P8192 dbc=%d] homomorphic_sin(%g): plaintext model decodes to %.9f (sin = %.9f); noise budget left: reference mode %d bits, relinearised %d bits"
+              % (dbc, v, orc.decode(want.astype(np.uint64)), math.sin(v), b_ref, b_rel))
         if b_ref > 0:
             assert np.array_equal(p_ref.astype(np.int64), want), ("reference mode", v)
         if b_rel > 0:
