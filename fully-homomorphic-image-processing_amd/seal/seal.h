@@ -509,7 +509,7 @@ struct UploadRing {
 // Process-wide, mutex-guarded; values are immutable, and Ciphertext::ptr() (the one mutable access) drops every copy.
 struct DownloadWindow {
     struct Entry { std::shared_ptr<Storage> st; size_t lo, hi, at, hits; };        // [lo, hi) of st (words) sits at arena word `at`
-    std::mutex mu;
+    std::recursive_mutex mu;              // also serialises every save (ciphertexts and keys): the save-side statistics are updated under it
     HostStage arena;
     size_t used = 0;
     std::vector<Entry> entries;
@@ -545,9 +545,10 @@ struct DownloadWindow {
         used += take;
         return arena.p + entries.back().at + (off - lo);
     }
-    void forget() { std::lock_guard<std::mutex> lk(mu); entries.clear(); strikes.clear(); used = 0; }
+    void forget() { std::lock_guard<std::recursive_mutex> lk(mu); entries.clear(); strikes.clear(); used = 0; }
 };
 inline void save_raw(std::ostream &os, const uint64_t *dev, size_t words, uint32_t polys, uint32_t k, uint32_t n) {
+    std::lock_guard<std::recursive_mutex> lk(DownloadWindow::instance().mu);
     const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', '1', 0};
     uint32_t hdr[4] = {polys, k, n, 0};
     os.write(magic, 8);
@@ -651,6 +652,8 @@ public:
     void save(std::ostream &os) const {
         if (!h_.p) { detail::save_raw(os, nullptr, 0, 0, 0, 0); return; }
         materialize();
+        detail::DownloadWindow &W = detail::DownloadWindow::instance();
+        std::lock_guard<std::recursive_mutex> lk(W.mu);
         const double t0 = detail::now_s();
         const detail::Node &nd = *h_.p;
         if (nd.st->words >= 2 * nd.words()) {
@@ -659,8 +662,6 @@ public:
             const uint32_t hdr[4] = {nd.size, nd.k, nd.n, 0};
             os.write(magic, 8);
             os.write((const char *)hdr, sizeof hdr);
-            detail::DownloadWindow &W = detail::DownloadWindow::instance();
-            std::lock_guard<std::mutex> lk(W.mu);
             const uint64_t *h = W.get(nd.st, nd.off, nd.words(), detail::io_seconds()[3]);
             if (h) os.write((const char *)h, (std::streamsize)(nd.words() * 8));
             else {                                            // saves that jump around a large allocation: one record at a time
