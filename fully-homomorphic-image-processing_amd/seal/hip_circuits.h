@@ -125,17 +125,38 @@ inline SamplePlan resize_sample_plan(uint32_t src_w, uint32_t src_h, uint32_t ds
 class Circuits {
 public:
     // the encoder arguments of seal::FractionalEncoder(t, poly, int_coeffs, frac_coeffs, 2) (homo/server_resize.cpp:110)
-    explicit Circuits(const SEALContext &ctx, int int_coeffs = 100, int frac_coeffs = 100) : ctx_(ctx), h_(nullptr) {
+    explicit Circuits(const SEALContext &ctx, int int_coeffs = 100, int frac_coeffs = 100) : ctx_(ctx), h_(nullptr), evk_() {
         detail::check(fhe_circuits_create(ctx.state()->h, int_coeffs, frac_coeffs, &h_), "circuits");
     }
+    // The RELINEARISED mode (include/fhe_circuits.h fhe_circuits_create_relin; SURVEY.md section 8(f) #4, not what the reference
+    // does): every multiply / square of every circuit is followed by evaluator.relinearize with these keys
+    // (KeyGenerator::generate_evaluation_keys(dbc, keys): the `dbc` the reference parses and never uses,
+    // homo/client_resize.cpp:26,47,72), so every result below has TWO polynomials (out_size()).  The keys are copied.
+    Circuits(const SEALContext &ctx, const EvaluationKeys &evk, int int_coeffs = 100, int frac_coeffs = 100) : ctx_(ctx), h_(nullptr), evk_(evk.buf) {
+        detail::check(fhe_circuits_create_relin(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, &h_), "circuits (relinearised)");
+    }
+    // the keys a context under FHE_FACADE_RELIN=<dbc> relinearises with (derived from the first secret key seen on it): a host that
+    // mixes the facade's one-at-a-time Evaluator calls with the batched circuits gets the SAME bits from both with these
+    static EvaluationKeys context_relin_keys(const SEALContext &ctx) {
+        const detail::CtxState &s = *ctx.state();
+        if (!s.relin_dbc || !s.relin_evk.words()) throw std::runtime_error("the context has no relinearisation keys (FHE_FACADE_RELIN unset, or no secret key seen yet)");
+        EvaluationKeys evk;
+        evk.buf = s.relin_evk;
+        evk.dbc = s.relin_dbc;
+        evk.digits = s.relin_digits;
+        return evk;
+    }
     ~Circuits() { if (h_) fhe_circuits_destroy(h_); }
+    // polynomials per output ciphertext of a circuit for this handle (FHE_CIRC_*; arg: operand size or degree)
+    uint32_t out_size(int circuit, uint32_t arg = 0) const { return fhe_circuits_out_size(h_, circuit, arg); }
+    bool relinearises() const { return fhe_circuits_relin_dbc(h_) != 0; }
     Circuits(const Circuits &) = delete;
     Circuits &operator=(const Circuits &) = delete;
 
     // Cubic (homo/fhe_resize.h:143-189) for A.count() independent tuples; t has size 2; result size A.size() + 2
     CiphertextBatch cubic(const CiphertextBatch &A, const CiphertextBatch &B, const CiphertextBatch &C, const CiphertextBatch &D, const CiphertextBatch &t) {
         same(A, B); same(A, C); same(A, D); need(t, A.count(), 2);
-        CiphertextBatch out(ctx_, A.count(), A.size() + 2);
+        CiphertextBatch out(ctx_, A.count(), out_size(FHE_CIRC_CUBIC, A.size()));
         const size_t bytes = scratch(fhe_cubic_scratch_bytes(h_, A.size(), A.count()));
         detail::check(fhe_cubic(h_, A.ptr(), B.ptr(), C.ptr(), D.ptr(), A.size(), t.ptr(), out.ptr(), A.count(), scratch_.ptr(), bytes, nullptr), "cubic");
         return out;
@@ -143,7 +164,7 @@ public:
     // Linear (homo/fhe_resize.h:191-204); result size A.size() + 1
     CiphertextBatch linear(const CiphertextBatch &A, const CiphertextBatch &B, const CiphertextBatch &t) {
         same(A, B); need(t, A.count(), 2);
-        CiphertextBatch out(ctx_, A.count(), A.size() + 1);
+        CiphertextBatch out(ctx_, A.count(), out_size(FHE_CIRC_LINEAR, A.size()));
         const size_t bytes = scratch(fhe_linear_scratch_bytes(h_, A.size(), A.count()));
         detail::check(fhe_linear(h_, A.ptr(), B.ptr(), A.size(), t.ptr(), out.ptr(), A.count(), scratch_.ptr(), bytes, nullptr), "linear");
         return out;
@@ -152,14 +173,14 @@ public:
     // indices into `pixels`; xfract / yfract = the offsets' encryptions (:230,234 / :262,266), one pair per output pixel
     CiphertextBatch sample_bicubic(const CiphertextBatch &pixels, const uint32_t *taps, const CiphertextBatch &xfract, const CiphertextBatch &yfract) {
         need(pixels, pixels.count(), 2); need(xfract, xfract.count(), 2); need(yfract, xfract.count(), 2);
-        CiphertextBatch out(ctx_, xfract.count(), 6);
+        CiphertextBatch out(ctx_, xfract.count(), out_size(FHE_CIRC_SAMPLE_BICUBIC));
         const size_t bytes = scratch(fhe_sample_bicubic_scratch_bytes(h_, xfract.count()));
         detail::check(fhe_sample_bicubic(h_, pixels.ptr(), pixels.count(), taps, xfract.ptr(), yfract.ptr(), out.ptr(), xfract.count(), scratch_.ptr(), bytes, nullptr), "sample_bicubic");
         return out;
     }
     CiphertextBatch sample_linear(const CiphertextBatch &pixels, const uint32_t *taps, const CiphertextBatch &xfract, const CiphertextBatch &yfract) {
         need(pixels, pixels.count(), 2); need(xfract, xfract.count(), 2); need(yfract, xfract.count(), 2);
-        CiphertextBatch out(ctx_, xfract.count(), 4);
+        CiphertextBatch out(ctx_, xfract.count(), out_size(FHE_CIRC_SAMPLE_LINEAR));
         const size_t bytes = scratch(fhe_sample_linear_scratch_bytes(h_, xfract.count()));
         detail::check(fhe_sample_linear(h_, pixels.ptr(), pixels.count(), taps, xfract.ptr(), yfract.ptr(), out.ptr(), xfract.count(), scratch_.ptr(), bytes, nullptr), "sample_linear");
         return out;
@@ -169,7 +190,7 @@ public:
     CiphertextBatch resize_bicubic(const CiphertextBatch &pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h,
                                    const CiphertextBatch &xfract, const CiphertextBatch &yfract, uint32_t batch = 256, uint32_t band_rows = 4) {
         need(pixels, (size_t)src_w * src_h, 2); need(xfract, dst_w, 2); need(yfract, dst_h, 2);
-        CiphertextBatch out(ctx_, (size_t)dst_w * dst_h, 6);
+        CiphertextBatch out(ctx_, (size_t)dst_w * dst_h, out_size(FHE_CIRC_SAMPLE_BICUBIC));
         const size_t bytes = scratch(fhe_resize_bicubic_shared_scratch_bytes(h_, src_w, src_h, dst_w, dst_h, batch, band_rows, 1));
         detail::check(fhe_resize_bicubic_shared(h_, pixels.ptr(), src_w, src_h, dst_w, dst_h, xfract.ptr(), yfract.ptr(), out.ptr(), batch, band_rows, nullptr, nullptr,
                                                 scratch_.ptr(), bytes, nullptr), "resize_bicubic");
@@ -192,7 +213,7 @@ public:
                                       uint32_t width, uint32_t height, const CiphertextBatch &zeros) {
         const size_t npos = (size_t)width * height;
         if (degree > 0) need(zeros, npos * degree * 2, 2);
-        CiphertextBatch out(ctx_, npos, fhe_approximated_step_out_size(degree));
+        CiphertextBatch out(ctx_, npos, out_size(FHE_CIRC_STEP, (uint32_t)degree));
         const size_t bytes = scratch(fhe_approximated_step_scratch_bytes(h_, degree, (uint32_t)npos));
         detail::check(fhe_approximated_step(h_, amplitude.ptr(), index.ptr(), count.ptr(), order, degree, delta, width, height, zeros.ptr(), out.ptr(), scratch_.ptr(), bytes,
                                             nullptr), "approximated_step");
@@ -207,7 +228,7 @@ public:
         const uint32_t pairs = (uint32_t)(runs.count() / 2);
         need(acc0, npos, 2);
         if (pairs) { need(runs, (size_t)pairs * 2, 2); if (degree > 0) need(zeros, (size_t)pairs * npos * degree * 2, 2); }
-        CiphertextBatch out(ctx_, npos, pairs ? fhe_approximated_step_out_size(degree) : 2);
+        CiphertextBatch out(ctx_, npos, pairs ? out_size(FHE_CIRC_DECODE, (uint32_t)degree) : 2);
         const size_t bytes = scratch(fhe_decode_channel_scratch_bytes(h_, degree, (uint32_t)npos, pairs));
         detail::check(fhe_decode_channel(h_, runs.ptr(), pairs, index.ptr(), acc0.ptr(), zeros.ptr(), order, degree, delta, width, height, out.ptr(), scratch_.ptr(), bytes,
                                          nullptr), "decode_channel");
@@ -218,7 +239,7 @@ public:
 private:
     CiphertextBatch sincos(int cosine, const CiphertextBatch &x, const CiphertextBatch &zero) {
         need(x, x.count(), 2); need(zero, x.count(), 2);
-        CiphertextBatch out(ctx_, x.count(), 11);
+        CiphertextBatch out(ctx_, x.count(), out_size(FHE_CIRC_SINCOS));
         const size_t bytes = scratch(fhe_homomorphic_sincos_scratch_bytes(h_, x.count()));
         detail::check(fhe_homomorphic_sincos(h_, cosine, x.ptr(), zero.ptr(), out.ptr(), x.count(), scratch_.ptr(), bytes, nullptr), "homomorphic_sincos");
         return out;
@@ -236,6 +257,7 @@ private:
     }
     SEALContext ctx_;
     fhe_circuits *h_;
+    detail::DevBuf evk_;                // relinearised mode: this handle's copy of the evaluation keys (must outlive h_)
     detail::DevBuf scratch_;
 };
 

@@ -11,11 +11,15 @@
 // facade's test hook and to (2) as arguments, from the same ciphertexts.
 //
 // usage: ref_vs_batched <n> <t>          (FHE_SEAL23_MODULI=1 selects SEAL 2.3's own moduli, as in the other harnesses)
+// FHE_FACADE_RELIN=<dbc>: the RELINEARISED mode on both sides -- (1) the reference's unchanged functions with the facade relinearising
+// after every multiply / square, (2) seal::hip::Circuits built with the same keys (fhe_circuits_create_relin): every ciphertext has
+// two polynomials and the two evaluations must still agree bit for bit.
 // Built at -O0 with the stack scrubbed before the decode circuits: homomorphic_cos has no return statement
 // (homo/fhe_decode.h:200), see ref_decode_circuit_main.cpp.
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <vector>
 
 #include "fhe_resize.h"   // the reference's headers, unchanged
@@ -75,10 +79,15 @@ int main(int argc, char **argv) {
         seal::detail::check(fhe_fill_random(st.h, b.ptr(), count * size, 0x5EA12026ULL + 977 * seed++, 0, nullptr), "fill");
         return b;
     };
-    seal::hip::Circuits circ(context, 100, 100);
+    const bool relin = std::getenv("FHE_FACADE_RELIN") != nullptr;
+    std::unique_ptr<seal::hip::Circuits> circ_p(relin ? new seal::hip::Circuits(context, seal::hip::Circuits::context_relin_keys(context), 100, 100)
+                                                      : new seal::hip::Circuits(context, 100, 100));
+    seal::hip::Circuits &circ = *circ_p;
+    if (relin != circ.relinearises()) { std::printf("MISMATCH: handle mode\n"); return 1; }
 
     // ---- Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 and 3 -> 4 ----------------------------
-    for (uint32_t size : {2u, 4u}) {
+    // (relinearised mode: every operand has two polynomials, so only the first of each)
+    for (uint32_t size : relin ? std::vector<uint32_t>{2u} : std::vector<uint32_t>{2u, 4u}) {
         const size_t cnt = 3;
         CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), C = random_batch(cnt, size), D = random_batch(cnt, size), T = random_batch(cnt, 2);
         CiphertextBatch got = circ.cubic(A, B, C, D, T);
@@ -88,7 +97,7 @@ int main(int argc, char **argv) {
             expect_equal(size == 2 ? "Cubic(2)" : "Cubic(4)", i, res, got, i);
         }
     }
-    for (uint32_t size : {2u, 3u}) {
+    for (uint32_t size : relin ? std::vector<uint32_t>{2u} : std::vector<uint32_t>{2u, 3u}) {
         const size_t cnt = 3;
         CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), T = random_batch(cnt, 2);
         CiphertextBatch got = circ.linear(A, B, T);

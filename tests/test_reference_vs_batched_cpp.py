@@ -12,7 +12,10 @@ from refrun import ref_bin
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,env", [(4096, {}), (8192, {"FHE_SEAL23_MODULI": "1"})])
+@pytest.mark.parametrize("n,env", [(4096, {}), (8192, {"FHE_SEAL23_MODULI": "1"}),
+                                   # the RELINEARISED mode on both sides: the reference's unchanged functions under FHE_FACADE_RELIN against
+                                   # seal::hip::Circuits built with the same keys (fhe_circuits_create_relin) -- size 2 everywhere, same bits
+                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_FACADE_RELIN": "30"}), (4096, {"FHE_FACADE_RELIN": "16"})])
 def test_reference_functions_equal_batched_cpp_api(n, env):
     exe = ref_bin("ref_vs_batched", True)
     if not exe:
