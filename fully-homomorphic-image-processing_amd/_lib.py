@@ -55,6 +55,7 @@ SIGNATURES = {
     "fhe_add": (_i, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "fhe_sub": (_i, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "fhe_negate": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "fhe_add_sizes": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u64, _i, _vp]),
     "fhe_plain_ntt_words": (_sz, [_vp]),
     "fhe_plain_prepare": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "fhe_plain_ntt_mul": (_i, [_vp, _vp, _vp, _vp, _vp]),

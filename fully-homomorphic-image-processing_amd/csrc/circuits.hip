@@ -1055,6 +1055,22 @@ int real_run(const fhe_circuits *cc, void *scratch, size_t bytes, fhe_stream s, 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// seal::Evaluator::add / sub on unequal sizes, batched (include/fhe_hip.h): k_add_general with identity maps
+extern "C" int fhe_add_sizes(const fhe_ctx *c, const uint64_t *a, uint32_t size_a, const uint64_t *b, uint32_t size_b, uint64_t *out, uint64_t count, int subtract,
+                             fhe_stream s) {
+    if (!c || !a || !b || !out) return fail(FHE_ERR_PARAM, "null argument");
+    if (size_a < 1 || size_b < 1) return fail(FHE_ERR_PARAM, "ciphertext sizes must be at least 1");
+    if (!count) return FHE_OK;
+    const u32 so = size_a > size_b ? size_a : size_b, half_n = c->n / 2;
+    const u64 nrp = count * so * c->k;
+    dim3 grid((half_n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+    hipStream_t st = (hipStream_t)s;
+    if (subtract) k_add_general<true><<<grid, 256, 0, st>>>((const ulonglong2 *)a, size_a, ident(), (const ulonglong2 *)b, size_b, ident(), (ulonglong2 *)out, so, c->qb.d_mod, c->k, half_n, nrp);
+    else k_add_general<false><<<grid, 256, 0, st>>>((const ulonglong2 *)a, size_a, ident(), (const ulonglong2 *)b, size_b, ident(), (ulonglong2 *)out, so, c->qb.d_mod, c->k, half_n, nrp);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
 extern "C" int fhe_circuits_create(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, fhe_circuits **out) {
     return fhe_circuits_create_relin(ctx, int_coeffs, frac_coeffs, nullptr, 0, out);
 }

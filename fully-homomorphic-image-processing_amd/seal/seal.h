@@ -790,14 +790,9 @@ inline void run_group(CtxState &s, const std::vector<Node *> &g, size_t lo, size
             if (sa == sb) {
                 const uint64_t *A = batch_operand(s, g, lo, hi, false, o, ta), *B = batch_operand(s, g, lo, hi, true, nullptr, tb);
                 check((sub ? fhe_sub : fhe_add)(s.h, A, B, o, (uint64_t)cnt * sa, nullptr), sub ? "sub" : "add");
-            } else {                       // destination grows (homo/fhe_resize.h:181-184, homo/fhe_decode.h:114-118,237); one value per group
-                const uint32_t m = std::min(sa, sb);
-                const uint64_t *A = f.a->ptr(), *B = f.b->ptr();
-                check((sub ? fhe_sub : fhe_add)(s.h, A, B, o, m, nullptr), sub ? "sub" : "add");
-                if (sa > sb) check(fhe_copy(o + m * pw, A + m * pw, (size_t)(sa - m) * pw * 8, nullptr), "copy");
-                else if (sub) check(fhe_negate(s.h, B + m * pw, o + m * pw, (uint64_t)(sb - m), nullptr), "negate");
-                else check(fhe_copy(o + m * pw, B + m * pw, (size_t)(sb - m) * pw * 8, nullptr), "copy");
-                ++s.stats.launches;
+            } else {                       // destination grows (homo/fhe_resize.h:181-184, homo/fhe_decode.h:114-118,237): fhe_add_sizes, batched like the rest
+                const uint64_t *A = batch_operand(s, g, lo, hi, false, nullptr, ta), *B = batch_operand(s, g, lo, hi, true, nullptr, tb);
+                check(fhe_add_sizes(s.h, A, sa, B, sb, o, cnt, sub ? 1 : 0, nullptr), sub ? "sub" : "add");
             }
             break;
         }
@@ -900,10 +895,9 @@ inline void flush(CtxState &s) {
             for (const Key &key : order) {
                 const std::vector<Node *> &g = groups[key];
                 const Node &f = *g[0];
-                const bool unequal = (f.op == Node::ADD || f.op == Node::SUB) && f.a->size != f.b->size;
-                // bound the staging memory of one launch (~1 GiB of operands); unequal-size additions go one at a time
+                // bound the staging memory of one launch (~1 GiB of operands)
                 const size_t words_each = (size_t)std::max(f.a->size, f.size) * s.poly_words();
-                const size_t chunk = unequal ? 1 : std::max<size_t>(1, std::min<size_t>(g.size(), ((size_t)1 << 27) / words_each));
+                const size_t chunk = std::max<size_t>(1, std::min<size_t>(g.size(), ((size_t)1 << 27) / words_each));
                 for (size_t lo = 0; lo < g.size(); lo += chunk) run_group(s, g, lo, std::min(g.size(), lo + chunk));
             }
         }

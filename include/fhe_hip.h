@@ -68,7 +68,7 @@ const char *fhe_last_error(void);
 /* ABI version of this header; bumped on any signature change and whenever entry points are added or a contract changes.
  *   1: rounds 1-3.
  *   2: + fhe_gather, fhe_host_alloc / fhe_host_free, fhe_stream_create / destroy, fhe_ctx_bind_thread / fhe_ctx_device,
- *      fhe_count_unreduced, the *_range / *_rows circuit shards, fhe_relinearize_to, the relinearised mode of the circuits
+ *      fhe_count_unreduced, fhe_add_sizes, the *_range / *_rows circuit shards, fhe_relinearize_to, the relinearised mode of the circuits
  *      (fhe_circuits_create_relin, fhe_circuits_out_size); fhe_ctx_create no longer builds or validates the ct x ct tables
  *      (auxiliary-prime failures surface at the first multiply or at fhe_circuits_create), fhe_arith_path builds them as
  *      a side effect, and the context's second stream exists only with FHE_DCT_PIPELINE=1.
@@ -136,6 +136,12 @@ int fhe_add(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *
 int fhe_sub(const fhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n_polys,
             fhe_stream stream);
 int fhe_negate(const fhe_ctx *ctx, const uint64_t *a, uint64_t *out, uint64_t n_polys, fhe_stream stream);
+/* The same add / sub for `count` pairs of ciphertexts of UNEQUAL sizes, batched (a: [count][size_a][k][n], b: [count][size_b][k][n],
+ * out: [count][max(size_a, size_b)][k][n]): the destination grows and the polynomials the shorter operand lacks count as zero
+ * (sub: the tail of b is negated), as seal::Evaluator does at homo/fhe_resize.h:181-184 and homo/fhe_decode.h:114-118,237 where a
+ * size-3 product meets a size-2 or a size-5 ciphertext.  out may alias the longer operand.  subtract: 0 = a + b, 1 = a - b. */
+int fhe_add_sizes(const fhe_ctx *ctx, const uint64_t *a, uint32_t size_a, const uint64_t *b, uint32_t size_b, uint64_t *out,
+                  uint64_t count, int subtract, fhe_stream stream);
 
 /* ---- plaintext operands ---------------------------------------------------------------------------
  * fhe_plain_prepare: centred lift of a seal::Plaintext (coefficients in [0,t), host memory) to the

@@ -161,6 +161,22 @@ int fhe_negate(const fhe_ctx *c, const uint64_t *a, uint64_t *out, uint64_t np, 
         }
     return FHE_OK;
 }
+int fhe_add_sizes(const fhe_ctx *c, const uint64_t *a, uint32_t sa, const uint64_t *b, uint32_t sb, uint64_t *out, uint64_t count,
+                  int subtract, fhe_stream s) {
+    (void)s;
+    const uint32_t so = sa > sb ? sa : sb;
+    uint64_t *tmp = (uint64_t *)malloc((size_t)so * pw(c) * 8);
+    if (!tmp) return fail(FHE_ERR_NOMEM, "out of memory");
+    for (uint64_t i = 0; i < count; i++) {              /* fo_add / fo_sub grow their first operand in place */
+        memset(tmp, 0, (size_t)so * pw(c) * 8);
+        memcpy(tmp, a + i * sa * pw(c), (size_t)sa * pw(c) * 8);
+        if (subtract) fo_sub(c->o, tmp, sa, b + i * sb * pw(c), sb);
+        else fo_add(c->o, tmp, sa, b + i * sb * pw(c), sb);
+        memcpy(out + i * so * pw(c), tmp, (size_t)so * pw(c) * 8);
+    }
+    free(tmp);
+    return FHE_OK;
+}
 
 int fhe_ntt_forward(const fhe_ctx *c, const uint64_t *in, uint64_t *out, uint64_t np, fhe_stream s) {
     (void)s;

@@ -1094,3 +1094,30 @@ def test_u64_fused_switch_selects_the_general_path(fhe, oracle_mod):
     want = fhe.to_host(fhe.Evaluator(ctx).dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), blocks))
     assert np.array_equal(fhe.to_host(fhe.Evaluator(alt).dct8x8_quant(fhe.DctPlan(alt, fhe.YQT), blocks)), want)
     assert np.array_equal(want[1], orc.dct_quant(fhe.to_host(blocks)[1], fhe.YQT))
+
+
+@pytest.mark.parametrize("preset", ["SMALL", "P8192"])
+def test_add_sub_of_unequal_sizes_batched(fhe, oracle_mod, preset):
+    """fhe_add_sizes: seal::Evaluator::add / sub where the destination grows (homo/fhe_resize.h:181-184, homo/fhe_decode.h:114-118,237),
+    for a whole batch in one launch -- against the oracle's fo_add / fo_sub and the golden big-integer vectors' conventions
+    (missing polynomials count as zero; a - b negates the tail of b); out aliasing the longer operand"""
+    import ctypes as C
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    L = fhe._lib
+    for sa, sb in ((2, 4), (4, 2), (3, 2), (2, 5), (1, 3)):
+        a, b = ctx.random_ct(5, size=sa, seed=60 + sa), ctx.random_ct(5, size=sb, seed=70 + sb)
+        a[1] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=a.device).view(1, ctx.k, 1).expand(sa, ctx.k, ctx.n)
+        ha, hb = fhe.to_host(a), fhe.to_host(b)
+        for sub in (0, 1):
+            out = ctx.empty(5, size=max(sa, sb))
+            L.call("fhe_add_sizes", ctx.h, C.c_void_p(a.data_ptr()), sa, C.c_void_p(b.data_ptr()), sb, C.c_void_p(out.data_ptr()), 5, sub, None)
+            got = fhe.to_host(out)
+            for i in (0, 1, 4):
+                assert np.array_equal(got[i], (orc.sub if sub else orc.add)(ha[i], hb[i])), (sa, sb, sub, i)
+        big, small, s_big = (a, b, sa) if sa > sb else (b, a, sb)
+        alias = big.clone()                                                      # in place on the longer operand
+        L.call("fhe_add_sizes", ctx.h, C.c_void_p(alias.data_ptr()), s_big, C.c_void_p(small.data_ptr()), min(sa, sb), C.c_void_p(alias.data_ptr()), 5, 0, None)
+        assert np.array_equal(fhe.to_host(alias)[2], orc.add(fhe.to_host(big)[2], fhe.to_host(small)[2]))
+    with pytest.raises(fhe._lib.FheError):
+        L.call("fhe_add_sizes", ctx.h, C.c_void_p(a.data_ptr()), 0, C.c_void_p(b.data_ptr()), 2, C.c_void_p(a.data_ptr()), 1, 0, None)
