@@ -379,7 +379,8 @@ def _row_windows(H, h, init_rows):
     return out
 
 
-def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None, rows=None, validate=True):
+def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, encrypt_fractions, rows_per_step=4, io_threads=8, slots=3, stats=None, rows=None, validate=True,
+                  relin=None):
     """homo/server_resize.cpp:127-146 + ResizeImage (homo/fhe_resize.h:308-392) on the GPU.
 
     Input stream: src_w * src_h pixels, row by row, three ciphertext records (R, G, B) per pixel
@@ -415,7 +416,8 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     pc = circuits.PlainCache(ctx)
     residues = _ResidueCheck(ctx, validate)
     init_rows = 4 if bicubic else 2
-    out_size = 6 if bicubic else 4
+    # relin=(evk_ntt, dbc): the RELINEARISED mode (circuits.py; every product of Cubic / Linear relinearised) -- records of size 2
+    out_size = 2 if relin is not None else (6 if bicubic else 4)
     if dst_w < 2 or dst_h < 2 or src_h < init_rows or src_w < 1:
         raise ValueError("image too small for the sampler")
     rec_in = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
@@ -553,7 +555,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
                 t_start.append(torch.cuda.Event(enable_timing=True))
                 t_start[-1].record(main)
             for ch in range(3):
-                dout[d][:npx, ch].copy_(sampler(ev, pc, ring_flat, taps + ch, xf, yf))   # [npx, out_size, k, n] into the interleaved record order
+                dout[d][:npx, ch].copy_(sampler(ev, pc, ring_flat, taps + ch, xf, yf, relin=relin))   # [npx, out_size, k, n] into the interleaved record order
             if stats is not None:
                 t_stop.append(torch.cuda.Event(enable_timing=True))
                 t_stop[-1].record(main)
@@ -610,7 +612,7 @@ def make_zero_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False)
     return encrypt
 
 
-def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, order=64, degree=12, delta=0.5, shard=None, group=None):
+def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, order=64, degree=12, delta=0.5, shard=None, group=None, relin=None):
     """homo/server_decode.cpp:113-148 on the GPU, with the HOMOMORPHIC overload of approximated_step
     (homo/fhe_decode.h:202-242; the reference's main passes its debugging Decryptor and thereby selects the
     decrypting overload, :244-282, which needs the secret key on the server -- out of scope).
@@ -703,10 +705,11 @@ def server_decode(ctx, in_path, out_path, width, height, pairs, encrypt_zeros, o
                 zeros = torch.stack([draw(base[ch] + 1 + npos + (r * npos + p0) * per_pos, np_ * per_pos) for r in range(p)])
                 zeros = zeros.reshape(p, np_, degree, 2, 2, ctx.k, ctx.n).contiguous()
         runs = dev[first_run[ch]:first_run[ch] + p].contiguous() if p else None
-        res.append(circuits.decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=(p0, p1)))
+        res.append(circuits.decode_channel(ev, pc, runs, index, acc0, zeros, order, degree, delta, width, height, positions=(p0, p1), relin=relin))
     torch.cuda.synchronize()
     # output stream: position-major, the three channels interleaved; record sizes follow from `pairs`, so every record has a fixed offset
-    so = [int(_lib_out_size(degree)) if pairs[ch] else 2 for ch in range(3)]
+    # relin=(evk_ntt, dbc): the relinearised mode (circuits.py) -- every record then has two polynomials
+    so = [(2 if relin is not None else int(_lib_out_size(degree))) if pairs[ch] else 2 for ch in range(3)]
     rec = [RECORD_HEADER + so[ch] * ctx.k * ctx.n * 8 for ch in range(3)]
     stride = sum(rec)
     fd = os.open(out_path, os.O_RDWR | os.O_CREAT, 0o644)

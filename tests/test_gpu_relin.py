@@ -256,3 +256,66 @@ def test_relin_handle_argument_errors(fhe, oracle_mod):
     assert L.fhe_circuits_relin_dbc(plain.h) == 0
     assert [plain.out_size(c, a) for c, a in ((K.CUBIC, 2), (K.CUBIC, 4), (K.LINEAR, 3), (K.SAMPLE_BICUBIC, 0), (K.SAMPLE_LINEAR, 0), (K.SINCOS, 0), (K.STEP, 12), (K.STEP, 0))] \
         == [4, 6, 4, 6, 4, 11, 22, 3]
+
+
+def test_streaming_servers_in_the_relinearised_mode(fhe, oracle_mod, tmp_path):
+    """server.server_resize / server.server_decode with relin=(evk, dbc): the streaming loops of homo/server_resize.cpp and
+    homo/server_decode.cpp with every product relinearised -- records of size 2, each equal to the oracle's relinearised
+    composition on the same stream (sampled pixels; every decode position)"""
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from refrun import clamp, parse_stream, read_records, sample_origins, write_record
+    ctx, orc, rorc, relin, _, _ = _setup(fhe, oracle_mod, "SEAL23_4096", 30)
+    W = H = 10
+    w = h = 6
+    pix = orc.random_ct(W * H * 3, seed=21).reshape(W * H, 3, 2, orc.k, orc.n)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for p in range(W * H):
+            for c in range(3):
+                write_record(f, pix[p, c])
+    bank = orc.random_ct(w * h * 2, seed=22)
+    pos = [0]
+
+    def encrypt(values):
+        out = bank[pos[0]:pos[0] + len(values)]
+        pos[0] += len(values)
+        return fhe.to_device(np.ascontiguousarray(out))
+    for bicubic in (True, False):
+        pos[0] = 0
+        assert fhe.server.server_resize(ctx, str(fin), str(fout), W, H, w, h, bicubic, encrypt, rows_per_step=3, relin=relin) == w * h
+        out = read_records(str(fout), 2, orc.k, orc.n, w * h * 3)
+        origins = sample_origins(W, H, w, h)
+        for o in (0, 7, w * h - 1):
+            xi, yi = origins[o]
+            P = lambda dx, dy, ch: pix[clamp(yi + dy, 0, H - 1) * W + clamp(xi + dx, 0, W - 1), ch]
+            for ch in (0, 2):
+                if bicubic:
+                    want = oracle_mod.oracle_sample_bicubic_calls(rorc, [P(dx, dy, ch) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)], bank[2 * o], bank[2 * o + 1])
+                else:
+                    want = oracle_mod.oracle_sample_linear_calls(rorc, [P(0, 0, ch), P(1, 0, ch), P(0, 1, ch), P(1, 1, ch)], bank[2 * o], bank[2 * o + 1])
+                assert np.array_equal(out[o * 3 + ch], want), (bicubic, o, ch)
+    # decode: two channels with runs, one without
+    from refrun import oracle_server_decode
+    pairs, width, height, order, degree, delta = (1, 0, 1), 2, 1, 64, 1, 0.5
+    runs = orc.random_ct(2 * sum(pairs), seed=31).reshape(sum(pairs), 2, 2, orc.k, orc.n)
+    hook = orc.random_ct(sum(1 + width * height + p * width * height * degree * 2 for p in pairs), seed=32)
+    din, dout = tmp_path / "dec_in.ct", tmp_path / "dec_out.ct"
+    with open(din, "wb") as f:
+        for r in range(runs.shape[0]):
+            write_record(f, runs[r, 0])
+            write_record(f, runs[r, 1])
+    at = [0]
+
+    def zeros(count):
+        out = hook[at[0]:at[0] + count]
+        at[0] += count
+        return fhe.to_device(np.ascontiguousarray(out))
+    zeros.seek = lambda i: at.__setitem__(0, i)
+    fhe.server.server_decode(ctx, str(din), str(dout), width, height, pairs, zeros, order=order, degree=degree, delta=delta, relin=relin)
+    got = parse_stream(open(dout, "rb").read(), orc.k, orc.n)
+    want = oracle_server_decode(rorc, oracle_mod, runs, pairs, width, height, hook, order, degree, delta)
+    assert len(got) == 3 * width * height
+    for i in range(width * height):
+        for ch in range(3):
+            assert got[i * 3 + ch].shape[0] == 2 and np.array_equal(got[i * 3 + ch], want[ch][i]), (i, ch)
