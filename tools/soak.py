@@ -48,6 +48,18 @@ def step_digest():
 
 
 ref_step = step_digest()
+# the relinearised mode (fhe_circuits_create_relin): the same circuits with a key switch after every product -- the wave-local
+# transposes of the digit transforms, the relinearisation scratch inside the arena, sizes 2 throughout
+relin = (fhe.KeyGenerator(ctx, seed=1).generate_evaluation_keys(30).contiguous(), 30)
+
+
+def relin_digests():
+    o = fhe.circuits.sample_bicubic(ev, pc, pix, taps[:half], xf[:half].contiguous(), yf[:half].contiguous(), relin=relin)
+    st = torch.cat(fhe.circuits.approximated_step(ev, pc, s_amp, s_idx, s_cnt, order=64, degree=3, delta=0.5, width=3, height=1, zeros=s_zeros, relin=relin))
+    return [ctx.digest(o.view(-1)), ctx.digest(st.view(-1))]
+
+
+ref_relin = relin_digests()
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -77,5 +89,8 @@ for i in range(iters):
         if step_digest() != ref_step:
             bad += 1
             print("approximated_step digest mismatch at iteration", i, flush=True)
+        if relin_digests() != ref_relin:
+            bad += 1
+            print("relinearised circuits digest mismatch at iteration", i, flush=True)
 print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
