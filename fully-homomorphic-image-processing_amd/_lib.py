@@ -12,7 +12,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h"), os.path.join(os.path.dirname(_HERE), "include", "fhe_stream.h")]
 
 FHE_OK = 0
-ABI_VERSION = 2      # FHE_ABI_VERSION of the include/fhe_hip.h this table was written against
+ABI_VERSION = 3      # FHE_ABI_VERSION of the include/fhe_hip.h this table was written against
 
 
 class FheError(RuntimeError):
@@ -89,6 +89,11 @@ SIGNATURES = {
     "fhe_fill_random": (_i, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "fhe_digest": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "fhe_count_unreduced": (_i, [_vp, _vp, _u64, _vp, _vp]),
+    "fhe_noise_cdt": (None, [_vp]),
+    "fhe_frac_encode_batch": (_i, [_vp, _vp, _u64, _i, _i, _vp, _vp]),
+    "fhe_encrypt_scratch_bytes": (_sz, [_vp, _u64]),
+    "fhe_encrypt_batch": (_i, [_vp, _vp, _vp, _u64, C.c_char_p, _u64, _vp, _vp, _sz, _vp]),
+    "fhe_encrypt_draws": (_i, [_vp, C.c_char_p, _u64, _u64, _vp, _vp]),
     # include/fhe_circuits.h
     "fhe_circuits_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "fhe_circuits_destroy": (_i, [_vp]),

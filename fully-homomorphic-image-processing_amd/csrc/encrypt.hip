@@ -1,0 +1,284 @@
+// encrypt.hip -- the servers' own encryptions as batches on the device (include/fhe_hip.h, "server-side encryptions").
+// The reference encrypts inside its loops: frac(x), frac(y) per output pixel (homo/fhe_resize.h:230,234,262,266), an encode(0)
+// per homomorphic_sin / cos (homo/fhe_decode.h:54,134), the index and the accumulators of server_decode (homo/server_decode.cpp:
+// 121,126).  One seal::Encryptor::encrypt is Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2): here `count` of them are
+//   k_enc_sample_u      u from the ChaCha20 stream of (key, first_index + i), as residues          [count][k][n]
+//   fhe_ntt_forward     in place
+//   k_enc_pk_mul        (pk0 u, pk1 u) per slot                                                    [count][2][k][n]
+//   fhe_ntt_inverse     in place
+//   k_enc_finish        + e1 / e2 from the same stream, + Delta m' on c0
+// -- five launches per BATCH where the Python and the facade encryptors made five per ciphertext plus three uploads.
+// All sampling is 32/64-bit integer work (no transcendental functions), so the oracle's restatement draws the same values.
+#include "internal.h"
+
+namespace {
+// floor(2^63 P(|e| <= i)), i = 0..18, for the rounded normal with sigma = 3.19 redrawn beyond 19 (tools/noise_cdt.py recomputes the
+// table with 90 digits; tests/test_encrypt_sampler.py compares)
+__constant__ u64 kNoiseCdtDev[FHE_NOISE_CDT_LEN] = {
+    0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL, 0x7aad3cf138611a69ULL,
+    0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL, 0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL,
+    0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL, 0x7ffffff3ceaa701fULL};
+const u64 kNoiseCdtHost[FHE_NOISE_CDT_LEN] = {
+    0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL, 0x7aad3cf138611a69ULL,
+    0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL, 0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL,
+    0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL, 0x7ffffff3ceaa701fULL};
+
+struct ChaChaKey { u32 w[8]; };
+
+__device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+#define CHACHA_QR(a, b, c, d)                \
+    a += b; d ^= a; d = rotl32(d, 16);       \
+    c += d; b ^= c; b = rotl32(b, 12);       \
+    a += b; d ^= a; d = rotl32(d, 8);        \
+    c += d; b ^= c; b = rotl32(b, 7);
+// one 64-byte block as eight little-endian u64: state = "expand 32-byte k" | key | block counter (64 bit) | nonce (64 bit), 20 rounds
+__device__ __forceinline__ void chacha20_block(const ChaChaKey &key, u64 counter, u64 nonce, u64 out[8]) {
+    const u32 s0 = 0x61707865u, s1 = 0x3320646eu, s2 = 0x79622d32u, s3 = 0x6b206574u;
+    const u32 s12 = (u32)counter, s13 = (u32)(counter >> 32), s14 = (u32)nonce, s15 = (u32)(nonce >> 32);
+    u32 x0 = s0, x1 = s1, x2 = s2, x3 = s3, x4 = key.w[0], x5 = key.w[1], x6 = key.w[2], x7 = key.w[3], x8 = key.w[4], x9 = key.w[5], x10 = key.w[6],
+        x11 = key.w[7], x12 = s12, x13 = s13, x14 = s14, x15 = s15;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        CHACHA_QR(x0, x4, x8, x12)
+        CHACHA_QR(x1, x5, x9, x13)
+        CHACHA_QR(x2, x6, x10, x14)
+        CHACHA_QR(x3, x7, x11, x15)
+        CHACHA_QR(x0, x5, x10, x15)
+        CHACHA_QR(x1, x6, x11, x12)
+        CHACHA_QR(x2, x7, x8, x13)
+        CHACHA_QR(x3, x4, x9, x14)
+    }
+    out[0] = (u64)(x0 + s0) | ((u64)(x1 + s1) << 32);
+    out[1] = (u64)(x2 + s2) | ((u64)(x3 + s3) << 32);
+    out[2] = (u64)(x4 + key.w[0]) | ((u64)(x5 + key.w[1]) << 32);
+    out[3] = (u64)(x6 + key.w[2]) | ((u64)(x7 + key.w[3]) << 32);
+    out[4] = (u64)(x8 + key.w[4]) | ((u64)(x9 + key.w[5]) << 32);
+    out[5] = (u64)(x10 + key.w[6]) | ((u64)(x11 + key.w[7]) << 32);
+    out[6] = (u64)(x12 + s12) | ((u64)(x13 + s13) << 32);
+    out[7] = (u64)(x14 + s14) | ((u64)(x15 + s15) << 32);
+}
+__device__ __forceinline__ int draw_ternary(u64 r) { return (int)__umul64hi(r, 3) - 1; }
+__device__ __forceinline__ int draw_noise(u64 r) {
+    const u64 x = r >> 1;
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < FHE_NOISE_CDT_LEN; ++i) m += x >= kNoiseCdtDev[i] ? 1 : 0;
+    return (r & 1) ? -m : m;
+}
+
+// one thread = one ChaCha block = eight consecutive coefficients of one encryption's u, written as its k residues
+__global__ __launch_bounds__(256) void k_enc_sample_u(ChaChaKey key, u64 first_index, u64 count, u64 *__restrict__ out, const Modulus *__restrict__ mods, u32 k,
+                                                      u32 n) {
+    const u64 per = n / 8, total = count * per;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 e = g / per, b = g % per;
+        u64 r[8];
+        chacha20_block(key, b, first_index + e, r);
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = draw_ternary(r[i]);
+        for (u32 p = 0; p < k; ++p) {
+            const u64 q = mods[p].q;
+            ulonglong2 *dst = (ulonglong2 *)(out + (e * k + p) * n + b * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ulonglong2 w;
+                w.x = v[2 * i] < 0 ? q - 1 : (u64)v[2 * i];
+                w.y = v[2 * i + 1] < 0 ? q - 1 : (u64)v[2 * i + 1];
+                dst[i] = w;
+            }
+        }
+    }
+}
+
+// out[e][j][p][s] = u_ntt[e][p][s] * pk_ntt[j][p][s]
+__global__ __launch_bounds__(256) void k_enc_pk_mul(const u64 *__restrict__ u_ntt, const u64 *__restrict__ pk_ntt, u64 *__restrict__ out,
+                                                    const Modulus *__restrict__ mods, u32 k, u32 n, u64 count) {
+    const u64 rows = count * k;
+    for (u64 rp = blockIdx.y; rp < rows; rp += gridDim.y) {
+        const u64 e = rp / k;
+        const u32 p = (u32)(rp % k);
+        const Modulus m = mods[p];
+        const u64 *u = u_ntt + rp * n, *p0 = pk_ntt + (u64)p * n, *p1 = pk_ntt + ((u64)k + p) * n;
+        u64 *o0 = out + ((e * 2) * k + p) * n, *o1 = out + ((e * 2 + 1) * k + p) * n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 x = u[i];
+            o0[i] = mul_barrett(x, p0[i], m);
+            o1[i] = mul_barrett(x, p1[i], m);
+        }
+    }
+}
+
+struct EncLift {                      // plaintext lifting of add_plain (fhe_hip.hip fhe_add_plain): Delta m' = delta m (+ q mod t for the upper half)
+    u64 t, threshold;
+    u64 delta[FHE_MAX_K], increment[FHE_MAX_K];
+};
+// one thread = eight consecutive coefficients of polynomial j of encryption e: its noise block, every residue
+__global__ __launch_bounds__(256) void k_enc_finish(ChaChaKey key, u64 first_index, u64 count, u64 *__restrict__ ct, const u64 *__restrict__ plain,
+                                                    const Modulus *__restrict__ mods, u32 k, u32 n, EncLift L) {
+    const u64 per = n / 8, total = count * 2 * per;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 b = g % per, ej = g / per, e = ej / 2;
+        const u32 j = (u32)(ej % 2);
+        u64 r[8];
+        chacha20_block(key, (u64)(1 + j) * per + b, first_index + e, r);
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = draw_noise(r[i]);
+        u64 m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool any = false;
+        if (j == 0 && plain) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { m[i] = plain[e * n + b * 8 + i]; any |= m[i] != 0; }
+        }
+        for (u32 p = 0; p < k; ++p) {
+            const Modulus md = mods[p];
+            const u64 q = md.q;
+            ulonglong2 *dst = (ulonglong2 *)(ct + (ej * k + p) * n + b * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ulonglong2 w = dst[i];
+                u64 a[2] = {w.x, w.y};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nv = v[2 * i + h];
+                    u64 x = addmod(a[h], nv < 0 ? q - (u64)(-nv) : (u64)nv, q);
+                    if (any) {
+                        const u64 mm = m[2 * i + h];
+                        if (mm) {
+                            u64 lift = mul_barrett(L.delta[p], mm % q, md);
+                            if (mm >= L.threshold) lift = addmod(lift, L.increment[p], q);
+                            x = addmod(x, lift, q);
+                        }
+                    }
+                    a[h] = x;
+                }
+                w.x = a[0];
+                w.y = a[1];
+                dst[i] = w;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_enc_draws(ChaChaKey key, u64 first_index, u64 count, signed char *__restrict__ out, u32 n) {
+    const u64 per = n / 8, total = count * 3 * per;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 b = g % (3 * per), e = g / (3 * per);               // b = block counter: role = b / per
+        u64 r[8];
+        chacha20_block(key, b, first_index + e, r);
+        const bool tern = b < per;
+        signed char *dst = out + e * 3 * n + b * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = (signed char)(tern ? draw_ternary(r[i]) : draw_noise(r[i]));
+    }
+}
+
+// FractionalEncoder::encode (fhe_frac_encode, fhe_hip.hip) per value: coefficient d < int_coeffs = bit d of |whole| (negated for a negative
+// value), coefficient n - i = bit i of the binary expansion of |frac| with flipped sign.  Bit i of |frac| is the low bit of
+// trunc(|frac| 2^i): the scaling is exact, and beyond 2^53 the product is an even integer (the host loop's doubling and
+// subtracting reaches the same digits: every step of it is exact)
+__global__ __launch_bounds__(256) void k_frac_encode(const double *__restrict__ values, u64 count, int int_coeffs, int frac_coeffs, u64 t, u64 *__restrict__ out,
+                                                     u32 n) {
+    for (u64 e = blockIdx.y; e < count; e += gridDim.y) {
+        const double value = values[e];
+        const long long whole = (long long)value;
+        const double frac = fabs(value - (double)whole);
+        const u64 mag = whole < 0 ? (u64)(-whole) : (u64)whole;
+        const bool negative = value < 0;
+        for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+            u64 coef = 0;
+            if (c < (u32)int_coeffs && c < 64 && ((mag >> c) & 1)) coef = whole < 0 ? t - 1 : 1;
+            const u32 i = n - c;                                       // digit of weight 2^-i
+            if (frac != 0.0 && i >= 1 && i <= (u32)frac_coeffs && i <= 1074) {
+                const double x = ldexp(frac, (int)i);                  // < 2^1074: finite
+                const bool bit = x < 9007199254740992.0 ? (((u64)x) & 1) != 0 : false;
+                if (bit) coef = negative ? 1 : t - 1;
+            }
+            out[e * n + c] = coef;
+        }
+    }
+}
+
+ChaChaKey load_key(const uint8_t key[32]) {
+    ChaChaKey k;
+    for (int i = 0; i < 8; ++i) k.w[i] = (u32)key[4 * i] | ((u32)key[4 * i + 1] << 8) | ((u32)key[4 * i + 2] << 16) | ((u32)key[4 * i + 3] << 24);
+    return k;
+}
+unsigned blocks_for(u64 threads) {
+    const u64 b = (threads + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+}  // namespace
+
+extern "C" void fhe_noise_cdt(uint64_t out[FHE_NOISE_CDT_LEN]) {
+    for (int i = 0; i < FHE_NOISE_CDT_LEN; ++i) out[i] = kNoiseCdtHost[i];
+}
+
+extern "C" int fhe_frac_encode_batch(const fhe_ctx *c, const double *values, uint64_t count, int int_coeffs, int frac_coeffs, uint64_t *d_plain, fhe_stream s) {
+    if (!c || (!values && count) || (!d_plain && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (int_coeffs < 0 || frac_coeffs < 0 || (uint32_t)(int_coeffs + frac_coeffs) > c->n) return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");
+    for (u64 i = 0; i < count; ++i) {                                  // the refusals of fhe_frac_encode, before anything is launched
+        const double v = values[i];
+        if (!std::isfinite(v) || std::fabs(v) >= 9.0e18) return fail(FHE_ERR_PARAM, "value %llu out of range", (unsigned long long)i);
+        const long long whole = (long long)v;
+        const u64 mag = whole < 0 ? (u64)(-whole) : (u64)whole;
+        if (int_coeffs < 64 && (mag >> int_coeffs)) return fail(FHE_ERR_PARAM, "integer part of value %llu needs more than %d coefficients", (unsigned long long)i, int_coeffs);
+    }
+    hipStream_t st = (hipStream_t)s;
+    const u64 per_slot = FHE_STAGE_SLOT_BYTES / sizeof(double);
+    for (u64 done = 0; done < count; done += per_slot) {
+        const u64 part = count - done < per_slot ? count - done : per_slot;
+        FheStage sg;
+        int rc = fhe_stage_acquire(values + done, part * sizeof(double), st, &sg);
+        if (rc) return rc;
+        dim3 grid((c->n + 255) / 256, (unsigned)(part < 32768 ? part : 32768));
+        k_frac_encode<<<grid, 256, 0, st>>>((const double *)sg.dev, part, int_coeffs, frac_coeffs, c->t, (u64 *)d_plain + done * c->n, c->n);
+        const hipError_t le = hipGetLastError();
+        rc = fhe_stage_release(sg, st);
+        if (le != hipSuccess) return fail(FHE_ERR_HIP, "kernel launch: %s", hipGetErrorString(le));
+        if (rc) return rc;
+    }
+    return FHE_OK;
+}
+
+extern "C" size_t fhe_encrypt_scratch_bytes(const fhe_ctx *c, uint64_t count) { return c ? (size_t)count * c->k * c->n * sizeof(u64) : 0; }
+
+extern "C" int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *d_pk_ntt, const uint64_t *d_plain, uint64_t count, const uint8_t key[32], uint64_t first_index,
+                                 uint64_t *d_out, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!c || !d_pk_ntt || !key || (!d_out && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (!count) return FHE_OK;
+    if (!scratch || scratch_bytes < fhe_encrypt_scratch_bytes(c, count)) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_encrypt_scratch_bytes()");
+    if (first_index + count < first_index) return fail(FHE_ERR_PARAM, "encryption index wraps: a (key, index) pair would repeat");
+    if (c->n % 8) return fail(FHE_ERR_PARAM, "n must be a multiple of 8");
+    hipStream_t st = (hipStream_t)s;
+    const ChaChaKey k = load_key(key);
+    u64 *u = (u64 *)scratch;
+    k_enc_sample_u<<<blocks_for(count * (c->n / 8)), 256, 0, st>>>(k, first_index, count, u, c->qb.d_mod, c->k, c->n);
+    KERNEL_CHECK();
+    int rc = fhe_ntt_forward(c, (const uint64_t *)u, (uint64_t *)u, count, s);
+    if (rc) return rc;
+    {
+        const u64 rows = count * c->k;
+        dim3 grid((c->n + 255) / 256, (unsigned)(rows < 32768 ? rows : 32768));
+        k_enc_pk_mul<<<grid, 256, 0, st>>>(u, (const u64 *)d_pk_ntt, (u64 *)d_out, c->qb.d_mod, c->k, c->n, count);
+        KERNEL_CHECK();
+    }
+    if ((rc = fhe_ntt_inverse(c, d_out, d_out, count * 2, s))) return rc;
+    EncLift L;
+    L.t = c->t;
+    L.threshold = c->upper_half_threshold;
+    for (u32 i = 0; i < FHE_MAX_K; ++i) { L.delta[i] = i < c->k ? c->delta_mod[i] : 0; L.increment[i] = i < c->k ? c->upper_half_increment[i] : 0; }
+    k_enc_finish<<<blocks_for(count * 2 * (c->n / 8)), 256, 0, st>>>(k, first_index, count, (u64 *)d_out, (const u64 *)d_plain, c->qb.d_mod, c->k, c->n, L);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+extern "C" int fhe_encrypt_draws(const fhe_ctx *c, const uint8_t key[32], uint64_t first_index, uint64_t count, int8_t *d_draws, fhe_stream s) {
+    if (!c || !key || (!d_draws && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (!count) return FHE_OK;
+    if (c->n % 8) return fail(FHE_ERR_PARAM, "n must be a multiple of 8");
+    k_enc_draws<<<blocks_for(count * 3 * (c->n / 8)), 256, 0, (hipStream_t)s>>>(load_key(key), first_index, count, (signed char *)d_draws, c->n);
+    KERNEL_CHECK();
+    return FHE_OK;
+}

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -401,53 +403,95 @@ extern "C" int fhe_gather(const uint64_t *const *src_host, uint64_t count, uint6
         KERNEL_CHECK();
         return FHE_OK;
     }
-    // Pointer tables go through a process-wide ring of page-locked host slots, each with its own device slot (allocated once): the
-    // caller's array is pageable (handing it to hipMemcpyAsync would make the call wait for the stream), and a slot pair is reused
-    // only after the gather KERNEL that read its device half has run (one event per slot, recorded behind the kernel).  A first
-    // version took the device table from hipMallocAsync / hipFreeAsync around every launch: on the default stream the kernel
-    // then read zeroed table entries now and then (memory access faults at addresses near 0 in the reference's server_resize
-    // through the lazy facade; tests/test_reference_published_resize.py) -- the stream-ordered pool is not used any more.
-    struct PtrRing {
-        enum : size_t { kSlots = 8, kSlotPtrs = 32768 };            // 256 KiB per slot
-        std::mutex mu;
-        void **pinned = nullptr, **device = nullptr;
-        hipEvent_t ev[kSlots] = {};
-        bool used[kSlots] = {};
-        int next = 0;
-    };
-    static PtrRing *rings[32] = {};                                  // one per device, never freed: static destructors may run after the runtime is gone
-    static std::mutex rings_mu;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));                                     // launches act on the calling thread's current device (include/fhe_hip.h)
-    if (dev < 0 || dev >= 32) return fail(FHE_ERR_PARAM, "gather: device %d out of range", dev);
-    PtrRing *ring;
-    {
-        std::lock_guard<std::mutex> lk0(rings_mu);
-        if (!rings[dev]) rings[dev] = new PtrRing();
-        ring = rings[dev];
-    }
-    std::lock_guard<std::mutex> lk(ring->mu);
-    if (!ring->pinned) {
-        hipError_t e = hipHostMalloc((void **)&ring->pinned, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&ring->device, PtrRing::kSlots * PtrRing::kSlotPtrs * sizeof(void *));
-        for (int i = 0; i < (int)PtrRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
-        if (e != hipSuccess) { ring->pinned = nullptr; return fail(FHE_ERR_HIP, "gather: pointer ring: %s", hipGetErrorString(e)); }
-    }
-    for (u64 done = 0; done < count; done += PtrRing::kSlotPtrs) {
-        const u64 part = std::min<u64>(PtrRing::kSlotPtrs, count - done);
-        const int slot = ring->next;
-        ring->next = (slot + 1) % (int)PtrRing::kSlots;
-        if (ring->used[slot]) HIP_TRY(hipEventSynchronize(ring->ev[slot]));
-        void **hp = ring->pinned + (size_t)slot * PtrRing::kSlotPtrs, **dp = ring->device + (size_t)slot * PtrRing::kSlotPtrs;
-        memcpy(hp, src_host + done, part * sizeof(void *));
-        HIP_TRY(hipMemcpyAsync(dp, hp, part * sizeof(void *), hipMemcpyHostToDevice, st));
-        k_gather_table<<<dim3(bx, (unsigned)part), 256, 0, st>>>((const ulonglong2 *const *)dp, part, (ulonglong2 *)(dst + done * dst_stride_words), pairs,
+    // Pointer tables go through the per-device staging ring (fhe_stage_acquire below): the caller's array is pageable (handing it to
+    // hipMemcpyAsync would make the call wait for the stream), and a slot is reused only after the gather KERNEL that read its
+    // device half has run.  A first version took the device table from hipMallocAsync / hipFreeAsync around every launch: on the
+    // default stream the kernel then read zeroed table entries now and then (memory access faults at addresses near 0 in the
+    // reference's server_resize through the lazy facade; tests/test_reference_published_resize.py) -- the stream-ordered pool is
+    // not used any more.
+    const u64 slot_ptrs = FHE_STAGE_SLOT_BYTES / sizeof(void *);
+    for (u64 done = 0; done < count; done += slot_ptrs) {
+        const u64 part = std::min<u64>(slot_ptrs, count - done);
+        FheStage sg;
+        int rc = fhe_stage_acquire(src_host + done, part * sizeof(void *), st, &sg);
+        if (rc) return rc;
+        k_gather_table<<<dim3(bx, (unsigned)part), 256, 0, st>>>((const ulonglong2 *const *)sg.dev, part, (ulonglong2 *)(dst + done * dst_stride_words), pairs,
                                                                 dst_stride_words / 2);
-        KERNEL_CHECK();
-        HIP_TRY(hipEventRecord(ring->ev[slot], st));
-        ring->used[slot] = true;
+        const hipError_t le = hipGetLastError();
+        rc = fhe_stage_release(sg, st);
+        if (le != hipSuccess) return fail(FHE_ERR_HIP, "kernel launch: %s", hipGetErrorString(le));
+        if (rc) return rc;
     }
     return FHE_OK;
+}
+
+// Small host -> device hand-overs (pointer tables, batches of doubles): a process-wide ring per device of kSlots page-locked host
+// slots, each with its own device slot, allocated once and never freed (static destructors may run after the runtime is gone).
+// acquire: copies `bytes` into a free slot, enqueues the upload on `st`, returns the device address; the caller launches the kernel
+// that reads it on the SAME stream and calls release, which records the slot's event behind that kernel -- the slot is handed out
+// again only after that event has completed.  Thread-safe: a slot between acquire and release is skipped by other threads.
+namespace {
+struct StageRing {
+    enum : int { kSlots = 8 };
+    std::mutex mu;
+    std::condition_variable cv;
+    char *pinned = nullptr, *device = nullptr;
+    hipEvent_t ev[kSlots] = {};
+    bool used[kSlots] = {}, busy[kSlots] = {};
+    int next = 0;
+};
+StageRing *g_stage_rings[32] = {};
+std::mutex g_stage_rings_mu;
+}  // namespace
+int fhe_stage_acquire(const void *host, size_t bytes, hipStream_t st, FheStage *out) {
+    if (!host || !out || !bytes || bytes > FHE_STAGE_SLOT_BYTES) return fail(FHE_ERR_PARAM, "staging: %zu bytes do not fit a slot", bytes);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));                                     // launches act on the calling thread's current device (include/fhe_hip.h)
+    if (dev < 0 || dev >= 32) return fail(FHE_ERR_PARAM, "staging: device %d out of range", dev);
+    StageRing *ring;
+    {
+        std::lock_guard<std::mutex> lk0(g_stage_rings_mu);
+        if (!g_stage_rings[dev]) g_stage_rings[dev] = new StageRing();
+        ring = g_stage_rings[dev];
+    }
+    std::unique_lock<std::mutex> lk(ring->mu);
+    if (!ring->pinned) {
+        hipError_t e = hipHostMalloc((void **)&ring->pinned, (size_t)StageRing::kSlots * FHE_STAGE_SLOT_BYTES, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&ring->device, (size_t)StageRing::kSlots * FHE_STAGE_SLOT_BYTES);
+        for (int i = 0; i < StageRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) { ring->pinned = nullptr; return fail(FHE_ERR_HIP, "staging ring: %s", hipGetErrorString(e)); }
+    }
+    int slot = -1;
+    for (;;) {
+        for (int i = 0; i < StageRing::kSlots; ++i) {
+            const int cand = (ring->next + i) % StageRing::kSlots;
+            if (!ring->busy[cand]) { slot = cand; break; }
+        }
+        if (slot >= 0) break;
+        ring->cv.wait(lk);
+    }
+    ring->next = (slot + 1) % StageRing::kSlots;
+    ring->busy[slot] = true;
+    const bool wait = ring->used[slot];
+    lk.unlock();
+    auto give_back = [&] { std::lock_guard<std::mutex> g(ring->mu); ring->busy[slot] = false; ring->cv.notify_one(); };
+    if (wait && hipEventSynchronize(ring->ev[slot]) != hipSuccess) { give_back(); return fail(FHE_ERR_HIP, "staging ring: event wait failed"); }
+    char *hp = ring->pinned + (size_t)slot * FHE_STAGE_SLOT_BYTES, *dp = ring->device + (size_t)slot * FHE_STAGE_SLOT_BYTES;
+    memcpy(hp, host, bytes);
+    if (hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { give_back(); return fail(FHE_ERR_HIP, "staging ring: upload failed"); }
+    out->dev = dp;
+    out->slot = slot;
+    out->ring = ring;
+    return FHE_OK;
+}
+int fhe_stage_release(const FheStage &sg, hipStream_t st) {
+    StageRing *ring = (StageRing *)sg.ring;
+    const hipError_t e = hipEventRecord(ring->ev[sg.slot], st);
+    std::lock_guard<std::mutex> g(ring->mu);
+    ring->used[sg.slot] = true;                                      // even after a failed record: the next user then waits on the slot's previous event at worst
+    ring->busy[sg.slot] = false;
+    ring->cv.notify_one();
+    return e == hipSuccess ? FHE_OK : fail(FHE_ERR_HIP, "staging ring: event record failed");
 }
 
 // ------------------------------------------------------------------------------------------------

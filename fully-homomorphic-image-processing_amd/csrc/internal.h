@@ -150,6 +150,12 @@ int fhe_multiply_plain_sum(const fhe_ctx *c, const PlainSumTerms &T, const u64 *
                            hipStream_t st);
 
 // cross-TU internals
+// small host -> device hand-overs through the per-device ring of page-locked slots (fhe_hip.hip): acquire copies `bytes` (at most one
+// slot) and enqueues the upload on `st`; the caller launches the kernel that reads `dev` on the same stream, then calls release
+#define FHE_STAGE_SLOT_BYTES ((size_t)256 << 10)
+struct FheStage { void *dev; int slot; void *ring; };
+int fhe_stage_acquire(const void *host, size_t bytes, hipStream_t st, FheStage *out);
+int fhe_stage_release(const FheStage &sg, hipStream_t st);
 int fhe_ntt_launch(bool inverse, const fhe_ctx *c, const BaseTables &B, const u64 *in, u64 *out, u64 n_res_polys, hipStream_t st);
 int fhe_build_base(BaseTables &B, const std::vector<u64> &primes, u32 n, u32 logn, bool want_f64);
 void fhe_free_base(BaseTables &B);

@@ -152,6 +152,66 @@ class Encryptor:
         return ct
 
 
+class DeviceEncryptor:
+    """Batches of fresh encryptions formed on the device (include/fhe_hip.h fhe_encrypt_batch; csrc/encrypt.hip) -- what a
+    SERVER needs: the reference's loops encrypt two fractions per output pixel (homo/fhe_resize.h:230,234,262,266) and an
+    encode(0) per homomorphic_sin / cos, accumulator and index (homo/fhe_decode.h:54,134; homo/server_decode.cpp:121,126).
+    u, e1, e2 come from the ChaCha20 stream of (key, index): the key is 32 bytes from the operating system's generator unless
+    `key` is given (tests; a key must never meet the same index twice), `index` counts the encryptions made under it --
+    `seek(i)` sets the number of the next one, so a shard of a job that starts at encryption i of the reference's sequence
+    produces the same ciphertexts as the whole job (the role _IndexedEncryptions plays for the host sampler)."""
+
+    def __init__(self, ctx, public_key, key=None, int_coeffs=None, frac_coeffs=None):
+        self.ctx = ctx
+        self._pk_ntt = _ntt(ctx, public_key.contiguous())
+        self._given_key = key is not None
+        self.key = os.urandom(32) if key is None else bytes(key)
+        if len(self.key) != 32:
+            raise ValueError("the sampler key has 32 bytes")
+        self.next = 0
+        self.int_coeffs = 100 if int_coeffs is None else int(int_coeffs)          # seal::FractionalEncoder(t, poly_modulus, 100, 100, 2), homo/server_resize.cpp
+        self.frac_coeffs = 100 if frac_coeffs is None else int(frac_coeffs)
+        self._scratch = None
+
+    def seek(self, i):
+        if not self._given_key:
+            raise RuntimeError("seek on an encryptor keyed by the OS generator could repeat a (key, index) pair; pass a key (tests) to position the stream")
+        self.next = int(i)
+
+    def _run(self, plain, count):
+        ctx = self.ctx
+        out = torch.empty((count, 2, ctx.k, ctx.n), dtype=torch.int64, device=ctx.device)
+        if count:
+            need = int(_lib.load().fhe_encrypt_scratch_bytes(ctx.h, count))
+            if self._scratch is None or self._scratch.numel() * 8 < need:
+                self._scratch = torch.empty((need + 7) // 8, dtype=torch.int64, device=ctx.device)
+            _lib.call("fhe_encrypt_batch", ctx.h, _ptr(self._pk_ntt), _ptr(plain) if plain is not None else None, count, self.key, self.next,
+                      _ptr(out), _ptr(self._scratch), self._scratch.numel() * 8, _stream())
+            self.next += count
+        return out
+
+    def encrypt_values(self, values):
+        """[len(values), 2, k, n]: Enc(encode(v)) for every v (FractionalEncoder::encode on the device, bit for bit the host encoder)"""
+        vals = np.ascontiguousarray(values, dtype=np.float64)
+        plain = torch.empty((len(vals), self.ctx.n), dtype=torch.int64, device=self.ctx.device)
+        if len(vals):
+            _lib.call("fhe_frac_encode_batch", self.ctx.h, vals.ctypes.data_as(C.c_void_p), len(vals), self.int_coeffs, self.frac_coeffs, _ptr(plain), _stream())
+        return self._run(plain, len(vals))
+
+    def encrypt_plains(self, plains):
+        """plains: [count, n] device tensor of coefficients below t"""
+        return self._run(plains.contiguous(), int(plains.shape[0]))
+
+    def encrypt_zeros(self, count):
+        return self._run(None, int(count))
+
+    def draws(self, first, count):
+        """[count, 3, n] int8 on the host: (u, e1, e2) of encryptions first .. first + count - 1 (for checks)"""
+        d = torch.empty((count, 3, self.ctx.n), dtype=torch.int8, device=self.ctx.device)
+        _lib.call("fhe_encrypt_draws", self.ctx.h, self.key, int(first), int(count), _ptr(d), _stream())
+        return d.cpu().numpy()
+
+
 class Decryptor:
     def __init__(self, ctx, secret_key):
         self.ctx = ctx

@@ -348,14 +348,35 @@ class _IndexedEncryptions:
         return self.er.encrypt(plain)
 
 
-def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False):
+def _sampler_key(seed):
+    """32-byte sampler key of a reproducible test encryptor (never for data that needs protecting: seed=None draws the key from the OS)"""
+    import hashlib
+    return hashlib.sha256(b"fhe-hip server-side encryptions\0" + repr(seed).encode()).digest()
+
+
+def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False, device=None):
     """The circuit's server-side encryptions (homo/fhe_resize.h:230,234,262,266): a callable
     values -> [len(values), 2, k, n] of fresh encryptions of encode(v) under `public_key`
     ([2, k, n] device tensor).  seed=None draws from the OS CSPRNG.  indexed=True (tests; needs a seed): the callable has
-    `seek(i)` and the i-th encryption depends on (seed, i) only, so sharded and whole-image runs agree bit for bit."""
+    `seek(i)` and the i-th encryption depends on (seed, i) only, so sharded and whole-image runs agree bit for bit.
+
+    device=True (the default without a seed): the whole batch is encoded and encrypted on the GPU -- keys.DeviceEncryptor,
+    fhe_frac_encode_batch + fhe_encrypt_batch, five launches per call -- from a ChaCha20 stream keyed by the OS generator
+    (or by the seed: then `seek(i)` exists whatever `indexed` says); encryption i of the callable's life uses stream i.  device=False:
+    the host sampler (numpy), one ciphertext at a time (five launches and three uploads each: what rounds 2-4 did)."""
     from .evaluator import FractionalEncoder
-    from .keys import Encryptor
+    from .keys import DeviceEncryptor, Encryptor
     enc = encoder or FractionalEncoder(ctx)
+    if device is None:
+        device = seed is None
+    if device:
+        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed), int_coeffs=enc.int_coeffs, frac_coeffs=enc.frac_coeffs)
+
+        def encrypt_batch(values):
+            return der.encrypt_values([float(v) for v in values])
+        if seed is not None:                           # a key from the OS generator only ever counts upwards: no (key, index) pair repeats
+            encrypt_batch.seek = der.seek
+        return encrypt_batch
     er = _IndexedEncryptions(ctx, public_key, seed) if indexed else Encryptor(ctx, public_key, seed=seed)
 
     def encrypt(values):
@@ -595,12 +616,22 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
 # ------------------------------------------------------------------------------------------------
 # server_decode: the run-length decoder's driver loop (homo/server_decode.cpp:113-148) over a ciphertext stream
 # ------------------------------------------------------------------------------------------------
-def make_zero_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False):
+def make_zero_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False, device=None):
     """The decode path's server-side encryptions (homo/server_decode.cpp:121,126; homo/fhe_decode.h:54,134): a
     callable count -> [count, 2, k, n] of fresh encryptions of encode(0.0) under `public_key` ([2, k, n] device
-    tensor).  seed=None draws from the OS CSPRNG.  indexed=True: as make_fraction_encryptor."""
+    tensor).  seed=None draws from the OS CSPRNG.  indexed=True / device: as make_fraction_encryptor."""
     from .evaluator import FractionalEncoder
-    from .keys import Encryptor
+    from .keys import DeviceEncryptor, Encryptor
+    if device is None:
+        device = seed is None
+    if device:
+        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed))
+
+        def encrypt_batch(count):
+            return der.encrypt_zeros(count)
+        if seed is not None:
+            encrypt_batch.seek = der.seek
+        return encrypt_batch
     enc = encoder or FractionalEncoder(ctx)
     er = _IndexedEncryptions(ctx, public_key, seed) if indexed else Encryptor(ctx, public_key, seed=seed)
     zero = enc.encode(0.0)

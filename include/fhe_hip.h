@@ -72,9 +72,10 @@ const char *fhe_last_error(void);
  *      (fhe_circuits_create_relin, fhe_circuits_out_size); fhe_ctx_create no longer builds or validates the ct x ct tables
  *      (auxiliary-prime failures surface at the first multiply or at fhe_circuits_create), fhe_arith_path builds them as
  *      a side effect, and the context's second stream exists only with FHE_DCT_PIPELINE=1.
+ *   3: + fhe_encrypt_batch / fhe_encrypt_scratch_bytes / fhe_encrypt_draws / fhe_noise_cdt, fhe_frac_encode_batch.
  * A host compiled against this header compares fhe_abi_version() with FHE_ABI_VERSION before anything else (the Python
  * binding and seal/seal.h do). */
-#define FHE_ABI_VERSION 2
+#define FHE_ABI_VERSION 3
 uint32_t fhe_abi_version(void);
 
 /* ---- context: replaces seal::EncryptionParameters + seal::SEALContext -------------------------
@@ -279,6 +280,39 @@ int fhe_rgb_to_ycc(const fhe_ctx *ctx, uint64_t *r, uint64_t *g, uint64_t *b, ui
  * [3 n_blocks][64][2][k][n] is the input layout of fhe_dct8x8_quant and the order homo/server_jpeg.cpp:146-153 saves. */
 int fhe_rgb_to_ycc_blocks(const fhe_ctx *ctx, uint64_t *blocks, uint64_t n_blocks, int int_coeffs, int frac_coeffs,
                           fhe_stream stream);
+
+/* ---- server-side encryptions (round 5) ------------------------------------------------------------
+ * The reference's servers ENCRYPT inside their loops: SampleLinear / SampleBicubic encrypt frac(x) and frac(y) for every output
+ * pixel (homo/fhe_resize.h:230,234,262,266: `encryptor.encrypt(encoder.encode(x - floor(x)), xfract)`), homomorphic_sin / cos an
+ * encode(0) per call (homo/fhe_decode.h:54,134), server_decode the index and the accumulators (homo/server_decode.cpp:121,126).
+ * With the circuits batched these encryptions were what a server spent its time on (host sampling, three uploads and five
+ * launches per ciphertext); the entry points below form a whole batch on the device:
+ *     Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2)        u ternary, e1, e2 rounded normals (sigma 3.19, redrawn beyond 19)
+ * (textbook BFV, SURVEY.md App. A.7 -- what seal::Encryptor::encrypt computes; like every ciphertext of this build the bits are
+ * the library's own: SEAL's sampler is not available here).
+ *
+ * Randomness: the ChaCha20 stream cipher (D. J. Bernstein's original layout: 256-bit key, 64-bit block counter, 64-bit nonce)
+ * under a caller-supplied key.  Encryption number e = first_index + i of a key uses nonce e; 64-bit draw d of it is bytes
+ * [8 d, 8 d + 8) of that stream (little endian): d = j for u_j, n + j for e1_j, 2 n + j for e2_j.  u_j = floor(3 r / 2^64) - 1;
+ * the noise takes x = r >> 1, |e| = #{i : x >= cdt[i]} with cdt[i] = floor(2^63 P(|e| <= i)) (fhe_noise_cdt; integer work only,
+ * so every implementation draws the same values), sign = low bit of r.  A (key, index) pair must never be used twice: draw the
+ * key from the operating system's generator (getrandom) once per Encryptor and count.  tests/ pin the stream against the
+ * published ChaCha20 vector, the table against a 90-digit evaluation, and the ciphertexts against the oracle's restatement. */
+#define FHE_NOISE_CDT_LEN 19
+void fhe_noise_cdt(uint64_t out[FHE_NOISE_CDT_LEN]);
+/* FractionalEncoder::encode of `count` host doubles into d_plain [count][n] (device, coefficients below t): bit for bit
+ * fhe_frac_encode of each value.  Asynchronous (the values travel through the staging ring). */
+int fhe_frac_encode_batch(const fhe_ctx *ctx, const double *values, uint64_t count, int int_coeffs, int frac_coeffs,
+                          uint64_t *d_plain, fhe_stream stream);
+/* d_pk_ntt: the public key [2][k][n] in NTT form (fhe_ntt_forward of (pk0, pk1)); d_plain: [count][n] plaintext coefficients
+ * below t, or NULL for encryptions of the zero plaintext; d_out: [count][2][k][n].  scratch: fhe_encrypt_scratch_bytes. */
+size_t fhe_encrypt_scratch_bytes(const fhe_ctx *ctx, uint64_t count);
+int fhe_encrypt_batch(const fhe_ctx *ctx, const uint64_t *d_pk_ntt, const uint64_t *d_plain, uint64_t count,
+                      const uint8_t key[32], uint64_t first_index, uint64_t *d_out, void *scratch, size_t scratch_bytes,
+                      fhe_stream stream);
+/* the draws alone, for tests and for anyone who wants to check a ciphertext: d_draws [count][3][n] int8 (u, e1, e2) */
+int fhe_encrypt_draws(const fhe_ctx *ctx, const uint8_t key[32], uint64_t first_index, uint64_t count, int8_t *d_draws,
+                      fhe_stream stream);
 
 /* ---- synthetic inputs and digests (bench / parity harness) --------------------------------------
  * fill: value = splitmix64(seed ^ (first_linear_index + linear index)) mod q_i */

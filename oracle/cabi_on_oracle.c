@@ -276,6 +276,39 @@ int fhe_add_plain(const fhe_ctx *c, uint64_t *ct, uint64_t stride, uint64_t coun
     return FHE_OK;
 }
 
+/* server-side encryptions (include/fhe_hip.h): the oracle's restatement of the keyed sampler; pk arrives in NTT form */
+void fhe_noise_cdt(uint64_t out[FHE_NOISE_CDT_LEN]) { fo_noise_cdt(out); }
+int fhe_frac_encode_batch(const fhe_ctx *c, const double *values, uint64_t count, int ic, int fc, uint64_t *d_plain, fhe_stream s) {
+    (void)s;
+    for (uint64_t i = 0; i < count; i++) {
+        memset(d_plain + i * c->n, 0, (size_t)c->n * 8);
+        int len = fhe_frac_encode(c->n, c->t, values[i], ic, fc, d_plain + i * c->n);
+        if (len < 0) return len;
+    }
+    return FHE_OK;
+}
+size_t fhe_encrypt_scratch_bytes(const fhe_ctx *c, uint64_t count) { return (size_t)count * pw(c) * 8; }
+int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *pk_ntt, const uint64_t *d_plain, uint64_t count, const uint8_t key[32], uint64_t first,
+                      uint64_t *out, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!c || !pk_ntt || !key || (!out && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (count && (!scratch || scratch_bytes < fhe_encrypt_scratch_bytes(c, count))) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_encrypt_scratch_bytes()");
+    uint64_t *pk = (uint64_t *)malloc(2 * pw(c) * 8);
+    if (!pk) return fail(FHE_ERR_HIP, "out of memory");
+    fhe_ntt_inverse(c, pk_ntt, pk, 2, s);
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t len = 0;
+        if (d_plain) { len = c->n; while (len && !d_plain[i * c->n + len - 1]) len--; }
+        fo_encrypt_keyed(c->o, pk, d_plain ? d_plain + i * c->n : NULL, len, key, first + i, out + i * 2 * pw(c));
+    }
+    free(pk);
+    return FHE_OK;
+}
+int fhe_encrypt_draws(const fhe_ctx *c, const uint8_t key[32], uint64_t first, uint64_t count, int8_t *d_draws, fhe_stream s) {
+    (void)s;
+    for (uint64_t i = 0; i < count; i++) fo_encrypt_draws(c->n, key, first + i, d_draws + i * 3 * c->n);
+    return FHE_OK;
+}
+
 size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint32_t sb, uint64_t count) {
     (void)c; (void)sa; (void)sb; (void)count;
     return 8;

@@ -707,6 +707,79 @@ void fo_encrypt(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint
     free(u); free(e);
 }
 
+/* ---- the keyed sampler of include/fhe_hip.h ("server-side encryptions"), restated -------------------------------------
+ * ChaCha20 in D. J. Bernstein's original layout (256-bit key, 64-bit block counter, 64-bit nonce), the published algorithm:
+ * state = "expand 32-byte k" | key | counter | nonce as sixteen little-endian words, ten double rounds of the quarter round
+ * (a += b; d ^= a; d <<<= 16; c += d; b ^= c; b <<<= 12; a += b; d ^= a; d <<<= 8; c += d; b ^= c; b <<<= 7) on columns then
+ * diagonals, output = state + input.  tests/test_encrypt_sampler.py pins it against the published all-zero-key block. */
+#define FO_ROTL(x, r) (((x) << (r)) | ((x) >> (32 - (r))))
+#define FO_QR(a, b, c, d) a += b; d ^= a; d = FO_ROTL(d, 16); c += d; b ^= c; b = FO_ROTL(b, 12); a += b; d ^= a; d = FO_ROTL(d, 8); c += d; b ^= c; b = FO_ROTL(b, 7);
+void fo_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce, uint8_t out[64]) {
+    uint32_t in[16], x[16];
+    in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+    for (int i = 0; i < 8; i++)
+        in[4 + i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) | ((uint32_t)key[4 * i + 3] << 24);
+    in[12] = (uint32_t)counter; in[13] = (uint32_t)(counter >> 32); in[14] = (uint32_t)nonce; in[15] = (uint32_t)(nonce >> 32);
+    memcpy(x, in, sizeof x);
+    for (int r = 0; r < 10; r++) {
+        FO_QR(x[0], x[4], x[8], x[12]) FO_QR(x[1], x[5], x[9], x[13]) FO_QR(x[2], x[6], x[10], x[14]) FO_QR(x[3], x[7], x[11], x[15])
+        FO_QR(x[0], x[5], x[10], x[15]) FO_QR(x[1], x[6], x[11], x[12]) FO_QR(x[2], x[7], x[8], x[13]) FO_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) {
+        uint32_t v = x[i] + in[i];
+        out[4 * i] = (uint8_t)v; out[4 * i + 1] = (uint8_t)(v >> 8); out[4 * i + 2] = (uint8_t)(v >> 16); out[4 * i + 3] = (uint8_t)(v >> 24);
+    }
+}
+/* floor(2^63 P(|e| <= i)) for the rounded normal, sigma 3.19, redrawn beyond 19 (tools/noise_cdt.py) */
+static const u64 fo_cdt[19] = {
+    0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL,
+    0x7aad3cf138611a69ULL, 0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL,
+    0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL, 0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL,
+    0x7ffffff3ceaa701fULL};
+void fo_noise_cdt(uint64_t out[19]) { memcpy(out, fo_cdt, sizeof fo_cdt); }
+/* the draws of encryption number `index` under `key`: draws [3][n] = u (ternary), e1, e2; 64-bit draw d = bytes [8 d, 8 d + 8) of the
+ * stream with nonce `index`; d = j, n + j, 2 n + j */
+void fo_encrypt_draws(uint32_t n, const uint8_t key[32], uint64_t index, int8_t *draws) {
+    uint8_t blk[64];
+    for (u64 d = 0; d < (u64)3 * n; d++) {
+        if (d % 8 == 0) fo_chacha20_block(key, d / 8, index, blk);
+        u64 r = 0;
+        for (int b = 7; b >= 0; b--) r = (r << 8) | blk[8 * (d % 8) + b];
+        if (d < n) {
+            draws[d] = (int8_t)((int)(u64)(((unsigned __int128)r * 3) >> 64) - 1);
+        } else {
+            u64 x = r >> 1;
+            int m = 0;
+            for (int i = 0; i < 19; i++) m += x >= fo_cdt[i];
+            draws[d] = (int8_t)((r & 1) ? -m : m);
+        }
+    }
+}
+/* Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2) from given draws; pk [2][k][n] in coefficient form */
+void fo_encrypt_with_draws(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t len, const int8_t *draws, uint64_t *ct) {
+    size_t pq = (size_t)c->k * c->n;
+    u64 *u = (u64 *)malloc(sizeof(u64) * pq);
+    for (u32 i = 0; i < c->k; i++)
+        for (u32 l = 0; l < c->n; l++) u[(size_t)i * c->n + l] = draws[l] < 0 ? c->q[i] - (u64)(-draws[l]) : (u64)draws[l];
+    for (u32 j = 0; j < 2; j++) {
+        ring_mul(c, pk + pq * j, u, ct + pq * j);
+        const int8_t *e = draws + (size_t)(1 + j) * c->n;
+        for (u32 i = 0; i < c->k; i++)
+            for (u32 l = 0; l < c->n; l++) {
+                size_t x = pq * j + (size_t)i * c->n + l;
+                ct[x] = addmod(ct[x], e[l] < 0 ? c->q[i] - (u64)(-e[l]) : (u64)e[l], c->q[i]);
+            }
+    }
+    if (len) fo_add_plain(c, ct, plain, len);
+    free(u);
+}
+void fo_encrypt_keyed(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t len, const uint8_t key[32], uint64_t index, uint64_t *ct) {
+    int8_t *draws = (int8_t *)malloc((size_t)3 * c->n);
+    fo_encrypt_draws(c->n, key, index, draws);
+    fo_encrypt_with_draws(c, pk, plain, len, draws, ct);
+    free(draws);
+}
+
 void fo_decrypt_phase(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size,
                       uint64_t *phase) {
     u32 n = c->n;

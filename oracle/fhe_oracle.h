@@ -107,6 +107,14 @@ double fo_frac_decode(const fo_ctx *c, const uint64_t *plain, int int_coeffs, in
 void fo_keygen(const fo_ctx *c, uint64_t seed, uint64_t *sk, uint64_t *pk);
 void fo_encrypt(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t plain_len,
                 uint64_t seed, uint64_t *ct /* [2][k][n] */);
+/* the keyed sampler of include/fhe_hip.h (fhe_encrypt_batch): ChaCha20 block function (64-bit counter, 64-bit nonce), the noise table,
+ * the draws of encryption `index` ([3][n]: u, e1, e2) and the encryption formed from them; pk in COEFFICIENT form */
+void fo_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce, uint8_t out[64]);
+void fo_noise_cdt(uint64_t out[19]);
+void fo_encrypt_draws(uint32_t n, const uint8_t key[32], uint64_t index, int8_t *draws);
+void fo_encrypt_with_draws(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t plain_len, const int8_t *draws, uint64_t *ct);
+void fo_encrypt_keyed(const fo_ctx *c, const uint64_t *pk, const uint64_t *plain, uint32_t plain_len, const uint8_t key[32], uint64_t index,
+                      uint64_t *ct);
 /* phase = [sum_j c_j s^j]_{q_i}, [k][n]; CRT + rounding is done by the caller */
 void fo_decrypt_phase(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size,
                       uint64_t *phase);

@@ -86,6 +86,11 @@ def lib(omp=False):
         L.fo_frac_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.fo_keygen.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.fo_encrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.fo_chacha20_block.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.fo_noise_cdt.argtypes = [C.c_void_p]
+        L.fo_encrypt_draws.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_void_p]
+        L.fo_encrypt_with_draws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.fo_encrypt_keyed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64, C.c_void_p]
         L.fo_decrypt_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.fo_decrypt.restype = C.c_int
         L.fo_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -112,6 +117,11 @@ def lib(omp=False):
 
 def _p(a):
     assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _pb(a):                      # byte-sized arrays (sampler draws, cipher blocks)
+    assert a.dtype in (np.int8, np.uint8) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -255,6 +265,24 @@ class Oracle:
         self.L.fo_encrypt(self.h, _p(pk), _p(p), ln, seed, _p(ct))
         return ct
 
+    # the keyed sampler of include/fhe_hip.h ("server-side encryptions"): key = 32 bytes, index = number of the encryption under that key
+    def encrypt_draws(self, key, index):
+        d = np.zeros((3, self.n), dtype=np.int8)
+        self.L.fo_encrypt_draws(self.n, bytes(key), int(index), _pb(d))
+        return d
+
+    def encrypt_with_draws(self, pk, plain, draws):
+        p, ln = self._plain(plain)
+        ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        self.L.fo_encrypt_with_draws(self.h, _p(np.ascontiguousarray(pk)), _p(p), ln, _pb(np.ascontiguousarray(draws, dtype=np.int8)), _p(ct))
+        return ct
+
+    def encrypt_keyed(self, pk, plain, key, index):
+        p, ln = self._plain(plain)
+        ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        self.L.fo_encrypt_keyed(self.h, _p(np.ascontiguousarray(pk)), _p(p), ln, bytes(key), int(index), _p(ct))
+        return ct
+
     def decrypt(self, sk, ct):
         ct = np.ascontiguousarray(ct)
         plain = np.zeros(self.n, dtype=np.uint64)
@@ -320,6 +348,19 @@ class Oracle:
         A, B, t = (np.ascontiguousarray(x) for x in (A, B, t))
         self.L.fo_linear(self.h, _p(A), _p(B), s, _p(t), _p(out))
         return out
+
+
+def chacha20_block(key, counter, nonce):
+    """64 bytes of the ChaCha20 stream (64-bit block counter, 64-bit nonce) -- the oracle's restatement"""
+    out = np.zeros(64, dtype=np.uint8)
+    lib().fo_chacha20_block(bytes(key), int(counter), int(nonce), _pb(out))
+    return out.tobytes()
+
+
+def noise_cdt():
+    out = np.zeros(19, dtype=np.uint64)
+    lib().fo_noise_cdt(_p(out))
+    return [int(v) for v in out]
 
 
 def digest(a):

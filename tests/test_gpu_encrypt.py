@@ -1,0 +1,170 @@
+"""GPU: the servers' own encryptions as device batches (include/fhe_hip.h fhe_encrypt_batch / fhe_frac_encode_batch / fhe_encrypt_draws,
+csrc/encrypt.hip) against the oracle's restatement of the keyed sampler (oracle/fhe_oracle.c fo_encrypt_draws / fo_encrypt_keyed; pinned
+on the CPU by tests/test_encrypt_sampler.py) -- bit for bit -- and through the streaming servers that use them.  The reference makes these
+encryptions one seal::Encryptor::encrypt at a time inside its loops: homo/fhe_resize.h:230,234,262,266, homo/fhe_decode.h:54,134,
+homo/server_decode.cpp:121,126."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+KEY = bytes(range(32))
+
+
+def _pair(fhe, om, preset):
+    return fhe.SEALContext.preset(preset), om.Oracle.preset(preset)
+
+
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_2048", "P8192"])
+def test_draws_equal_the_oracle_restatement(fhe, oracle_mod, preset):
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    kg = fhe.KeyGenerator(ctx, seed=1)
+    for key, first in ((KEY, 0), (bytes(32), 7), (os.urandom(32), (1 << 40) + 5), (KEY, (1 << 64) - 4)):
+        der = fhe.DeviceEncryptor(ctx, kg.public_key(), key=key)
+        got = der.draws(first, 3)
+        for i in range(3):
+            assert np.array_equal(got[i], orc.encrypt_draws(key, first + i)), (preset, first, i)
+
+
+def test_device_encoder_equals_host_encoder(fhe, oracle_mod):
+    ctx = fhe.SEALContext.preset("P4096")
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([rng.uniform(-1, 1, 200), rng.uniform(-300, 300, 200), rng.integers(-1000, 1000, 50).astype(np.float64),
+                           [0.0, -0.0, 0.5, -0.5, 2.0 ** -60, -2.0 ** -99, 2.0 ** -100, 2.0 ** -101, 1 - 2.0 ** -53, 255.999999, 2.0 ** 62, -2.0 ** 62, 3.0e18,
+                            0.1, 1 / 3, -1 / 3, 0.7071067811865476, 123456789.123456789, 5e-324, 2.0 ** -1074 * 3]])
+    for ic, fc in ((100, 100), (64, 32), (10, 1200)):
+        use = vals if ic >= 64 else vals[np.abs(vals) < 2.0 ** ic]
+        fe = fhe.FractionalEncoder(ctx, ic, fc)
+        want = np.stack([fe.encode(float(v)) for v in use])
+        got = torch.empty((len(use), ctx.n), dtype=torch.int64, device=ctx.device)
+        fhe._lib.call("fhe_frac_encode_batch", ctx.h, np.ascontiguousarray(use).ctypes.data_as(C.c_void_p), len(use), ic, fc, C.c_void_p(got.data_ptr()), None)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want), (ic, fc)
+    bad = torch.empty((1, ctx.n), dtype=torch.int64, device=ctx.device)
+    for v, ic in ((float("nan"), 100), (float("inf"), 100), (1.0e19, 100), (1024.0, 10)):       # the host encoder's refusals
+        arr = np.array([v])
+        with pytest.raises(fhe.FheError):
+            fhe._lib.call("fhe_frac_encode_batch", ctx.h, arr.ctypes.data_as(C.c_void_p), 1, ic, 10, C.c_void_p(bad.data_ptr()), None)
+    # more values than one staging slot holds (32768 doubles): two slots, same result
+    many = rng.uniform(-4, 4, 40000)
+    small = fhe.SEALContext.preset("SEAL23_2048")
+    got = torch.empty((len(many), small.n), dtype=torch.int64, device=small.device)
+    fhe._lib.call("fhe_frac_encode_batch", small.h, many.ctypes.data_as(C.c_void_p), len(many), 100, 100, C.c_void_p(got.data_ptr()), None)
+    fe = fhe.FractionalEncoder(small)
+    for i in (0, 1, 32767, 32768, 39999):
+        assert np.array_equal(got[i].cpu().numpy().view(np.uint64), fe.encode(float(many[i]))), i
+
+
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_4096", "SEAL23_2048", "P8192", "SEAL3_8192"])
+def test_encrypt_batch_equals_the_oracle_bit_for_bit(fhe, oracle_mod, preset):
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    kg = fhe.KeyGenerator(ctx, seed=11)
+    pk, sk = fhe.to_host(kg.public_key()), fhe.to_host(kg.secret_key())
+    vals = [0.0, 0.40625, -0.40625, 0.9990234375, 77.0, -200.75, 1 / 3, 2.0 ** -30]
+    first = (1 << 33) + 9
+    der = fhe.DeviceEncryptor(ctx, kg.public_key(), key=KEY)
+    der.seek(first)
+    got = fhe.to_host(der.encrypt_values(vals))
+    assert der.next == first + len(vals)
+    dec = fhe.Decryptor(ctx, kg.secret_key())
+    fe = fhe.FractionalEncoder(ctx)
+    for i, v in enumerate(vals):
+        plain = orc.encode(v)
+        assert np.array_equal(got[i], orc.encrypt_keyed(pk, plain, KEY, first + i)), (preset, i)
+        p, budget = orc.decrypt(sk, got[i])
+        assert np.array_equal(p, plain) and budget > 20
+        assert fe.decode(dec.decrypt(fhe.to_device(got[i]))) == fe.decode(plain)
+    # batches are independent of how they are cut, and of what else ran in between
+    der.seek(first + 2)
+    again = fhe.to_host(der.encrypt_values(vals[2:5]))
+    assert np.array_equal(again, got[2:5])
+    # encryptions of zero (no plaintext array) and explicit plaintext arrays
+    der.seek(5)
+    z = fhe.to_host(der.encrypt_zeros(3))
+    zero = np.zeros(ctx.n, dtype=np.uint64)
+    for i in range(3):
+        assert np.array_equal(z[i], orc.encrypt_keyed(pk, zero, KEY, 5 + i))
+    rng = np.random.default_rng(5)
+    plains = rng.integers(0, ctx.t, size=(2, ctx.n), dtype=np.uint64)                   # dense plaintexts, both halves of [0, t)
+    der.seek(100)
+    d = fhe.to_host(der.encrypt_plains(torch.from_numpy(plains.view(np.int64)).to(ctx.device)))
+    for i in range(2):
+        assert np.array_equal(d[i], orc.encrypt_keyed(pk, plains[i], KEY, 100 + i))
+        assert np.array_equal(orc.decrypt(sk, d[i])[0], plains[i])
+
+
+def test_encrypt_argument_errors_and_key_discipline(fhe):
+    ctx = fhe.SEALContext.preset("SEAL23_2048")
+    kg = fhe.KeyGenerator(ctx, seed=2)
+    der = fhe.DeviceEncryptor(ctx, kg.public_key())                 # key from the OS generator
+    with pytest.raises(RuntimeError):
+        der.seek(0)                                                  # would allow a (key, index) pair to repeat
+    a, b = der.encrypt_zeros(2), der.encrypt_zeros(2)
+    assert der.next == 4 and not torch.equal(a, b) and not torch.equal(a[0], a[1])
+    assert fhe.DeviceEncryptor(ctx, kg.public_key()).key != der.key
+    with pytest.raises(ValueError):
+        fhe.DeviceEncryptor(ctx, kg.public_key(), key=b"short")
+    out = ctx.empty(1)
+    pkn = der._pk_ntt
+    small = torch.empty(8, dtype=torch.int64, device=ctx.device)
+    with pytest.raises(fhe.FheError):                                # scratch too small
+        fhe._lib.call("fhe_encrypt_batch", ctx.h, C.c_void_p(pkn.data_ptr()), None, 1, der.key, 0, C.c_void_p(out.data_ptr()), C.c_void_p(small.data_ptr()), 64, None)
+    with pytest.raises(fhe.FheError):                                # the index must not wrap
+        big = torch.empty(2 * ctx.k * ctx.n, dtype=torch.int64, device=ctx.device)
+        fhe._lib.call("fhe_encrypt_batch", ctx.h, C.c_void_p(pkn.data_ptr()), None, 2, der.key, (1 << 64) - 1, C.c_void_p(ctx.empty(2).data_ptr()),
+                      C.c_void_p(big.data_ptr()), big.numel() * 8, None)
+
+
+def test_servers_with_device_encryptions(fhe, oracle_mod, tmp_path):
+    """server_resize with the device encryptor: a seeded run equals the circuit called directly on the same encryptions, two row shards write
+    the whole run's bytes, and the result decrypts to the interpolated image; server_decode the same with its zeros"""
+    ctx = fhe.SEALContext.preset("P4096")
+    kg = fhe.KeyGenerator(ctx, seed=21)
+    dec, fe, ev = fhe.Decryptor(ctx, kg.secret_key()), fhe.FractionalEncoder(ctx), fhe.Evaluator(ctx)
+    W, H, w, h = 6, 5, 4, 3
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(H, W, 3))
+    client = fhe.DeviceEncryptor(ctx, kg.public_key(), key=bytes(32))
+    pix = client.encrypt_values(img.reshape(-1).astype(np.float64))             # [H * W * 3, 2, k, n], the stream's order
+    fin, fout, fsh = str(tmp_path / "in.ct"), str(tmp_path / "out.ct"), str(tmp_path / "shards.ct")
+    with open(fin, "wb") as f:
+        for c in fhe.to_host(pix):
+            fhe.server.write_ciphertext(f, c)
+    enc = fhe.server.make_fraction_encryptor(ctx, kg.public_key(), seed=9, device=True)
+    assert hasattr(enc, "seek")
+    assert fhe.server.server_resize(ctx, fin, fout, W, H, w, h, False, enc, rows_per_step=2) == w * h
+    whole = open(fout, "rb").read()
+    for rows in ((0, 2), (2, 3)):
+        fhe.server.server_resize(ctx, fin, fsh, W, H, w, h, False, fhe.server.make_fraction_encryptor(ctx, kg.public_key(), seed=9, device=True), rows_per_step=1, rows=rows)
+    assert open(fsh, "rb").read() == whole
+    # the circuit called directly with the same encryptions
+    taps, xs, ys = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=False)
+    direct = fhe.server.make_fraction_encryptor(ctx, kg.public_key(), seed=9, device=True)
+    fr = direct([v for pair in zip(xs, ys) for v in pair])
+    pc = fhe.circuits.PlainCache(ctx)
+    rec = fhe.server.RECORD_HEADER + 4 * ctx.k * ctx.n * 8
+    for ch in range(3):
+        out = fhe.to_host(fhe.circuits.sample_linear(ev, pc, pix, np.asarray(taps, dtype=np.uint32) * 3 + ch, fr[0::2].contiguous(), fr[1::2].contiguous()))
+        for p in (0, 5, w * h - 1):
+            off = (p * 3 + ch) * rec + fhe.server.RECORD_HEADER
+            assert np.array_equal(np.frombuffer(whole[off:off + rec - fhe.server.RECORD_HEADER], dtype=np.uint64).reshape(4, ctx.k, ctx.n), out[p])
+            # and the value: bilinear interpolation of the plain image at this pixel
+            flat = img.reshape(-1, 3)
+            q = [[float(flat[taps[p][0], ch]), float(flat[taps[p][1], ch])], [float(flat[taps[p][2], ch]), float(flat[taps[p][3], ch])]]   # p00 p10 / p01 p11
+            fx, fy = float(xs[p]), float(ys[p])
+            want = (q[0][0] * (1 - fx) + q[0][1] * fx) * (1 - fy) + (q[1][0] * (1 - fx) + q[1][1] * fx) * fy
+            assert abs(fe.decode(dec.decrypt(fhe.to_device(out[p]))) - want) < 1e-3
+    # a production encryptor (key from the OS) has no seek and never repeats itself
+    prod = fhe.server.make_fraction_encryptor(ctx, kg.public_key())
+    assert not hasattr(prod, "seek")
+    assert fhe.server.server_resize(ctx, fin, fsh, W, H, w, h, False, prod, rows_per_step=2) == w * h
+    assert open(fsh, "rb").read() != whole
+    zeros = fhe.server.make_zero_encryptor(ctx, kg.public_key(), seed=4, device=True)
+    zeros.seek(3)
+    z = zeros(2)
+    assert [fe.decode(dec.decrypt(c)) for c in z] == [0.0, 0.0] and not torch.equal(z[0], z[1])
+    zeros.seek(4)
+    assert torch.equal(zeros(1)[0], z[1])

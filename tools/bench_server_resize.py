@@ -19,6 +19,9 @@ ap.add_argument("--bilinear", action="store_true")
 ap.add_argument("--rows", type=int, default=4)
 ap.add_argument("--io-threads", type=int, default=16)
 ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--encrypt", choices=["bank", "host", "device"], default="bank",
+                help="the circuit's server-side encryptions (two per output pixel): bank = pre-made ciphertexts (the circuit alone, rounds 2-4), "
+                     "host = keys.Encryptor one at a time (numpy sampler), device = keys.DeviceEncryptor batches (fhe_encrypt_batch)")
 a = ap.parse_args()
 ctx = fhe.SEALContext.preset(a.preset)
 fin, fout = os.path.join(a.dir, "fhe_rs_in.ct"), os.path.join(a.dir, "fhe_rs_out.ct")
@@ -40,6 +43,10 @@ def fractions(values):
     return bank[:len(values)]
 
 
+if a.encrypt != "bank":
+    fractions = fhe.server.make_fraction_encryptor(ctx, fhe.KeyGenerator(ctx).public_key(), device=a.encrypt == "device")
+
+
 try:
     sin = fhe.server.StreamFile(fin)
     sout = fhe.server.StreamFile(fout, write=True, size=n_out * rec_out)
@@ -58,7 +65,7 @@ finally:
         if os.path.exists(p):
             os.remove(p)
 print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s, files in %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset, a.dir),
-                  "output_pixels": done, "rows_per_step": a.rows, "seconds": dt, "pixels_per_s": done / dt,
+                  "output_pixels": done, "rows_per_step": a.rows, "server_side_encryptions": a.encrypt, "seconds": dt, "pixels_per_s": done / dt,
                   "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
                   "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
                   "file_read_seconds": stats["file_read_seconds"], "file_write_seconds": stats["file_write_seconds"],
