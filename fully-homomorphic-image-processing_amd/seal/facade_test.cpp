@@ -6,6 +6,7 @@
 #include <sstream>
 
 #include "seal/seal.h"
+#include "seal/hip_circuits.h"
 
 using namespace seal;
 
@@ -142,6 +143,31 @@ int main(int argc, char **argv) {
         Plaintext z; CHECK(z.significant_coeff_count() == 0 && z.coeff_count() == 0 && z.to_string() == "0", "empty plaintext");
         bool threw = false; try { Ciphertext c(a); evaluator.multiply_plain(c, encoder.encode(0.0)); } catch (const std::invalid_argument &) { threw = true; }
         CHECK(threw, "multiply_plain by encode(0) must throw");
+    }
+
+    {   // Encryptor::encrypt is one stream of the library's keyed device sampler (fhe_encrypt_batch): a batch made by
+        // seal::hip::DeviceEncryptor under the same (key, index) holds the same ciphertexts, bit for bit
+        Encryptor e2(context, pk);
+        const uint64_t i0 = e2.next_index();
+        const std::vector<double> vals = {0.71875, -3.5, 0.0, 19.0, 0.333251953125};
+        std::vector<Ciphertext> one(vals.size());
+        for (size_t i = 0; i < vals.size(); ++i) e2.encrypt(encoder.encode(vals[i]), one[i]);
+        CHECK(e2.next_index() == i0 + vals.size(), "every encryption takes the next stream of the key");
+        hip::DeviceEncryptor de(context, pk, 100, 100, e2.sampler_key().data(), i0);
+        hip::CiphertextBatch batch = de.encrypt_values(vals);
+        for (size_t i = 0; i < vals.size(); ++i) {
+            std::stringstream s1, s2;
+            one[i].save(s1);
+            batch.get(i).save(s2);
+            CHECK(s1.str() == s2.str(), "encryption %d: batch and single call differ", (int)i);
+            CHECK(dec(batch.get(i)) == vals[i] && decryptor.invariant_noise_budget(batch.get(i)) > 20, "batched encryption %d decrypts to %g", (int)i, dec(batch.get(i)));
+        }
+        hip::CiphertextBatch z = de.encrypt_zeros(2);
+        std::stringstream z0, z1;
+        z.get(0).save(z0); z.get(1).save(z1);
+        CHECK(dec(z.get(0)) == 0.0 && dec(z.get(1)) == 0.0 && z0.str() != z1.str(), "two encryptions of zero decrypt to zero and differ");
+        Encryptor e3(context, pk);
+        CHECK(e3.sampler_key() != e2.sampler_key(), "every Encryptor draws its own key");
     }
 
     // fused block circuit on one encrypted 8x8 block

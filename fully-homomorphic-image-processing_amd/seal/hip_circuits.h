@@ -4,6 +4,8 @@
 //   seal::hip::CiphertextBatch   `count` ciphertexts of one size in ONE device allocation ([count][size][k][n]); loads and
 //                                saves the same stream records as seal::Ciphertext (a saved batch is a concatenation of
 //                                Ciphertext::save records), converts to / from std::vector<seal::Ciphertext>
+//   seal::hip::DeviceEncryptor   the servers' own encryptions as device batches (fhe_encrypt_batch): encrypt_values / encrypt_zeros ->
+//                                CiphertextBatch; with the key and index of a seal::Encryptor it makes that object's ciphertexts
 //   seal::hip::Circuits          one fhe_circuits handle + scratch: cubic, linear, sample_bicubic, sample_linear,
 //                                resize_bicubic (shared offsets), homomorphic_sin / _cos, approximated_step, decode_channel
 //
@@ -103,6 +105,49 @@ private:
     detail::DevBuf buf_;
     size_t count_;
     uint32_t size_, k_, n_;
+};
+
+// The encryptions a server makes inside the reference's loops -- frac(x), frac(y) per output pixel (homo/fhe_resize.h:230,234,262,266), an
+// encode(0) per homomorphic_sin / cos, accumulator and index (homo/fhe_decode.h:54,134; homo/server_decode.cpp:121,126) -- as ONE
+// batch on the device: FractionalEncoder::encode of every value (fhe_frac_encode_batch) and Enc(m) = (Delta m' + pk0 u + e1,
+// pk1 u + e2) with u, e1, e2 from the ChaCha20 stream of (key, index) (fhe_encrypt_batch; include/fhe_hip.h).  The key comes from
+// the operating system's generator unless one is passed (tests); encryption i of this object's life uses stream i.
+class DeviceEncryptor {
+public:
+    DeviceEncryptor(const SEALContext &ctx, const PublicKey &pk, int int_coeffs = 100, int frac_coeffs = 100, const uint8_t *key = nullptr, uint64_t first_index = 0)
+        : ctx_(ctx), ic_(int_coeffs), fc_(frac_coeffs), next_(first_index) {
+        const detail::CtxState &s = *ctx.state();
+        if (pk.buf.words() != 2 * s.poly_words()) throw std::invalid_argument("public key does not match the context");
+        pk_ntt_.resize(2 * s.poly_words());
+        detail::check(fhe_ntt_forward(s.h, pk.buf.ptr(), pk_ntt_.ptr(), 2, nullptr), "ntt");
+        if (key) std::memcpy(key_.data(), key, 32);
+        else key_ = detail::Sampler::fresh_key();
+    }
+    CiphertextBatch encrypt_values(const std::vector<double> &values) {
+        const detail::CtxState &s = *ctx_.state();
+        detail::DevBuf plain(values.size() * s.n);
+        if (!values.empty()) detail::check(fhe_frac_encode_batch(s.h, values.data(), values.size(), ic_, fc_, plain.ptr(), nullptr), "frac_encode_batch");
+        return run(values.empty() ? nullptr : plain.ptr(), values.size());
+    }
+    CiphertextBatch encrypt_zeros(size_t count) { return run(nullptr, count); }
+    uint64_t next_index() const { return next_; }
+private:
+    CiphertextBatch run(const uint64_t *plain, size_t count) {
+        const detail::CtxState &s = *ctx_.state();
+        CiphertextBatch out(ctx_, count, 2);
+        if (!count) return out;
+        if (next_ + count < next_) throw std::runtime_error("DeviceEncryptor: the encryption index would wrap");
+        const size_t need = (fhe_encrypt_scratch_bytes(s.h, count) + 7) / 8;
+        if (scratch_.words() < need) scratch_.resize(need);
+        detail::check(fhe_encrypt_batch(s.h, pk_ntt_.ptr(), plain, count, key_.data(), next_, out.ptr(), scratch_.ptr(), scratch_.words() * 8, nullptr), "encrypt_batch");
+        next_ += count;
+        return out;
+    }
+    SEALContext ctx_;
+    detail::DevBuf pk_ntt_, scratch_;
+    std::array<uint8_t, 32> key_;
+    int ic_, fc_;
+    uint64_t next_;
 };
 
 // sample plan of ResizeImage (homo/fhe_resize.h:350-351,381-382 and the tap order of SampleBicubic / SampleLinear)

@@ -1019,7 +1019,6 @@ public:
             for (uint32_t c = 0; c < s_.n; ++c) v[(size_t)i * s_.n + c] = rng_.below(s_.q[i]);
         return v;
     }
-private:
     static std::array<uint8_t, 32> fresh_key() {
         std::array<uint8_t, 32> key;
 #ifdef FHE_FACADE_TEST_SEED
@@ -1035,6 +1034,7 @@ private:
         os_entropy(key.data(), key.size());
         return key;
     }
+private:
     const CtxState &s_;
     ChaCha20 rng_;
 };
@@ -1143,8 +1143,12 @@ public:
         if (pk.buf.words() != 2 * s.poly_words()) throw std::invalid_argument("public key does not match the context");
         pk_ntt_.resize(2 * s.poly_words());
         detail::check(fhe_ntt_forward(s.h, pk.buf.ptr(), pk_ntt_.ptr(), 2, nullptr), "ntt");
+        key_ = detail::Sampler::fresh_key();
     }
-    // Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2)   
+    // Enc(m) = (Delta m' + pk0 u + e1, pk1 u + e2)    through the library's keyed device sampler
+    // (include/fhe_hip.h fhe_encrypt_batch): this object's key comes from the OS generator once, every call uses the next stream
+    // of it -- five launches, nothing sampled or uploaded by the host, no synchronisation (rounds 2-4: host sampling, three
+    // uploads and a stream sync per call; the reference's servers encrypt twice per output pixel, homo/fhe_resize.h:230,234,262,266)
     void encrypt(const Plaintext &plain, Ciphertext &out) {
         const detail::CtxState &s = *st_;
         const size_t pw = s.poly_words();
@@ -1154,25 +1158,24 @@ public:
         // circuit's output can be compared bit for bit with the oracle's.
         if (detail::encrypt_hook() && detail::encrypt_hook()(plain, out)) return;
 #endif
-        detail::Sampler smp(s);
-        std::vector<uint64_t> u = smp.ternary(), e = smp.noise(), e2 = smp.noise();
-        e.insert(e.end(), e2.begin(), e2.end());
-        detail::DevBuf du(pw), de(2 * pw), un(pw);
-        du.upload(u.data(), pw);
-        de.upload(e.data(), 2 * pw);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (next_ == ~0ull) throw std::runtime_error("Encryptor: 2^64 encryptions under one sampler key");
+        const size_t need = (fhe_encrypt_scratch_bytes(s.h, 1) + 7) / 8;
+        if (scratch_.words() < need) scratch_.resize(need);
         out.shape(2, s.k, s.n);
-        detail::check(fhe_ntt_forward(s.h, du.ptr(), un.ptr(), 1, nullptr), "ntt");
-        for (int j = 0; j < 2; ++j)
-            detail::check(fhe_dyadic_multiply(s.h, pk_ntt_.ptr() + j * pw, un.ptr(), out.ptr() + j * pw, 1, nullptr), "dyadic");
-        detail::check(fhe_ntt_inverse(s.h, out.ptr(), out.ptr(), 2, nullptr), "intt");
-        detail::check(fhe_add(s.h, out.ptr(), de.ptr(), out.ptr(), 2, nullptr), "add");
+        detail::check(fhe_encrypt_batch(s.h, pk_ntt_.ptr(), nullptr, 1, key_.data(), next_++, out.ptr(), scratch_.ptr(), scratch_.words() * 8, nullptr), "encrypt");
         const int len = plain.significant_coeff_count();
         if (len) detail::check(fhe_add_plain(s.h, out.ptr(), 2 * pw, 1, plain.data().data(), (uint32_t)len, +1, nullptr), "add_plain");
-        detail::check(fhe_stream_sync(nullptr), "sync");
     }
+    // tests: the key and the number of the next encryption (seal::hip::DeviceEncryptor with the same pair makes the same ciphertexts)
+    const std::array<uint8_t, 32> &sampler_key() const { return key_; }
+    uint64_t next_index() const { return next_; }
 private:
     std::shared_ptr<detail::CtxState> st_;
-    detail::DevBuf pk_ntt_;
+    detail::DevBuf pk_ntt_, scratch_;
+    std::array<uint8_t, 32> key_;
+    uint64_t next_ = 0;
+    std::mutex mu_;
 };
 
 class Decryptor {
