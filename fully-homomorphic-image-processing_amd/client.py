@@ -166,12 +166,7 @@ def send_jpeg(ctx, encryptor, encoder, rgb, out_path):
     h, w, _ = rgb.shape
     chans = [blocks_of(rgb[:, :, c].astype(np.float64), w, h) for c in range(3)]
     with open(out_path, "wb") as f:
-        for b in range(len(chans[0])):
-            for c in range(3):
-                for v in chans[c][b]:
-                    ct = encryptor.encrypt(encoder.encode(float(v)))
-                    torch.cuda.synchronize()
-                    server.write_ciphertext(f, ct.cpu().numpy().view(np.uint64))
+        _encrypt_values(ctx, encryptor, encoder, [v for b in range(len(chans[0])) for c in range(3) for v in chans[c][b]], f)
     return len(chans[0])
 
 
@@ -204,8 +199,20 @@ def rms_error(a, b):
 # ------------------------------------------------------------------------------------------------
 # client halves of the resize and decode pipelines (homo/client_resize.cpp, homo/client_decode.cpp)
 # ------------------------------------------------------------------------------------------------
-def _encrypt_values(ctx, encryptor, encoder, values, f):
+def _encrypt_values(ctx, encryptor, encoder, values, f, chunk=1024):
+    """encode + encrypt + write, in stream order.  A keys.DeviceEncryptor (anything with `encrypt_values`) works in device batches
+    (fhe_frac_encode_batch + fhe_encrypt_batch, one download per chunk); a keys.Encryptor one ciphertext at a time."""
     import torch
+    if hasattr(encryptor, "encrypt_values"):
+        if (encryptor.int_coeffs, encryptor.frac_coeffs) != (encoder.int_coeffs, encoder.frac_coeffs):
+            raise ValueError("the encryptor's encoder parameters differ from the encoder's")
+        values = [float(v) for v in values]
+        for s in range(0, len(values), chunk):
+            cts = encryptor.encrypt_values(values[s:s + chunk])
+            torch.cuda.synchronize()
+            for ct in cts.cpu().numpy().view(np.uint64):
+                server.write_ciphertext(f, ct)
+        return
     for v in values:
         ct = encryptor.encrypt(encoder.encode(float(v)))
         torch.cuda.synchronize()

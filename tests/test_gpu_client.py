@@ -50,7 +50,8 @@ def test_receive_half_writes_the_same_jpeg_as_the_reference_client(fhe, tmp_path
     assert open(tmp_path / "image" / "mine.jpg", "rb").read() == open(tmp_path / "image" / "ref_out.jpg", "rb").read()
 
 
-def test_send_and_receive_round_trip_through_the_streaming_server(fhe, tmp_path):
+@pytest.mark.parametrize("device", [False, True])
+def test_send_and_receive_round_trip_through_the_streaming_server(fhe, tmp_path, device):
     """client.send_jpeg (keygen, encode, encrypt with the OS CSPRNG) -> server_jpeg -> client.receive_jpeg: the JPEG
     decodes to the input image (8x8 DCT with unit quantisation: only rounding and colour-conversion error)."""
     Image = pytest.importorskip("PIL.Image")
@@ -59,7 +60,8 @@ def test_send_and_receive_round_trip_through_the_streaming_server(fhe, tmp_path)
     enc = fhe.FractionalEncoder(ctx)
     w, h = 8, 8
     rgb = _image(w, h)
-    n_blocks = fhe.client.send_jpeg(ctx, fhe.Encryptor(ctx, kg.public_key()), enc, rgb, str(tmp_path / "in.ct"))
+    encryptor = (fhe.DeviceEncryptor if device else fhe.Encryptor)(ctx, kg.public_key())          # device batches / the host sampler
+    n_blocks = fhe.client.send_jpeg(ctx, encryptor, enc, rgb, str(tmp_path / "in.ct"))
     assert n_blocks == 1
     fhe.server.server_jpeg(ctx, str(tmp_path / "in.ct"), str(tmp_path / "out.ct"), n_blocks, wave_blocks=1)
     fhe.client.receive_jpeg(ctx, fhe.Decryptor(ctx, kg.secret_key()), enc, str(tmp_path / "out.ct"), w, h, str(tmp_path / "out.jpg"))
@@ -116,6 +118,12 @@ def test_resize_client_halves_equal_the_reference_client(fhe, tmp_path, bicubic)
     assert os.path.getsize(tmp_path / "image" / "mine_in.txt") == os.path.getsize(tmp_path / "image" / "ct_in.txt")
     back = fhe.client.receive_pixels(ctx, fhe.Decryptor(ctx, sk), enc, str(tmp_path / "image" / "mine_in.txt"), W, H)
     assert np.array_equal(back, rgb)
+    # and in device batches (keys.DeviceEncryptor: fhe_frac_encode_batch + fhe_encrypt_batch): same stream shape, same image, fresh randomness
+    first = open(tmp_path / "image" / "mine_in.txt", "rb").read()
+    assert fhe.client.send_resize(ctx, fhe.DeviceEncryptor(ctx, pk), enc, rgb, str(tmp_path / "image" / "mine_in.txt")) == (W, H)
+    second = open(tmp_path / "image" / "mine_in.txt", "rb").read()
+    assert len(second) == len(first) and second != first
+    assert np.array_equal(fhe.client.receive_pixels(ctx, fhe.Decryptor(ctx, sk), enc, str(tmp_path / "image" / "mine_in.txt"), W, H), rgb)
 
 
 def test_decode_client_halves_and_run_length_pairs(fhe, tmp_path):
