@@ -35,6 +35,12 @@ python tools/bench_rgb.py > $O/bench_rgb.txt 2>&1
 python tools/bench_server.py > $O/bench_server.txt 2>&1
 python tools/bench_server_resize.py > $O/bench_server_resize.txt 2>&1
 python tools/bench_server_resize.py --bilinear >> $O/bench_server_resize.txt 2>&1
+# the servers' own encryptions (csrc/encrypt.hip): per-ciphertext rates, and the two streaming servers with their encryptions made for real
+python tools/bench_encrypt.py P8192 512 2>/dev/null | tail -1 > $O/bench_encrypt.txt
+python tools/bench_encrypt.py P4096 512 2>/dev/null | tail -1 >> $O/bench_encrypt.txt
+python tools/bench_encrypt.py P8192 8192 2>/dev/null | tail -1 >> $O/bench_encrypt.txt
+for m in bank device host; do python tools/bench_server_resize.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_resize_encryptions.txt; done
+for m in device host; do python tools/bench_server_decode.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_decode_encryptions.txt; done
 fully-homomorphic-image-processing_amd/seal/multi_gpu_dct 1024 4 64 1 > $O/cpp_multi_gpu_dct.json 2>&1
 fully-homomorphic-image-processing_amd/seal/bench_resize > $O/bench_resize_cpp_host.txt 2>&1
 python tools/run_ref_cli.py 48 48 --golden --pmod 3001 > $O/ref_cli_config0_lazy.txt 2>&1
@@ -49,9 +55,11 @@ tools/prof.sh ${1}_decode python $R/bench_circuits.py decode > $O/kernel_stats_d
 tools/prof.sh ${1}_decode_relin30 python $R/bench_circuits.py decode --relin 30 > $O/kernel_stats_decode_relin30.txt 2>&1
 tools/prof.sh ${1}_resize_shared_relin30 python $R/bench_circuits.py resize --shared --relin 30 > $O/kernel_stats_resize_shared_relin30.txt 2>&1
 tools/prof.sh ${1}_ops8192 python $R/tools/bench_ops.py P8192 2048 > $O/kernel_stats_ops_P8192.txt 2>&1
+tools/prof.sh ${1}_encrypt python $R/tools/bench_encrypt.py P8192 512 > $O/kernel_stats_encrypt.txt 2>&1
 tools/prof.sh ${1}_seal23 python $R/bench.py --preset SEAL23_4096 --cpu-blocks 0 --no-verify --blocks 512 > $O/kernel_stats_bench_SEAL23_4096.txt 2>&1
-for d in bench resize resize_shared decode decode_relin30 resize_shared_relin30 ops8192 seal23; do cp $R/gpurun_out/prof_${1}_$d/p_kernel_stats.csv $O/kernel_stats_$d.csv 2>/dev/null; done
+for d in bench resize resize_shared decode decode_relin30 resize_shared_relin30 ops8192 seal23 encrypt; do cp $R/gpurun_out/prof_${1}_$d/p_kernel_stats.csv $O/kernel_stats_$d.csv 2>/dev/null; done
 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1
 python tools/soak.py > $O/soak.txt 2>&1
 python tools/soak.py 320 P8192 >> $O/soak.txt 2>&1
+python tools/soak.py 320 SEAL23_4096 >> $O/soak.txt 2>&1
 ls -la $O

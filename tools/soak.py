@@ -60,6 +60,18 @@ def relin_digests():
 
 
 ref_relin = relin_digests()
+# the servers' own encryptions as device batches (csrc/encrypt.hip): the staging ring of the encoder's values, the scratch reuse, the
+# keyed sampler -- the same (key, index) range must give the same ciphertexts every time
+der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx, seed=2).public_key(), key=bytes(range(32)))
+enc_vals = [i / 97.0 - 1.5 for i in range(192)]
+
+
+def enc_digest():
+    der.seek(1 << 33)
+    return ctx.digest(der.encrypt_values(enc_vals).view(-1))
+
+
+ref_enc = enc_digest()
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -92,5 +104,8 @@ for i in range(iters):
         if relin_digests() != ref_relin:
             bad += 1
             print("relinearised circuits digest mismatch at iteration", i, flush=True)
+    if i % 8 == 0 and enc_digest() != ref_enc:
+        bad += 1
+        print("device encryption digest mismatch at iteration", i, flush=True)
 print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
