@@ -81,6 +81,24 @@ def _timed(fn, dist, reps=1):
     return res, wall / reps, e0.elapsed_time(e1) / reps
 
 
+def _server_side_encryptions(fhe, ctx, count, values, wall, units, what):
+    """The encryptions the reference's function makes for this workload (inside SampleBicubic: homo/fhe_resize.h:262,266; inside
+    homomorphic_sin / cos: homo/fhe_decode.h:54,134), which the timed region above takes as resident inputs -- timed
+    here as the device batch a server runs (keys.DeviceEncryptor: fhe_frac_encode_batch + fhe_encrypt_batch), so the line also says
+    what the job costs with them.  values=None: encryptions of encode(0)."""
+    import torch
+    der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx).public_key())
+    run = (lambda: der.encrypt_values(values)) if values is not None else (lambda: der.encrypt_zeros(count))
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"count": count, "what": what, "ms": dt * 1e3, "share_of_step": dt / wall, "value_including_them": units / (wall + dt),
+            "note": "not in `value` (inputs resident, SURVEY 8d); one device batch, wall time incl. the host call; 1.2 ms EACH with the host sampler of rounds 2-4"}
+
+
 def _cpu_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -233,6 +251,12 @@ def resize(args):
                                      wl, n_mine if args.preset == "P8192" else 0, issue),
                "job_executions": 4, "units_per_job": n_mine,
                "output_digest": "%016x" % digest}
+        if world == 1 and not args.max_pixels:
+            _, fxs, fys = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+            vals = ([fxs[x] for x in range(w)] + [fys[y * w] for y in range(h)]) if args.shared else [v for pair in zip(fxs, fys) for v in pair]
+            res["server_side_encryptions"] = _server_side_encryptions(fhe, ctx, len(vals), vals, wall, n_out,
+                                                                      "Enc(encode(frac)) per output column and row" if args.shared else
+                                                                      "Enc(encode(frac(x))), Enc(encode(frac(y))) per output pixel (shared by the three channels; all charged to this one)")
         if args.cpu_pixels:
             from oracle import oracle as om
             orc = om.Oracle.preset(args.preset)
@@ -294,6 +318,8 @@ def decode(args):
                                      (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0, issue),
                "job_executions": 2, "units_per_job": p1 - p0,
                "output_digest": "%016x" % digest}
+        if world == 1 and degree:
+            res["server_side_encryptions"] = _server_side_encryptions(fhe, ctx, npos * degree * 2, None, wall, 1, "Enc(encode(0)) per (position, harmonic) for homomorphic_sin and homomorphic_cos")
         if args.cpu_terms:
             from oracle import oracle as om
             orc = om.Oracle.preset(args.preset)

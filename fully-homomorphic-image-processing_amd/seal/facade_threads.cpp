@@ -122,6 +122,23 @@ int main(int argc, char **argv) {
             });
         for (auto &t : th) t.join();
         for (int i = 0; i < T; ++i) CHECK(got2[i] == 2.0 + 0.5 + i, "copies of a pending value, thread %d: %g", i, got2[i]);
+        // ONE Encryptor shared by all threads (SEAL's Encryptor is used that way by the reference's helpers): every call takes its own
+        // stream index of the object's sampler key under the object's mutex -- all results decrypt, no index is handed out twice
+        const uint64_t before = encryptor.next_index();
+        std::vector<double> got3(T, 0.0);
+        th.clear();
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] {
+                Decryptor my_dec(context, keygen.secret_key());
+                Ciphertext c;
+                for (int r = 0; r < 8; ++r) encryptor.encrypt(encoder.encode(1.5 * i + r), c);
+                Plaintext p;
+                my_dec.decrypt(c, p);
+                got3[i] = encoder.decode(p);
+            });
+        for (auto &t : th) t.join();
+        for (int i = 0; i < T; ++i) CHECK(got3[i] == 1.5 * i + 7, "shared encryptor, thread %d: %g", i, got3[i]);
+        CHECK(encryptor.next_index() == before + 8ull * T, "shared encryptor: %llu indices used, want %d", (unsigned long long)(encryptor.next_index() - before), 8 * T);
     }
 
     // ---- 4. a flush that throws ------------------------------------------------------------------------------------------

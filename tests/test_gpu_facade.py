@@ -18,6 +18,17 @@ def test_facade_self_test(n):
     assert r.returncode == 0 and "FACADE TEST OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"FHE_FACADE_EAGER": "1"}])
+def test_facade_from_several_threads_on_the_device(env):
+    """seal/facade_threads.cpp (the program the CPU suite runs under ASan / TSan on the oracle-backed ABI) on the MI355X: two contexts on
+    two threads, one Evaluator and one Encryptor shared by four threads (every encryption its own index of the object's sampler key),
+    copies of a pending value, a failing flush, a ciphertext that outlives its context"""
+    exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "facade_threads")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe, "4096", "4", "4"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "FACADE THREADS TEST OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_reference_circuit_code_through_facade_equals_oracle(oracle_mod, tmp_path):
     """encrypted_dct, quantize_fhe and rgb_to_ycc_fhe exactly as written in the reference's
     homo/fhe_image.h (compiled unchanged against seal/seal.h in the build container) produce, on the
