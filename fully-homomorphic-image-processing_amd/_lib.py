@@ -94,6 +94,9 @@ SIGNATURES = {
     "fhe_encrypt_scratch_bytes": (_sz, [_vp, _u64]),
     "fhe_encrypt_batch": (_i, [_vp, _vp, _vp, _u64, C.c_char_p, _u64, _vp, _vp, _sz, _vp]),
     "fhe_encrypt_draws": (_i, [_vp, C.c_char_p, _u64, _u64, _vp, _vp]),
+    "fhe_ctx_modulus_bits": (_u32, [_vp]),
+    "fhe_decrypt_scratch_bytes": (_sz, [_vp, _u32, _u64]),
+    "fhe_decrypt_batch": (_i, [_vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _sz, _vp]),
     # include/fhe_circuits.h
     "fhe_circuits_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "fhe_circuits_destroy": (_i, [_vp]),

@@ -173,18 +173,20 @@ def send_jpeg(ctx, encryptor, encoder, rgb, out_path):
 def receive_jpeg(ctx, decryptor, encoder, in_path, width, height, out_path):
     """Decrypt the server's stream (per block: 64 Y, 64 Cb, 64 Cr) and write the JPEG.  Returns the rounded
     coefficient blocks [n_blocks][3][64]."""
-    import torch
     n_blocks = (width // 8) * (height // 8)
-    ct = np.zeros((2, ctx.k, ctx.n), dtype=np.uint64)
     blocks = []
     with open(in_path, "rb") as f:
         for _ in range(n_blocks):
+            recs = []
+            for _ in range(192):
+                ct = np.zeros((2, ctx.k, ctx.n), dtype=np.uint64)
+                server.read_ciphertext_into(f, ct)
+                recs.append(ct)
+            plains = _decrypt_records(ctx, decryptor, recs)                 # one block's 64 Y, 64 Cb, 64 Cr in one fhe_decrypt_batch
             blk = np.zeros((3, 64), dtype=np.int64)
             for ch in range(3):
                 for j in range(64):
-                    server.read_ciphertext_into(f, ct)
-                    plain = decryptor.decrypt(torch.from_numpy(ct.view(np.int64)).to(ctx.device))
-                    blk[ch, j] = round_half_away(encoder.decode(plain))
+                    blk[ch, j] = round_half_away(encoder.decode(plains[ch * 64 + j]))
             blocks.append(blk)
     write_jpeg_from_coefficients(out_path, blocks, width, height)
     return blocks
@@ -240,29 +242,46 @@ def to_pixel(value, clamp=True):
     return pixel & 0xFF
 
 
+def _decrypt_records(ctx, decryptor, recs):
+    """recs: host arrays [size, k, n] (sizes may differ: a decode stream interleaves 22- and 2-polynomial records) -> plaintexts in the
+    same order; records of one size go through keys.Decryptor.decrypt_batch (fhe_decrypt_batch) together"""
+    import torch
+    plains = [None] * len(recs)
+    if not hasattr(decryptor, "decrypt_batch"):
+        return [decryptor.decrypt(torch.from_numpy(r.view(np.int64).copy()).to(ctx.device)) for r in recs]
+    for size in sorted({r.shape[0] for r in recs}):
+        idx = [i for i, r in enumerate(recs) if r.shape[0] == size]
+        batch = torch.from_numpy(np.stack([recs[i] for i in idx]).view(np.int64)).to(ctx.device)
+        for i, p in zip(idx, decryptor.decrypt_batch(batch)):
+            plains[i] = p
+    return plains
+
+
 def receive_pixels(ctx, decryptor, encoder, in_path, width, height, clamp=True, decoded=None):
     """The receiving half shared by homo/client_resize.cpp:197-211 and homo/client_decode.cpp:200-209: width * height * 3
     records (ciphertexts of any size: 4 or 6 polynomials after a resize, 22 after the run-length decoder), each
     decrypted, decoded and converted by to_pixel.  Returns uint8 [height, width, 3]; `decoded` (a list) receives the
     decoded doubles in stream order."""
-    import torch
     out = np.zeros(width * height * 3, dtype=np.uint8)
     with open(in_path, "rb") as f:
-        for i in range(out.size):
-            hdr = f.read(server.RECORD_HEADER)
-            if len(hdr) != server.RECORD_HEADER:
-                raise EOFError("ciphertext stream ended")
-            magic, size, k, n, _ = server.HEADER.unpack(hdr)
-            if magic != server.MAGIC or (k, n) != (ctx.k, ctx.n) or not 1 <= size <= 64:
-                raise ValueError("not a ciphertext record of this context")
-            ct = np.frombuffer(f.read(size * k * n * 8), dtype=np.uint64)
-            if ct.size != size * k * n:
-                raise EOFError("truncated ciphertext record")
-            plain = decryptor.decrypt(torch.from_numpy(ct.view(np.int64).reshape(size, k, n).copy()).to(ctx.device))
-            v = encoder.decode(plain)
-            if decoded is not None:
-                decoded.append(v)
-            out[i] = to_pixel(v, clamp)
+        for first in range(0, out.size, 256):
+            recs = []
+            for i in range(first, min(first + 256, out.size)):
+                hdr = f.read(server.RECORD_HEADER)
+                if len(hdr) != server.RECORD_HEADER:
+                    raise EOFError("ciphertext stream ended")
+                magic, size, k, n, _ = server.HEADER.unpack(hdr)
+                if magic != server.MAGIC or (k, n) != (ctx.k, ctx.n) or not 1 <= size <= 64:
+                    raise ValueError("not a ciphertext record of this context")
+                ct = np.frombuffer(f.read(size * k * n * 8), dtype=np.uint64)
+                if ct.size != size * k * n:
+                    raise EOFError("truncated ciphertext record")
+                recs.append(ct.reshape(size, k, n))
+            for i, plain in enumerate(_decrypt_records(ctx, decryptor, recs)):
+                v = encoder.decode(plain)
+                if decoded is not None:
+                    decoded.append(v)
+                out[first + i] = to_pixel(v, clamp)
     return out.reshape(height, width, 3)
 
 

@@ -11,6 +11,11 @@
 // All sampling is 32/64-bit integer work (no transcendental functions), so the oracle's restatement draws the same values.
 #include "internal.h"
 
+#include <cmath>
+#include <cstring>
+
+#include "host_math.h"
+
 namespace {
 // floor(2^63 P(|e| <= i)), i = 0..18, for the rounded normal with sigma = 3.19 redrawn beyond 19 (tools/noise_cdt.py recomputes the
 // table with 90 digits; tests/test_encrypt_sampler.py compares)
@@ -200,6 +205,102 @@ __global__ __launch_bounds__(256) void k_frac_encode(const double *__restrict__ 
     }
 }
 
+
+// ---- decryption (the clients' half: homo/client_jpeg.cpp:266-280, homo/client_resize.cpp:190-210) ----------------------------------
+// phase = sum_j c_j s^j by Horner's rule per NTT slot: acc = c_{size-1}; acc = acc s + c_j
+__global__ __launch_bounds__(256) void k_dec_horner(const u64 *__restrict__ ct_ntt, const u64 *__restrict__ sk_ntt, u64 *__restrict__ acc_out,
+                                                    const Modulus *__restrict__ mods, u32 k, u32 n, u32 size, u64 count) {
+    const u64 rows = count * k;
+    for (u64 rp = blockIdx.y; rp < rows; rp += gridDim.y) {
+        const u64 e = rp / k;
+        const u32 p = (u32)(rp % k);
+        const Modulus m = mods[p];
+        const u64 *s = sk_ntt + (u64)p * n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 sv = s[i];
+            u64 acc = ct_ntt[((e * size + (size - 1)) * k + p) * n + i];
+            for (int j = (int)size - 2; j >= 0; --j) acc = addmod(mul_barrett(acc, sv, m), ct_ntt[((e * size + j) * k + p) * n + i], m.q);
+            acc_out[rp * n + i] = acc;
+        }
+    }
+}
+
+// m = floor((t x + floor(q/2)) / q) mod t for x = the CRT value of the phase residues, EXACTLY, without composing x:
+//   y_i = phase_i (q/q_i)^-1 mod q_i,   x = sum_i y_i (q/q_i) - v q,   t y_i = a_i q_i + r_i
+//   => t x + floor(q/2) = (sum_i a_i - t v) q + (sum_i r_i (q/q_i) + floor(q/2)),  so  m = (sum_i a_i + j) mod t  with
+//   j = floor((sum_i r_i (q/q_i) + floor(q/2)) / q) in [0, k]  -- k multi-word comparisons against the multiples of q --
+//   and the invariant noise |t x - (quotient) q| = |sum_i r_i (q/q_i) - j q| (its bit length goes to noise_bits by atomicMax).
+// a_i comes from an exact division: t y_i - r_i is a multiple of the odd q_i and a_i < t < 2^64, so a_i = low64(t y_i - r_i) q_i^-1 mod 2^64.
+#define DEC_K FHE_MAX_K
+#define DEC_L (FHE_MAX_K + 1)
+struct DecConsts {
+    u32 k, limbs;
+    u64 t;
+    u64 inv_punct[DEC_K], t_mod_q[DEC_K], qinv64[DEC_K];
+    u64 punct[DEC_K][DEC_L];          // q / q_i
+    u64 jq[DEC_K + 1][DEC_L];         // j q, j = 0 .. k
+    u64 qhalf[DEC_L];                 // floor(q / 2)
+};
+__device__ __forceinline__ bool big_ge(const u64 *a, const u64 *b, u32 limbs) {
+    for (int l = (int)limbs - 1; l >= 0; --l)
+        if (a[l] != b[l]) return a[l] > b[l];
+    return true;
+}
+__global__ __launch_bounds__(256) void k_dec_round(const u64 *__restrict__ phase, u64 *__restrict__ plain, u32 *__restrict__ noise_bits,
+                                                   const Modulus *__restrict__ mods, u32 n, u64 count, const DecConsts C) {
+    const u64 total = count * n;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 e = g / n;
+        const u32 c = (u32)(g % n);
+        u64 N[DEC_L];
+#pragma unroll
+        for (int l = 0; l < DEC_L; ++l) N[l] = 0;
+        u64 A = 0;
+        for (u32 i = 0; i < C.k; ++i) {
+            const Modulus md = mods[i];
+            const u64 y = mul_barrett(phase[(e * C.k + i) * n + c], C.inv_punct[i], md);
+            const u64 r = mul_barrett(C.t_mod_q[i], y, md);
+            const u64 a = (C.t * y - r) * C.qinv64[i];
+            A += a;
+            if (A >= C.t) A -= C.t;
+            u64 carry = 0;
+            for (u32 l = 0; l < C.limbs; ++l) {                      // N += r * punct_i
+                const u64 lo = r * C.punct[i][l], hi = __umul64hi(r, C.punct[i][l]);
+                const u64 s1 = N[l] + lo, c1 = s1 < lo;
+                const u64 s2 = s1 + carry, c2 = s2 < carry;
+                N[l] = s2;
+                carry = hi + c1 + c2;
+            }
+        }
+        u64 M[DEC_L];                                                // N + floor(q/2)
+        u64 cy = 0;
+        for (u32 l = 0; l < C.limbs; ++l) {
+            const u64 s1 = N[l] + C.qhalf[l], c1 = s1 < N[l];
+            const u64 s2 = s1 + cy, c2 = s2 < cy;
+            M[l] = s2;
+            cy = c1 + c2;
+        }
+        u32 j = 0;
+        for (u32 m = 1; m <= C.k; ++m) j += big_ge(M, C.jq[m], C.limbs) ? 1 : 0;
+        u64 v = A + j;
+        while (v >= C.t) v -= C.t;
+        plain[g] = v;
+        if (noise_bits) {
+            const bool pos = big_ge(N, C.jq[j], C.limbs);
+            const u64 *hi_ = pos ? N : C.jq[j], *lo_ = pos ? C.jq[j] : N;
+            u64 borrow = 0;
+            int bits = 0;
+            for (u32 l = 0; l < C.limbs; ++l) {
+                const u64 d1 = hi_[l] - lo_[l], b1 = hi_[l] < lo_[l];
+                const u64 d2 = d1 - borrow, b2 = d1 < borrow;
+                borrow = b1 + b2;
+                if (d2) bits = (int)(64 * l) + (64 - __clzll((long long)d2));
+            }
+            atomicMax(noise_bits + e, (u32)bits);
+        }
+    }
+}
+
 ChaChaKey load_key(const uint8_t key[32]) {
     ChaChaKey k;
     for (int i = 0; i < 8; ++i) k.w[i] = (u32)key[4 * i] | ((u32)key[4 * i + 1] << 8) | ((u32)key[4 * i + 2] << 16) | ((u32)key[4 * i + 3] << 24);
@@ -279,6 +380,69 @@ extern "C" int fhe_encrypt_draws(const fhe_ctx *c, const uint8_t key[32], uint64
     if (!count) return FHE_OK;
     if (c->n % 8) return fail(FHE_ERR_PARAM, "n must be a multiple of 8");
     k_enc_draws<<<blocks_for(count * 3 * (c->n / 8)), 256, 0, (hipStream_t)s>>>(load_key(key), first_index, count, (signed char *)d_draws, c->n);
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
+// ---- decryption ---------------------------------------------------------------------------------------------------------------
+extern "C" uint32_t fhe_ctx_modulus_bits(const fhe_ctx *c) {
+    if (!c) return 0;
+    hostmath::BigUInt Q(1);
+    for (u32 i = 0; i < c->k; ++i) Q.mul_small(c->qb.primes[i]);
+    return (uint32_t)Q.bits();
+}
+extern "C" size_t fhe_decrypt_scratch_bytes(const fhe_ctx *c, uint32_t size, uint64_t count) {
+    return c ? (size_t)count * ((size_t)size + 1) * c->k * c->n * sizeof(u64) : 0;
+}
+extern "C" int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *d_sk_ntt, const uint64_t *d_ct, uint32_t size, uint64_t count, uint64_t *d_plain,
+                                 uint32_t *d_noise_bits, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    using namespace hostmath;
+    if (!c || !d_sk_ntt || (!d_ct && count) || (!d_plain && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (size < 2) return fail(FHE_ERR_PARAM, "a ciphertext has at least two polynomials");
+    if (!count) return FHE_OK;
+    if (!scratch || scratch_bytes < fhe_decrypt_scratch_bytes(c, size, count)) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_decrypt_scratch_bytes()");
+    if (c->t >> 60) return fail(FHE_ERR_PARAM, "plain modulus too large for the exact rounding kernel");
+    hipStream_t st = (hipStream_t)s;
+    const u32 k = c->k, n = c->n;
+    DecConsts C;
+    std::memset(&C, 0, sizeof C);
+    C.k = k;
+    C.limbs = k + 1;
+    C.t = c->t;
+    BigUInt Q(1, DEC_L + 1);
+    for (u32 i = 0; i < k; ++i) Q.mul_small(c->qb.primes[i]);
+    for (u32 i = 0; i < k; ++i) {
+        const u64 qi = c->qb.primes[i];
+        BigUInt P(1, DEC_L + 1);
+        for (u32 j = 0; j < k; ++j)
+            if (j != i) P.mul_small(c->qb.primes[j]);
+        for (u32 l = 0; l < DEC_L; ++l) C.punct[i][l] = P.w[l];
+        C.inv_punct[i] = invmod(P.mod_small(qi), qi);
+        C.t_mod_q[i] = c->t % qi;
+        u64 inv = qi;                                               // Newton: q^-1 mod 2^64 for odd q (5 steps double the correct low bits from 3)
+        for (int it = 0; it < 6; ++it) inv *= 2 - qi * inv;
+        C.qinv64[i] = inv;
+    }
+    BigUInt J(0, DEC_L + 1);
+    for (u32 j = 0; j <= k; ++j) {
+        for (u32 l = 0; l < DEC_L; ++l) C.jq[j][l] = J.w[l];
+        J.add(Q);
+    }
+    BigUInt H = Q;
+    H.shr1();
+    for (u32 l = 0; l < DEC_L; ++l) C.qhalf[l] = H.w[l];
+    u64 *ntt = (u64 *)scratch, *acc = ntt + (size_t)count * size * k * n;
+    int rc = fhe_ntt_forward(c, d_ct, (uint64_t *)ntt, count * size, s);
+    if (rc) return rc;
+    {
+        const u64 rows = count * k;
+        dim3 grid((n + 255) / 256, (unsigned)(rows < 32768 ? rows : 32768));
+        k_dec_horner<<<grid, 256, 0, st>>>(ntt, (const u64 *)d_sk_ntt, acc, c->qb.d_mod, k, n, size, count);
+        KERNEL_CHECK();
+    }
+    if ((rc = fhe_ntt_inverse(c, (const uint64_t *)acc, (uint64_t *)acc, count, s))) return rc;
+    if (d_noise_bits) HIP_TRY(hipMemsetAsync(d_noise_bits, 0, count * sizeof(u32), st));
+    k_dec_round<<<blocks_for(count * n), 256, 0, st>>>(acc, (u64 *)d_plain, d_noise_bits, c->qb.d_mod, n, count, C);
     KERNEL_CHECK();
     return FHE_OK;
 }

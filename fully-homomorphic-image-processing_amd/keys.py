@@ -230,7 +230,35 @@ class Decryptor:
         _lib.call("fhe_ntt_inverse", ctx.h, _ptr(out), _ptr(out), 1, _stream())
         return to_host(out)[0]
 
+    def decrypt_batch(self, cts, with_budget=False):
+        """cts: [count, size, k, n] device tensor -> plaintext coefficients [count, n] (numpy uint64) (and the invariant noise budgets):
+        fhe_decrypt_batch -- phase by Horner's rule per NTT slot and the exact rounding floor((t x + floor(q/2)) / q) mod t on the
+        device (csrc/encrypt.hip k_dec_round), no big-integer loop on the host"""
+        ctx = self.ctx
+        cts = cts.contiguous()
+        count, size = int(cts.shape[0]), int(cts.shape[1])
+        plain = torch.empty((count, ctx.n), dtype=torch.int64, device=ctx.device)
+        bits = torch.zeros(max(count, 1), dtype=torch.int32, device=ctx.device)
+        if count:
+            L = _lib.load()
+            need = int(L.fhe_decrypt_scratch_bytes(ctx.h, size, count))
+            scratch = torch.empty((need + 7) // 8, dtype=torch.int64, device=ctx.device)
+            _lib.call("fhe_decrypt_batch", ctx.h, _ptr(self._sk_ntt), _ptr(cts), size, count, _ptr(plain), _ptr(bits), _ptr(scratch), scratch.numel() * 8, _stream())
+        out = plain.cpu().numpy().view(np.uint64)
+        if with_budget:
+            qbits = int(_lib.load().fhe_ctx_modulus_bits(ctx.h))
+            return out, [max(0, qbits - int(b) - 1) for b in bits.cpu().numpy()[:count]]
+        return out
+
     def decrypt(self, ct, with_budget=False):
+        """one ciphertext [size, k, n] -> plaintext coefficients [n] (and the invariant noise budget)"""
+        if with_budget:
+            plain, budget = self.decrypt_batch(ct[None], with_budget=True)
+            return plain[0], budget[0]
+        return self.decrypt_batch(ct[None])[0]
+
+    def decrypt_host(self, ct, with_budget=False):
+        """the same by CRT composition and big-integer rounding on the host (rounds 1-4; kept as an independent check of the device rounding)"""
         ph = self._phase(ct)
         Q, t = self.Q, self.ctx.t
         plain = np.zeros(self.ctx.n, dtype=np.uint64)

@@ -72,7 +72,8 @@ const char *fhe_last_error(void);
  *      (fhe_circuits_create_relin, fhe_circuits_out_size); fhe_ctx_create no longer builds or validates the ct x ct tables
  *      (auxiliary-prime failures surface at the first multiply or at fhe_circuits_create), fhe_arith_path builds them as
  *      a side effect, and the context's second stream exists only with FHE_DCT_PIPELINE=1.
- *   3: + fhe_encrypt_batch / fhe_encrypt_scratch_bytes / fhe_encrypt_draws / fhe_noise_cdt, fhe_frac_encode_batch.
+ *   3: + fhe_encrypt_batch / fhe_encrypt_scratch_bytes / fhe_encrypt_draws / fhe_noise_cdt, fhe_frac_encode_batch,
+ *      fhe_decrypt_batch / fhe_decrypt_scratch_bytes / fhe_ctx_modulus_bits.
  * A host compiled against this header compares fhe_abi_version() with FHE_ABI_VERSION before anything else (the Python
  * binding and seal/seal.h do). */
 #define FHE_ABI_VERSION 3
@@ -313,6 +314,18 @@ int fhe_encrypt_batch(const fhe_ctx *ctx, const uint64_t *d_pk_ntt, const uint64
 /* the draws alone, for tests and for anyone who wants to check a ciphertext: d_draws [count][3][n] int8 (u, e1, e2) */
 int fhe_encrypt_draws(const fhe_ctx *ctx, const uint8_t key[32], uint64_t first_index, uint64_t count, int8_t *d_draws,
                       fhe_stream stream);
+
+/* ---- decryption in batches (the clients' half: homo/client_jpeg.cpp:266-280, homo/client_resize.cpp:190-210) -----------------------
+ * seal::Decryptor::decrypt of `count` ciphertexts of `size` polynomials: phase = sum_j c_j s^j (Horner per NTT slot), then
+ * m = floor((t x + floor(q/2)) / q) mod t EXACTLY for x = the CRT value of the phase -- formed per coefficient from the residues with
+ * multi-word integers on the device (no big-integer loop on the host).  d_sk_ntt: the secret key [k][n] in NTT form; d_ct:
+ * [count][size][k][n]; d_plain: [count][n] coefficients below t; d_noise_bits (or NULL): [count] u32, the bit length of the largest
+ * |t x - m q| of each ciphertext -- seal::Decryptor::invariant_noise_budget = max(0, fhe_ctx_modulus_bits - that - 1).
+ * Bit for bit the oracle's big-integer decryption (tests/test_gpu_encrypt.py), also beyond the noise budget. */
+uint32_t fhe_ctx_modulus_bits(const fhe_ctx *ctx);
+size_t fhe_decrypt_scratch_bytes(const fhe_ctx *ctx, uint32_t size, uint64_t count);
+int fhe_decrypt_batch(const fhe_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_ct, uint32_t size, uint64_t count,
+                      uint64_t *d_plain, uint32_t *d_noise_bits, void *scratch, size_t scratch_bytes, fhe_stream stream);
 
 /* ---- synthetic inputs and digests (bench / parity harness) --------------------------------------
  * fill: value = splitmix64(seed ^ (first_linear_index + linear index)) mod q_i */

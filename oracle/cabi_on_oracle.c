@@ -309,6 +309,33 @@ int fhe_encrypt_draws(const fhe_ctx *c, const uint8_t key[32], uint64_t first, u
     return FHE_OK;
 }
 
+/* decryption in batches (include/fhe_hip.h): the oracle's big-integer decryption per ciphertext; the key arrives in NTT form */
+uint32_t fhe_ctx_modulus_bits(const fhe_ctx *c) {
+    int nb = 0, mb = 0;
+    uint64_t *z = (uint64_t *)calloc(3 * pw(c) + c->n, 8);
+    if (!z) return 0;
+    fo_decrypt_noise_bits(c->o, z, z + pw(c), 2, z + 3 * pw(c), &nb, &mb);
+    free(z);
+    return (uint32_t)mb;
+}
+size_t fhe_decrypt_scratch_bytes(const fhe_ctx *c, uint32_t size, uint64_t count) { return (size_t)count * (size + 1) * pw(c) * 8; }
+int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *sk_ntt, const uint64_t *ct, uint32_t size, uint64_t count, uint64_t *plain, uint32_t *noise_bits,
+                      void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!c || !sk_ntt || (!ct && count) || (!plain && count)) return fail(FHE_ERR_PARAM, "null argument");
+    if (size < 2) return fail(FHE_ERR_PARAM, "a ciphertext has at least two polynomials");
+    if (count && (!scratch || scratch_bytes < fhe_decrypt_scratch_bytes(c, size, count))) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_decrypt_scratch_bytes()");
+    uint64_t *sk = (uint64_t *)malloc(pw(c) * 8);
+    if (!sk) return fail(FHE_ERR_HIP, "out of memory");
+    fhe_ntt_inverse(c, sk_ntt, sk, 1, s);
+    for (uint64_t i = 0; i < count; i++) {
+        int nb = 0;
+        fo_decrypt_noise_bits(c->o, sk, ct + i * size * pw(c), size, plain + i * c->n, &nb, NULL);
+        if (noise_bits) noise_bits[i] = (uint32_t)nb;
+    }
+    free(sk);
+    return FHE_OK;
+}
+
 size_t fhe_multiply_scratch_bytes(const fhe_ctx *c, uint32_t sa, uint32_t sb, uint64_t count) {
     (void)c; (void)sa; (void)sb; (void)count;
     return 8;

@@ -803,7 +803,12 @@ void fo_decrypt_phase(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, u
     free(s); free(acc); free(x);
 }
 
+int fo_decrypt_noise_bits(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain, int *noise_bits, int *modulus_bits);
 int fo_decrypt(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain) {
+    return fo_decrypt_noise_bits(c, sk, ct, size, plain, NULL, NULL);
+}
+/* the same with the raw figures: *noise_bits = bit length of the largest |t x - m q|, *modulus_bits = bit length of q */
+int fo_decrypt_noise_bits(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain, int *noise_bits, int *modulus_bits) {
     u32 n = c->n, k = c->k;
     u64 *phase = (u64 *)malloc(sizeof(u64) * (size_t)k * n);
     fo_decrypt_phase(c, sk, ct, size, phase);
@@ -840,6 +845,8 @@ int fo_decrypt(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t
         if (nb_ > max_noise_bits) max_noise_bits = nb_;
     }
     free(phase);
+    if (noise_bits) *noise_bits = max_noise_bits;
+    if (modulus_bits) *modulus_bits = big_bits(&c->qbig);
     int budget = big_bits(&c->qbig) - max_noise_bits - 1;
     return budget < 0 ? 0 : budget;
 }

@@ -120,6 +120,8 @@ void fo_decrypt_phase(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, u
                       uint64_t *phase);
 /* exact decryption: plain[n] = round(t * phase / q) mod t; returns invariant noise budget in bits */
 int fo_decrypt(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain);
+/* the same with the raw figures behind the budget: bit length of the largest |t x - m q| and of q (fhe_decrypt_batch reports the former) */
+int fo_decrypt_noise_bits(const fo_ctx *c, const uint64_t *sk, const uint64_t *ct, uint32_t size, uint64_t *plain, int *noise_bits, int *modulus_bits);
 
 /* evaluation keys for relinearising s^2: layout [k (prime idx)][n_digits][2][k][n], NTT form.
  * n_digits = ceil(bits(q_i)/dbc) computed per context as max over primes. */

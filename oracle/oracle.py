@@ -94,6 +94,8 @@ def lib(omp=False):
         L.fo_decrypt_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.fo_decrypt.restype = C.c_int
         L.fo_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fo_decrypt_noise_bits.restype = C.c_int
+        L.fo_decrypt_noise_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.fo_evk_digits.restype = C.c_uint32
         L.fo_evk_digits.argtypes = [C.c_void_p, C.c_uint32]
         L.fo_evk_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
@@ -288,6 +290,14 @@ class Oracle:
         plain = np.zeros(self.n, dtype=np.uint64)
         budget = self.L.fo_decrypt(self.h, _p(sk), _p(ct), ct.shape[0], _p(plain))
         return plain, int(budget)
+
+    def decrypt_noise_bits(self, sk, ct):
+        """(plain, bit length of the largest |t x - m q|, bit length of q): the raw figures behind the noise budget"""
+        ct = np.ascontiguousarray(ct)
+        plain = np.zeros(self.n, dtype=np.uint64)
+        nb, mb = C.c_int(0), C.c_int(0)
+        self.L.fo_decrypt_noise_bits(self.h, _p(np.ascontiguousarray(sk)), _p(ct), ct.shape[0], _p(plain), C.byref(nb), C.byref(mb))
+        return plain, nb.value, mb.value
 
     def decrypt_phase(self, sk, ct):
         ct = np.ascontiguousarray(ct)

@@ -117,6 +117,23 @@ def test_oracle_backed_c_abi_encrypts_like_the_oracle(oracle_mod):
     assert L.fhe_encrypt_batch(ctx, pk_ntt.ctypes.data_as(vp), None, 2, key, 0, zero.ctypes.data_as(vp), scratch.ctypes.data_as(vp), nbytes, None) == 0
     assert np.array_equal(zero[1], orc.encrypt_keyed(pk, np.zeros(orc.n, dtype=np.uint64), key, 1))
     assert L.fhe_encrypt_batch(ctx, pk_ntt.ctypes.data_as(vp), None, 2, key, 0, zero.ctypes.data_as(vp), scratch.ctypes.data_as(vp), 8, None) < 0
+    # fhe_decrypt_batch of the shim = the oracle's decryption, with the raw noise figure
+    sk_ntt = np.ascontiguousarray(sk).copy()
+    assert L.fhe_ntt_forward(ctx, sk_ntt.ctypes.data_as(vp), sk_ntt.ctypes.data_as(vp), 1, None) == 0
+    L.fhe_decrypt_scratch_bytes.restype = C.c_size_t
+    L.fhe_decrypt_scratch_bytes.argtypes = [vp, C.c_uint32, C.c_uint64]
+    L.fhe_decrypt_batch.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp, vp, C.c_size_t, vp]
+    L.fhe_ctx_modulus_bits.restype = C.c_uint32
+    L.fhe_ctx_modulus_bits.argtypes = [vp]
+    dbytes = L.fhe_decrypt_scratch_bytes(ctx, 2, len(vals))
+    dscr = np.zeros(dbytes // 8 + 1, dtype=np.uint64)
+    got_plain = np.zeros((len(vals), orc.n), dtype=np.uint64)
+    bits = np.zeros(len(vals), dtype=np.uint32)
+    assert L.fhe_decrypt_batch(ctx, sk_ntt.ctypes.data_as(vp), out.ctypes.data_as(vp), 2, len(vals), got_plain.ctypes.data_as(vp), bits.ctypes.data_as(vp),
+                               dscr.ctypes.data_as(vp), dbytes, None) == 0
+    for i in range(len(vals)):
+        want, nb, mb = orc.decrypt_noise_bits(sk, out[i])
+        assert np.array_equal(got_plain[i], want) and np.array_equal(want, plain[i]) and bits[i] == nb and mb == L.fhe_ctx_modulus_bits(ctx)
     draws = np.zeros((3, 3, orc.n), dtype=np.int8)
     L.fhe_encrypt_draws.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_uint64, vp, vp]
     assert L.fhe_encrypt_draws(ctx, key, 11, 3, draws.ctypes.data_as(vp), None) == 0

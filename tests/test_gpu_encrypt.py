@@ -168,3 +168,47 @@ def test_servers_with_device_encryptions(fhe, oracle_mod, tmp_path):
     assert [fe.decode(dec.decrypt(c)) for c in z] == [0.0, 0.0] and not torch.equal(z[0], z[1])
     zeros.seek(4)
     assert torch.equal(zeros(1)[0], z[1])
+
+
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_2048", "SEAL23_4096", "P8192", "SEAL3_8192"])
+def test_decrypt_batch_equals_the_oracle_big_integer_decryption(fhe, oracle_mod, preset):
+    """fhe_decrypt_batch (phase by Horner per slot + the exact rounding with multi-word integers on the device, csrc/encrypt.hip k_dec_round)
+    against the oracle's CRT composition and big-integer rounding (oracle/fhe_oracle.c fo_decrypt): plaintexts AND the bit length of the
+    invariant noise, for fresh ciphertexts, products (sizes 3 and 5) and uniformly random residues (far beyond the noise budget: the
+    rounding is exact there too); k = 1 .. 5 primes"""
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    kg = fhe.KeyGenerator(ctx, seed=31)
+    sk = fhe.to_host(kg.secret_key())
+    dec, ev = fhe.Decryptor(ctx, kg.secret_key()), fhe.Evaluator(ctx)
+    der = fhe.DeviceEncryptor(ctx, kg.public_key(), key=KEY)
+    vals = [0.0, 1.5, -2.25, 0.40625, 100.0, -0.001953125]
+    fresh = der.encrypt_values(vals)
+    qbits = int(fhe._lib.load().fhe_ctx_modulus_bits(ctx.h))
+
+    def check(cts, label):
+        plains, budgets = dec.decrypt_batch(cts, with_budget=True)
+        host = fhe.to_host(cts)
+        for i in range(host.shape[0]):
+            want, nb, mb = orc.decrypt_noise_bits(sk, host[i])
+            assert mb == qbits
+            assert np.array_equal(plains[i], want), (preset, label, i)
+            assert budgets[i] == max(0, mb - nb - 1), (preset, label, i, budgets[i], nb)
+        return plains, budgets
+
+    plains, budgets = check(fresh, "fresh")
+    fe = fhe.FractionalEncoder(ctx)
+    assert [fe.decode(p) for p in plains] == vals and min(budgets) > 20
+    one, b1 = dec.decrypt(fresh[2], with_budget=True)                       # the single-ciphertext form and the host big-integer form agree
+    hostp, hb = dec.decrypt_host(fresh[2], with_budget=True)
+    assert np.array_equal(one, plains[2]) and np.array_equal(hostp, one) and b1 == hb == budgets[2]
+    if ctx.k >= 2:                                                          # a product needs room: not the one-prime set
+        prod = ev.multiply(fresh[:3].contiguous(), fresh[3:6].contiguous())
+        assert prod.shape[1] == 3
+        p3, _ = check(prod, "size 3")
+        assert [fe.decode(p) for p in p3] == [vals[i] * vals[i + 3] for i in range(3)]
+        check(ev.multiply(prod, prod), "size 5")                           # whatever the budget says, the same bits as the oracle
+    noise = ctx.random_ct(3, size=2, seed=77)                              # uniformly random residues: no budget at all
+    _, b = check(noise, "random")
+    assert b == [0, 0, 0]
+    check(ctx.random_ct(2, size=4, seed=78), "random size 4")
+    assert dec.decrypt_batch(ctx.empty(0)).shape == (0, ctx.n)
