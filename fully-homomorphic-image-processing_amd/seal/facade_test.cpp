@@ -168,6 +168,26 @@ int main(int argc, char **argv) {
         CHECK(dec(z.get(0)) == 0.0 && dec(z.get(1)) == 0.0 && z0.str() != z1.str(), "two encryptions of zero decrypt to zero and differ");
         Encryptor e3(context, pk);
         CHECK(e3.sampler_key() != e2.sampler_key(), "every Encryptor draws its own key");
+        // and the receiving side: one fhe_decrypt_batch for the whole batch = seal::Decryptor one ciphertext at a time (plaintext and budget)
+        hip::DeviceDecryptor dd(context, sk);
+        std::vector<int> budgets;
+        std::vector<Plaintext> plains = dd.decrypt(batch, &budgets);
+        CHECK(plains.size() == vals.size() && budgets.size() == vals.size(), "batched decryption returns one plaintext and budget per ciphertext");
+        for (size_t i = 0; i < plains.size(); ++i) {
+            Plaintext p;
+            decryptor.decrypt(one[i], p);
+            CHECK(plains[i].data() == p.data() && encoder.decode(plains[i]) == vals[i], "batched decryption %d", (int)i);
+            CHECK(budgets[i] == decryptor.invariant_noise_budget(one[i]), "batched budget %d: %d", (int)i, budgets[i]);
+        }
+        {   // a product (size 3) through both paths
+            Ciphertext prod(one[0]);
+            evaluator.multiply(prod, one[1]);
+            std::vector<Ciphertext> v(1, prod);
+            std::vector<int> b3;
+            std::vector<Plaintext> p3 = dd.decrypt(hip::CiphertextBatch::from(context, v), &b3);
+            CHECK(encoder.decode(p3[0]) == vals[0] * vals[1] && b3[0] == decryptor.invariant_noise_budget(prod) && b3[0] > 0, "batched decryption of a product: %g, budget %d",
+                  encoder.decode(p3[0]), b3[0]);
+        }
     }
 
     // fused block circuit on one encrypted 8x8 block

@@ -6,6 +6,7 @@
 //                                Ciphertext::save records), converts to / from std::vector<seal::Ciphertext>
 //   seal::hip::DeviceEncryptor   the servers' own encryptions as device batches (fhe_encrypt_batch): encrypt_values / encrypt_zeros ->
 //                                CiphertextBatch; with the key and index of a seal::Encryptor it makes that object's ciphertexts
+//   seal::hip::DeviceDecryptor   seal::Decryptor::decrypt (+ noise budgets) of a whole CiphertextBatch in one fhe_decrypt_batch
 //   seal::hip::Circuits          one fhe_circuits handle + scratch: cubic, linear, sample_bicubic, sample_linear,
 //                                resize_bicubic (shared offsets), homomorphic_sin / _cos, approximated_step, decode_channel
 //
@@ -148,6 +149,43 @@ private:
     std::array<uint8_t, 32> key_;
     int ic_, fc_;
     uint64_t next_;
+};
+
+// seal::Decryptor::decrypt of a whole batch (the clients' loops: homo/client_jpeg.cpp:266-280, homo/client_resize.cpp:190-210): ONE
+// fhe_decrypt_batch -- phase and exact rounding on the device -- and one download of the plaintext coefficients
+class DeviceDecryptor {
+public:
+    DeviceDecryptor(const SEALContext &ctx, const SecretKey &sk) : ctx_(ctx) {
+        const detail::CtxState &s = *ctx.state();
+        if (sk.buf.words() != s.poly_words()) throw std::invalid_argument("secret key does not match the context");
+        sk_ntt_.resize(s.poly_words());
+        detail::check(fhe_ntt_forward(s.h, sk.buf.ptr(), sk_ntt_.ptr(), 1, nullptr), "ntt");
+    }
+    // plaintexts in batch order; budgets (optional) receives seal::Decryptor::invariant_noise_budget of each ciphertext
+    std::vector<Plaintext> decrypt(const CiphertextBatch &cts, std::vector<int> *budgets = nullptr) {
+        const detail::CtxState &s = *ctx_.state();
+        std::vector<Plaintext> out;
+        const size_t count = cts.count();
+        if (!count) return out;
+        const size_t need = (fhe_decrypt_scratch_bytes(s.h, cts.size(), count) + 7) / 8, tail = count * s.n + (count + 1) / 2;
+        if (scratch_.words() < need + tail) scratch_.resize(need + tail);
+        uint64_t *d_plain = scratch_.ptr() + need;
+        uint32_t *d_bits = (uint32_t *)(d_plain + count * s.n);
+        detail::check(fhe_decrypt_batch(s.h, sk_ntt_.ptr(), cts.ptr(), cts.size(), count, d_plain, d_bits, scratch_.ptr(), need * 8, nullptr), "decrypt_batch");
+        std::vector<uint64_t> host(tail);
+        scratch_.download(host.data(), tail, need);
+        detail::check(fhe_stream_sync(nullptr), "sync");
+        const uint32_t *bits = (const uint32_t *)(host.data() + count * s.n);
+        const int qbits = (int)fhe_ctx_modulus_bits(s.h);
+        for (size_t i = 0; i < count; ++i) {
+            out.push_back(Plaintext(std::vector<uint64_t>(host.begin() + i * s.n, host.begin() + (i + 1) * s.n)));
+            if (budgets) budgets->push_back(std::max(0, qbits - (int)bits[i] - 1));
+        }
+        return out;
+    }
+private:
+    SEALContext ctx_;
+    detail::DevBuf sk_ntt_, scratch_;
 };
 
 // sample plan of ResizeImage (homo/fhe_resize.h:350-351,381-382 and the tap order of SampleBicubic / SampleLinear)

@@ -72,6 +72,16 @@ def enc_digest():
 
 
 ref_enc = enc_digest()
+soak_dec = fhe.Decryptor(ctx, fhe.KeyGenerator(ctx, seed=2).secret_key())
+
+
+def dec_digest():                      # fhe_decrypt_batch of the same batch: the per-ciphertext atomicMax of the noise bits and the plaintexts
+    der.seek(1 << 33)
+    plains, budgets = soak_dec.decrypt_batch(der.encrypt_values(enc_vals), with_budget=True)
+    return hash((plains.tobytes(), tuple(budgets)))
+
+
+ref_dec = dec_digest()
 bad = 0
 t0 = time.time()
 for i in range(iters):
@@ -107,5 +117,8 @@ for i in range(iters):
     if i % 8 == 0 and enc_digest() != ref_enc:
         bad += 1
         print("device encryption digest mismatch at iteration", i, flush=True)
+    if i % 8 == 4 and dec_digest() != ref_dec:
+        bad += 1
+        print("device decryption mismatch at iteration", i, flush=True)
 print("soak %s: %d iterations, %d mismatches, %.1f s" % (preset, iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
