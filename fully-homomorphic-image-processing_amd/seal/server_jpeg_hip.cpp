@@ -160,23 +160,33 @@ struct Server {
         hcheck(hipMemsetAsync(d_bad, 0, 8, main), "memset");
         const double t0 = now();
         try {
-            for (long w = 0; w < waves; ++w) {
+            // wave w: page-locked slot -> device buffer w & 1 on the upload stream (blocks until the reader thread has the wave); returns the slot
+            auto upload = [&](long w) {
                 const int d = (int)(w & 1);
-                const uint64_t nb = count_of(w);
                 const Ready r = ready_in.get();
                 if (r.wave < 0) throw Fail{"reader: " + reader_err};
                 if (done_used[d]) hcheck(hipStreamWaitEvent(h2d, ev_done[d], 0), "wait");          // the device buffer is free again
                 if (drained_used[d]) hcheck(hipStreamWaitEvent(h2d, ev_drained[d], 0), "wait");
-                hcheck(hipMemcpyAsync(din[d], hin[r.slot], nb * block_words * 8, hipMemcpyHostToDevice, h2d), "h2d");
+                hcheck(hipMemcpyAsync(din[d], hin[r.slot], count_of(w) * block_words * 8, hipMemcpyHostToDevice, h2d), "h2d");
                 hcheck(hipEventRecord(ev_copied[r.slot], h2d), "record");
                 free_in.put(InSlot{r.slot, ev_copied[r.slot], true});
-                hcheck(hipStreamWaitEvent(main, ev_copied[r.slot], 0), "wait");
+                return r.slot;
+            };
+            int next_slot = upload(0);
+            for (long w = 0; w < waves; ++w) {
+                const int d = (int)(w & 1);
+                const uint64_t nb = count_of(w);
+                hcheck(hipStreamWaitEvent(main, ev_copied[next_slot], 0), "wait");
                 if (drained_used[d]) hcheck(hipStreamWaitEvent(main, ev_drained[d], 0), "wait");   // dout[d] has been copied out
                 check(fhe_count_unreduced(ctx, din[d], nb * 3 * 64 * 2, d_bad, main), "fhe_count_unreduced");  // the payload is a client's: what Ciphertext::load would reject
                 check(fhe_rgb_to_ycc_blocks(ctx, din[d], nb, 100, 100, main), "fhe_rgb_to_ycc_blocks");      // in place: Y, Cb, Cr in the stream's block layout
                 check(fhe_dct8x8_quant(ctx, plan, din[d], dout[d], nb * 3, scratch, scratch_bytes, main), "fhe_dct8x8_quant");
                 hcheck(hipEventRecord(ev_done[d], main), "record");
                 done_used[d] = true;
+                // the NEXT wave's upload goes into its stream before THIS wave's download: the runtime maps streams onto a few hardware
+                // queues and the two copy streams can share one -- a download waiting for this wave's kernels at the head of that queue
+                // would hold the next upload back until the kernels are done (measured in the Python server_resize: 2.05 -> 1.25 s)
+                if (w + 1 < waves) next_slot = upload(w + 1);
                 const int oslot = free_out.get();
                 if (oslot < 0) throw Fail{"writer: " + writer_err};
                 hcheck(hipStreamWaitEvent(d2h, ev_done[d], 0), "wait");

@@ -141,6 +141,15 @@ class _ResidueCheck:
                                  "discarded (an output mapping kept open by the caller is NOT truncated: discard its contents)" % bad)
 
 
+def _copy_streams():
+    """(upload stream, download stream), both of the default priority.  The runtime maps streams onto a few hardware queues and two
+    streams can share one (measured in server_resize: both copy streams on HSA queue 4): what matters then is the ORDER of their work
+    in that queue -- the servers enqueue the next wave's upload before this wave's download, see the loops.  Tried and rejected: a
+    high-priority download stream (its own queue): its blit kernels then pre-empt the compute kernels (server_resize 1.25 -> 1.38 s,
+    device compute 0.87 -> 1.25 s; server_jpeg 937 -> 662 colour blocks/s)."""
+    return torch.cuda.Stream(), torch.cuda.Stream()
+
+
 def _refuser(own_out, fout, out_path):
     """what a server does with its output stream when the input turns out to be invalid: a file it opened itself is closed and
     truncated to zero bytes (any reader then fails on the first record); a StreamFile the caller keeps open (a reused spool
@@ -201,7 +210,7 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
     din = [torch.empty(shape, dtype=torch.int64, device=ctx.device) for _ in range(2)]
     dout = [torch.empty(shape, dtype=torch.int64, device=ctx.device) for _ in range(2)] if do_dct else din
     main = torch.cuda.current_stream()
-    h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+    h2d, d2h = _copy_streams()
     rec = RECORD_HEADER + 2 * ctx.k * ctx.n * 8
     if (in_path.size if isinstance(in_path, StreamFile) else os.path.getsize(in_path)) < n_blocks * 192 * rec:
         raise EOFError("ciphertext stream ended")
@@ -263,7 +272,11 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
         wt.start()
         computed, drained = [None, None], [None, None]       # per device buffer: compute finished / left for the host
         t_start, t_stop = [], []
-        for wi, (s, e) in enumerate(waves):
+        copied_of = {}
+
+        def upload(wi):
+            """wave wi: page-locked slot -> device buffer wi & 1, on the upload stream (blocks until the reader thread has the wave)"""
+            s, e = waves[wi]
             nb, d = e - s, wi & 1
             got, slot = ready_in.get()
             if got is None:
@@ -276,7 +289,12 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
                 copied = torch.cuda.Event()
                 copied.record(h2d)
             free_in.put((slot, copied))
-            main.wait_event(copied)
+            copied_of[wi] = copied
+
+        upload(0)
+        for wi, (s, e) in enumerate(waves):
+            nb, d = e - s, wi & 1
+            main.wait_event(copied_of.pop(wi))
             if drained[d] is not None:
                 main.wait_event(drained[d])                      # dout[d] has been copied out
             if stats is not None:
@@ -292,6 +310,8 @@ def server_jpeg(ctx, in_path, out_path, n_blocks, wave_blocks=8, quant=None, do_
             done = torch.cuda.Event()
             done.record(main)
             computed[d] = done
+            if wi + 1 < len(waves):
+                upload(wi + 1)                                   # before this wave's download: see _copy_streams
             t_w = time.perf_counter()
             oslot = free_out.get()
             if oslot is None:
@@ -478,7 +498,7 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
     hout = [_pinned(("rs_out", i, out_size), (max_px, 3, out_size, ctx.k, ctx.n)) for i in range(slots)]
     dout = [torch.empty((max_px, 3, out_size, ctx.k, ctx.n), dtype=torch.int64, device=ctx.device) for _ in range(2)]
     main = torch.cuda.current_stream()
-    h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+    h2d, d2h = _copy_streams()
     fin = StreamFile(in_path) if own_in else in_path
     fout = StreamFile(out_path, write=True, size=dst_w * dst_h * 3 * rec_out) if own_out else out_path
     if fout.size < dst_w * dst_h * 3 * rec_out:
@@ -533,7 +553,10 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         t_start, t_stop = [], []
         sampler = circuits.sample_bicubic if bicubic else circuits.sample_linear
         offs = ([(dx, dy) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)] if bicubic else [(0, 0), (1, 0), (0, 1), (1, 1)])
-        for si, (y0, y1) in enumerate(steps):
+        copied_of = {}
+
+        def upload(si):
+            """rows of step si: page-locked slot -> ring, on the upload stream (blocks until the reader thread has them)"""
             got, slot = ready_in.get()
             if got is None:
                 raise errors[0]
@@ -553,7 +576,11 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
                 copied = torch.cuda.Event()
                 copied.record(h2d)
             free_in.put((slot, copied))
-            main.wait_event(copied)
+            copied_of[si] = copied
+
+        upload(0)
+        for si, (y0, y1) in enumerate(steps):
+            main.wait_event(copied_of.pop(si))
             # sample plan of these destination rows in terms of ring slots
             taps, fracs = [], []
             for yy in range(y0, y1):
@@ -583,6 +610,11 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
             done = torch.cuda.Event()
             done.record(main)
             computed.append(done)
+            # the NEXT step's upload is enqueued before THIS step's download: the runtime maps streams onto a few hardware queues and both
+            # copy streams can land on one (measured: they did) -- a download waiting for this step's kernels at the head of that queue
+            # held the next upload back until the kernels were done, and upload, compute and download took turns (2.05 s for a 0.9 s job)
+            if si + 1 < len(steps):
+                upload(si + 1)
             oslot = free_out.get()
             if oslot is None:
                 raise errors[0]
