@@ -241,30 +241,41 @@ struct DecConsts {
     u64 jq[DEC_K + 1][DEC_L];         // j q, j = 0 .. k
     u64 qhalf[DEC_L];                 // floor(q / 2)
 };
-__device__ __forceinline__ bool big_ge(const u64 *a, const u64 *b, u32 limbs) {
-    for (int l = (int)limbs - 1; l >= 0; --l)
-        if (a[l] != b[l]) return a[l] > b[l];
-    return true;
+template <int L>
+__device__ __forceinline__ bool big_ge(const u64 (&a)[L], const u64 *b) {
+    bool ge = true;                                                    // from the least significant word up: the last difference decides
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        if (a[l] != b[l]) ge = a[l] > b[l];
+    return ge;
 }
+// K = number of primes (compile-time: every multi-word value lives in registers), L = K + 1 words.  One atomicMax per WAVE: a wave's
+// 64 consecutive coefficients belong to one ciphertext (n is a multiple of 64), the lanes' maxima are folded with shuffles first
+// (8,192 atomics on one address per ciphertext made the first version of this kernel 25 x slower than it is now).
+template <int K>
 __global__ __launch_bounds__(256) void k_dec_round(const u64 *__restrict__ phase, u64 *__restrict__ plain, u32 *__restrict__ noise_bits,
                                                    const Modulus *__restrict__ mods, u32 n, u64 count, const DecConsts C) {
+    constexpr int L = K + 1;
     const u64 total = count * n;
-    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+    for (u64 g0 = (u64)blockIdx.x * blockDim.x; g0 < total; g0 += (u64)gridDim.x * blockDim.x) {
+        const u64 g = g0 + threadIdx.x;                               // total is a multiple of 256: no partial blocks
         const u64 e = g / n;
         const u32 c = (u32)(g % n);
-        u64 N[DEC_L];
+        u64 N[L];
 #pragma unroll
-        for (int l = 0; l < DEC_L; ++l) N[l] = 0;
+        for (int l = 0; l < L; ++l) N[l] = 0;
         u64 A = 0;
-        for (u32 i = 0; i < C.k; ++i) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
             const Modulus md = mods[i];
-            const u64 y = mul_barrett(phase[(e * C.k + i) * n + c], C.inv_punct[i], md);
+            const u64 y = mul_barrett(phase[(e * K + i) * n + c], C.inv_punct[i], md);
             const u64 r = mul_barrett(C.t_mod_q[i], y, md);
             const u64 a = (C.t * y - r) * C.qinv64[i];
             A += a;
             if (A >= C.t) A -= C.t;
             u64 carry = 0;
-            for (u32 l = 0; l < C.limbs; ++l) {                      // N += r * punct_i
+#pragma unroll
+            for (int l = 0; l < L; ++l) {                              // N += r * punct_i
                 const u64 lo = r * C.punct[i][l], hi = __umul64hi(r, C.punct[i][l]);
                 const u64 s1 = N[l] + lo, c1 = s1 < lo;
                 const u64 s2 = s1 + carry, c2 = s2 < carry;
@@ -272,31 +283,45 @@ __global__ __launch_bounds__(256) void k_dec_round(const u64 *__restrict__ phase
                 carry = hi + c1 + c2;
             }
         }
-        u64 M[DEC_L];                                                // N + floor(q/2)
+        u64 M[L];                                                      // N + floor(q/2)
         u64 cy = 0;
-        for (u32 l = 0; l < C.limbs; ++l) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
             const u64 s1 = N[l] + C.qhalf[l], c1 = s1 < N[l];
             const u64 s2 = s1 + cy, c2 = s2 < cy;
             M[l] = s2;
             cy = c1 + c2;
         }
         u32 j = 0;
-        for (u32 m = 1; m <= C.k; ++m) j += big_ge(M, C.jq[m], C.limbs) ? 1 : 0;
+#pragma unroll
+        for (int m = 1; m <= K; ++m) j += big_ge<L>(M, C.jq[m]) ? 1 : 0;
         u64 v = A + j;
         while (v >= C.t) v -= C.t;
         plain[g] = v;
         if (noise_bits) {
-            const bool pos = big_ge(N, C.jq[j], C.limbs);
-            const u64 *hi_ = pos ? N : C.jq[j], *lo_ = pos ? C.jq[j] : N;
+            u64 J[L];                                                  // j q, selected without indexing the argument block by a lane value
+#pragma unroll
+            for (int l = 0; l < L; ++l) J[l] = 0;
+#pragma unroll
+            for (int m = 1; m <= K; ++m)
+                if (j == (u32)m) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) J[l] = C.jq[m][l];
+                }
+            const bool pos = big_ge<L>(N, J);
             u64 borrow = 0;
             int bits = 0;
-            for (u32 l = 0; l < C.limbs; ++l) {
-                const u64 d1 = hi_[l] - lo_[l], b1 = hi_[l] < lo_[l];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const u64 hi_ = pos ? N[l] : J[l], lo_ = pos ? J[l] : N[l];
+                const u64 d1 = hi_ - lo_, b1 = hi_ < lo_;
                 const u64 d2 = d1 - borrow, b2 = d1 < borrow;
                 borrow = b1 + b2;
-                if (d2) bits = (int)(64 * l) + (64 - __clzll((long long)d2));
+                if (d2) bits = 64 * l + (64 - __clzll((long long)d2));
             }
-            atomicMax(noise_bits + e, (u32)bits);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(noise_bits + e, (u32)bits);
         }
     }
 }
@@ -442,7 +467,14 @@ extern "C" int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *d_sk_ntt, con
     }
     if ((rc = fhe_ntt_inverse(c, (const uint64_t *)acc, (uint64_t *)acc, count, s))) return rc;
     if (d_noise_bits) HIP_TRY(hipMemsetAsync(d_noise_bits, 0, count * sizeof(u32), st));
-    k_dec_round<<<blocks_for(count * n), 256, 0, st>>>(acc, (u64 *)d_plain, d_noise_bits, c->qb.d_mod, n, count, C);
+    if (n % 256) return fail(FHE_ERR_PARAM, "n must be a multiple of 256");
+    const unsigned blocks = blocks_for(count * n);
+    switch (k) {
+#define GO(KK) case KK: k_dec_round<KK><<<blocks, 256, 0, st>>>(acc, (u64 *)d_plain, d_noise_bits, c->qb.d_mod, n, count, C); break;
+        GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
+#undef GO
+        default: return fail(FHE_ERR_PARAM, "unsupported number of primes");
+    }
     KERNEL_CHECK();
     return FHE_OK;
 }

@@ -288,9 +288,7 @@ struct CtxState {
     uint32_t n, k;
     uint64_t t;
     std::vector<uint64_t> q;
-    Big Q, Qhalf;
-    std::vector<Big> punct;            // Q / q_i
-    std::vector<uint64_t> inv_punct;   // (Q/q_i)^-1 mod q_i
+    Big Q;                             // the coefficient modulus (its bit length enters the noise budget; the CRT constants of decryption live in the library since round 5)
     // lazy mode: values recorded and not yet computed, in creation order (operands before consumers)
     // Threads: SEAL's Evaluator may be shared by threads working on distinct ciphertexts; here every Evaluator call appends to
     // this one graph and any observation flushes all of it, so recording, flushing and materialising hold `mu` (recursive: a
@@ -364,14 +362,6 @@ public:
         s.stats.create_s = detail::now_s() - tc;
         s.Q = detail::Big(1);
         for (uint64_t qi : s.q) s.Q.mul_small(qi);
-        s.Qhalf = s.Q;
-        s.Qhalf.shr1();
-        for (uint32_t i = 0; i < s.k; ++i) {
-            detail::Big pi(1);
-            for (uint32_t j = 0; j < s.k; ++j) if (j != i) pi.mul_small(s.q[j]);
-            s.inv_punct.push_back(detail::powmod(pi.mod_small(s.q[i]), s.q[i] - 2, s.q[i]));
-            s.punct.push_back(pi);
-        }
         total_ = BigUInt(s.Q.bits());
         {
             std::lock_guard<std::mutex> lk(detail::known_moduli_mu());
