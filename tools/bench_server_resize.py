@@ -60,6 +60,21 @@ try:
     dt = time.time() - t0
     sin.close()
     sout.close()
+    # the same job from the C++ host (seal/server_resize_hip.cpp): three passes over its own mappings, the last one reported
+    cpp = None
+    exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_resize_hip")
+    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096"):
+        import subprocess
+        fpk = os.path.join(a.dir, "fhe_rs_pk.txt")
+        with open(fpk, "wb") as f:
+            fhe.server.write_ciphertext(f, fhe.to_host(fhe.KeyGenerator(ctx).public_key()))
+        env = dict(os.environ, FHE_SEAL23_MODULI="1") if a.preset != "P4096" else dict(os.environ)
+        try:
+            r = subprocess.run([exe, fin, fout, fpk, str(a.src), str(a.src), str(a.dst), str(a.dst), "0" if a.bilinear else "1", str(a.rows), str(a.io_threads), str(ctx.n), str(ctx.t), "-", "3"],
+                               capture_output=True, text=True, timeout=900, env=env)
+            cpp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+        finally:
+            os.remove(fpk)
 finally:
     for p in (fin, fout):
         if os.path.exists(p):
@@ -69,4 +84,4 @@ print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three cha
                   "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
                   "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
                   "file_read_seconds": stats["file_read_seconds"], "file_write_seconds": stats["file_write_seconds"],
-                  "first_pass_seconds_incl_page_locking_and_page_allocation": fresh.get("seconds")}))
+                  "first_pass_seconds_incl_page_locking_and_page_allocation": fresh.get("seconds"), "cpp_host": cpp}))
