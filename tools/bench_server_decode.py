@@ -36,8 +36,22 @@ try:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_enc = sum(1 + w * h + p * w * h * a.degree * 2 for p in pairs)
+    # the same job from the C++ host (seal/server_decode_hip.cpp); a single process: includes its context, tables and first-touch allocations
+    cpp = None
+    exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_decode_hip")
+    if os.path.exists(exe) and a.encrypt == "device":
+        import subprocess
+        fpk = os.path.join(d, "pk.txt")
+        with open(fpk, "wb") as f:
+            fhe.server.write_ciphertext(f, fhe.to_host(kg.public_key()))
+        env = dict(os.environ, FHE_SEAL23_MODULI="1") if a.preset != "P4096" else dict(os.environ)
+        t1 = time.perf_counter()
+        r = subprocess.run([exe, fin, fout, fpk, str(w), str(h)] + [str(p) for p in pairs] + ["64", str(a.degree), "0.5", str(ctx.n), str(ctx.t)], capture_output=True, text=True, timeout=900, env=env)
+        cpp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+        cpp["process_wall_seconds"] = time.perf_counter() - t1
+        os.remove(fpk)
     print(json.dumps({"workload": "server_decode stream, 4x4 image, runs per channel %s, order 64, degree %d, %s" % (pairs, a.degree, a.preset),
-                      "server_side_encryptions": a.encrypt, "encryptions": n_enc, "runs": sum(pairs), "seconds": dt, "ms_per_run": dt * 1e3 / sum(pairs)}))
+                      "server_side_encryptions": a.encrypt, "encryptions": n_enc, "runs": sum(pairs), "seconds": dt, "ms_per_run": dt * 1e3 / sum(pairs), "cpp_host": cpp}))
 finally:
     for p in (fin, fout):
         if os.path.exists(p):
