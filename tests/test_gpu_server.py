@@ -440,3 +440,47 @@ def test_cpp_server_resize_writes_the_python_servers_bytes(fhe, tmp_path, bicubi
         fhe.client.receive_resize(ctx, dec, enc, f_py, w, h, decoded=a)
         fhe.client.receive_resize(ctx, dec, enc, f_cpp, w, h, decoded=b)
         assert a == b
+
+
+def test_server_resize_with_shared_offsets(fhe, tmp_path):
+    """server_resize(shared_offsets=True): one offset ciphertext per output column and row instead of two per output pixel.  Not the
+    reference's ciphertexts -- but the bytes equal the shared-offset circuit called on the whole image with the same encryptions, two row
+    shards write the whole run's file, and the decrypted image equals the per-pixel mode's, value for value"""
+    ctx = fhe.SEALContext.preset("P8192")
+    kg = fhe.KeyGenerator(ctx, seed=14)
+    enc, ev = fhe.FractionalEncoder(ctx), fhe.Evaluator(ctx)
+    W, H, w, h = 6, 7, 4, 4
+    rgb = np.random.default_rng(2).integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    fin, f_sh, f_parts, f_px = (str(tmp_path / x) for x in ("in.ct", "shared.ct", "parts.ct", "pixel.ct"))
+    client = fhe.DeviceEncryptor(ctx, kg.public_key(), key=bytes(32))
+    pix = client.encrypt_values(rgb.reshape(-1).astype(np.float64))                 # [H * W * 3, 2, k, n], the stream's order
+    with open(fin, "wb") as f:
+        for c in fhe.to_host(pix):
+            fhe.server.write_ciphertext(f, c)
+    mk = lambda: fhe.server.make_fraction_encryptor(ctx, kg.public_key(), enc, seed=3, device=True)
+    assert fhe.server.server_resize(ctx, fin, f_sh, W, H, w, h, True, mk(), rows_per_step=2, shared_offsets=True) == w * h
+    whole = open(f_sh, "rb").read()
+    for rows in ((0, 1), (1, 4)):
+        fhe.server.server_resize(ctx, fin, f_parts, W, H, w, h, True, mk(), rows_per_step=2, rows=rows, shared_offsets=True)
+    assert open(f_parts, "rb").read() == whole
+    # the circuit called directly on the whole image with the same encryptions (columns first, then rows)
+    _, xs, ys = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
+    direct = mk()
+    fr = direct([xs[x] for x in range(w)] + [ys[y * w] for y in range(h)])
+    pc = fhe.circuits.PlainCache(ctx)
+    rec = fhe.server.RECORD_HEADER + 6 * ctx.k * ctx.n * 8
+    pix3 = pix.view(H * W, 3, 2, ctx.k, ctx.n)
+    for ch in range(3):
+        out = fhe.to_host(fhe.circuits.resize_bicubic_shared(ev, pc, pix3[:, ch].contiguous(), W, H, w, h, fr[:w].contiguous(), fr[w:].contiguous()))
+        for p in range(w * h):
+            off = (p * 3 + ch) * rec + fhe.server.RECORD_HEADER
+            assert np.array_equal(np.frombuffer(whole[off:off + rec - fhe.server.RECORD_HEADER], dtype=np.uint64).reshape(6, ctx.k, ctx.n), out[p]), (ch, p)
+    # the per-pixel mode (the reference's) decrypts to the same values
+    assert fhe.server.server_resize(ctx, fin, f_px, W, H, w, h, True, mk(), rows_per_step=2) == w * h
+    dec = fhe.Decryptor(ctx, kg.secret_key())
+    a, b = [], []
+    fhe.client.receive_resize(ctx, dec, enc, f_sh, w, h, decoded=a)
+    fhe.client.receive_resize(ctx, dec, enc, f_px, w, h, decoded=b)
+    assert a == b and len(a) == w * h * 3
+    with pytest.raises(ValueError):
+        fhe.server.server_resize(ctx, fin, f_px, W, H, w, h, False, mk(), shared_offsets=True)

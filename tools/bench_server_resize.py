@@ -18,6 +18,7 @@ ap.add_argument("--dst", type=int, default=64)
 ap.add_argument("--bilinear", action="store_true")
 ap.add_argument("--rows", type=int, default=4)
 ap.add_argument("--io-threads", type=int, default=16)
+ap.add_argument("--shared", action="store_true", help="one offset ciphertext per output column / row (server_resize(shared_offsets=True)) instead of two per output pixel")
 ap.add_argument("--dir", default="/dev/shm")
 ap.add_argument("--encrypt", choices=["bank", "host", "device"], default="bank",
                 help="the circuit's server-side encryptions (two per output pixel): bank = pre-made ciphertexts (the circuit alone, rounds 2-4), "
@@ -36,7 +37,7 @@ for r in range(a.src):
     row.copy_(ctx.random_ct(a.src, 3, size=2, seed=fhe.SEED, first_index=r * a.src * 3 * 2 * ctx.k * ctx.n))
     sin.transfer(r * a.src * 3, a.src * 3, 2, ctx, row, 8)
 sin.close()
-bank = ctx.random_ct(a.rows * a.dst * 2, size=2, seed=5)
+bank = ctx.random_ct(max(a.rows * a.dst * 2, a.dst), size=2, seed=5)
 
 
 def fractions(values):
@@ -51,11 +52,11 @@ try:
     sin = fhe.server.StreamFile(fin)
     sout = fhe.server.StreamFile(fout, write=True, size=n_out * rec_out)
     fresh = {}
-    fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=fresh)   # first pass: page-locking, page allocation
+    fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=fresh, shared_offsets=a.shared)   # first pass: page-locking, page allocation
     torch.cuda.synchronize()
     stats = {}
     t0 = time.time()
-    done = fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=stats)
+    done = fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=stats, shared_offsets=a.shared)
     torch.cuda.synchronize()
     dt = time.time() - t0
     sin.close()
@@ -63,7 +64,7 @@ try:
     # the same job from the C++ host (seal/server_resize_hip.cpp): three passes over its own mappings, the last one reported
     cpp = None
     exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_resize_hip")
-    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096"):
+    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096") and not a.shared:
         import subprocess
         fpk = os.path.join(a.dir, "fhe_rs_pk.txt")
         with open(fpk, "wb") as f:
@@ -80,7 +81,7 @@ finally:
         if os.path.exists(p):
             os.remove(p)
 print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s, files in %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset, a.dir),
-                  "output_pixels": done, "rows_per_step": a.rows, "server_side_encryptions": a.encrypt, "seconds": dt, "pixels_per_s": done / dt,
+                  "output_pixels": done, "rows_per_step": a.rows, "server_side_encryptions": a.encrypt, "offsets": "shared (one per output column / row)" if a.shared else "per output pixel (the reference's)", "seconds": dt, "pixels_per_s": done / dt,
                   "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
                   "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
                   "file_read_seconds": stats["file_read_seconds"], "file_write_seconds": stats["file_write_seconds"],
