@@ -279,6 +279,18 @@ public:
                                                 scratch_.ptr(), bytes, nullptr), "resize_bicubic");
         return out;
     }
+    // destination rows [row0, row1) only (fhe_resize_bicubic_shared_rows: a shard of the rows, or one step of a streaming server):
+    // `pixels` holds source rows [src_row0, src_row0 + n_src_rows) (fhe_resize_source_rows), yfract the offsets of rows [row0, row1)
+    CiphertextBatch resize_bicubic_rows(const CiphertextBatch &pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, uint32_t row0, uint32_t row1,
+                                        uint32_t src_row0, uint32_t n_src_rows, const CiphertextBatch &xfract, const CiphertextBatch &yfract, uint32_t batch = 256,
+                                        uint32_t band_rows = 4) {
+        need(pixels, (size_t)src_w * n_src_rows, 2); need(xfract, dst_w, 2); need(yfract, row1 - row0, 2);
+        CiphertextBatch out(ctx_, (size_t)dst_w * (row1 - row0), out_size(FHE_CIRC_SAMPLE_BICUBIC));
+        const size_t bytes = scratch(fhe_resize_bicubic_shared_rows_scratch_bytes(h_, src_w, src_h, dst_w, dst_h, row0, row1, src_row0, n_src_rows, batch, band_rows, 1));
+        detail::check(fhe_resize_bicubic_shared_rows(h_, pixels.ptr(), src_w, src_h, dst_w, dst_h, row0, row1, src_row0, n_src_rows, xfract.ptr(), yfract.ptr(), out.ptr(), batch,
+                                                     band_rows, nullptr, nullptr, scratch_.ptr(), bytes, nullptr), "resize_bicubic_rows");
+        return out;
+    }
     // the same with the output bands handed to `consume` (e.g. a stream writer) instead of being kept resident
     void resize_bicubic(const CiphertextBatch &pixels, uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, const CiphertextBatch &xfract,
                         const CiphertextBatch &yfract, fhe_band_consumer consume, void *user, uint32_t batch = 256, uint32_t band_rows = 4) {

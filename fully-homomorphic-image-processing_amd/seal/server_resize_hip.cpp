@@ -17,6 +17,10 @@
 //
 // usage: server_resize_hip <in.ct> <out.ct> <public key file> <src_w> <src_h> <dst_w> <dst_h> <bicubic 0|1>
 //                          [rows_per_step=4] [io_threads=16] [n=8192] [plain_modulus=16384] [sampler key: 64 hex digits, or -] [passes=1]
+//                          [shared offsets 0|1 = 0]
+//   shared = 1 (bicubic only; server.server_resize(shared_offsets=True)): ONE offset ciphertext per output column (once per job) and per
+//   output row instead of two per output pixel, and the shared-offset circuit (fhe_resize_bicubic_shared_rows) per channel and step --
+//   not the reference's ciphertexts, the same decrypted image.
 //   The sampler key is for reproducible tests only (default: getrandom()).  passes > 1 repeats the job with the stream files left mapped
 //   and the staging buffers locked (a long-lived server's steady state); the JSON line reports the last pass.  FHE_SEAL23_MODULI=1 selects SEAL 2.3.1's coefficient moduli.
 #include <hip/hip_runtime_api.h>
@@ -75,10 +79,12 @@ int main(int argc, char **argv) {
     const int n_arg = argc > 11 ? std::atoi(argv[11]) : 8192;
     const uint64_t t = argc > 12 ? std::strtoull(argv[12], nullptr, 10) : 16384;
     const int passes = argc > 14 ? std::atoi(argv[14]) : 1;
+    const bool shared = argc > 15 && std::atoi(argv[15]) != 0;
     uint8_t key[32];
     const bool have_key = argc > 13 && std::strlen(argv[13]) == 64;
     for (int i = 0; have_key && i < 32; ++i) { unsigned v = 0; std::sscanf(argv[13] + 2 * i, "%2x", &v); key[i] = (uint8_t)v; }
     const uint32_t init_rows = bicubic ? 4 : 2;
+    if (shared && !bicubic) { std::fprintf(stderr, "server_resize_hip: shared offsets exist for the bicubic sampler only\n"); return 2; }
     if (w < 2 || h < 2 || H < init_rows || W < 1 || !rows_per_step || io_threads < 1 || passes < 1) { std::fprintf(stderr, "server_resize_hip: image too small for the sampler\n"); return 2; }
     fhe_io_file *fin = nullptr, *fout = nullptr;
     int rc = 0;
@@ -232,6 +238,12 @@ int main(int argc, char **argv) {
                 return r.slot;
             };
             const int offs_n = bicubic ? 16 : 4;
+            hip::CiphertextBatch xcols;
+            if (shared) {                                                                         // one offset ciphertext per output column, once per job
+                std::vector<double> fx(w);
+                for (uint32_t x = 0; x < w; ++x) fx[x] = (double)(us[x] - std::floor(us[x]));
+                xcols = enc.encrypt_values(fx);
+            }
             int next_slot = upload(0);
             std::vector<uint32_t> taps, taps_ch;
             std::vector<double> fracs;
@@ -241,6 +253,27 @@ int main(int argc, char **argv) {
                 const uint32_t npx = (s.y1 - s.y0) * w;
                 const int d = (int)(si & 1);
                 hcheck(hipStreamWaitEvent(main, ev_copied[next_slot], 0), "wait");
+                if (shared) {
+                    std::vector<double> fy(s.y1 - s.y0);
+                    for (uint32_t yy = s.y0; yy < s.y1; ++yy) fy[yy - s.y0] = (double)(vs[yy] - std::floor(vs[yy]));
+                    hip::CiphertextBatch yrows = enc.encrypt_values(fy);                          // row y of the job at position w + y of the key's stream
+                    uint32_t s0 = 0, sc = 0;
+                    check(fhe_resize_source_rows(H, h, s.y0, s.y1, 1, &s0, &sc), "fhe_resize_source_rows");
+                    if (s0 < s.lo || s0 + sc > s.hi) throw Fail{"the rows the taps touch are not resident"};
+                    if (drained_used[d]) hcheck(hipStreamWaitEvent(main, ev_drained[d], 0), "wait");
+                    hip::CiphertextBatch chan(context, (size_t)sc * W, 2);
+                    src.resize((size_t)sc * W);
+                    for (uint32_t ch = 0; ch < 3; ++ch) {
+                        for (uint32_t r = 0; r < sc; ++r)
+                            for (uint32_t x = 0; x < W; ++x) src[(size_t)r * W + x] = ring.at(((size_t)((s0 + r) % R) * W + x) * 3 + ch);
+                        check(fhe_gather(src.data(), (uint64_t)sc * W, ct_in, chan.ptr(), ct_in, main), "fhe_gather");         // this channel's resident rows, contiguous
+                        hip::CiphertextBatch out = circ.resize_bicubic_rows(chan, W, H, w, h, s.y0, s.y1, s0, sc, xcols, yrows);
+                        src.resize(std::max(src.size(), (size_t)npx));
+                        for (uint32_t i = 0; i < npx; ++i) src[i] = out.at(i);
+                        check(fhe_gather(src.data(), npx, ct_out, dout[d] + (size_t)ch * ct_out, 3 * ct_out, main), "fhe_gather");
+                        src.resize((size_t)sc * W);
+                    }
+                } else {
                 // sample plan of these destination rows in terms of ring slots; fractions in the reference's order (per pixel: x, then y)
                 taps.assign((size_t)npx * offs_n, 0);
                 fracs.assign((size_t)npx * 2, 0.0);
@@ -275,6 +308,7 @@ int main(int argc, char **argv) {
                     hip::CiphertextBatch out = bicubic ? circ.sample_bicubic(ring, taps_ch.data(), xf, yf) : circ.sample_linear(ring, taps_ch.data(), xf, yf);
                     for (uint32_t i = 0; i < npx; ++i) src[i] = out.at(i);
                     check(fhe_gather(src.data(), npx, ct_out, dout[d] + (size_t)ch * ct_out, 3 * ct_out, main), "fhe_gather");   // into the interleaved record order
+                }
                 }
                 hcheck(hipEventRecord(ev_computed[si], main), "record");
                 if (si + 1 < steps.size()) next_slot = upload(si + 1);                            // before this step's download

@@ -406,8 +406,9 @@ def test_cpp_server_decode_writes_the_python_servers_bytes(fhe, tmp_path):
     assert r.returncode == 1 and "not reduced" in r.stderr and (not os.path.exists(f_bad_out) or os.path.getsize(f_bad_out) == 0)
 
 
-@pytest.mark.parametrize("bicubic,W,H,w,h,rows", [(True, 7, 9, 5, 6, 2), (False, 6, 5, 4, 3, 4), (True, 12, 16, 3, 3, 1)])
-def test_cpp_server_resize_writes_the_python_servers_bytes(fhe, tmp_path, bicubic, W, H, w, h, rows):
+@pytest.mark.parametrize("bicubic,W,H,w,h,rows,shared", [(True, 7, 9, 5, 6, 2, False), (False, 6, 5, 4, 3, 4, False), (True, 12, 16, 3, 3, 1, False), (True, 7, 9, 5, 6, 2, True),
+                                                         (True, 12, 16, 3, 3, 4, True)])
+def test_cpp_server_resize_writes_the_python_servers_bytes(fhe, tmp_path, bicubic, W, H, w, h, rows, shared):
     """seal/server_resize_hip.cpp (C++ host: reader / upload / circuits / download / writer pipeline over seal/hip_circuits.h + fhe_stream.h,
     one fhe_encrypt_batch per step) against server.server_resize with the same sampler key: the same output stream byte for byte -- the
     reference's sliding row window, float index arithmetic, tap order and encryption order restated twice and compared; incl. strong
@@ -423,16 +424,17 @@ def test_cpp_server_resize_writes_the_python_servers_bytes(fhe, tmp_path, bicubi
     with open(f_pk, "wb") as f:
         fhe.server.write_ciphertext(f, fhe.to_host(kg.public_key()))
     fractions = fhe.server.make_fraction_encryptor(ctx, kg.public_key(), enc, seed=5, device=True)
-    assert fhe.server.server_resize(ctx, fin, f_py, W, H, w, h, bicubic, fractions, rows_per_step=rows) == w * h
+    assert fhe.server.server_resize(ctx, fin, f_py, W, H, w, h, bicubic, fractions, rows_per_step=rows, shared_offsets=shared) == w * h
     argv = [exe, fin, f_cpp, f_pk, str(W), str(H), str(w), str(h), "1" if bicubic else "0", str(rows), "4", str(ctx.n), str(ctx.t), fhe.server._sampler_key(5).hex()]
-    r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    tail = ["1", "1"] if shared else []                            # passes, shared offsets (one ciphertext per output column / row)
+    r = subprocess.run(argv + tail, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert os.path.getsize(f_cpp) == os.path.getsize(f_py)
     assert open(f_cpp, "rb").read() == open(f_py, "rb").read()
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    assert '"server_side_encryptions": %d' % (2 * w * h) in line
+    assert '"server_side_encryptions": %d' % ((w + h) if shared else 2 * w * h) in line
     # and the image it decrypts to equals the Python server's (fresh randomness without the key argument)
-    r = subprocess.run(argv[:-1], capture_output=True, text=True, timeout=600)
+    r = subprocess.run(argv[:-1] + (["-"] + tail if shared else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and open(f_cpp, "rb").read() != open(f_py, "rb").read()
     if not bicubic:                              # the bicubic circuit leaves no noise budget to speak of at n = 4096: fresh randomness may flip a high coefficient
         dec = fhe.Decryptor(ctx, kg.secret_key())

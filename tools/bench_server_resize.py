@@ -64,14 +64,14 @@ try:
     # the same job from the C++ host (seal/server_resize_hip.cpp): three passes over its own mappings, the last one reported
     cpp = None
     exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_resize_hip")
-    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096") and not a.shared:
+    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096"):
         import subprocess
         fpk = os.path.join(a.dir, "fhe_rs_pk.txt")
         with open(fpk, "wb") as f:
             fhe.server.write_ciphertext(f, fhe.to_host(fhe.KeyGenerator(ctx).public_key()))
         env = dict(os.environ, FHE_SEAL23_MODULI="1") if a.preset != "P4096" else dict(os.environ)
         try:
-            r = subprocess.run([exe, fin, fout, fpk, str(a.src), str(a.src), str(a.dst), str(a.dst), "0" if a.bilinear else "1", str(a.rows), str(a.io_threads), str(ctx.n), str(ctx.t), "-", "3"],
+            r = subprocess.run([exe, fin, fout, fpk, str(a.src), str(a.src), str(a.dst), str(a.dst), "0" if a.bilinear else "1", str(a.rows), str(a.io_threads), str(ctx.n), str(ctx.t), "-", "3", "1" if a.shared else "0"],
                                capture_output=True, text=True, timeout=900, env=env)
             cpp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
         finally:

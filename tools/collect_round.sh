@@ -35,6 +35,7 @@ python tools/bench_rgb.py > $O/bench_rgb.txt 2>&1
 python tools/bench_server.py > $O/bench_server.txt 2>&1
 python tools/bench_server_resize.py > $O/bench_server_resize.txt 2>&1
 python tools/bench_server_resize.py --bilinear >> $O/bench_server_resize.txt 2>&1
+python tools/bench_server_resize.py --encrypt device --shared >> $O/bench_server_resize.txt 2>&1
 # the servers' own encryptions (csrc/encrypt.hip): per-ciphertext rates, and the two streaming servers with their encryptions made for real
 python tools/bench_encrypt.py P8192 512 2>/dev/null | tail -1 > $O/bench_encrypt.txt
 python tools/bench_encrypt.py P4096 512 2>/dev/null | tail -1 >> $O/bench_encrypt.txt
