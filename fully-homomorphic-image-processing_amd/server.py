@@ -595,64 +595,44 @@ def server_resize(ctx, in_path, out_path, src_w, src_h, dst_w, dst_h, bicubic, e
         upload(0)
         for si, (y0, y1) in enumerate(steps):
             main.wait_event(copied_of.pop(si))
+            npx, d = (y1 - y0) * dst_w, si & 1
             if shared_offsets:
-                npx, d = (y1 - y0) * dst_w, si & 1
                 if hasattr(encrypt_fractions, "seek"):
                     encrypt_fractions.seek(dst_w + y0)
                 yrows = encrypt_fractions([float(windows[yy][0] - f32(np.floor(windows[yy][0]))) for yy in range(y0, y1)]).contiguous()
                 s0, sc = circuits.resize_source_rows(src_h, dst_h, y0, y1)
                 assert span[si][0] <= s0 and s0 + sc <= span[si][1], (span[si], s0, sc)          # the rows the taps touch are resident
                 slots_of = torch.tensor([r % R for r in range(s0, s0 + sc)], dtype=torch.int64, device=ctx.device)
-                if drained[d] is not None:
-                    main.wait_event(drained[d])
-                if stats is not None:
-                    t_start.append(torch.cuda.Event(enable_timing=True))
-                    t_start[-1].record(main)
-                for ch in range(3):
-                    chan = ring[slots_of, :, ch].reshape(sc * src_w, 2, ctx.k, ctx.n)           # this channel's resident rows, contiguous
-                    dout[d][:npx, ch].copy_(circuits.resize_bicubic_shared(ev, pc, chan, src_w, src_h, dst_w, dst_h, xcols, yrows, rows=(y0, y1), src_rows=(s0, sc), relin=relin))
-                if stats is not None:
-                    t_stop.append(torch.cuda.Event(enable_timing=True))
-                    t_stop[-1].record(main)
-                done = torch.cuda.Event()
-                done.record(main)
-                computed.append(done)
-                if si + 1 < len(steps):
-                    upload(si + 1)
-                oslot = free_out.get()
-                if oslot is None:
-                    raise errors[0]
-                with torch.cuda.stream(d2h):
-                    d2h.wait_event(done)
-                    hout[oslot][:npx].copy_(dout[d][:npx], non_blocking=True)
-                    landed = torch.cuda.Event()
-                    landed.record(d2h)
-                drained[d] = landed
-                to_write.put((y0 * dst_w, npx, oslot, landed))
-                continue
-            # sample plan of these destination rows in terms of ring slots
-            taps, fracs = [], []
-            for yy in range(y0, y1):
-                v = windows[yy][0]
-                yi = int(v)
-                for xx in range(dst_w):
-                    u = us[xx]
-                    xi = int(u)
-                    taps.append([((min(max(yi + dy, 0), src_h - 1) % R) * src_w + min(max(xi + dx, 0), src_w - 1)) * 3 for dx, dy in offs])
-                    fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
-            taps = np.asarray(taps, dtype=np.uint32)
-            if hasattr(encrypt_fractions, "seek"):
-                encrypt_fractions.seek(2 * y0 * dst_w)
-            fr = encrypt_fractions(fracs)                                            # xfract, yfract per pixel, in order
-            xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
-            npx, d = (y1 - y0) * dst_w, si & 1
+
+                def channel(ch):                                # this channel's resident rows, contiguous -> the shared-offset circuit on rows [y0, y1)
+                    chan = ring[slots_of, :, ch].reshape(sc * src_w, 2, ctx.k, ctx.n)
+                    return circuits.resize_bicubic_shared(ev, pc, chan, src_w, src_h, dst_w, dst_h, xcols, yrows, rows=(y0, y1), src_rows=(s0, sc), relin=relin)
+            else:
+                # sample plan of these destination rows in terms of ring slots
+                taps, fracs = [], []
+                for yy in range(y0, y1):
+                    v = windows[yy][0]
+                    yi = int(v)
+                    for xx in range(dst_w):
+                        u = us[xx]
+                        xi = int(u)
+                        taps.append([((min(max(yi + dy, 0), src_h - 1) % R) * src_w + min(max(xi + dx, 0), src_w - 1)) * 3 for dx, dy in offs])
+                        fracs += [float(u - f32(np.floor(u))), float(v - f32(np.floor(v)))]
+                taps = np.asarray(taps, dtype=np.uint32)
+                if hasattr(encrypt_fractions, "seek"):
+                    encrypt_fractions.seek(2 * y0 * dst_w)
+                fr = encrypt_fractions(fracs)                                        # xfract, yfract per pixel, in order
+                xf, yf = fr[0::2].contiguous(), fr[1::2].contiguous()
+
+                def channel(ch):                                # the taps index the interleaved R, G, B records of the ring directly
+                    return sampler(ev, pc, ring_flat, taps + ch, xf, yf, relin=relin)
             if drained[d] is not None:
                 main.wait_event(drained[d])                                          # dout[d] has left for the host
             if stats is not None:
                 t_start.append(torch.cuda.Event(enable_timing=True))
                 t_start[-1].record(main)
             for ch in range(3):
-                dout[d][:npx, ch].copy_(sampler(ev, pc, ring_flat, taps + ch, xf, yf, relin=relin))   # [npx, out_size, k, n] into the interleaved record order
+                dout[d][:npx, ch].copy_(channel(ch))                                 # [npx, out_size, k, n] into the interleaved record order
             if stats is not None:
                 t_stop.append(torch.cuda.Event(enable_timing=True))
                 t_stop[-1].record(main)
