@@ -137,6 +137,7 @@ private:
         const detail::CtxState &s = *ctx_.state();
         CiphertextBatch out(ctx_, count, 2);
         if (!count) return out;
+        std::lock_guard<std::mutex> lk(mu_);                                 // the stream index and the scratch buffer are per object
         if (next_ + count < next_) throw std::runtime_error("DeviceEncryptor: the encryption index would wrap");
         const size_t need = (fhe_encrypt_scratch_bytes(s.h, count) + 7) / 8;
         if (scratch_.words() < need) scratch_.resize(need);
@@ -149,6 +150,7 @@ private:
     std::array<uint8_t, 32> key_;
     int ic_, fc_;
     uint64_t next_;
+    std::mutex mu_;
 };
 
 // seal::Decryptor::decrypt of a whole batch (the clients' loops: homo/client_jpeg.cpp:266-280, homo/client_resize.cpp:190-210): ONE
@@ -167,6 +169,7 @@ public:
         std::vector<Plaintext> out;
         const size_t count = cts.count();
         if (!count) return out;
+        std::lock_guard<std::mutex> lk(mu_);                                 // the scratch buffer is per object
         const size_t need = (fhe_decrypt_scratch_bytes(s.h, cts.size(), count) + 7) / 8, tail = count * s.n + (count + 1) / 2;
         if (scratch_.words() < need + tail) scratch_.resize(need + tail);
         uint64_t *d_plain = scratch_.ptr() + need;
@@ -186,6 +189,7 @@ public:
 private:
     SEALContext ctx_;
     detail::DevBuf sk_ntt_, scratch_;
+    std::mutex mu_;
 };
 
 // sample plan of ResizeImage (homo/fhe_resize.h:350-351,381-382 and the tap order of SampleBicubic / SampleLinear)
