@@ -19,14 +19,12 @@
 namespace {
 // floor(2^63 P(|e| <= i)), i = 0..18, for the rounded normal with sigma = 3.19 redrawn beyond 19 (tools/noise_cdt.py recomputes the
 // table with 90 digits; tests/test_encrypt_sampler.py compares)
-__constant__ u64 kNoiseCdtDev[FHE_NOISE_CDT_LEN] = {
-    0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL, 0x7aad3cf138611a69ULL,
-    0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL, 0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL,
-    0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL, 0x7ffffff3ceaa701fULL};
-const u64 kNoiseCdtHost[FHE_NOISE_CDT_LEN] = {
-    0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL, 0x7aad3cf138611a69ULL,
-    0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL, 0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL,
-    0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL, 0x7ffffff3ceaa701fULL};
+#define FHE_NOISE_CDT_VALUES                                                                                                                                   \
+    {0x0ff141e3023416d2ULL, 0x2e4f850f76b8d9a6ULL, 0x488c5acec8fd6db3ULL, 0x5d1ca569fc3e4ccbULL, 0x6bbb5699bdd65b9cULL, 0x75291bf8371e7eccULL, 0x7aad3cf138611a69ULL,  \
+     0x7d9aa4d4ab7c76bdULL, 0x7f0368341f79807cULL, 0x7fa0f21e3a554470ULL, 0x7fdf5971c6494be2ULL, 0x7ff5c5a33f74a4e1ULL, 0x7ffd148ddcc40605ULL, 0x7fff3db0052c58c3ULL,  \
+     0x7fffd206471c7fcfULL, 0x7ffff61ba7b56e58ULL, 0x7ffffe11d76ecb8aULL, 0x7fffffa9c1e61510ULL, 0x7ffffff3ceaa701fULL}
+__constant__ u64 kNoiseCdtDev[FHE_NOISE_CDT_LEN] = FHE_NOISE_CDT_VALUES;      // what the kernels compare against
+const u64 kNoiseCdtHost[FHE_NOISE_CDT_LEN] = FHE_NOISE_CDT_VALUES;            // what fhe_noise_cdt reports: the same initialiser
 
 struct ChaChaKey { u32 w[8]; };
 
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(256) void k_enc_pk_mul(const u64 *__restrict__ u_nt
 }
 
 struct EncLift {                      // plaintext lifting of add_plain (fhe_hip.hip fhe_add_plain): Delta m' = delta m (+ q mod t for the upper half)
-    u64 t, threshold;
+    u64 threshold;
     u64 delta[FHE_MAX_K], increment[FHE_MAX_K];
 };
 // one thread = eight consecutive coefficients of polynomial j of encryption e: its noise block, every residue
@@ -234,7 +232,6 @@ __global__ __launch_bounds__(256) void k_dec_horner(const u64 *__restrict__ ct_n
 #define DEC_K FHE_MAX_K
 #define DEC_L (FHE_MAX_K + 1)
 struct DecConsts {
-    u32 k, limbs;
     u64 t;
     u64 inv_punct[DEC_K], t_mod_q[DEC_K], qinv64[DEC_K];
     u64 punct[DEC_K][DEC_L];          // q / q_i
@@ -392,7 +389,6 @@ extern "C" int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *d_pk_ntt, con
     }
     if ((rc = fhe_ntt_inverse(c, d_out, d_out, count * 2, s))) return rc;
     EncLift L;
-    L.t = c->t;
     L.threshold = c->upper_half_threshold;
     for (u32 i = 0; i < FHE_MAX_K; ++i) { L.delta[i] = i < c->k ? c->delta_mod[i] : 0; L.increment[i] = i < c->k ? c->upper_half_increment[i] : 0; }
     k_enc_finish<<<blocks_for(count * 2 * (c->n / 8)), 256, 0, st>>>(k, first_index, count, (u64 *)d_out, (const u64 *)d_plain, c->qb.d_mod, c->k, c->n, L);
@@ -431,8 +427,6 @@ extern "C" int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *d_sk_ntt, con
     const u32 k = c->k, n = c->n;
     DecConsts C;
     std::memset(&C, 0, sizeof C);
-    C.k = k;
-    C.limbs = k + 1;
     C.t = c->t;
     BigUInt Q(1, DEC_L + 1);
     for (u32 i = 0; i < k; ++i) Q.mul_small(c->qb.primes[i]);
