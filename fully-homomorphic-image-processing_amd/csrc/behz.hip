@@ -1545,6 +1545,13 @@ extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64
     if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
     if (out_stride < (u64)2 * c->k * c->n) return fail(FHE_ERR_PARAM, "output stride smaller than a size-2 ciphertext");
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
+    // workgroup c reads ciphertext c while it writes output c: only the exact in-place case (same pointer, same stride) and fully
+    // disjoint ranges are safe -- with another stride output c lands inside an input another workgroup has not read yet
+    if (!(out2 == ct3 && out_stride == stride)) {
+        const uintptr_t i0 = (uintptr_t)ct3, i1 = i0 + ((count - 1) * stride + (u64)3 * c->k * c->n) * sizeof(u64);
+        const uintptr_t o0 = (uintptr_t)out2, o1 = o0 + ((count - 1) * out_stride + (u64)2 * c->k * c->n) * sizeof(u64);
+        if (o0 < i1 && i0 < o1) return fail(FHE_ERR_PARAM, "output range overlaps the input range (only out2 == ct3 with out_stride == stride may alias)");
+    }
     hipStream_t st = (hipStream_t)s;
     const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
     const BehzDev *T = c->behz->dev;

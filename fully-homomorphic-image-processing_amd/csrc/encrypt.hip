@@ -423,6 +423,9 @@ extern "C" int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *d_sk_ntt, con
     if (!count) return FHE_OK;
     if (!scratch || scratch_bytes < fhe_decrypt_scratch_bytes(c, size, count)) return fail(FHE_ERR_PARAM, "scratch too small: need fhe_decrypt_scratch_bytes()");
     if (c->t >> 60) return fail(FHE_ERR_PARAM, "plain modulus too large for the exact rounding kernel");
+    // everything the last kernel (k_dec_round: full 256-thread workgroups, full-wave shuffle folds) needs, before anything is enqueued
+    if (c->n % 256) return fail(FHE_ERR_PARAM, "n must be a multiple of 256");
+    if (c->k < 1 || c->k > 8) return fail(FHE_ERR_PARAM, "unsupported number of primes");
     hipStream_t st = (hipStream_t)s;
     const u32 k = c->k, n = c->n;
     DecConsts C;
@@ -461,7 +464,6 @@ extern "C" int fhe_decrypt_batch(const fhe_ctx *c, const uint64_t *d_sk_ntt, con
     }
     if ((rc = fhe_ntt_inverse(c, (const uint64_t *)acc, (uint64_t *)acc, count, s))) return rc;
     if (d_noise_bits) HIP_TRY(hipMemsetAsync(d_noise_bits, 0, count * sizeof(u32), st));
-    if (n % 256) return fail(FHE_ERR_PARAM, "n must be a multiple of 256");
     const unsigned blocks = blocks_for(count * n);
     switch (k) {
 #define GO(KK) case KK: k_dec_round<KK><<<blocks, 256, 0, st>>>(acc, (u64 *)d_plain, d_noise_bits, c->qb.d_mod, n, count, C); break;

@@ -446,7 +446,9 @@ std::mutex g_stage_rings_mu;
 int fhe_stage_acquire(const void *host, size_t bytes, hipStream_t st, FheStage *out) {
     if (!host || !out || !bytes || bytes > FHE_STAGE_SLOT_BYTES) return fail(FHE_ERR_PARAM, "staging: %zu bytes do not fit a slot", bytes);
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));                                     // launches act on the calling thread's current device (include/fhe_hip.h)
+    // the slot must live on the device the upload and its reader run on: the stream's device (null / legacy stream: the calling
+    // thread's current device, on which every launch of this library acts, include/fhe_hip.h)
+    if (!st || hipStreamGetDevice(st, &dev) != hipSuccess) HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 32) return fail(FHE_ERR_PARAM, "staging: device %d out of range", dev);
     StageRing *ring;
     {
@@ -459,7 +461,14 @@ int fhe_stage_acquire(const void *host, size_t bytes, hipStream_t st, FheStage *
         hipError_t e = hipHostMalloc((void **)&ring->pinned, (size_t)StageRing::kSlots * FHE_STAGE_SLOT_BYTES, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&ring->device, (size_t)StageRing::kSlots * FHE_STAGE_SLOT_BYTES);
         for (int i = 0; i < StageRing::kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ring->ev[i], hipEventDisableTiming);
-        if (e != hipSuccess) { ring->pinned = nullptr; return fail(FHE_ERR_HIP, "staging ring: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) {                                       // give back whatever was obtained: the next call starts from nothing
+            for (int i = 0; i < StageRing::kSlots; ++i)
+                if (ring->ev[i]) { (void)hipEventDestroy(ring->ev[i]); ring->ev[i] = nullptr; }
+            if (ring->device) (void)hipFree(ring->device);
+            if (ring->pinned) (void)hipHostFree(ring->pinned);
+            ring->pinned = ring->device = nullptr;
+            return fail(FHE_ERR_HIP, "staging ring: %s", hipGetErrorString(e));
+        }
     }
     int slot = -1;
     for (;;) {
@@ -1610,7 +1619,9 @@ __global__ __launch_bounds__(NttShape<L>::TP) void k_rgb2ycc(u64 *__restrict__ R
         v[i] = submod(submod(M(r[i], 6), M(g[i], 7), q), M(b[i], 8), q);
     }
     ntt_inv_regs<L>(y, itw, q, lds, tid);
+    ntt_lds_release();                         // the inverse transform's last transpose reads across waves (ntt_core.h, CONTRACT)
     ntt_inv_regs<L>(u, itw, q, lds, tid);
+    ntt_lds_release();
     ntt_inv_regs<L>(v, itw, q, lds, tid);
 #pragma unroll
     for (int i = 0; i < 16; i++) {

@@ -225,9 +225,27 @@ __device__ __forceinline__ void ntt_inv_pass4t(u64 (&x)[16], const ulonglong2 *_
 // exchange needs no workgroup barrier at all, only that the compiler keeps the writes before the reads (wave-level fences):
 // n = 8192 keeps 2 of its 6 s_barriers per transform (the first, 512-thread-wide transpose), n = 4096 2 of 4.  (Round 5; before,
 // every transpose was bracketed by two __syncthreads.  NTT_WAVE_LOCAL_TRANSPOSE 0 restores that for A/B measurements.)
+//
+// CONTRACT of every driver below (ntt_fwd_regs* / ntt_inv_regs*): on entry no OTHER wave may still be reading `lds`.  That holds
+// at kernel start and after a forward transform (its last transposes read wave-locally; a forward transform of L >= 11 also opens
+// with a workgroup-wide transpose, i.e. with a barrier).  It does NOT hold after an inverse transform of L >= 11: that one ends
+// with a workgroup-wide transpose whose READ phase fetches elements from every wave's region, and the next inverse transform
+// opens with a wave-local transpose that writes its region without a barrier -- a lagging wave would read clobbered data.  A
+// kernel that runs a second transform on the same buffer after an inverse one calls ntt_lds_release() in between (k_rgb2ycc).
 #ifndef NTT_WAVE_LOCAL_TRANSPOSE
 #define NTT_WAVE_LOCAL_TRANSPOSE 1
 #endif
+// wave64: the wave-local transposes and every 64-lane shuffle fold of csrc/ assume it.  ROCm 7 no longer defines
+// __AMDGCN_WAVEFRONT_SIZE; gfx9 has no wave32 mode, so "compiled for gfx950" is the assertion (and the macro is checked where it exists)
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__)
+#error "csrc/ is written for gfx950 (wave64) only"
+#endif
+#if defined(__AMDGCN_WAVEFRONT_SIZE)
+static_assert(__AMDGCN_WAVEFRONT_SIZE == 64, "wave64 only");
+#endif
+#endif
+__device__ __forceinline__ void ntt_lds_release() { __syncthreads(); }   // every wave is done reading the exchange buffer
 template <int LO_FROM, int LO_TO>
 __device__ __forceinline__ void ntt_transpose(u64 (&x)[16], u64 *lds, int tid) {
     constexpr int PL = imin(LO_FROM, LO_TO);

@@ -157,14 +157,19 @@ class DeviceEncryptor:
     SERVER needs: the reference's loops encrypt two fractions per output pixel (homo/fhe_resize.h:230,234,262,266) and an
     encode(0) per homomorphic_sin / cos, accumulator and index (homo/fhe_decode.h:54,134; homo/server_decode.cpp:121,126).
     u, e1, e2 come from the ChaCha20 stream of (key, index): the key is 32 bytes from the operating system's generator unless
-    `key` is given (tests; a key must never meet the same index twice), `index` counts the encryptions made under it --
+    `key` is given (a key must never meet the same index twice), `index` counts the encryptions made under it and only ever
+    counts UPWARDS -- unless the encryptor was made with reproducible=True (tests, seeded benchmark runs; needs a key): then
     `seek(i)` sets the number of the next one, so a shard of a job that starts at encryption i of the reference's sequence
-    produces the same ciphertexts as the whole job (the role _IndexedEncryptions plays for the host sampler)."""
+    produces the same ciphertexts as the whole job (the role _IndexedEncryptions plays for the host sampler).  A caller who
+    passes a real key without the flag gets a stream that cannot be rewound: seek() refuses, and server_resize /
+    server_decode (which position any encryptor that exposes `seek`) never see one."""
 
-    def __init__(self, ctx, public_key, key=None, int_coeffs=None, frac_coeffs=None):
+    def __init__(self, ctx, public_key, key=None, int_coeffs=None, frac_coeffs=None, reproducible=False):
         self.ctx = ctx
         self._pk_ntt = _ntt(ctx, public_key.contiguous())
-        self._given_key = key is not None
+        if reproducible and key is None:
+            raise ValueError("reproducible=True needs an explicit key (the OS generator's key is never reused)")
+        self.reproducible = bool(reproducible)
         self.key = os.urandom(32) if key is None else bytes(key)
         if len(self.key) != 32:
             raise ValueError("the sampler key has 32 bytes")
@@ -174,8 +179,9 @@ class DeviceEncryptor:
         self._scratch = None
 
     def seek(self, i):
-        if not self._given_key:
-            raise RuntimeError("seek on an encryptor keyed by the OS generator could repeat a (key, index) pair; pass a key (tests) to position the stream")
+        if not self.reproducible:
+            raise RuntimeError("seek could repeat a (key, index) pair -- identical u, e1, e2 under two plaintexts; only an encryptor made with "
+                               "reproducible=True (tests, seeded runs) may position its stream")
         self.next = int(i)
 
     def _run(self, plain, count):

@@ -390,7 +390,8 @@ def make_fraction_encryptor(ctx, public_key, encoder=None, seed=None, indexed=Fa
     if device is None:
         device = seed is None
     if device:
-        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed), int_coeffs=enc.int_coeffs, frac_coeffs=enc.frac_coeffs)
+        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed), int_coeffs=enc.int_coeffs, frac_coeffs=enc.frac_coeffs,
+                              reproducible=seed is not None)
 
         def encrypt_batch(values):
             return der.encrypt_values([float(v) for v in values])
@@ -686,7 +687,7 @@ def make_zero_encryptor(ctx, public_key, encoder=None, seed=None, indexed=False,
     if device is None:
         device = seed is None
     if device:
-        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed))
+        der = DeviceEncryptor(ctx, public_key, key=None if seed is None else _sampler_key(seed), reproducible=seed is not None)
 
         def encrypt_batch(count):
             return der.encrypt_zeros(count)

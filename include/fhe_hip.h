@@ -245,7 +245,9 @@ size_t fhe_relinearize_scratch_bytes(const fhe_ctx *ctx, uint32_t dbc, uint64_t 
 /* The same with the result written elsewhere: out2[c * out_stride_words ...] = the relinearised size-2 ciphertext of
  * ct3[c * ct_stride_words ...] (a batch of products becomes a compact [count][2][k][n] batch without a copy of its own;
  * the relinearised mode of the circuits, include/fhe_circuits.h, is built on it).  out2 == ct3 with equal strides is
- * fhe_relinearize.  Same scratch. */
+ * fhe_relinearize.  Same scratch.  Aliasing rule: the output range [out2, out2 + (count-1) out_stride + 2kn) either IS the
+ * input (same pointer, same stride) or does not overlap [ct3, ct3 + (count-1) stride + 3kn) at all; any other overlap
+ * returns FHE_ERR_PARAM (a compacting in-place relinearisation would let one ciphertext's output land on another's input). */
 int fhe_relinearize_to(const fhe_ctx *ctx, const uint64_t *ct3, uint64_t ct_stride_words, uint64_t *out2,
                        uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,
                        size_t scratch_bytes, fhe_stream stream);

@@ -65,7 +65,7 @@ def test_encrypt_batch_equals_the_oracle_bit_for_bit(fhe, oracle_mod, preset):
     pk, sk = fhe.to_host(kg.public_key()), fhe.to_host(kg.secret_key())
     vals = [0.0, 0.40625, -0.40625, 0.9990234375, 77.0, -200.75, 1 / 3, 2.0 ** -30]
     first = (1 << 33) + 9
-    der = fhe.DeviceEncryptor(ctx, kg.public_key(), key=KEY)
+    der = fhe.DeviceEncryptor(ctx, kg.public_key(), key=KEY, reproducible=True)
     der.seek(first)
     got = fhe.to_host(der.encrypt_values(vals))
     assert der.next == first + len(vals)
@@ -105,6 +105,13 @@ def test_encrypt_argument_errors_and_key_discipline(fhe):
     a, b = der.encrypt_zeros(2), der.encrypt_zeros(2)
     assert der.next == 4 and not torch.equal(a, b) and not torch.equal(a[0], a[1])
     assert fhe.DeviceEncryptor(ctx, kg.public_key()).key != der.key
+    keyed = fhe.DeviceEncryptor(ctx, kg.public_key(), key=KEY)      # a caller's own key WITHOUT reproducible=True: counts upwards only
+    keyed.encrypt_zeros(3)
+    with pytest.raises(RuntimeError):
+        keyed.seek(0)
+    assert keyed.next == 3
+    with pytest.raises(ValueError):
+        fhe.DeviceEncryptor(ctx, kg.public_key(), reproducible=True)    # reproducible needs an explicit key
     with pytest.raises(ValueError):
         fhe.DeviceEncryptor(ctx, kg.public_key(), key=b"short")
     out = ctx.empty(1)

@@ -62,7 +62,7 @@ def relin_digests():
 ref_relin = relin_digests()
 # the servers' own encryptions as device batches (csrc/encrypt.hip): the staging ring of the encoder's values, the scratch reuse, the
 # keyed sampler -- the same (key, index) range must give the same ciphertexts every time
-der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx, seed=2).public_key(), key=bytes(range(32)))
+der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx, seed=2).public_key(), key=bytes(range(32)), reproducible=True)
 enc_vals = [i / 97.0 - 1.5 for i in range(192)]
 
 
