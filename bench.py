@@ -232,6 +232,35 @@ def cpu_baseline_all_cores(blocks_per_thread=1):
             "sample": "%d blocks, OpenMP over blocks, %d threads, same oracle" % (nb, threads)}
 
 
+OUT_BYTES_PER_CT_WORD = 8
+XGMI_LINK_GBS = 153.0                      # MI355X_MICROARCH.md: 7 xGMI links per GPU, ~153 GB/s each, point to point
+PCIE_GBS = 64.0                            # PCIe Gen5 x16 per direction (nominal); 55-60 GB/s is what pinned copies sustain
+
+
+class Watchdog:
+    """Bounds a leg that contains point-to-point transfers no box has run yet (the RCCL wave gather between two devices): when the
+    deadline passes, `on_timeout()` runs (rank 0: print the line measured so far, with the leg marked as timed out) and the process
+    ends with os._exit(0) -- every rank arms the same deadline after the same barrier, so the whole job ends instead of one rank
+    waiting for another inside a collective.  `value` (the compute-only leg) is measured BEFORE any such leg."""
+
+    def __init__(self, seconds, on_timeout):
+        import threading
+        self.cancelled = threading.Event()
+        self.t = threading.Thread(target=self._run, args=(seconds, on_timeout), daemon=True)
+        self.t.start()
+
+    def _run(self, seconds, on_timeout):
+        if not self.cancelled.wait(seconds):
+            try:
+                on_timeout()
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+
+    def cancel(self):
+        self.cancelled.set()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,11 +271,17 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--preset", default="P4096", help="parameter set (default: the BASELINE.json configuration)")
     ap.add_argument("--gather", choices=["none", "wave", "local"], default="none",
-                    help="wave: every wave of output ciphertexts is sent to rank 0 (RCCL send/recv over xGMI, overlapped with the "
-                         "next wave's compute) and drained there by digest; local: every rank drains ITS OWN waves to pinned host "
-                         "memory over its own PCIe link (parallel.LocalDrain; the consumer that scales with the GPU count); "
-                         "none (default): outputs stay sharded in HBM (SURVEY.md 8e)")
+                    help="what the TIMED region (`value`) does with the outputs.  wave: every wave of output ciphertexts is sent to rank 0 "
+                         "(RCCL send/recv over xGMI, overlapped with the next wave's compute) and drained there by digest; local: every "
+                         "rank drains ITS OWN waves to pinned host memory over its own PCIe link (parallel.LocalDrain; the consumer that "
+                         "scales with the GPU count); none (default): outputs stay sharded in HBM (SURVEY.md 8e).  With N > 1 and the "
+                         "default, both gather variants are ALSO measured after the timed region and reported in `gather` (--gather-legs)")
     ap.add_argument("--gather-wave-blocks", type=int, default=64)
+    ap.add_argument("--gather-legs", choices=["auto", "on", "off"], default="auto",
+                    help="the `gather` object of the line (with-gather figures next to the compute-only `value`): auto = when N > 1")
+    ap.add_argument("--gather-steps", type=int, default=3, help="timed steps of each gather leg (one untimed step before them)")
+    ap.add_argument("--n1-leg", choices=["auto", "on", "off"], default="auto",
+                    help="rank 0 alone times the same step before the all-rank region (in-run N = 1 figure -> weak_scaling.efficiency): auto = when N > 1")
     args = ap.parse_args()
     ensure_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
@@ -262,7 +297,9 @@ def main():
     # FHE_BENCH_BACKEND=gloo (tests only): the world > 1 code path of this file on a box with fewer devices than ranks -- RCCL refuses
     # two ranks on one device, gloo does not care; ranks then share devices round-robin and the collectives run on host tensors
     backend = os.environ.get("FHE_BENCH_BACKEND", "nccl")
+    shared_devices = False
     if backend == "gloo":
+        shared_devices = world > torch.cuda.device_count()
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
@@ -282,17 +319,29 @@ def main():
     plan = fhe.DctPlan(ctx, fhe.YQT)
     B = args.blocks
     words_per_block = 64 * 2 * ctx.k * ctx.n
+    out_bytes_per_block = words_per_block * 8                # 64 ct(2) written per block: 12 MiB at n=4096, k=3
     # global block index g = rank * B + b: any GPU count generates the same bytes for block g
     first_index = rank * B * words_per_block
     blocks = ctx.random_ct(B, 64, seed=fhe.SEED, first_index=first_index)
     out = torch.empty_like(blocks)
     torch.cuda.synchronize()
 
-    gather = None
-    if args.gather == "wave":
+    legs = args.gather_legs == "on" or (args.gather_legs == "auto" and world > 1 and args.gather == "none")
+    need_waves = args.gather != "none" or legs
+    wave = n_waves = None
+    if need_waves:
         if B % args.gather_wave_blocks:
             raise SystemExit("--blocks must be a multiple of --gather-wave-blocks")
         wave, n_waves = args.gather_wave_blocks, B // args.gather_wave_blocks
+    wave_shape = ((wave,) + tuple(blocks.shape[1:])) if need_waves else None
+
+    # ---- the three step functions: outputs stay in HBM / waves to rank 0 over RCCL / waves to pinned host memory --------------------
+    def step_none():
+        ev.dct8x8_quant(plan, blocks, out=out)
+
+    gather = None
+    wave_digests = None
+    if args.gather == "wave" or legs:
         # rank 0 drains every wave (its own and the peers') by digest: one u64 per (source rank, wave)
         wave_digests = torch.zeros(world * n_waves, dtype=torch.int64, device=blocks.device)
 
@@ -300,30 +349,9 @@ def main():
             ctx.digest_into(t.view(-1), wave_digests[src * n_waves + w:src * n_waves + w + 1],
                             index0=(src * B + w * wave) * words_per_block)
         if world > 1:
-            gather = fhe.parallel.WaveGather((wave,) + tuple(blocks.shape[1:]), blocks.dtype, blocks.device, n_waves, consume=consume)
-    local = None
-    if args.gather == "local":
-        if B % args.gather_wave_blocks:
-            raise SystemExit("--blocks must be a multiple of --gather-wave-blocks")
-        wave, n_waves = args.gather_wave_blocks, B // args.gather_wave_blocks
-        drained = [0]
+            gather = fhe.parallel.WaveGather(wave_shape, blocks.dtype, blocks.device, n_waves, consume=consume)
 
-        def on_host(w, host_tensor):                            # where a per-GPU stream writer would take over
-            drained[0] += host_tensor.numel() * 8
-        local = fhe.parallel.LocalDrain((wave,) + tuple(blocks.shape[1:]), blocks.dtype, blocks.device, consume=on_host)
-
-    def step():
-        if args.gather == "local":
-            for w in range(n_waves):
-                buf = local.acquire()
-                ev.dct8x8_quant(plan, blocks[w * wave:(w + 1) * wave], out=buf)
-                local.commit(w)
-            local.finish()
-            local.reset()
-            return
-        if args.gather != "wave":
-            ev.dct8x8_quant(plan, blocks, out=out)
-            return
+    def step_wave():
         for w in range(n_waves):
             src = blocks[w * wave:(w + 1) * wave]
             if gather is None:                                   # one GPU: nothing to move, drain in place
@@ -337,8 +365,22 @@ def main():
             gather.finish()
             gather.reset()
 
-    for _ in range(args.warmup):
-        step()
+    local = None
+    drained = [0]
+    if args.gather == "local" or legs:
+        def on_host(w, host_tensor):                            # where a per-GPU stream writer would take over
+            drained[0] += host_tensor.numel() * 8
+        local = fhe.parallel.LocalDrain(wave_shape, blocks.dtype, blocks.device, consume=on_host)
+
+    def step_local():
+        for w in range(n_waves):
+            buf = local.acquire()
+            ev.dct8x8_quant(plan, blocks[w * wave:(w + 1) * wave], out=buf)
+            local.commit(w)
+        local.finish()
+        local.reset()
+
+    step = {"none": step_none, "wave": step_wave, "local": step_local}[args.gather]
 
     def barrier():
         torch.cuda.synchronize()
@@ -346,48 +388,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- timed region: exactly K steps ------------------------------------------------------------
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()                      # same stream the C ABI launches on (torch current stream)
-    for _ in range(args.steps):
+    def timed(fn, steps):
+        """exactly `steps` calls of fn bracketed by barrier + synchronize on both sides; (max-over-ranks wall s, this rank's wall s,
+        this rank's device ms per step from HIP events on the launch stream)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()                      # same stream the C ABI launches on (torch current stream)
+        for _ in range(steps):
+            fn()
+        e1.record()
+        barrier()
+        mine = time.perf_counter() - t0
+        worst = mine
+        if dist is not None:
+            tt = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            worst = float(tt.item())
+        return worst, mine, e0.elapsed_time(e1) / steps
+
+    for _ in range(args.warmup):
         step()
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
-    rank_ms, rccl_ranks = [wall / args.steps * 1e3], 1
+
+    # ---- in-run N = 1 leg: rank 0 alone, the other ranks idle at the barrier (weak scaling: the same B blocks per GPU) ----------------
+    n1 = None
+    if args.n1_leg == "on" or (args.n1_leg == "auto" and world > 1):
+        barrier()
+        if rank == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(args.steps):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            n1_wall = time.perf_counter() - t0
+            n1 = {"blocks_per_s": B * args.steps / n1_wall, "ms_per_step": n1_wall / args.steps * 1e3, "device_ms_per_step": e0.elapsed_time(e1) / args.steps}
+        barrier()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------
+    wall, my_wall, dev_ms_per_step = timed(step, args.steps)
+    rank_ms, rank_dev_ms, rccl_ranks = [my_wall / args.steps * 1e3], [dev_ms_per_step], 1
     if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         # self-check of the multi-GPU run: every rank contributes 1 to a SUM all-reduce (= ranks RCCL really connected)
-        # and its own per-step time to an all-gather, so the one JSON line shows the whole job
+        # and its own per-step times to an all-gather, so the one JSON line shows the whole job
         ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         rccl_ranks = int(ones.item())
-        mine = torch.tensor([wall / args.steps * 1e3], dtype=torch.float64, device=coll_dev)
+        mine = torch.tensor([my_wall / args.steps * 1e3, dev_ms_per_step], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        rank_ms = [float(t.item()) for t in every]
-        wall = float(tt.item())
+        rank_ms = [float(t[0].item()) for t in every]
+        rank_dev_ms = [float(t[1].item()) for t in every]
 
     # ---- verification: sampled blocks against the CPU oracle, digest over everything -----------------
-    if args.gather == "local":
-        # the timed path ends in page-locked HOST buffers: one more pass whose consumer brings every drained wave back and digests
-        # it with its global index -- the bytes that really left over PCIe -- next to the digest of an in-HBM evaluation
-        back = torch.empty((wave,) + tuple(blocks.shape[1:]), dtype=blocks.dtype, device=blocks.device)
+    def verify_local_drain():
+        """the drained path ends in page-locked HOST buffers: one more pass whose consumer brings every drained wave back and digests
+        it with its global index -- the bytes that really left over PCIe -- next to the digest of an in-HBM evaluation"""
+        back = torch.empty(wave_shape, dtype=blocks.dtype, device=blocks.device)
         host_digests = torch.zeros(n_waves, dtype=torch.int64, device=blocks.device)
 
         def verify_on_host(w, host_tensor):
             back.copy_(host_tensor)
             ctx.digest_into(back.view(-1), host_digests[w:w + 1], index0=first_index + w * wave * words_per_block)
-        local.consume = verify_on_host
-        step()
+        keep, local.consume = local.consume, verify_on_host
+        step_local()
         torch.cuda.synchronize()
+        local.consume = keep
         drained_digest = int(host_digests.cpu().numpy().view(np.uint64).sum(dtype=np.uint64))
         ev.dct8x8_quant(plan, blocks, out=out)
         in_hbm = ctx.digest(out.view(-1), index0=first_index)
+        return drained_digest, in_hbm
+
+    if args.gather == "local":
+        drained_digest, in_hbm = verify_local_drain()
         if drained_digest != in_hbm:
             raise SystemExit("--gather local: the waves drained to host memory differ from the in-HBM result (%016x != %016x)" % (drained_digest, in_hbm))
         digest_all = fhe.parallel.combine_digests(in_hbm)
@@ -413,6 +488,7 @@ def main():
             ok &= bool(np.array_equal(fhe.to_host(out[b]), ref))
         verified = ok
 
+    res = None
     if rank == 0:
         total_blocks = B * world * args.steps
         value = total_blocks / wall
@@ -459,6 +535,20 @@ def main():
                          "ms_per_launch": dev_ms_per_step},
             "verified_bit_exact_vs_oracle": verified, "output_digest": "%016x" % digest_all,
         }
+        if world > 1:
+            # per GPU above (rank 0's own events); the whole job beside it: every rank's algorithmic bytes over ITS device time, summed,
+            # against N x the per-GPU peak
+            per_rank = [B * bytes_per_block / (ms * 1e-3) / 1e9 for ms in rank_dev_ms]
+            res["roofline"]["per_gpu"] = "rank 0's launches; `aggregate` sums every rank"
+            res["roofline"]["aggregate"] = {"achieved": sum(per_rank), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": sum(per_rank) / (HBM_PEAK_GBS * world),
+                                            "achieved_per_rank": per_rank, "device_ms_per_step_per_rank": rank_dev_ms}
+        if n1 is not None:
+            res["weak_scaling"] = {
+                "n1_blocks_per_s": n1["blocks_per_s"], "n1_ms_per_step": n1["ms_per_step"], "n1_device_ms_per_step": n1["device_ms_per_step"],
+                "per_gpu_blocks_per_s": value / world, "efficiency": value / (world * n1["blocks_per_s"]),
+                "how": "rank 0 alone ran the same %d steps of %d blocks right before the all-rank region while the other ranks waited at a barrier; "
+                       "efficiency = value / (n_gpus x n1_blocks_per_s)" % (args.steps, B) +
+                       ("; TEST MODE: the ranks share %d device(s), so the efficiency is ~1/ranks-per-device by construction" % torch.cuda.device_count() if shared_devices else "")}
         # Which resource the pair really runs against: the counters (profiles/*_counters_summary.txt) show VALU issue, not HBM --
         # `roofline` above stays the HBM figure BASELINE.json asks for, this object is the issue-side one, from tracked files
         names = {1: ["k_dct_rows", "k_dct_cols"], 2: ["k_dct_rows_u64", "k_dct_cols_u64"]}.get(path)
@@ -472,13 +562,89 @@ def main():
                     ir["frac"], ir["frac_at_nominal_clock"])
             res["roofline"]["limiter"] = ("valu-issue at the package power limit (see issue_roofline; 1.37 kW and sclk 2.13-2.20 GHz measured under this pair, "
                                           "profiles/r04_power_clocks_headline.txt); the HBM fraction is reported because BASELINE.json's metric asks for it")
-        if world == 1 and args.cpu_blocks > 0 and args.preset == "P4096":
+        # SEAL's own CPU path "in the same run" (north_star): rank 0's host, every N; the other ranks wait at the barrier below
+        if args.cpu_blocks > 0 and args.preset == "P4096":
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
             try:
                 res["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             except Exception as exc:      # the extra field must never break the bench line
                 res["cpu_baseline_all_cores"] = {"error": str(exc)}
+
+    # ---- the gather legs: the same step WITH the final ciphertext gather, both ways, after `value` was measured -----------------------
+    broken = False
+    if legs:
+        gsteps = max(1, args.gather_steps)
+        limit = float(os.environ.get("FHE_BENCH_GATHER_TIMEOUT", "150"))
+        link_blocks = XGMI_LINK_GBS * 1e9 / out_bytes_per_block
+        gobj = {"steps": gsteps, "wave_blocks": wave, "output_bytes_per_block": out_bytes_per_block,
+                "note": "`value` is the compute-only figure (outputs stay sharded in HBM); these are the same step with the final ciphertext gather "
+                        "(SURVEY.md 8e: with and without the gather), measured after it in the same process"}
+        if res is not None:
+            res["gather"] = gobj
+
+        def run_leg(name, fn, finish, check=None):
+            """one untimed + gsteps timed steps (+ the leg's verification) under a watchdog; a leg that fails or hangs is reported as such
+            and ends the job cleanly -- every collective of the leg sits inside the watchdog's window"""
+            nonlocal broken
+            if broken:
+                gobj[name] = {"error": "skipped: an earlier leg failed"}
+                return
+            torch.cuda.synchronize()
+
+            def give_up():
+                if res is not None:
+                    gobj[name] = {"error": "no completion within %.0f s (watchdog): the leg was abandoned, the figures above it stand" % limit}
+                    print(json.dumps(res), flush=True)
+            dog = Watchdog(limit, give_up)
+            try:
+                fn()
+                w_all, _, _ = timed(fn, gsteps)
+                gobj[name] = finish(w_all / gsteps)
+                if check is not None:
+                    gobj[name].update(check())
+            except Exception as exc:                            # the other ranks may be inside a transfer: no further collectives
+                gobj[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                broken = True
+            finally:
+                dog.cancel()
+
+        def wave_done(sec):
+            dg = int(wave_digests.cpu().numpy().view(np.uint64).sum(dtype=np.uint64)) if rank == 0 else 0
+            into_root = (world - 1) * B * out_bytes_per_block / sec / 1e9
+            return {"blocks_per_s": B * world / sec, "ms_per_step": sec * 1e3, "fraction_of_compute_only": (B * world / sec) / (res["value"] if res else 1.0),
+                    "xgmi_GB_per_s_into_root": into_root, "peers": world - 1,
+                    "link_ceiling_blocks_per_s_per_peer": link_blocks,
+                    "root_ceiling_blocks_per_s": (world - 1) * link_blocks + (res["value"] / world if res else 0.0),
+                    "digest_matches_compute_only": (dg == digest_all) if rank == 0 else None,
+                    "how": "every %d-block wave of every peer goes to rank 0 by RCCL send/recv (one xGMI link per peer, ~%.0f GB/s each: a peer can ship "
+                           "~%.1f k blocks/s of %.0f MiB outputs while it computes ~%.0f k), overlapped with the next wave's compute; rank 0 drains every wave by digest.  "
+                           "The ceiling of this consumer is the links into ONE root, not a defect of the overlap" % (
+                               wave, XGMI_LINK_GBS, link_blocks / 1e3, out_bytes_per_block / 2 ** 20, (res["value"] / world / 1e3) if res else 0.0) +
+                           ("; TEST MODE (gloo, shared device): the transfer is a host copy" if backend != "nccl" else "")}
+
+        def local_done(sec):
+            per_gpu = B * out_bytes_per_block / sec / 1e9
+            return {"blocks_per_s": B * world / sec, "ms_per_step": sec * 1e3, "fraction_of_compute_only": (B * world / sec) / (res["value"] if res else 1.0),
+                    "pcie_GB_per_s_per_gpu": per_gpu, "pcie_GB_per_s_aggregate": per_gpu * world,
+                    "link_ceiling_blocks_per_s_per_gpu": PCIE_GBS * 1e9 / out_bytes_per_block,
+                    "how": "every rank copies ITS OWN %d-block waves to page-locked host memory on a side stream (its own PCIe Gen5 x16 link, ~%.0f GB/s nominal), "
+                           "overlapped with the next wave's compute; no inter-GPU traffic, so this consumer scales with the GPU count" % (wave, PCIE_GBS)}
+
+        def local_check():
+            dd, ih = verify_local_drain()
+            ok_all = torch.tensor([1 if dd == ih else 0], dtype=torch.int64, device=coll_dev)
+            if dist is not None:
+                dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            return {"drained_bytes_equal_in_hbm_result_on_every_rank": bool(ok_all.item())}
+
+        run_leg("local", step_local, local_done, local_check)
+        run_leg("wave", step_wave, wave_done)
+
+    if rank == 0:
         print(json.dumps(res), flush=True)
+    if broken:                          # a failed leg may have left a peer inside a transfer: leave without another collective
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

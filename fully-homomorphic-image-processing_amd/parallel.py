@@ -178,6 +178,12 @@ class WaveGather:
         self.side = torch.cuda.Stream(device=device) if self.is_cuda else None
         # root: receive ring, `slots` waves deep per peer; receives for wave w are posted as soon as slot w % slots is free
         self.rx = {r: [torch.empty(wave_shape, dtype=dtype, device=device) for _ in range(self.slots)] for r in self.peers} if self.rank == dst else {}
+        # TEST MODE only (gloo with device tensors: the world > 1 path on a box with fewer devices than ranks): gloo moves host
+        # memory, so a wave goes device -> page-locked host -> gloo -> page-locked host -> device.  RCCL takes device pointers.
+        self.stage = self.is_cuda and dist.get_backend(group) != "nccl"
+        if self.stage:
+            self.tx_host = [torch.empty(wave_shape, dtype=dtype).pin_memory() for _ in range(self.slots)] if self.rank != dst else []
+            self.rx_host = {r: [torch.empty(wave_shape, dtype=dtype).pin_memory() for _ in range(self.slots)] for r in self.peers} if self.rank == dst else {}
         self.rx_work = {}                                   # wave -> list of (src, work)
         self.next, self.posted, self.consumed = 0, 0, 0
 
@@ -194,7 +200,8 @@ class WaveGather:
         """keep up to `slots` waves of receives in flight (each slot is reposted once its wave was consumed)"""
         while self.posted < self.n_waves and self.posted - self.consumed < self.slots and self.peers:
             w = self.posted
-            ops = [self.dist.P2POp(self.dist.irecv, self.rx[r][w % self.slots], self._global(r), self.group) for r in self.peers]
+            into = self.rx_host if self.stage else self.rx
+            ops = [self.dist.P2POp(self.dist.irecv, into[r][w % self.slots], self._global(r), self.group) for r in self.peers]
             works = self.dist.batch_isend_irecv(ops)
             self.rx_work[w] = list(zip(self.peers, works if len(works) == len(ops) else [works[0]] * len(ops)))
             self.posted += 1
@@ -218,7 +225,11 @@ class WaveGather:
         assert wave_index == self.next
         buf = self.ring[slot]
         if self.rank != self.dst:
-            if self.is_cuda:                                # the transfer waits for the compute of this wave only;
+            if self.stage:                                  # test mode: the wave leaves through host memory
+                self.tx_host[slot].copy_(buf, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                self.sends[slot] = self._send(self.tx_host[slot])
+            elif self.is_cuda:                              # the transfer waits for the compute of this wave only;
                 self.side.wait_stream(torch.cuda.current_stream())   # the caller's stream goes on with the next wave
                 with torch.cuda.stream(self.side):
                     self.sends[slot] = self._send(buf)
@@ -234,6 +245,9 @@ class WaveGather:
             w = self.consumed
             for src, work in self.rx_work.pop(w):
                 work.wait()
+                if self.stage:
+                    self.rx[src][w % self.slots].copy_(self.rx_host[src][w % self.slots], non_blocking=True)
+                    torch.cuda.current_stream().synchronize()        # the host slot is handed to the next receive right after
                 self.consume(src, w, self.rx[src][w % self.slots])
             self.consumed += 1
             self._post_receives()

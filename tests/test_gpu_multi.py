@@ -86,6 +86,50 @@ def test_bench_gpus_2_is_the_whole_launch():
     assert two["output_digest"] == one["output_digest"] and two["verified_bit_exact_vs_oracle"]
 
 
+def test_the_one_driver_command_prints_the_whole_multi_gpu_record():
+    """`python bench.py --gpus 2 --steps 3` -- the command the driver runs at N > 1, nothing else on the line -- prints ONE JSON line that
+    carries the compute-only `value`, the CPU baseline of the same run, an in-run N = 1 leg with the weak-scaling efficiency, BOTH
+    gather legs (wave-to-root with its xGMI link ceiling, local PCIe drain) and the aggregate roofline.  On a one-GPU box the two ranks
+    share the device over gloo (FHE_BENCH_BACKEND=gloo): the schema and every code path of the record, not the physics."""
+    import torch
+    shared = torch.cuda.device_count() < 2
+    r = _direct("bench.py", ["--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "2"], **({"FHE_BENCH_BACKEND": "gloo"} if shared else {}))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["config"]["gather"] == "none"
+    assert d["verified_bit_exact_vs_oracle"] and len(d["output_digest"]) == 16
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "blocks/s"
+    ws = d["weak_scaling"]
+    assert ws["n1_blocks_per_s"] > 0 and abs(ws["per_gpu_blocks_per_s"] - d["value"] / 2) < 1e-6 * d["value"]
+    assert abs(ws["efficiency"] - d["value"] / (2 * ws["n1_blocks_per_s"])) < 1e-9
+    if shared:
+        assert 0.3 < ws["efficiency"] < 0.75 and "TEST MODE" in ws["how"]       # two ranks on one device: about one half by construction
+    g = d["gather"]
+    wave, local = g["wave"], g["local"]
+    assert "error" not in wave and "error" not in local, g
+    assert wave["digest_matches_compute_only"] is True and wave["peers"] == 1
+    assert abs(wave["link_ceiling_blocks_per_s_per_peer"] - 153e9 / g["output_bytes_per_block"]) < 1e-6 * wave["link_ceiling_blocks_per_s_per_peer"]
+    assert wave["xgmi_GB_per_s_into_root"] > 0 and 0 < wave["blocks_per_s"] <= 1.05 * d["value"]
+    assert local["drained_bytes_equal_in_hbm_result_on_every_rank"] is True
+    assert local["pcie_GB_per_s_per_gpu"] > 0 and abs(local["pcie_GB_per_s_aggregate"] - 2 * local["pcie_GB_per_s_per_gpu"]) < 1e-9 * local["pcie_GB_per_s_aggregate"]
+    agg = d["roofline"]["aggregate"]
+    assert agg["peak"] == 2 * d["roofline"]["peak"] and len(agg["achieved_per_rank"]) == 2 and abs(agg["frac"] - agg["achieved"] / agg["peak"]) < 1e-12
+
+
+def test_a_gather_leg_that_hangs_is_abandoned_and_the_line_still_appears():
+    """the RCCL wave gather has never run between two devices: a leg that does not complete must not take the line with it.  With
+    FHE_BENCH_GATHER_TIMEOUT=0.001 the watchdog of the first leg fires at once on every rank: rank 0 prints the line measured so far
+    (value, cpu_baseline, weak_scaling) with the leg marked, and every rank leaves with exit code 0."""
+    r = _direct("bench.py", ["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "128", "--cpu-blocks", "0"], FHE_BENCH_BACKEND="gloo", FHE_BENCH_GATHER_TIMEOUT="0.001")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["weak_scaling"]["efficiency"] > 0
+    assert "watchdog" in d["gather"]["local"]["error"]
+
+
 def test_bench_gpus_more_than_devices_fails_loudly():
     """--gpus 8 on a box with fewer devices must not print an N = 1 line labelled as 8: non-zero exit with the device count in the
     message; and a launcher whose WORLD_SIZE disagrees with --gpus is refused the same way"""

@@ -264,6 +264,31 @@ def test_rgb_to_ycc_fp64_path_equals_u64_path_and_extremes(fhe, oracle_mod, monk
         assert np.array_equal(fhe.to_host(fast[2])[i], v)
 
 
+@pytest.mark.parametrize("preset,switches", [("SEAL23_4096", {"FHE_NTT_NOPM": 1}), ("P8192", {"FHE_NTT_NOPM": 1}), ("P4096", {"FHE_DCT_FORCE_U64": 1})])
+def test_rgb_to_ycc_one_launch_kernel_back_to_back_inverse_transforms(fhe, oracle_mod, preset, switches):
+    """k_rgb2ycc (the path of bases that are not pseudo-Mersenne and of FHE_NTT_NOPM=1) runs three inverse transforms back to back on
+    ONE LDS buffer; an inverse transform ends with a transpose that reads across waves, the next one opens with a wave-local write
+    (csrc/ntt_core.h, CONTRACT) -- the ntt_lds_release() between them is what this stresses: 512 pixels x 4 rounds at n = 4096 / 8192
+    (8 and 16 waves per workgroup, thousands of workgroups in flight), every round bit-equal to the default three-launch / FP64 path,
+    sampled pixels equal to the oracle."""
+    import torch
+    ctx, orc = _pair(fhe, oracle_mod, preset)
+    alt = _variant(fhe, ctx, **switches)
+    ev, ev2 = fhe.Evaluator(ctx), fhe.Evaluator(alt)
+    base = [ctx.random_ct(512, seed=301 + i) for i in range(3)]
+    want = [t.clone() for t in base]
+    ev.rgb_to_ycc(*want)
+    for rnd in range(4):
+        got = [t.clone() for t in base]
+        ev2.rgb_to_ycc(*got)
+        for p, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (preset, rnd, p)
+    for i in (0, 255, 511):
+        y, u, v = orc.rgb_to_ycc(*(fhe.to_host(t[i:i + 1])[0] for t in base))
+        assert np.array_equal(fhe.to_host(want[0][i:i + 1])[0], y) and np.array_equal(fhe.to_host(want[1][i:i + 1])[0], u)
+        assert np.array_equal(fhe.to_host(want[2][i:i + 1])[0], v)
+
+
 def test_dct_known_answer_through_decrypt(fhe, oracle_mod):
     """decrypt(GPU circuit(encrypt(pixels))) == the plaintext DCT of homo/fhe_image.h:400-484 / quant"""
     from oracle import bigint_model as bm
@@ -705,6 +730,17 @@ def test_c_abi_error_codes(fhe, oracle_mod):
     assert L.fhe_add_plain(ctx.h, p, 2 * ctx.k * ctx.n, 1, bad_plain.ctypes.data_as(C.c_void_p), 8, 0, None) == -1   # sign must be +-1
     assert L.fhe_multiply(ctx.h, p, 2, p, 2, p, 1, None, 0, None) == -1                 # scratch too small
     assert L.fhe_relinearize(ctx.h, p, 10, 1, p, 30, None, 0, None) == -1               # stride below a size-3 ciphertext
+    # fhe_relinearize_to: the output either IS the input (same pointer and stride) or is disjoint from it -- a compacting in-place
+    # call (3-polynomial inputs, 2-polynomial outputs at the same address) would let output c land on an input not yet read
+    kn = ctx.k * ctx.n
+    scr_bytes = L.fhe_relinearize_scratch_bytes(ctx.h, 30, 4)
+    import torch
+    scr = torch.empty(scr_bytes // 8 + 1, dtype=torch.int64, device=a.device)
+    ps = C.c_void_p(scr.data_ptr())
+    assert L.fhe_relinearize_to(ctx.h, p, 3 * kn, p, 2 * kn, 4, p, 30, ps, scr_bytes, None) == -1
+    assert b"overlaps" in L.fhe_last_error()
+    inside = C.c_void_p(a.data_ptr() + 8 * kn)
+    assert L.fhe_relinearize_to(ctx.h, p, 3 * kn, inside, 3 * kn, 4, p, 30, ps, scr_bytes, None) == -1
     with pytest.raises(fhe.FheError):
         fhe._lib.call("fhe_ntt_forward", ctx.h, None, None, 1, None)
     h = C.c_void_p()
