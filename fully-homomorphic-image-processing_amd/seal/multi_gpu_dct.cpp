@@ -16,7 +16,15 @@
 // contract of the C ABI (contexts shared by nothing, fhe_ctx_bind_thread, per-rank streams) and the digests are still
 // exercised; only the RCCL transfers need two devices.
 //
-// usage: multi_gpu_dct [total_blocks=512] [ranks=<device count>] [wave_blocks=64] [gather=1]
+// Two timing modes:
+//   verify   (default) every wave generates its inputs and digests its outputs INSIDE the loop: two wave buffers, any job size;
+//            a verifier -- its rate is about half of what the kernels deliver (fill + digest are two more passes over 12 MiB per block)
+//   resident the shape of bench.py's timed region: the rank's inputs are generated BEFORE the clock starts and stay in HBM, the
+//            outputs of every wave stay in HBM too and are digested AFTER the last synchronisation, `reps` passes over the shard are
+//            timed: nothing but fhe_dct8x8_quant (and, with gather, the transfers and the root's drain) is inside the clock.  The
+//            single-rank figure next to it is ONE rank over the per-rank share (weak scaling: the same work per GPU).
+//
+// usage: multi_gpu_dct [total_blocks=512] [ranks=<device count>] [wave_blocks=64] [gather=1] [mode=verify|resident] [reps=1]
 // prints one JSON line; exit code 0 iff every check held.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -69,8 +77,8 @@ struct Job {
     uint32_t n = 4096, k = 3;
     uint64_t q[FHE_MAX_K] = {0}, t = 1 << 14;
     uint64_t total = 512, wave = 64, words_per_block = 0;
-    int world = 1, devices = 1;
-    bool gather = false;
+    int world = 1, devices = 1, reps = 1;
+    bool gather = false, resident = false;
     std::vector<ncclComm_t> comms;
 };
 
@@ -113,10 +121,17 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
         check(fhe_dct_plan_create(ctx, YQT, 100, 100, st, &plan), "fhe_dct_plan_create");
         const uint64_t wpb = J.words_per_block, mine = R.end - R.start;
         const uint64_t n_waves = (mine + J.wave - 1) / J.wave;
-        uint64_t *in = dalloc(J.wave * wpb), *out[2] = {dalloc(J.wave * wpb), dalloc(J.wave * wpb)};
+        const bool res = J.resident;
+        std::vector<void *> owned;                                                      // freed before the rank returns (a second run follows in this process)
+        auto take = [&](uint64_t words) { uint64_t *p = dalloc(words); owned.push_back(p); return p; };
+        // verify: one input wave and two output waves; resident: the whole shard in and out
+        uint64_t *in = take((res ? (mine ? mine : 1) : J.wave) * wpb);
+        uint64_t *out_all = res ? take((mine ? mine : 1) * wpb) : nullptr;
+        uint64_t *out[2] = {res ? nullptr : take(J.wave * wpb), res ? nullptr : take(J.wave * wpb)};
         const size_t scr_bytes = fhe_dct8x8_scratch_bytes(ctx, J.wave);
         void *scr = nullptr;
         check(fhe_dev_alloc(scr_bytes, &scr), "fhe_dev_alloc(scratch)");
+        owned.push_back(scr);
         hipEvent_t computed[2], sent[2];
         for (int i = 0; i < 2; ++i) {
             hcheck(hipEventCreateWithFlags(&computed[i], hipEventDisableTiming), "event");
@@ -142,37 +157,54 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
         }
         if (J.gather && R.rank == 0)
             for (int b = 0; b < 2; ++b)
-                for (int r = 1; r < J.world; ++r) rx[b].push_back(dalloc(J.wave * wpb));
+                for (int r = 1; r < J.world; ++r) rx[b].push_back(take(J.wave * wpb));
+        // resident + gather: a wave's region of out_all is rewritten by the next pass only after its transfer has left
+        std::vector<hipEvent_t> sent_wave(res && J.gather && R.rank != 0 ? max_waves : 0);
+        for (auto &e : sent_wave) hcheck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
         // digest slots: one per own wave, one per (wave, peer) on the root; zeroed once, summed once after the loop
         const uint64_t n_own = max_waves, n_rx = (J.gather && R.rank == 0) ? max_waves * (uint64_t)(J.world - 1) : 0;
-        uint64_t *d_own = dalloc(n_own + 1), *d_rx = dalloc(n_rx + 1);
+        uint64_t *d_own = take(n_own + 1), *d_rx = take(n_rx + 1);
         hcheck(hipMemsetAsync(d_own, 0, (n_own + 1) * 8, (hipStream_t)st), "memset");
         hcheck(hipMemsetAsync(d_rx, 0, (n_rx + 1) * 8, (hipStream_t)st), "memset");
+        if (res && mine) check(fhe_fill_random(ctx, in, mine * 64 * 2, SEED, R.start * wpb, st), "fhe_fill_random");   // block g = splitmix64(seed ^ global index)
+        if (res && mine) {                                                               // one untimed pass: first-use costs (plan constants, code objects) stay outside the clock
+            for (uint64_t w = 0; w < n_waves; ++w) {
+                const uint64_t b0 = w * J.wave, nb = b0 + J.wave <= mine ? J.wave : mine - b0;
+                check(fhe_dct8x8_quant(ctx, plan, in + b0 * wpb, out_all + b0 * wpb, nb, scr, scr_bytes, st), "fhe_dct8x8_quant");
+            }
+        }
         check(fhe_stream_sync(st), "sync");
         arrived.fetch_add(1);
         while (arrived.load() < J.world) std::this_thread::yield();                      // every rank is set up: start the clock together
         const double t0 = now();
+        for (int rep = 0; rep < J.reps; ++rep)
         for (uint64_t w = 0; w < max_waves; ++w) {
-            const int slot = (int)(w & 1);
+            const uint64_t it = (uint64_t)rep * max_waves + w;
+            const int slot = (int)(it & 1);
             const uint64_t b0 = R.start + w * J.wave, nb = w < n_waves ? (b0 + J.wave <= R.end ? J.wave : R.end - b0) : 0;
+            uint64_t *dst = res ? out_all + w * J.wave * wpb : out[slot];
             if (nb) {
-                if (w >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st, sent[slot], 0), "wait(sent)");      // out[slot] has left for the root
-                check(fhe_fill_random(ctx, in, nb * 64 * 2, SEED, b0 * wpb, st), "fhe_fill_random");       // block g = splitmix64(seed ^ global index)
-                check(fhe_dct8x8_quant(ctx, plan, in, out[slot], nb, scr, scr_bytes, st), "fhe_dct8x8_quant");
-                digest_into(ctx, out[slot], nb * wpb, b0 * wpb, d_own + w, st);
+                if (!res) {
+                    if (it >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st, sent[slot], 0), "wait(sent)");      // out[slot] has left for the root
+                    check(fhe_fill_random(ctx, in, nb * 64 * 2, SEED, b0 * wpb, st), "fhe_fill_random");
+                } else if (rep && !sent_wave.empty()) {
+                    hcheck(hipStreamWaitEvent((hipStream_t)st, sent_wave[w], 0), "wait(sent)");
+                }
+                check(fhe_dct8x8_quant(ctx, plan, res ? in + w * J.wave * wpb : in, dst, nb, scr, scr_bytes, st), "fhe_dct8x8_quant");
+                if (!res) digest_into(ctx, dst, nb * wpb, b0 * wpb, d_own + w, st);
                 hcheck(hipEventRecord(computed[slot], (hipStream_t)st), "record");
             }
             if (!J.gather) continue;
             if (R.rank != 0) {
                 if (nb) {                                                                // the transfer overlaps the next wave's compute
                     hcheck(hipStreamWaitEvent((hipStream_t)st_comm, computed[slot], 0), "wait(computed)");
-                    ncheck(ncclSend(out[slot], nb * wpb, ncclUint64, 0, J.comms[R.rank], (hipStream_t)st_comm), "ncclSend");
-                    hcheck(hipEventRecord(sent[slot], (hipStream_t)st_comm), "record");
+                    ncheck(ncclSend(dst, nb * wpb, ncclUint64, 0, J.comms[R.rank], (hipStream_t)st_comm), "ncclSend");
+                    hcheck(hipEventRecord(res ? sent_wave[w] : sent[slot], (hipStream_t)st_comm), "record");
                 }
             } else {
                 // wave w of every peer that has one, as ONE group: the transfers arrive concurrently, each over its peer's own link
                 std::vector<std::pair<int, uint64_t>> got;
-                if (w >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st_comm, digested[slot], 0), "wait(digested)");     // rx[slot] has been read
+                if (it >= 2) hcheck(hipStreamWaitEvent((hipStream_t)st_comm, digested[slot], 0), "wait(digested)");     // rx[slot] has been read
                 ncheck(ncclGroupStart(), "ncclGroupStart");
                 for (int r = 1; r < J.world; ++r) {
                     const uint64_t done = w * J.wave;
@@ -196,8 +228,14 @@ void run_rank(const Job &J, Rank &R, std::atomic<int> &arrived) {
         check(fhe_stream_sync(st_comm), "sync");
         check(fhe_stream_sync(st_dig), "sync");
         R.seconds = now() - t0;                                                           // the ONE host synchronisation of the loop
+        if (res)                                                                          // resident: the outputs are still there -- digested after the clock stopped
+            for (uint64_t w = 0; w < n_waves; ++w) {
+                const uint64_t b0 = w * J.wave, nb = b0 + J.wave <= mine ? J.wave : mine - b0;
+                digest_into(ctx, out_all + b0 * wpb, nb * wpb, (R.start + b0) * wpb, d_own + w, st);
+            }
         R.digest = sum_slots(d_own, n_own, st);
         R.received_digest = sum_slots(d_rx, n_rx, st);
+        for (void *p : owned) (void)fhe_dev_free(p);
     } catch (const Fail &f) {
         R.error = f.what;
         arrived.fetch_add(J.world);                                                       // release the others' start barrier
@@ -222,7 +260,9 @@ int main(int argc, char **argv) {
     J.world = argc > 2 ? std::atoi(argv[2]) : ndev;
     J.wave = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 64;
     const bool want_gather = argc > 4 ? std::atoi(argv[4]) != 0 : true;
-    if (J.world < 1 || !J.wave || !J.total) return 2;
+    J.resident = argc > 5 && std::string(argv[5]) == "resident";
+    J.reps = argc > 6 ? std::atoi(argv[6]) : 1;
+    if (J.world < 1 || !J.wave || !J.total || J.reps < 1) return 2;
     J.gather = want_gather && J.world > 1 && J.world <= ndev;                             // RCCL: one rank per device
     const int kk = fhe_default_coeff_modulus(J.n, 0, J.q);
     if (kk < 1) return 2;
@@ -255,22 +295,45 @@ int main(int argc, char **argv) {
             sum += R.digest;
             if (R.rank) peers += R.digest;
         }
-        // the reference point: ONE rank over all N blocks (rank 0's device, the same wave loop)
+        // the reference point: ONE rank over all N blocks (rank 0's device, the verifying wave loop: two wave buffers whatever N is)
         Job one = J;
         one.world = 1;
         one.gather = false;
+        one.resident = false;
+        one.reps = 1;
         Rank solo;
         block_range(0, 1, J.total, solo.start, solo.end);
         std::atomic<int> a1{0};
         run_rank(one, solo, a1);
         if (!solo.error.empty()) throw Fail{"single-rank run: " + solo.error};
+        double solo_rate = J.total / solo.seconds;
+        if (J.resident) {                                  // the N = 1 figure of the weak-scaling pair: one rank, the per-rank share, the same resident loop
+            Job share = J;
+            share.world = 1;
+            share.gather = false;
+            share.total = ranks[0].end - ranks[0].start;
+            Rank alone;
+            alone.start = 0;
+            alone.end = share.total;
+            std::atomic<int> a2{0};
+            run_rank(share, alone, a2);
+            if (!alone.error.empty()) throw Fail{"single-rank resident run: " + alone.error};
+            solo_rate = share.total * (double)J.reps / alone.seconds;
+        }
+        const double rate = J.total * (double)J.reps / slowest;
         const bool digests_ok = solo.digest == sum, gather_ok = !J.gather || ranks[0].received_digest == peers;
         std::printf("{\"workload\": \"homomorphic 8x8 DCT+quant, %llu blocks over %d ranks on %d device(s), C++ host over include/fhe_hip.h (n=%u, k=%u)\", "
+                    "\"mode\": \"%s\", \"reps\": %d, "
                     "\"ranks\": %d, \"devices\": %d, \"wave_blocks\": %llu, \"seconds\": %.4f, \"blocks_per_s\": %.1f, \"single_rank_blocks_per_s\": %.1f, "
+                    "\"single_rank_is\": \"%s\", \"efficiency_vs_single_rank\": %.4f, "
                     "\"output_digest\": \"%016llx\", \"single_rank_digest\": \"%016llx\", \"digests_equal\": %s, "
                     "\"gather\": \"%s\", \"gathered_digest_equals_senders\": %s}\n",
-                    (unsigned long long)J.total, J.world, ndev, J.n, J.k, J.world, ndev, (unsigned long long)J.wave, slowest, J.total / slowest,
-                    J.total / solo.seconds, (unsigned long long)sum, (unsigned long long)solo.digest, digests_ok ? "true" : "false",
+                    (unsigned long long)J.total, J.world, ndev, J.n, J.k,
+                    J.resident ? "resident: inputs generated before the clock, outputs digested after it, only fhe_dct8x8_quant (+ transfers) timed" : "verify: fill + digest inside the loop",
+                    J.reps, J.world, ndev, (unsigned long long)J.wave, slowest, rate, solo_rate,
+                    J.resident ? "one rank over the per-rank share, same resident loop (weak scaling)" : "one rank over all blocks, verifying loop",
+                    rate / (solo_rate * (J.resident ? J.world : 1)),
+                    (unsigned long long)sum, (unsigned long long)solo.digest, digests_ok ? "true" : "false",
                     J.gather ? "rccl send/recv per wave to rank 0" : (want_gather && J.world > 1 ? "skipped: ranks share a device" : "none"),
                     J.gather ? (gather_ok ? "true" : "false") : "null");
         rc = digests_ok && gather_ok ? 0 : 1;

@@ -272,9 +272,24 @@ def test_cpp_host_block_shards_equal_one_rank(fhe):
     assert "%016x" % ctx.digest(out.view(-1), index0=0) == res["output_digest"]
 
 
+def test_cpp_host_resident_mode_times_what_bench_py_times(fhe):
+    """`multi_gpu_dct ... resident`: inputs generated before the clock, outputs digested after it, 256-block waves, several passes --
+    the timed region of bench.py from a C++ host.  One rank over 1024 blocks: the digest is the verifying loop's, and the rate is the
+    kernels' (bench.py: ~80 k blocks/s; the verifying loop: ~39 k), asserted here at >= 70 k so that box-to-box noise does not flake.
+    Ragged resident shards (3 ranks over 200 blocks in waves of 32) add up to the same digest as one rank."""
+    res = _multi_gpu_dct(1024, 1, 256, 0, "resident", 10)
+    assert res["mode"].startswith("resident") and res["reps"] == 10 and res["digests_equal"] is True
+    assert res["blocks_per_s"] >= 70000, res
+    assert abs(res["efficiency_vs_single_rank"] - 1.0) < 0.1
+    ragged = _multi_gpu_dct(200, 3, 32, 1, "resident", 2)
+    assert ragged["ranks"] == 3 and ragged["digests_equal"] is True
+
+
 def test_cpp_host_two_devices_rccl_gather():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two HIP devices (RCCL refuses two ranks on one device)")
     res = _multi_gpu_dct(256, 2, 32, 1)
+    assert res["digests_equal"] is True and res["gathered_digest_equals_senders"] is True
+    res = _multi_gpu_dct(512, 2, 64, 1, "resident", 3)
     assert res["digests_equal"] is True and res["gathered_digest_equals_senders"] is True
