@@ -153,16 +153,42 @@ def _roofline(alg_bytes, dev_ms, kernels, workload=None, units=0, issue=None):
 
 
 def _relin(args, fhe, ctx):
-    """(evk, dbc) for --relin: keys of a seeded key pair (the inputs are random residues, so any well-formed keys do)"""
+    """(evk, dbc[, "cubic"]) for --relin: keys of a seeded key pair (the inputs are random residues, so any well-formed keys do)"""
     if not args.relin:
         return None
-    return (fhe.KeyGenerator(ctx, seed=1).generate_evaluation_keys(args.relin).contiguous(), args.relin)
+    kg = fhe.KeyGenerator(ctx, seed=1)
+    if args.relin_placement == "cubic":        # keys for s^2 and s^3: one evaluator.relinearize takes a Cubic's size-4 result to 2
+        return (kg.generate_evaluation_keys(args.relin, 2).contiguous(), args.relin, "cubic")
+    return (kg.generate_evaluation_keys(args.relin).contiguous(), args.relin)
 
 
 def _mode(args):
+    if args.relin and args.relin_placement == "cubic":
+        return ("the reference's Cubic sequence unchanged + ONE evaluator.relinearize of its size-4 result (keys for s^2, s^3: two key switches per Cubic), "
+                "dbc = %d (NOT the reference's bits: the reference never relinearises)" % args.relin)
     if args.relin:
         return "relinearised after every multiply / square, dbc = %d (NOT the reference's bits: the reference never relinearises)" % args.relin
     return "reference (no relinearisation: homo/fhe_resize.h:174-179, homo/fhe_decode.h:67-98,235,239)"
+
+
+def _wl_suffix(args):
+    return ("_relin%d%s" % (args.relin, "_cubic" if args.relin_placement == "cubic" else "")) if args.relin else ""
+
+
+def _oracle_for_mode(args, om, orc):
+    """the checker object whose op-by-op composition defines the mode that is being timed (cpu_baseline of the --relin lines)"""
+    if not args.relin:
+        return orc
+    sk, _ = orc.keygen(1)
+    if args.relin_placement == "cubic":
+        return om.TailRelinOracle(orc, orc.evk_gen_powers(sk, dbc=args.relin, count=2), args.relin)
+    return om.RelinOracle(orc, orc.evk_gen(sk, dbc=args.relin), args.relin)
+
+
+def _strong_scaling(n1_seconds, wall, world, what):
+    return {"n1_seconds": n1_seconds, "speedup": n1_seconds / wall, "efficiency": n1_seconds / wall / world,
+            "how": "rank 0 alone ran the WHOLE job (%s) once, after a warm-up pass, while the other ranks waited at a barrier; speedup = that time / the "
+                   "all-rank time of the same job" % what}
 
 
 def resize(args):
@@ -185,60 +211,82 @@ def resize(args):
         if world > 1:
             raise SystemExit("--max-pixels is a single-GPU profiling switch")
         y1 = min(y1, y0 + (args.max_pixels + w - 1) // w)
-    first, count = fhe.parallel.source_rows(H, h, y0, y1, True)
-    # this rank's rows +- halo of ONE colour channel, resident in HBM; the global pixel index seeds the bytes, so any GPU count sees the same image
-    pixels = ctx.random_ct(count * W, size=2, seed=fhe.SEED, first_index=first * W * ctw)
     taps, _, _ = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
-    my_taps = (taps[y0 * w:y1 * w].astype(np.int64) - first * W).astype(np.uint32)
-    n_mine = (y1 - y0) * w
-    n_out = n_mine if args.max_pixels else w * h
-    P = min(args.pixels, n_mine)
     words = so * ctx.k * ctx.n
-    if args.shared:
-        # SURVEY.md 8(d) configs[2] input convention: one offset ciphertext per distinct fractional value, i.e. per output column / row
-        xc = ctx.random_ct(w, size=2, seed=11)
-        yc = ctx.random_ct(y1 - y0, size=2, seed=12, first_index=y0 * ctw)
-        acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
 
-        def consume(first_px, t):
-            part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
-            ctx.digest_into(t, part, index0=first_px * words)
-            acc.add_(part)
+    def build(y0, y1):
+        """the job of destination rows [y0, y1): its resident inputs (rows +- halo, offsets) and the callable"""
+        first, count = fhe.parallel.source_rows(H, h, y0, y1, True)
+        # this rank's rows +- halo of ONE colour channel, resident in HBM; the global pixel index seeds the bytes, so any GPU count sees the same image
+        pixels = ctx.random_ct(count * W, size=2, seed=fhe.SEED, first_index=first * W * ctw)
+        my_taps = (taps[y0 * w:y1 * w].astype(np.int64) - first * W).astype(np.uint32)
+        n_mine = (y1 - y0) * w
+        n_out = n_mine if args.max_pixels else w * h
+        P = min(args.pixels, n_mine)
+        if args.shared:
+            # SURVEY.md 8(d) configs[2] input convention: one offset ciphertext per distinct fractional value, i.e. per output column / row
+            xc = ctx.random_ct(w, size=2, seed=11)
+            yc = ctx.random_ct(y1 - y0, size=2, seed=12, first_index=y0 * ctw)
+            acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
 
-        def job(digest=False):          # the timed passes hand the bands to a no-op consumer; one untimed pass digests them
-            acc.zero_()
-            fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=consume if digest else (lambda first_px, t: None),
-                                               rows=(y0, y1), src_rows=(first, count), relin=relin)
-            return None
-        alg = (W * (H if not args.max_pixels else count) + w + h) * ctw * 8 + n_out * words * 8
-        form = "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"
-    else:
-        # one offset ciphertext pair per output pixel, as the reference's server draws them (homo/fhe_resize.h:262,266)
-        xf = ctx.random_ct(n_mine, size=2, seed=11, first_index=y0 * w * ctw)
-        yf = ctx.random_ct(n_mine, size=2, seed=12, first_index=y0 * w * ctw)
-        acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+            def consume(first_px, t):
+                part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+                ctx.digest_into(t, part, index0=first_px * words)
+                acc.add_(part)
 
-        def job(digest=False):
-            acc.zero_()
-            for s in range(0, n_mine, P):
-                e = min(s + P, n_mine)
-                out = fhe.circuits.sample_bicubic(ev, pc, pixels, my_taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous(), relin=relin)
-                if digest:
-                    part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
-                    ctx.digest_into(out, part, index0=(y0 * w + s) * words)
-                    acc.add_(part)
-            return None
-        alg = (W * (H if not args.max_pixels else count) + 2 * n_out) * ctw * 8 + n_out * words * 8
-        form = "one offset ciphertext pair per output pixel (five Cubic evaluations per pixel)"
+            def job(digest=False):          # the timed passes hand the bands to a no-op consumer; one untimed pass digests them
+                acc.zero_()
+                fhe.circuits.resize_bicubic_shared(ev, pc, pixels, W, H, w, h, xc, yc, batch=P, consume=consume if digest else (lambda first_px, t: None),
+                                                   rows=(y0, y1), src_rows=(first, count), relin=relin)
+                return None
+            alg = (W * (H if not args.max_pixels else count) + w + h) * ctw * 8 + n_out * words * 8
+            form = "one offset ciphertext per output column / row; repeated row Cubics, squares and prepared operands formed once"
+        else:
+            # one offset ciphertext pair per output pixel, as the reference's server draws them (homo/fhe_resize.h:262,266)
+            xf = ctx.random_ct(n_mine, size=2, seed=11, first_index=y0 * w * ctw)
+            yf = ctx.random_ct(n_mine, size=2, seed=12, first_index=y0 * w * ctw)
+            acc = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+
+            def job(digest=False):
+                acc.zero_()
+                for s in range(0, n_mine, P):
+                    e = min(s + P, n_mine)
+                    out = fhe.circuits.sample_bicubic(ev, pc, pixels, my_taps[s:e], xf[s:e].contiguous(), yf[s:e].contiguous(), relin=relin)
+                    if digest:
+                        part = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+                        ctx.digest_into(out, part, index0=(y0 * w + s) * words)
+                        acc.add_(part)
+                return None
+            alg = (W * (H if not args.max_pixels else count) + 2 * n_out) * ctw * 8 + n_out * words * 8
+            form = "one offset ciphertext pair per output pixel (five Cubic evaluations per pixel)"
+        return {"job": job, "acc": acc, "n_mine": n_mine, "n_out": n_out, "P": P, "alg": alg, "form": form, "pixels": pixels}
+
+    J = build(y0, y1)
+    job, acc, n_mine, n_out, P, alg, form, pixels = (J[k] for k in ("job", "acc", "n_mine", "n_out", "P", "alg", "form", "pixels"))
     job()                                                       # warm-up at full size: ct x ct tables, cached plaintexts, the allocator's pools
     _, first_pass, _ = _timed(job, dist)
     _, wall, dev_ms = _timed(job, dist)
     job(digest=True)                                            # untimed: the position-dependent digest of everything produced
     torch.cuda.synchronize()
     digest = fhe.parallel.combine_digests(int(acc.cpu().numpy().view(np.uint64)[0]))
+    n1_seconds = None
+    if world > 1:                                               # in-run N = 1 leg of the fixed-size job: rank 0 alone over ALL destination rows
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            del J, job, pixels
+            whole = build(0, h)
+            whole["job"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            whole["job"]()
+            torch.cuda.synchronize()
+            n1_seconds = time.perf_counter() - t0
+            del whole
+        dist.barrier()
     if rank == 0:
         from bench import issue_roofline_workload
-        wl = ("resize_shared" if args.shared else "resize") + ("_relin%d" % args.relin if relin else "")
+        wl = ("resize_shared" if args.shared else "resize") + _wl_suffix(args)
         issue = issue_roofline_workload(wl) if args.preset == "P8192" else None
         res = {"metric": "bicubic-resized output pixels/sec (one colour channel)", "value": n_out / wall, "unit": "pixels/s", "n_gpus": world,
                "steps": 1, "warmup": 2, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -251,6 +299,8 @@ def resize(args):
                                      wl, n_mine if args.preset == "P8192" else 0, issue),
                "job_executions": 4, "units_per_job": n_mine,
                "output_digest": "%016x" % digest}
+        if n1_seconds is not None:
+            res["strong_scaling"] = _strong_scaling(n1_seconds, wall, world, "all %d destination rows" % h)
         if world == 1 and not args.max_pixels:
             _, fxs, fys = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
             vals = ([fxs[x] for x in range(w)] + [fys[y * w] for y in range(h)]) if args.shared else [v for pair in zip(fxs, fys) for v in pair]
@@ -260,16 +310,20 @@ def resize(args):
         if args.cpu_pixels:
             from oracle import oracle as om
             orc = om.Oracle.preset(args.preset)
-            hp = fhe.to_host(pixels[:16])
+            hp = fhe.to_host(ctx.random_ct(16, size=2, seed=fhe.SEED))
             t = fhe.to_host(ctx.random_ct(1, size=2, seed=11))[0]
+            mode_orc = _oracle_for_mode(args, om, orc)           # --relin: the op-by-op composition that defines the mode (RelinOracle / TailRelinOracle)
             t0 = time.perf_counter()
             for _ in range(args.cpu_pixels):
-                cols = [orc.cubic(hp[4 * r], hp[4 * r + 1], hp[4 * r + 2], hp[4 * r + 3], t) for r in range(4)]
-                orc.cubic(cols[0], cols[1], cols[2], cols[3], t)
+                if relin:
+                    om.oracle_sample_bicubic_calls(mode_orc, list(hp), t, t)
+                else:
+                    cols = [orc.cubic(hp[4 * r], hp[4 * r + 1], hp[4 * r + 2], hp[4 * r + 3], t) for r in range(4)]
+                    orc.cubic(cols[0], cols[1], cols[2], cols[3], t)
             cdt = time.perf_counter() - t0
             res["cpu_baseline"] = {"value": args.cpu_pixels / cdt, "unit": "pixels/s", "cores": 1, "kind": "port",
-                                   "sample": "%d output pixels (5 Cubic each) of the same workload, oracle/libfhe_oracle.so op at a time, 1 thread of %d on %s"
-                                             % (args.cpu_pixels, os.cpu_count() or 0, _cpu_name())}
+                                   "sample": "%d output pixels (5 Cubic each%s) of the same workload, oracle/libfhe_oracle.so op at a time, 1 thread of %d on %s"
+                                             % (args.cpu_pixels, ", every Evaluator call of the relinearised mode's definition" if relin else "", os.cpu_count() or 0, _cpu_name())}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -291,20 +345,38 @@ def decode(args):
         raise SystemExit("more GPUs than output positions")
     amp, idx, cnt = (ctx.random_ct(1, size=2, seed=900 + i) for i in range(3))
     ctw = 2 * ctx.k * ctx.n
-    # the Enc(0) accumulators are inputs: [position][harmonic][sin, cos], seeded by the global position
-    zeros = ctx.random_ct((p1 - p0) * degree * 2, size=2, seed=1000, first_index=p0 * degree * 2 * ctw).reshape(p1 - p0, degree, 2, 2, ctx.k, ctx.n) if degree else None
     so = fhe.circuits.circuits_of(pc, relin).out_size(fhe.circuits.STEP, degree)
 
-    def job():
-        return fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, positions=(p0, p1),
-                                              relin=relin)
+    def build(p0, p1):
+        # the Enc(0) accumulators are inputs: [position][harmonic][sin, cos], seeded by the global position
+        zeros = ctx.random_ct((p1 - p0) * degree * 2, size=2, seed=1000, first_index=p0 * degree * 2 * ctw).reshape(p1 - p0, degree, 2, 2, ctx.k, ctx.n) if degree else None
+
+        def job():
+            return fhe.circuits.approximated_step(ev, pc, amp, idx, cnt, order=64, degree=degree, delta=0.5, width=npos, height=1, zeros=zeros, positions=(p0, p1),
+                                                  relin=relin)
+        return job, zeros
+    job, zeros = build(p0, p1)
     job()                                                       # warm-up at full size: scratch buffers and the allocator cache reach their steady state
     run, wall, dev_ms = _timed(job, dist)
     out = torch.cat(run)
     digest = fhe.parallel.combine_digests(ctx.digest(out, index0=p0 * so * ctx.k * ctx.n))
+    n1_seconds = None
+    if world > 1:                                               # in-run N = 1 leg of the fixed-size job: rank 0 alone over ALL positions
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            whole, _z = build(0, npos)
+            whole()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            whole()
+            torch.cuda.synchronize()
+            n1_seconds = time.perf_counter() - t0
+            del whole, _z
+        dist.barrier()
     if rank == 0:
         from bench import issue_roofline_workload
-        wl = "decode" + ("_relin%d" % args.relin if relin else "")
+        wl = "decode" + _wl_suffix(args)
         issue = issue_roofline_workload(wl) if (args.preset == "P8192" and degree == 12) else None
         alg = (3 + npos * degree * 2) * ctw * 8 + npos * so * ctx.k * ctx.n * 8
         res = {"metric": "approximated_step runs/sec (all W*H output positions of one run)", "value": 1 / wall, "unit": "runs/s", "n_gpus": world,
@@ -318,6 +390,8 @@ def decode(args):
                                      (p1 - p0) / npos if (args.preset == "P8192" and degree == 12) else 0, issue),
                "job_executions": 2, "units_per_job": p1 - p0,
                "output_digest": "%016x" % digest}
+        if n1_seconds is not None:
+            res["strong_scaling"] = _strong_scaling(n1_seconds, wall, world, "all %d output positions" % npos)
         if world == 1 and degree:
             res["server_side_encryptions"] = _server_side_encryptions(fhe, ctx, npos * degree * 2, None, wall, 1, "Enc(encode(0)) per (position, harmonic) for homomorphic_sin and homomorphic_cos")
         if args.cpu_terms:
@@ -326,7 +400,7 @@ def decode(args):
             h_amp, h_idx, h_cnt = (fhe.to_host(t)[0] for t in (amp, idx, cnt))
             hz = fhe.to_host(zeros[:1, :args.cpu_terms].reshape(-1, 2, ctx.k, ctx.n))
             t0 = time.perf_counter()
-            om.oracle_approximated_step(orc, h_amp, h_idx, h_cnt, 64, args.cpu_terms, 0.5, 1, 1, lambda i, j, wh: hz[2 * (j - 1) + (wh == "cos")])
+            om.oracle_approximated_step(_oracle_for_mode(args, om, orc), h_amp, h_idx, h_cnt, 64, args.cpu_terms, 0.5, 1, 1, lambda i, j, wh: hz[2 * (j - 1) + (wh == "cos")])
             cdt = time.perf_counter() - t0
             res["cpu_baseline"] = {"value": 1 / (cdt * npos * max(degree, 1) / args.cpu_terms), "unit": "runs/s", "cores": 1, "kind": "port",
                                    "sample": "one output position with %d of the %d harmonics (sin + cos Taylor polynomials and their 11 x 11 product each), scaled by positions x harmonics; "
@@ -352,6 +426,9 @@ if __name__ == "__main__":
     ap.add_argument("--degree", type=int, default=12)
     ap.add_argument("--positions", type=int, default=16)
     ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="relinearised mode with this decomposition bit count (0 = the reference's mode)")
+    ap.add_argument("--relin-placement", choices=["product", "cubic"], default="product",
+                    help="product: evaluator.relinearize after every multiply / square (five key switches per Cubic); cubic (resize only): the reference's "
+                         "Cubic unchanged and ONE relinearize of its size-4 result (two key switches, keys for s^2 and s^3) -- include/fhe_circuits.h FHE_RELIN_PER_CUBIC")
     a = ap.parse_args()
     from bench import ensure_world
     ensure_world(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # `python bench_circuits.py <workload> --gpus N` starts its N ranks itself

@@ -12,7 +12,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(os.path.dirname(_HERE), "include", "fhe_circuits.h"), os.path.join(os.path.dirname(_HERE), "include", "fhe_stream.h")]
 
 FHE_OK = 0
-ABI_VERSION = 3      # FHE_ABI_VERSION of the include/fhe_hip.h this table was written against
+ABI_VERSION = 4      # FHE_ABI_VERSION of the include/fhe_hip.h this table was written against
 
 
 class FheError(RuntimeError):
@@ -78,6 +78,9 @@ SIGNATURES = {
     "fhe_relinearize": (_i, [_vp, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_relinearize_scratch_bytes": (_sz, [_vp, _u32, _u64]),
     "fhe_relinearize_to": (_i, [_vp, _vp, _u64, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
+    "fhe_relinearize_poly": (_i, [_vp, _vp, _u64, _u32, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
+    "fhe_relinearize_n": (_i, [_vp, _vp, _u32, _u64, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
+    "fhe_evk_words": (_sz, [_vp, _u32]),
     "fhe_dct_plan_create": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(_vp)]),
     "fhe_dct_plan_destroy": (_i, [_vp]),
     "fhe_dct8x8_scratch_bytes": (_sz, [_vp, _u64]),
@@ -102,6 +105,8 @@ SIGNATURES = {
     "fhe_circuits_destroy": (_i, [_vp]),
     "fhe_circuits_create_relin": (_i, [_vp, _i, _i, _vp, _u32, C.POINTER(_vp)]),
     "fhe_circuits_relin_dbc": (_u32, [_vp]),
+    "fhe_circuits_create_relin_at": (_i, [_vp, _i, _i, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "fhe_circuits_relin_placement": (_u32, [_vp]),
     "fhe_circuits_out_size": (_u32, [_vp, _i, _u32]),
     "fhe_resize_sample_plan": (_i, [_u32, _u32, _u32, _u32, _i, _vp, _vp, _vp]),
     "fhe_cubic_scratch_bytes": (_sz, [_vp, _u32, _u64]),

@@ -66,7 +66,10 @@ class Circuits:
     """fhe_circuits: the constants of the resize / decode circuits for one context and encoder.
     relin=(evk_ntt, dbc): the RELINEARISED mode (fhe_circuits_create_relin; SURVEY.md section 8(f) #4, not what the
     reference does): evaluator.relinearize after every multiply / square, so every ciphertext of every circuit has two
-    polynomials.  evk_ntt as KeyGenerator.generate_evaluation_keys(dbc) returns it; the handle keeps it alive."""
+    polynomials.  evk_ntt as KeyGenerator.generate_evaluation_keys(dbc) returns it; the handle keeps it alive.
+    relin=(evk_ntt, dbc, "cubic"): the second placement (FHE_RELIN_PER_CUBIC, include/fhe_circuits.h): the reference's Cubic /
+    Linear sequences unchanged and ONE relinearize at the end of each (size 4 / 3 -> 2; two key switches per Cubic where the
+    first placement spends five); evk_ntt = generate_evaluation_keys(dbc, 2): the keys for s^2 and s^3.  Resize circuits only."""
 
     def __init__(self, ctx, int_coeffs=100, frac_coeffs=100, relin=None):
         self.ctx = ctx
@@ -74,9 +77,12 @@ class Circuits:
         if relin is None:
             _lib.call("fhe_circuits_create", ctx.h, int_coeffs, frac_coeffs, C.byref(h))
         else:
-            self._evk, dbc = relin
+            self._evk, dbc = relin[0], relin[1]
+            per_cubic = relin_placement(relin) == 1
             assert self._evk.is_contiguous() and self._evk.dtype == torch.int64
-            _lib.call("fhe_circuits_create_relin", ctx.h, int_coeffs, frac_coeffs, _ptr(self._evk), int(dbc), C.byref(h))
+            if per_cubic:
+                assert self._evk.dim() == 6 and self._evk.shape[0] >= 2, "per-Cubic placement: keys for s^2 and s^3 (generate_evaluation_keys(dbc, 2))"
+            _lib.call("fhe_circuits_create_relin_at", ctx.h, int_coeffs, frac_coeffs, _ptr(self._evk), int(dbc), 1 if per_cubic else 0, C.byref(h))
         self.h = h
         self._scratch = None
 
@@ -101,12 +107,21 @@ class Circuits:
         return self._scratch
 
 
+def relin_placement(relin):
+    """0: after every product (relin=(evk, dbc)), 1: once per Cubic / Linear (relin=(evk, dbc, "cubic"))"""
+    if relin is None or len(relin) < 3 or relin[2] in (0, None, "product", "every"):
+        return 0
+    if relin[2] in (1, "cubic"):
+        return 1
+    raise ValueError("relin placement must be 'product' or 'cubic', got %r" % (relin[2],))
+
+
 def circuits_of(pc, relin=None):
     """the fhe_circuits handle that goes with a PlainCache (same context and encoder), created on first use;
     relin=(evk_ntt, dbc): the relinearising handle for those keys"""
     if relin is not None:
         cache = pc.__dict__.setdefault("_circuits_relin", {})
-        key = (relin[0].data_ptr(), int(relin[1]))
+        key = (relin[0].data_ptr(), int(relin[1]), relin_placement(relin))
         if key not in cache:
             cache[key] = Circuits(pc.ctx, pc.enc.int_coeffs, pc.enc.frac_coeffs, relin=relin)
         return cache[key]
@@ -153,22 +168,25 @@ def cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin=None):
     section 8(f) #4, NOT what the reference does), so the result has size 2 instead of s+2; ciphertext bits
     then differ from the reference path by construction (key-switching noise), the decrypted value does not."""
     M, P = ev.multiply_plain, pc.prepared
+    each = relin is not None and relin_placement(relin) == 0     # relinearize after every product
+    tail = relin is not None and relin_placement(relin) == 1     # the reference's sequence, ONE relinearize of the result (relin=(evk, dbc, "cubic"))
 
     def mul(x, y):
         z = ev.multiply(x, y)
-        return ev.relinearize(z, relin[0], relin[1]) if relin is not None and z.shape[-3] == 3 else z
+        return ev.relinearize(z, relin[0], relin[1]) if each and z.shape[-3] == 3 else z
 
     a = ev.add(ev.sub(ev.sub(M(B, P(3)), A), M(C, P(3))), D)
     b = ev.sub(ev.add(ev.sub(M(A, P(2)), M(B, P(5))), M(C, P(4))), D)
     c = ev.sub(C, A)
     t2 = ev.square(t)
-    if relin is not None and t2.shape[-3] == 3:
+    if each and t2.shape[-3] == 3:
         t2 = ev.relinearize(t2, relin[0], relin[1])
-    t3 = t2 if relin is not None else ev.multiply(t, t)          # t3 = t * t exactly as the reference computes it (:175)
+    t3 = t2 if each else ev.multiply(t, t)                       # t3 = t * t exactly as the reference computes it (:175)
     a, b, c = mul(a, t3), mul(b, t2), mul(c, t)
     a = ev.add(ev.add(a, b), c)
     a = M(a, P(0.5))
-    return ev.add(a, B)
+    a = ev.add(a, B)
+    return ev.relinearize(a, relin[0], relin[1]) if tail else a
 
 
 def cubic(ev, pc, A, B, C, D, t, relin=None):

@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void k_behz_floor3_combine_pm(const u64 *__res
 // relinearisation ------------------------------------------------------------------------------
 // digits: for ciphertext c, source prime i, digit d, target prime ii: ((c2_i >> (dbc d)) & mask) mod q_ii
 __global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, const BehzDev *__restrict__ Tp,
-                                                      u32 n, u32 nd, u32 dbc, u64 count) {
+                                                      u32 n, u32 nd, u32 dbc, u64 count, u32 src_poly) {
     const BehzDev &T = *Tp;
     const u32 k = T.k;
     const u64 mask = dbc >= 64 ? ~0ULL : ((1ULL << dbc) - 1);
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void k_relin_digits(const u64 *__restrict__ ct
         const u32 d = (u32)(u % nd);
         const u32 i = (u32)((u / nd) % k);
         const u64 c = u / ((u64)nd * k);
-        const u64 *c2 = ct + c * stride + ((u64)2 * k + i) * n;
+        const u64 *c2 = ct + c * stride + ((u64)src_poly * k + i) * n;
         for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
             const u64 v = (c2[s] >> (dbc * d)) & mask;
             for (u32 ii = 0; ii < k; ii++) dig[(u * k + ii) * n + s] = reduce64(v, T.q[ii].q, T.r64q[ii]);
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void k_relin_add(const u64 *ct, u64 stride, u6
 // modulo q_ii (the k workgroups of one digit sit next to each other: the repeated reads of c2_i hit L2); a digit of
 // dbc >= bits(q_ii) bits is folded first.  dig [count][k][nd][k][n], NTT form, canonical.
 template <int L, typename C>
-__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, RnsBase base, u32 nd, u32 dbc) {
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, RnsBase base, u32 nd, u32 dbc, u32 src_poly) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *
     const u64 mask = (1ULL << dbc) - 1;            // dbc <= 60
     const PmMod m = base.pm[ii];
     u64 x[1][16];
-    load_coeff<L>(x[0], ct + c * stride + ((u64)2 * k + i) * N, tid);
+    load_coeff<L>(x[0], ct + c * stride + ((u64)src_poly * k + i) * N, tid);
     const bool wide = dbc >= m.sh + 32;            // the digit may reach q_ii
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -1530,25 +1530,46 @@ extern "C" size_t fhe_relinearize_scratch_bytes(const fhe_ctx *c, uint32_t dbc, 
     const size_t kn = (size_t)c->k * c->n;
     return (count * c->k * fhe_evk_digits(c, dbc) * kn + count * 2 * kn) * sizeof(u64);
 }
+extern "C" size_t fhe_evk_words(const fhe_ctx *c, uint32_t dbc) {
+    if (!c || !dbc) return 0;
+    return (size_t)c->k * fhe_evk_digits(c, dbc) * 2 * c->k * c->n;
+}
+extern "C" int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
+                                 const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    if (!c || !ct || !evk || !out2) return fail(FHE_ERR_PARAM, "null argument");
+    if (size < 3 || size > FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "relinearize: %u polynomials (3 .. %d)", size, FHE_MAX_POLYS);
+    if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
+    const size_t ew = fhe_evk_words(c, dbc);
+    for (uint32_t p = size - 1; p >= 3; --p)                 // the top polynomial first, with the keys for s^p, in place
+        if (int rc = fhe_relinearize_poly(c, ct, stride, p, ct, stride, count, evk + (size_t)(p - 2) * ew, dbc, scratch, scratch_bytes, s)) return rc;
+    return fhe_relinearize_poly(c, ct, stride, 2, out2, out_stride, count, evk, dbc, scratch, scratch_bytes, s);
+}
 extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride, uint64_t count, const uint64_t *evk, uint32_t dbc,
                                void *scratch, size_t scratch_bytes, fhe_stream s) {
     return fhe_relinearize_to(cc, ct3, stride, ct3, stride, count, evk, dbc, scratch, scratch_bytes, s);
 }
 extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
                                   const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
+    return fhe_relinearize_poly(cc, ct3, stride, 2, out2, out_stride, count, evk, dbc, scratch, scratch_bytes, s);
+}
+// One key-switch step (SEAL 2.3 relinearize_one_step): polynomial `src_poly` (the last one of a size src_poly + 1 ciphertext) is
+// decomposed and folded into c0 / c1 with the keys for s^src_poly; out gets c0', c1' only.
+extern "C" int fhe_relinearize_poly(const fhe_ctx *cc, const uint64_t *ct3, uint64_t stride, uint32_t src_poly, uint64_t *out2, uint64_t out_stride, uint64_t count,
+                                    const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
     if (!cc || !ct3 || !evk || !out2) return fail(FHE_ERR_PARAM, "null argument");
     if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (!count) return FHE_OK;
     const fhe_ctx *c = cc;
     int rc;
     if (int erc = fhe_behz_ensure(c)) return erc;
-    if (stride < (u64)3 * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-3 ciphertext");
+    if (src_poly < 2 || src_poly >= FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "key-switch source polynomial %u out of range", src_poly);
+    if (stride < (u64)(src_poly + 1) * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-%u ciphertext", src_poly + 1);
     if (out_stride < (u64)2 * c->k * c->n) return fail(FHE_ERR_PARAM, "output stride smaller than a size-2 ciphertext");
     if (!scratch || scratch_bytes < fhe_relinearize_scratch_bytes(c, dbc, count)) return fail(FHE_ERR_PARAM, "scratch too small");
     // workgroup c reads ciphertext c while it writes output c: only the exact in-place case (same pointer, same stride) and fully
     // disjoint ranges are safe -- with another stride output c lands inside an input another workgroup has not read yet
     if (!(out2 == ct3 && out_stride == stride)) {
-        const uintptr_t i0 = (uintptr_t)ct3, i1 = i0 + ((count - 1) * stride + (u64)3 * c->k * c->n) * sizeof(u64);
+        const uintptr_t i0 = (uintptr_t)ct3, i1 = i0 + ((count - 1) * stride + (u64)(src_poly + 1) * c->k * c->n) * sizeof(u64);
         const uintptr_t o0 = (uintptr_t)out2, o1 = o0 + ((count - 1) * out_stride + (u64)2 * c->k * c->n) * sizeof(u64);
         if (o0 < i1 && i0 < o1) return fail(FHE_ERR_PARAM, "output range overlaps the input range (only out2 == ct3 with out_stride == stride may alias)");
     }
@@ -1561,7 +1582,7 @@ extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64
         const RnsBase base = c->qb.dev();
 #define GO_PM(CC)                                                                                                                          \
     DISPATCH_L(c->logn, {                                                                                                                  \
-        k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc);      \
+        k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc, src_poly); \
         if (!c->opt.relin_fused) {                                                                                                        \
             k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                       \
             k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, base); \
@@ -1575,7 +1596,7 @@ extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64
         KERNEL_CHECK();
         return FHE_OK;
     }
-    k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count);
+    k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count, src_poly);
     if ((rc = qbase_ntt(false, c, dig, dig, count * k * nd, st))) return rc;
     k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);
     if ((rc = qbase_ntt(true, c, acc, acc, count * 2, st))) return rc;

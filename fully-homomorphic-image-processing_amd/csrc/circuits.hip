@@ -199,12 +199,23 @@ struct CircConst {
     u64 *d_scaled = nullptr;    // [k][len] Delta * m' for add_plain, built on first use when the plaintext has too many terms for the argument path
 };
 
+// out[omap(c)][rp][:] = src[c][rp][:], rp < rp_per_ct residue polynomials of half_n 16-byte pairs
+__global__ __launch_bounds__(256) void k_scatter_ct(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ out, CMap omap, u32 rp_per_ct, u32 half_n, u64 nrp) {
+    for (u64 rp = blockIdx.y; rp < nrp; rp += gridDim.y) {
+        const u64 c = rp / rp_per_ct, r = rp % rp_per_ct;
+        const ulonglong2 *s = src + rp * half_n;
+        ulonglong2 *d = out + (omap(c) * rp_per_ct + r) * half_n;
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < half_n; i += gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
+
 struct fhe_circuits {
     const fhe_ctx *c = nullptr;
     int ic = 0, fc = 0;
     bool base2 = false;         // the encoder writes Cubic's constants as the fused passes assume
-    const u64 *evk = nullptr;   // relinearised mode (fhe_circuits_create_relin): evaluation keys for s^2, NTT form, caller-owned
+    const u64 *evk = nullptr;   // relinearised mode (fhe_circuits_create_relin): evaluation keys for s^2 (placement 1: s^2 then s^3), NTT form, caller-owned
     u32 dbc = 0;                // its decomposition bit count; 0 = the reference's mode (no relinearisation)
+    u32 placement = FHE_RELIN_EVERY_PRODUCT;      // where the relinearised mode relinearises (include/fhe_circuits.h)
     mutable std::mutex mu;
     mutable std::map<u64, std::unique_ptr<CircConst>> consts;     // keyed by the bits of the double
     // pinned staging ring for index arrays: host memcpy + stream-ordered copy, the host never waits for the device
@@ -311,17 +322,21 @@ struct Run {
     bool dry;
     bool query = false;                    // a *_scratch_bytes query: placeholder scalars, so constants are neither required to fit the encoder nor to be non-zero
     bool relin;                            // the handle relinearises after every multiply / square: every ciphertext has two polynomials
+    bool tail;                             // the handle relinearises ONCE at the end of every Cubic / Linear (size 4 / 3 -> 2): inside them the reference's sizes
     uintptr_t base = 0;
     size_t cap = 0, top = 0, high = 0;     // bytes
     u32 k, n;
     size_t pw;                             // words of one RNS polynomial
 
     Run(const fhe_circuits *circ, void *scratch, size_t bytes, fhe_stream s, bool dry_run)
-        : cc(circ), c(circ->c), st((hipStream_t)s), dry(dry_run), relin(circ->dbc != 0), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
+        : cc(circ), c(circ->c), st((hipStream_t)s), dry(dry_run), relin(circ->dbc != 0 && circ->placement == FHE_RELIN_EVERY_PRODUCT),
+          tail(circ->dbc != 0 && circ->placement == FHE_RELIN_PER_CUBIC), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
           pw((size_t)circ->c->k * circ->c->n) {}
 
     // polynomials of a ciphertext that has `ref` of them in the reference's evaluation
     u32 S(u32 ref) const { return relin && ref > 2 ? 2 : ref; }
+    // polynomials of a Cubic's / Linear's / sampler's RESULT (either relinearised mode: 2)
+    u32 O(u32 ref) const { return (relin || tail) && ref > 2 ? 2 : ref; }
 
     // 256-byte aligned bump allocation; in a dry run only the high-water mark is real
     u64 *alloc(size_t words) {
@@ -420,6 +435,27 @@ struct Run {
         release(m);
         return rc;
     }
+    // evaluator.relinearize(result, evk) at the end of a Cubic / Linear (placement per Cubic): raw [count][size] -> out [count][2], size - 2
+    // key switches (keys for s^(size-1) .. s^2); raw is scratch afterwards
+    int relin_n(u64 *raw, u32 size, u64 *out, u64 count) {
+        const size_t bytes = fhe_relinearize_scratch_bytes(c, cc->dbc, count);
+        const size_t m = mark();
+        void *scr = alloc((bytes + 7) / 8);
+        int rc = FHE_OK;
+        if (!dry && count) rc = fhe_relinearize_n(c, mu(raw), size, (u64)size * pw, mu(out), 2 * pw, count, cu(cc->evk), cc->dbc, scr, bytes, st);
+        release(m);
+        return rc;
+    }
+    // out[omap(c)] = src[c] (ciphertexts of `size` polynomials)
+    int scatter(const u64 *src, u32 size, u64 *out, CMap omap, u64 count) {
+        if (dry || !count) return FHE_OK;
+        const u64 nrp = count * size * k;
+        const u32 half_n = n / 2;
+        dim3 grid((half_n + 255) / 256, (unsigned)(nrp < 32768 ? nrp : 32768));
+        k_scatter_ct<<<grid, 256, 0, st>>>((const ulonglong2 *)src, (ulonglong2 *)out, omap, size * k, half_n, nrp);
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     // a product of the circuit: `raw` forms it; in the relinearised mode it lands in a temporary and is relinearised into `out`
     template <typename F>
     int product(u32 sa, u32 sb, u64 *out, u64 count, F &&raw) {
@@ -488,7 +524,24 @@ struct Src {
 // p2 / p1: prepared t^2 (size 3; 2 in the relinearised mode) and t (size 2), indexed by the pair number through `tmap` (identity
 // map: `count` entries).  Relinearised mode: size == 2, and the three products come back as size-2 ciphertexts (each relinearised
 // on its own, as evaluator.relinearize after :176-178 would), so the output has 2 polynomials instead of size + 2.
+int cubic_core_ref(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, const u64 *p1, CMap tmap, u64 *out, CMap omap, u64 count);
+// Placement per Cubic: the reference's sequence unchanged on size-2 operands (result: 4 polynomials, the fused tail included), then
+// ONE evaluator.relinearize(result, evk) -- two key switches, keys for s^3 and s^2 -- into the compact size-2 output.
 int cubic_core(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, const u64 *p1, CMap tmap, u64 *out, CMap omap, u64 count) {
+    if (!R.tail) return cubic_core_ref(R, A, B, C, D, size, p2, p1, tmap, out, omap, count);
+    if (!count) return FHE_OK;
+    if (size != 2) return fail(FHE_ERR_PARAM, "relinearised mode: Cubic takes size-2 ciphertexts");
+    const size_t m = R.mark();
+    u64 *raw = R.alloc(count * 4 * R.pw);
+    TRY(cubic_core_ref(R, A, B, C, D, 2, p2, p1, tmap, raw, ident(), count));
+    const bool direct = !omap.idx && !omap.cnt;
+    u64 *dst = direct ? out : R.alloc(count * 2 * R.pw);
+    TRY(R.relin_n(raw, 4, dst, count));
+    if (!direct) TRY(R.scatter(dst, 2, out, omap, count));
+    R.release(m);
+    return FHE_OK;
+}
+int cubic_core_ref(Run &R, Src A, Src B, Src C, Src D, u32 size, const u64 *p2, const u64 *p1, CMap tmap, u64 *out, CMap omap, u64 count) {
     if (!count) return FHE_OK;
     const fhe_ctx *c = R.c;
     const size_t m = R.mark();
@@ -587,7 +640,17 @@ int run_cubic(Run &R, const u64 *A, const u64 *B, const u64 *C, const u64 *D, u3
 // ------------------------------------------------------------------------------------------------
 // pomt / pt: prepared (1 - t) and t, indexed through tmap; A, B contiguous [count][size]
 int linear_core(Run &R, const u64 *A, const u64 *B, u32 size, const u64 *pomt, const u64 *pt, CMap tmap, u64 *out, u64 count) {
-    if (R.relin && size != 2) return fail(FHE_ERR_PARAM, "relinearised mode: Linear takes size-2 ciphertexts");
+    if ((R.relin || R.tail) && size != 2) return fail(FHE_ERR_PARAM, "relinearised mode: Linear takes size-2 ciphertexts");
+    if (R.tail) {                                                       // :196-199 unchanged (3 polynomials), then one evaluator.relinearize
+        const size_t m = R.mark();
+        u64 *x = R.alloc(count * 3 * R.pw), *y = R.alloc(count * 3 * R.pw);
+        TRY(R.multiply(A, 2, nullptr, pomt, 2, tmap, x, count));
+        TRY(R.multiply(B, 2, nullptr, pt, 2, tmap, y, count));
+        TRY(R.add(x, y, x, count * 3));
+        TRY(R.relin_n(x, 3, out, count));
+        R.release(m);
+        return FHE_OK;
+    }
     const size_t m = R.mark();
     const u32 so = R.S(size + 1);
     u64 *tmp = R.alloc(count * so * R.pw);
@@ -635,7 +698,7 @@ int run_sample_bicubic(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps,
     }
     u64 *px2, *px1;
     TRY(cubic_powers(R, xfract, count, &px2, &px1));
-    const u32 sr = R.S(4);                                              // size of a row Cubic's result
+    const u32 sr = R.O(4);                                              // size of a row Cubic's result
     u64 *cols = R.alloc(rows * sr * R.pw);                              // [4][count][sr][k][n]
     const CMap xm = periodic(1, count);                                 // pair r * count + c multiplies xfract[c]
     TRY(cubic_core(R, Src{pixels, by_index(d_idx)}, Src{pixels, by_index(d_idx + rows)}, Src{pixels, by_index(d_idx + 2 * rows)},
@@ -665,7 +728,7 @@ int run_sample_linear(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps, 
     TRY(R.gather_pad(pixels, 2, by_index(d_idx + rows), B, 2, rows));
     u64 *pomx, *ptx;
     TRY(linear_operands(R, xfract, count, &pomx, &ptx));
-    const u32 sr = R.S(3);
+    const u32 sr = R.O(3);
     u64 *cols = R.alloc(rows * sr * R.pw);                              // [2][count][sr][k][n]
     TRY(linear_core(R, A, B, 2, pomx, ptx, periodic(1, count), cols, rows));
     u64 *pomy, *pty;
@@ -737,7 +800,7 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
             band_need.push_back(need);
         }
     }
-    const u32 sr = R.S(4), sout = R.S(6);                               // polynomials of a row Cubic's result and of an output pixel
+    const u32 sr = R.O(4), sout = R.O(6);                               // polynomials of a row Cubic's result and of an output pixel
     const size_t slot_words = (size_t)dst_w * sr * R.pw;
     u64 *cache = R.alloc((size_t)max_live * slot_words);
     const u32 call_px = rows_per_call * dst_w;
@@ -1025,6 +1088,12 @@ int run_decode_channel(Run &R, const u64 *runs, u32 pairs, u64 *index, const u64
 }
 
 bool args_ok(const fhe_circuits *cc) { return cc && cc->c && cc->c->behz; }
+// the decode circuits have no Cubic / Linear whose end the per-Cubic placement could relinearise at
+int decode_mode_ok(const fhe_circuits *cc) {
+    if (cc && cc->dbc && cc->placement == FHE_RELIN_PER_CUBIC)
+        return fail(FHE_ERR_PARAM, "this handle relinearises per Cubic (FHE_RELIN_PER_CUBIC): the decode circuits take FHE_RELIN_EVERY_PRODUCT or the reference's mode");
+    return FHE_OK;
+}
 
 template <typename F>
 size_t dry_bytes(const fhe_circuits *cc, F &&f) {
@@ -1090,8 +1159,14 @@ extern "C" uint32_t fhe_circuits_out_size(const fhe_circuits *cc, int circuit, u
     return cc->dbc && ref > 2 ? 2 : ref;
 }
 extern "C" int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc, fhe_circuits **out) {
+    return fhe_circuits_create_relin_at(ctx, int_coeffs, frac_coeffs, d_evk_ntt, dbc, FHE_RELIN_EVERY_PRODUCT, out);
+}
+extern "C" uint32_t fhe_circuits_relin_placement(const fhe_circuits *cc) { return cc ? cc->placement : 0; }
+extern "C" int fhe_circuits_create_relin_at(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc, uint32_t placement,
+                                            fhe_circuits **out) {
     if (!ctx || !out) return fail(FHE_ERR_PARAM, "null argument");
     *out = nullptr;
+    if (placement != FHE_RELIN_EVERY_PRODUCT && placement != FHE_RELIN_PER_CUBIC) return fail(FHE_ERR_PARAM, "unknown relinearisation placement %u", placement);
     if ((d_evk_ntt != nullptr) != (dbc != 0)) return fail(FHE_ERR_PARAM, "evaluation keys and a decomposition bit count come together");
     if (dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (int_coeffs < 1 || frac_coeffs < 0 || (u32)(int_coeffs + frac_coeffs) > ctx->n) return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");
@@ -1100,6 +1175,7 @@ extern "C" int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int
     cc->c = ctx;
     cc->evk = (const u64 *)d_evk_ntt;
     cc->dbc = dbc;
+    cc->placement = dbc ? placement : FHE_RELIN_EVERY_PRODUCT;
     cc->ic = int_coeffs;
     cc->fc = frac_coeffs;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1284,11 +1360,13 @@ extern "C" int fhe_resize_bicubic_shared_rows(const fhe_circuits *cc, const uint
 }
 
 extern "C" size_t fhe_homomorphic_sincos_scratch_bytes(const fhe_circuits *cc, uint64_t count) {
+    if (decode_mode_ok(cc)) return 0;
     return dry_bytes(cc, [&](Run &R) { return run_sincos(R, 0, nullptr, nullptr, nullptr, count); });
 }
 extern "C" int fhe_homomorphic_sincos(const fhe_circuits *cc, int cosine, const uint64_t *x, const uint64_t *zero, uint64_t *out, uint64_t count,
                                       void *scratch, size_t scratch_bytes, fhe_stream s) {
     if (!x || !zero || !out) return fail(FHE_ERR_PARAM, "null argument");
+    TRY(decode_mode_ok(cc));
     if (!count) return FHE_OK;
     return real_run(cc, scratch, scratch_bytes, s, [&](Run &R) { return run_sincos(R, cosine, (const u64 *)x, (const u64 *)zero, (u64 *)out, count); });
 }
@@ -1296,6 +1374,7 @@ extern "C" int fhe_homomorphic_sincos(const fhe_circuits *cc, int cosine, const 
 extern "C" uint32_t fhe_approximated_step_out_size(int degree) { return degree >= 1 ? 22 : 3; }
 static int step_args(const fhe_circuits *cc, int order, int degree, uint32_t npos) {
     if (!args_ok(cc)) return fail(FHE_ERR_PARAM, "null circuits handle (or a context without ct x ct tables)");
+    TRY(decode_mode_ok(cc));
     if (order < 1 || degree < 0 || degree > 4096) return fail(FHE_ERR_PARAM, "order must be positive and degree in [0, 4096]");
     if (!npos || (u64)npos * (degree ? degree : 1) > (1u << 24)) return fail(FHE_ERR_PARAM, "width * height * degree out of range");
     return FHE_OK;

@@ -358,14 +358,23 @@ class Evaluator:
         return out
 
     def relinearize(self, a, evk_ntt, dbc):
-        assert a.shape[-3] == 3
-        work = a.clone()
-        stride = 3 * self.ctx.k * self.ctx.n
-        count = work.numel() // stride
+        """evaluator.relinearize(a, evk): ciphertexts of any size >= 2 down to 2, one key switch per polynomial above the second, the top
+        one first (SEAL 2.3).  evk_ntt: KeyGenerator.generate_evaluation_keys(dbc) for size 3, generate_evaluation_keys(dbc, size - 2)
+        ([size - 2][k][digits][2][k][n]: keys for s^2 .. s^(size-1)) above."""
+        size = a.shape[-3]
+        if size == 2:
+            return a
+        kn = self.ctx.k * self.ctx.n
+        have = evk_ntt.shape[0] if evk_ntt.dim() == 6 else 1
+        if have < size - 2:
+            raise ValueError("relinearize: a ciphertext of %d polynomials needs the keys for s^2 .. s^%d (got %d key set(s))" % (size, size - 1, have))
+        work = a.clone()                                   # the steps above the last one run in place
+        count = work.numel() // (size * kn)
+        out = torch.empty(tuple(a.shape[:-3]) + (2, self.ctx.k, self.ctx.n), dtype=a.dtype, device=a.device)
         nbytes = _lib.load().fhe_relinearize_scratch_bytes(self.ctx.h, dbc, count)
         scr = self._scratch_buf(nbytes)
-        _lib.call("fhe_relinearize", self.ctx.h, _ptr(work), stride, count, _ptr(evk_ntt), dbc, _ptr(scr), nbytes, _stream())
-        return work[..., :2, :, :].contiguous()
+        _lib.call("fhe_relinearize_n", self.ctx.h, _ptr(work), size, size * kn, _ptr(out), 2 * kn, count, _ptr(evk_ntt), dbc, _ptr(scr), nbytes, _stream())
+        return out
 
     # -- primitives named by the north star ---------------------------------------------------------
     def cubic_coeffs(self, A, B, C, D):

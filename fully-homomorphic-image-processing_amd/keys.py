@@ -108,25 +108,33 @@ class KeyGenerator:
     def public_key(self):
         return self._pk
 
-    def generate_evaluation_keys(self, dbc):
-        """[k][digits][2][k][n] in NTT form (library slot order), for Evaluator.relinearize."""
+    def generate_evaluation_keys(self, dbc, count=1):
+        """Evaluation keys in NTT form (library slot order) for Evaluator.relinearize: count == 1 (SEAL 2.3
+        generate_evaluation_keys(dbc, keys)): [k][digits][2][k][n], the keys for s^2; count > 1 (generate_evaluation_keys(dbc, count,
+        keys)): [count][k][digits][2][k][n], the keys for s^2 .. s^(count+1) -- what relinearising a ciphertext of count + 2
+        polynomials takes (Circuits(relin=(keys, dbc, "cubic")): count = 2)."""
         ctx = self.ctx
         nd = int(_lib.load().fhe_evk_digits(ctx.h, dbc))
-        s2 = to_host(_ring_mul(ctx, self._sk, self._sk_ntt))[0]
-        evk = np.zeros((ctx.k, nd, 2, ctx.k, ctx.n), dtype=np.uint64)
-        for i in range(ctx.k):
-            for d in range(nd):
-                a = self._smp.uniform()
-                e = to_device(self._smp.noise()[None], ctx.device)
-                k0 = _ring_mul(ctx, to_device(a[None], ctx.device), self._sk_ntt)
-                _lib.call("fhe_add", ctx.h, _ptr(k0), _ptr(e), _ptr(k0), 1, _stream())
-                _lib.call("fhe_negate", ctx.h, _ptr(k0), _ptr(k0), 1, _stream())
-                h0 = to_host(k0)[0].copy()
-                qi = ctx.q[i]
-                wd = pow(2, dbc * d, qi)
-                h0[i] = np.array([(int(x) + int(s) * wd) % qi for x, s in zip(h0[i], s2[i])], dtype=np.uint64)
-                evk[i, d, 0], evk[i, d, 1] = h0, a
-        return _ntt(ctx, to_device(evk, ctx.device))
+        out = []
+        power = self._sk                                                        # s^j, coefficient form [1, k, n]
+        for _ in range(count):
+            power = _ring_mul(ctx, power, self._sk_ntt)
+            sp = to_host(power)[0]
+            evk = np.zeros((ctx.k, nd, 2, ctx.k, ctx.n), dtype=np.uint64)
+            for i in range(ctx.k):
+                for d in range(nd):
+                    a = self._smp.uniform()
+                    e = to_device(self._smp.noise()[None], ctx.device)
+                    k0 = _ring_mul(ctx, to_device(a[None], ctx.device), self._sk_ntt)
+                    _lib.call("fhe_add", ctx.h, _ptr(k0), _ptr(e), _ptr(k0), 1, _stream())
+                    _lib.call("fhe_negate", ctx.h, _ptr(k0), _ptr(k0), 1, _stream())
+                    h0 = to_host(k0)[0].copy()
+                    qi = ctx.q[i]
+                    wd = pow(2, dbc * d, qi)
+                    h0[i] = np.array([(int(x) + int(s) * wd) % qi for x, s in zip(h0[i], sp[i])], dtype=np.uint64)
+                    evk[i, d, 0], evk[i, d, 1] = h0, a
+            out.append(_ntt(ctx, to_device(evk, ctx.device)))
+        return out[0] if count == 1 else torch.stack(out).contiguous()
 
 
 class Encryptor:

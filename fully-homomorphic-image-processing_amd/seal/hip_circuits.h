@@ -219,8 +219,14 @@ public:
     // does): every multiply / square of every circuit is followed by evaluator.relinearize with these keys
     // (KeyGenerator::generate_evaluation_keys(dbc, keys): the `dbc` the reference parses and never uses,
     // homo/client_resize.cpp:26,47,72), so every result below has TWO polynomials (out_size()).  The keys are copied.
-    Circuits(const SEALContext &ctx, const EvaluationKeys &evk, int int_coeffs = 100, int frac_coeffs = 100) : ctx_(ctx), h_(nullptr), evk_(evk.buf) {
-        detail::check(fhe_circuits_create_relin(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, &h_), "circuits (relinearised)");
+    // per_cubic = true: the second placement (FHE_RELIN_PER_CUBIC): the reference's Cubic / Linear unchanged and ONE relinearize of each
+    // result (size 4 / 3 -> 2); the keys then come from generate_evaluation_keys(dbc, 2, keys) (s^2 and s^3).  Resize circuits only.
+    Circuits(const SEALContext &ctx, const EvaluationKeys &evk, int int_coeffs = 100, int frac_coeffs = 100, bool per_cubic = false) : ctx_(ctx), h_(nullptr), evk_(evk.buf) {
+        if (per_cubic && evk.count < 2) throw std::invalid_argument("per-Cubic relinearisation needs the keys for s^2 and s^3: generate_evaluation_keys(dbc, 2, keys)");
+        evk.device_keys();                                     // key objects handed out by mutable_data() are folded back first
+        evk_ = evk.buf;
+        detail::check(fhe_circuits_create_relin_at(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, per_cubic ? FHE_RELIN_PER_CUBIC : FHE_RELIN_EVERY_PRODUCT, &h_),
+                      "circuits (relinearised)");
     }
     // the keys a context under FHE_FACADE_RELIN=<dbc> relinearises with (derived from the first secret key seen on it): a host that
     // mixes the facade's one-at-a-time Evaluator calls with the batched circuits gets the SAME bits from both with these
@@ -231,6 +237,9 @@ public:
         evk.buf = s.relin_evk;
         evk.dbc = s.relin_dbc;
         evk.digits = s.relin_digits;
+        evk.count = 1;
+        evk.k = s.k;
+        evk.n = s.n;
         return evk;
     }
     ~Circuits() { if (h_) fhe_circuits_destroy(h_); }

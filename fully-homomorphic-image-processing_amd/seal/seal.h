@@ -617,14 +617,17 @@ struct CtView {
 class Ciphertext {
 public:
     Ciphertext() : tag_(kTag) {}
-    Ciphertext(const Ciphertext &o) : tag_(kTag) { h_.p = o.h_.p; retain(); }
-    Ciphertext(Ciphertext &&o) noexcept : tag_(kTag) { h_.p = std::move(o.h_.p); o.h_.p.reset(); }
+    Ciphertext(const Ciphertext &o) : tag_(kTag) { o.sync_mirror(); h_.p = o.h_.p; retain(); }
+    Ciphertext(Ciphertext &&o) noexcept : tag_(kTag) { o.sync_mirror_noexcept(); h_.p = std::move(o.h_.p); o.h_.p.reset(); }
     Ciphertext &operator=(const Ciphertext &o) {
+        if (this == &o) return *this;
+        o.sync_mirror();
+        drop_mirror();
         if (h_.p != o.h_.p) { release(); h_.p = o.h_.p; retain(); }
         return *this;
     }
     Ciphertext &operator=(Ciphertext &&o) noexcept {
-        if (this != &o) { release(); h_.p = std::move(o.h_.p); o.h_.p.reset(); }
+        if (this != &o) { o.sync_mirror_noexcept(); drop_mirror(); release(); h_.p = std::move(o.h_.p); o.h_.p.reset(); }
         return *this;
     }
     // The reference's homomorphic_cos is declared to return a Ciphertext and falls off its end without a return statement
@@ -636,11 +639,42 @@ public:
         if (tag_ != kTag) return;
         release();
         h_.p.~shared_ptr();
+        delete mirror_;
+        mirror_ = nullptr;
         *(volatile uint64_t *)&tag_ = 0;
     }
     int size() const { return h_.p ? (int)h_.p->size : 0; }
+    // ---- SEAL 2.3's raw accessors (ciphertext.h: resize(parms, size), pointer(), mutable_pointer()).  The facade's values live in
+    // HBM, so these hand out a HOST mirror in SEAL's logical layout [poly][prime][coeff]: mutable_pointer() downloads the value and
+    // from then on the handle's next use by anything else (an Evaluator call, save, a copy, decrypt) uploads the mirror first;
+    // an operation that gives the handle a new value drops the mirror.  Meant for oracle/seal_crosscheck.cpp and for hosts that
+    // build ciphertexts from raw residues; the reference never touches these.
+    void resize(const EncryptionParameters &parms, int size) {
+        if (size < 2 || size > FHE_FACADE_MAX_POLYS) throw std::invalid_argument("ciphertext size");
+        const uint32_t kk = (uint32_t)parms.coeff_modulus().size(), nn = (uint32_t)parms.poly_modulus().degree();
+        if (h_.p && (int)h_.p->size == size && h_.p->k == kk && h_.p->n == nn) return;
+        shape((uint32_t)size, kk, nn);
+        std::vector<uint64_t> z((size_t)size * kk * nn, 0);
+        buffer().upload(z.data(), z.size());
+    }
+    int coeff_mod_count() const { return (int)k(); }
+    int poly_coeff_count() const { return h_.p ? (int)h_.p->n + 1 : 0; }
+    uint64_t *mutable_pointer() {
+        if (!h_.p) return nullptr;
+        fetch_mirror();
+        mirror_live_ = true;
+        return mirror_->data();
+    }
+    uint64_t *mutable_pointer(int poly_index) { uint64_t *p = mutable_pointer(); return p ? p + (size_t)poly_index * k() * n() : nullptr; }
+    const uint64_t *pointer() const {
+        if (!h_.p) return nullptr;
+        if (!mirror_live_) const_cast<Ciphertext *>(this)->fetch_mirror();
+        return mirror_->data();
+    }
+    const uint64_t *pointer(int poly_index) const { const uint64_t *p = pointer(); return p ? p + (size_t)poly_index * k() * n() : nullptr; }
     void save(std::ostream &os) const {
         if (!h_.p) { detail::save_raw(os, nullptr, 0, 0, 0, 0); return; }
+        sync_mirror();
         materialize();
         detail::DownloadWindow &W = detail::DownloadWindow::instance();
         std::lock_guard<std::recursive_mutex> lk(W.mu);
@@ -699,6 +733,8 @@ public:
     // mutable access: the value is computed, and copied first if another handle shares it (copy on write)
     uint64_t *ptr() {
         if (!h_.p) return nullptr;
+        sync_mirror();
+        drop_mirror();                                        // the caller is about to change the value on the device: the mirror is history
         materialize();
         detail::DownloadWindow::instance().forget();          // the caller may write through this pointer: no host copy of the allocation stays valid
         if (h_.p->handles > 1 || h_.p.use_count() > 1) {
@@ -710,13 +746,13 @@ public:
         }
         return h_.p->ptr();
     }
-    const uint64_t *ptr() const { if (!h_.p) return nullptr; materialize(); return h_.p->ptr(); }
+    const uint64_t *ptr() const { if (!h_.p) return nullptr; sync_mirror(); materialize(); return h_.p->ptr(); }
     uint32_t k() const { return h_.p ? h_.p->k : 0; }
     uint32_t n() const { return h_.p ? h_.p->n : 0; }
     detail::CtView buffer() { uint64_t *p = ptr(); return detail::CtView{p, h_.p ? h_.p->words() : 0}; }
     detail::CtView buffer() const { const uint64_t *p = ptr(); return detail::CtView{const_cast<uint64_t *>(p), h_.p ? h_.p->words() : 0}; }
-    const std::shared_ptr<detail::Node> &node() const { return h_.p; }
-    void set_node(std::shared_ptr<detail::Node> v) { release(); h_.p = std::move(v); retain(); }
+    const std::shared_ptr<detail::Node> &node() const { sync_mirror(); return h_.p; }
+    void set_node(std::shared_ptr<detail::Node> v) { drop_mirror(); release(); h_.p = std::move(v); retain(); }
     void materialize() const {
         if (!h_.p || h_.p->done()) return;
         if (std::shared_ptr<detail::CtxState> c = h_.p->ctx.lock()) detail::flush(*c);
@@ -725,8 +761,31 @@ public:
 private:
     void retain() { if (h_.p) ++h_.p->handles; }
     void release() { if (h_.p) { --h_.p->handles; h_.p.reset(); } }
+    // host mirror (mutable_pointer / pointer): a plain pointer, null for every ciphertext the reference's code ever makes -- an object
+    // that was never constructed (the tag comment above) has garbage here, which only code behind the tag check looks at
+    void fetch_mirror() {
+        if (mirror_live_) return;                          // the caller's writes are in it: it IS the value
+        const uint64_t *src = static_cast<const Ciphertext *>(this)->ptr();
+        if (!mirror_) mirror_ = new std::vector<uint64_t>();
+        mirror_->resize(h_.p->words());
+        detail::check(fhe_download(mirror_->data(), src, mirror_->size() * 8, nullptr), "download");
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+    void sync_mirror() const {                             // the mirror may have been written through: it becomes the value
+        if (!mirror_live_) return;
+        Ciphertext *self = const_cast<Ciphertext *>(this);
+        self->mirror_live_ = false;
+        uint64_t *dst = self->ptr();                       // copy on write if the value is shared
+        detail::check(fhe_upload(dst, mirror_->data(), mirror_->size() * 8, nullptr), "upload");
+        detail::check(fhe_stream_sync(nullptr), "sync");
+        self->mirror_live_ = true;                         // the pointer handed out stays valid: later writes are picked up as well
+    }
+    void sync_mirror_noexcept() const noexcept { try { sync_mirror(); } catch (...) {} }
+    void drop_mirror() { mirror_live_ = false; }
     static constexpr uint64_t kTag = 0xC1F7E87A5EA1FACEULL;
     uint64_t tag_;
+    std::vector<uint64_t> *mirror_ = nullptr;
+    bool mirror_live_ = false;
     union Hold {
         std::shared_ptr<detail::Node> p;
         Hold() { new (&p) std::shared_ptr<detail::Node>(); }
@@ -918,12 +977,60 @@ public:
     detail::DevBuf buf;   // [k][n] coefficient form
     uint32_t k = 0, n = 0;
 };
+// SEAL 2.3: data()[j][l] is the l-th key (a size-2 ciphertext in NTT form) for s^(j+2), l = prime * digits + digit.  The facade keeps
+// the keys as ONE device array, `buf`; mutable_data() hands out per-key Ciphertext objects (filled from `buf` the first time) and
+// marks the object so that the next relinearize reassembles `buf` from them -- the path oracle/seal_crosscheck.cpp uses to install
+// keys with known contents through the SEAL API (resize + mutable_pointer + Evaluator::transform_to_ntt).
 class EvaluationKeys {
 public:
     int decomposition_bit_count() const { return (int)dbc; }
-    detail::DevBuf buf;   // [k][digits][2][k][n], NTT form (library slot order)
-    uint32_t dbc = 0, digits = 0;
+    int size() const { return (int)count; }
+    inline std::vector<std::vector<Ciphertext>> &mutable_data();
+    inline const std::vector<std::vector<Ciphertext>> &data() const { return const_cast<EvaluationKeys *>(this)->expand(); }
+    inline const uint64_t *device_keys() const;       // facade internal: `buf`, reassembled from the key objects when they were handed out
+    detail::DevBuf buf;   // [count][k][digits][2][k][n], NTT form (library slot order)
+    uint32_t dbc = 0, digits = 0, count = 0, k = 0, n = 0;
+private:
+    inline std::vector<std::vector<Ciphertext>> &expand();
+    std::shared_ptr<std::vector<std::vector<Ciphertext>>> keys_;     // shared_ptr: Ciphertext is an incomplete type here
+    bool handed_out_ = false;
 };
+
+inline std::vector<std::vector<Ciphertext>> &EvaluationKeys::expand() {
+    if (!keys_) {
+        keys_ = std::make_shared<std::vector<std::vector<Ciphertext>>>();
+        const size_t pw = (size_t)k * n;
+        keys_->resize(count);
+        for (uint32_t j = 0; j < count; ++j) {
+            (*keys_)[j].resize((size_t)k * digits);
+            for (size_t l = 0; l < (size_t)k * digits; ++l) {
+                Ciphertext &c = (*keys_)[j][l];
+                c.shape(2, k, n);
+                detail::check(fhe_copy(c.ptr(), buf.ptr() + ((size_t)j * k * digits + l) * 2 * pw, 2 * pw * 8, nullptr), "copy");
+            }
+        }
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+    return *keys_;
+}
+inline std::vector<std::vector<Ciphertext>> &EvaluationKeys::mutable_data() {
+    handed_out_ = true;
+    return expand();
+}
+inline const uint64_t *EvaluationKeys::device_keys() const {
+    if (handed_out_) {                                     // the key objects may have been rewritten: they are the keys now
+        EvaluationKeys *self = const_cast<EvaluationKeys *>(this);
+        const size_t pw = (size_t)k * n;
+        for (uint32_t j = 0; j < count; ++j)
+            for (size_t l = 0; l < (size_t)k * digits; ++l) {
+                const Ciphertext &c = (*keys_)[j][l];
+                if (c.size() != 2 || c.k() != k || c.n() != n) throw std::invalid_argument("evaluation key " + std::to_string(l) + " is not a size-2 ciphertext of this context");
+                detail::check(fhe_copy(self->buf.ptr() + ((size_t)j * k * digits + l) * 2 * pw, c.ptr(), 2 * pw * 8, nullptr), "copy");
+            }
+        detail::check(fhe_stream_sync(nullptr), "sync");
+    }
+    return buf.ptr();
+}
 
 namespace detail {
 // ChaCha20 (RFC 8439 block function) as a deterministic random bit generator.  Every Sampler keys
@@ -1038,15 +1145,20 @@ inline void ring_mul(const CtxState &s, const DevBuf &a, size_t a_polys, const D
 }
 // evaluation keys for s^2 (SEAL 2.3 generate_evaluation_keys(dbc, keys)): evk[i][d] = (-(a s + e) + 2^(dbc d) s^2 E_i, a),
 // [k][digits][2][k][n], NTT form.  sk: [k][n] coefficient form, sk_ntt its transform.
-inline void make_evk(const CtxState &s, const DevBuf &sk, const DevBuf &sk_ntt, int decomposition_bit_count, DevBuf &out, uint32_t &digits) {
+// count > 1 (generate_evaluation_keys(dbc, count, keys)): the keys for s^2 .. s^(count+1) one after the other, [count][k][digits][2][k][n]
+inline void make_evk(const CtxState &s, const DevBuf &sk, const DevBuf &sk_ntt, int decomposition_bit_count, DevBuf &out, uint32_t &digits, int count = 1) {
     if (decomposition_bit_count < 1 || decomposition_bit_count > 60) throw std::invalid_argument("decomposition_bit_count");
+    if (count < 1 || count > FHE_MAX_POLYS - 2) throw std::invalid_argument("evaluation key count");
     Sampler smp(s);
     const size_t pw = s.poly_words();
     const uint32_t nd = fhe_evk_digits(s.h, (uint32_t)decomposition_bit_count);
     digits = nd;
-    out.resize((size_t)s.k * nd * 2 * pw);
-    DevBuf s2;
-    ring_mul(s, sk, 1, sk_ntt, s2);
+    const size_t set_words = (size_t)s.k * nd * 2 * pw;
+    out.resize((size_t)count * set_words);
+    DevBuf s2, nxt;
+    for (int j = 0; j < count; ++j) {
+    if (j == 0) ring_mul(s, sk, 1, sk_ntt, s2);                    // s^(j+2)
+    else { ring_mul(s, s2, 1, sk_ntt, nxt); check(fhe_copy(s2.ptr(), nxt.ptr(), pw * 8, nullptr), "copy"); check(fhe_stream_sync(nullptr), "sync"); }
     std::vector<uint64_t> hs2(pw);
     s2.download(hs2.data(), pw);
     for (uint32_t i = 0; i < s.k; ++i)
@@ -1065,12 +1177,13 @@ inline void make_evk(const CtxState &s, const DevBuf &sk, const DevBuf &sk_ntt, 
                 uint64_t &x = k0[(size_t)i * s.n + c];
                 x = (uint64_t)(((u128)x + mulmod(hs2[(size_t)i * s.n + c], wd, qi)) % qi);
             }
-            uint64_t *dst = out.ptr() + (((size_t)i * nd + d) * 2) * pw;
+            uint64_t *dst = out.ptr() + (size_t)j * set_words + (((size_t)i * nd + d) * 2) * pw;
             check(fhe_upload(dst, k0.data(), pw * 8, nullptr), "upload");
             check(fhe_upload(dst + pw, a.data(), pw * 8, nullptr), "upload");
             check(fhe_stream_sync(nullptr), "sync");
         }
-    check(fhe_ntt_forward(s.h, out.ptr(), out.ptr(), (uint64_t)s.k * nd * 2, nullptr), "ntt");
+    }
+    check(fhe_ntt_forward(s.h, out.ptr(), out.ptr(), (uint64_t)count * s.k * nd * 2, nullptr), "ntt");
     check(fhe_stream_sync(nullptr), "sync");
 }
 // FHE_FACADE_RELIN: the context's own keys for s^2, made once from the first secret key seen on it
@@ -1108,9 +1221,15 @@ public:
     const PublicKey &public_key() const { return pk_; }
     const SecretKey &secret_key() const { return sk_; }
     // evaluation keys for s^2 (SEAL 2.3 generate_evaluation_keys(dbc, keys))
-    void generate_evaluation_keys(int decomposition_bit_count, EvaluationKeys &evk) {
-        detail::make_evk(*st_, sk_.buf, sk_ntt_, decomposition_bit_count, evk.buf, evk.digits);
+    void generate_evaluation_keys(int decomposition_bit_count, EvaluationKeys &evk) { generate_evaluation_keys(decomposition_bit_count, 1, evk); }
+    // SEAL 2.3: keys for s^2 .. s^(count+1) -- what relinearize needs for a ciphertext of count + 2 polynomials
+    void generate_evaluation_keys(int decomposition_bit_count, int count, EvaluationKeys &evk) {
+        evk = EvaluationKeys();
+        detail::make_evk(*st_, sk_.buf, sk_ntt_, decomposition_bit_count, evk.buf, evk.digits, count);
         evk.dbc = (uint32_t)decomposition_bit_count;
+        evk.count = (uint32_t)count;
+        evk.k = st_->k;
+        evk.n = st_->n;
     }
 private:
     std::shared_ptr<detail::CtxState> st_;
@@ -1272,22 +1391,35 @@ public:
         auto_relin(a);
     }
     void square(Ciphertext &a) { need(a); record(detail::Node::SQR, a, nullptr, nullptr, (uint32_t)(2 * a.size() - 1)); auto_relin(a); }
-    // repeated until size 2, as SEAL does.  Not deferred (the reference never calls it; the keys are the caller's object).
+    // repeated until size 2, as SEAL does: one key switch per polynomial above the second, the top one first, with the keys for
+    // s^(size-1) .. s^2 (generate_evaluation_keys(dbc, count, keys) with count >= size - 2).  Not deferred (the reference never
+    // calls it; the keys are the caller's object).
     void relinearize(Ciphertext &a, const EvaluationKeys &evk) {
         need(a);
-        if (a.size() > 3) throw std::invalid_argument("relinearize: only size-3 ciphertexts are supported (keys for s^2)");
         if (a.size() < 3) return;
+        if ((int)evk.count < a.size() - 2)
+            throw std::invalid_argument("relinearize: a ciphertext of " + std::to_string(a.size()) + " polynomials needs " + std::to_string(a.size() - 2) +
+                                        " evaluation keys (generate_evaluation_keys(dbc, count, keys)), these hold " + std::to_string(evk.count));
+        const uint32_t sz = (uint32_t)a.size();
         const size_t bytes = fhe_relinearize_scratch_bytes(st_->h, evk.dbc, 1);
         detail::DevBuf scratch_((bytes + 7) / 8);                              // per call: an Evaluator may be shared by threads
         const size_t pw = st_->poly_words();
+        const uint64_t *keys = evk.device_keys();
         const uint64_t *src = static_cast<const Ciphertext &>(a).ptr();        // computes the value; no copy-on-write
+        detail::DevBuf work((size_t)sz * pw);                                  // the steps above the last one run in place on a copy
+        detail::check(fhe_copy(work.ptr(), src, (size_t)sz * pw * 8, nullptr), "copy");
         std::shared_ptr<detail::Node> v = std::make_shared<detail::Node>();
         v->size = 2; v->k = st_->k; v->n = st_->n;
-        v->set_storage(std::make_shared<detail::Storage>(3 * pw), 0);          // the key switch works in place on three polynomials
-        detail::check(fhe_copy(v->ptr(), src, 3 * pw * 8, nullptr), "copy");
-        detail::check(fhe_relinearize(st_->h, v->ptr(), 3 * pw, 1, evk.buf.ptr(), evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
+        v->set_storage(std::make_shared<detail::Storage>(2 * pw), 0);
+        detail::check(fhe_relinearize_n(st_->h, work.ptr(), sz, (size_t)sz * pw, v->ptr(), 2 * pw, 1, keys, evk.dbc, scratch_.ptr(), bytes, nullptr), "relinearize");
+        detail::check(fhe_stream_sync(nullptr), "sync");                       // `work` goes away with this call
         a.set_node(std::move(v));
     }
+    // SEAL 2.3 Evaluator::transform_to_ntt / transform_from_ntt(Ciphertext&): every polynomial of the ciphertext, in place.  The
+    // facade's NTT form is the library's slot order (include/fhe_hip.h) -- an internal order, like SEAL's own: only values that
+    // stay inside the library (evaluation keys) are kept in it.
+    void transform_to_ntt(Ciphertext &a) { need(a); uint64_t *p = a.ptr(); detail::check(fhe_ntt_forward(st_->h, p, p, (uint64_t)a.size(), nullptr), "ntt"); }
+    void transform_from_ntt(Ciphertext &a) { need(a); uint64_t *p = a.ptr(); detail::check(fhe_ntt_inverse(st_->h, p, p, (uint64_t)a.size(), nullptr), "intt"); }
     // compute everything recorded so far (observing a value does this implicitly)
     void flush() { detail::flush(*st_); }
 private:

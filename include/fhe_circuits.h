@@ -49,6 +49,24 @@ int fhe_circuits_destroy(fhe_circuits *circ);
  * NTT form); they must outlive the handle.  Everything else is as for fhe_circuits_create. */
 int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc,
                               fhe_circuits **out);
+/* WHERE the relinearised mode relinearises.
+ *   FHE_RELIN_EVERY_PRODUCT  (fhe_circuits_create_relin) after every multiply / square, as described above: five key switches per
+ *                            Cubic (t^2, t * t and the three products), two per Linear; every circuit of this header.
+ *   FHE_RELIN_PER_CUBIC      the reference's call sequence of Cubic / Linear UNCHANGED (homo/fhe_resize.h:150-184,196-199: products
+ *                            grow to 3 and 4 polynomials, the fused tail of fhe_cubic included) and ONE evaluator.relinearize(result, evk)
+ *                            at the end of each, taking the size-4 (Cubic) / size-3 (Linear) result to 2 the way SEAL's relinearize
+ *                            does: one key switch per polynomial above the second, the top one first -- TWO per Cubic, one per
+ *                            Linear.  d_evk_ntt then holds the keys for s^2 followed by the keys for s^3 (fhe_evk_words(ctx, dbc)
+ *                            words each; KeyGenerator::generate_evaluation_keys(dbc, 2, keys)).  Operands and results of fhe_cubic /
+ *                            fhe_linear / the samplers / the shared resize have two polynomials, as in the other placement; bit-identical
+ *                            to the oracle's composition `reference sequence -> relinearize` (oracle/oracle.py TailRelinOracle).  The
+ *                            decode circuits (sin / cos, approximated_step, decode_channel) have no Cubic to end: they return
+ *                            FHE_ERR_PARAM for such a handle. */
+#define FHE_RELIN_EVERY_PRODUCT 0
+#define FHE_RELIN_PER_CUBIC 1
+int fhe_circuits_create_relin_at(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc,
+                                 uint32_t placement, fhe_circuits **out);
+uint32_t fhe_circuits_relin_placement(const fhe_circuits *circ);
 /* the decomposition bit count of a relinearising handle, 0 for a handle in the reference's mode */
 uint32_t fhe_circuits_relin_dbc(const fhe_circuits *circ);
 /* polynomials per output ciphertext of a circuit for this handle.  `arg`: FHE_CIRC_CUBIC / FHE_CIRC_LINEAR the operand

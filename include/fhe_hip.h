@@ -59,6 +59,7 @@ extern "C" {
 #define FHE_ERR_NOMEM (-3)
 
 #define FHE_MAX_K 8
+#define FHE_MAX_POLYS 64      /* polynomials per ciphertext (the deepest reference circuit reaches 22, homo/fhe_decode.h:239) */
 
 typedef struct fhe_ctx fhe_ctx;
 typedef struct fhe_dct_plan fhe_dct_plan;
@@ -74,9 +75,12 @@ const char *fhe_last_error(void);
  *      a side effect, and the context's second stream exists only with FHE_DCT_PIPELINE=1.
  *   3: + fhe_encrypt_batch / fhe_encrypt_scratch_bytes / fhe_encrypt_draws / fhe_noise_cdt, fhe_frac_encode_batch,
  *      fhe_decrypt_batch / fhe_decrypt_scratch_bytes / fhe_ctx_modulus_bits.
+ *   4: + fhe_relinearize_poly / fhe_relinearize_n (key switches for s^3 ..: a size-4 Cubic result goes to size 2 in one
+ *      evaluator.relinearize, as SEAL's does), fhe_circuits_create_relin_at (include/fhe_circuits.h: where the relinearised mode
+ *      relinearises); fhe_relinearize_to rejects partially overlapping input / output ranges.
  * A host compiled against this header compares fhe_abi_version() with FHE_ABI_VERSION before anything else (the Python
  * binding and seal/seal.h do). */
-#define FHE_ABI_VERSION 3
+#define FHE_ABI_VERSION 4
 uint32_t fhe_abi_version(void);
 
 /* ---- context: replaces seal::EncryptionParameters + seal::SEALContext -------------------------
@@ -251,6 +255,24 @@ size_t fhe_relinearize_scratch_bytes(const fhe_ctx *ctx, uint32_t dbc, uint64_t 
 int fhe_relinearize_to(const fhe_ctx *ctx, const uint64_t *ct3, uint64_t ct_stride_words, uint64_t *out2,
                        uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,
                        size_t scratch_bytes, fhe_stream stream);
+
+/* One key-switch step (what SEAL 2.3's relinearize repeats until size 2): polynomial `src_poly` >= 2 -- the LAST one of a
+ * ciphertext of src_poly + 1 polynomials -- is decomposed into digits and folded into c0 / c1 with the keys for
+ * s^src_poly (d_evk_ntt: [k][n_digits][2][k][n], same form as above, made from s^src_poly instead of s^2).  Only c0' and c1'
+ * are written (out2, same aliasing rule as fhe_relinearize_to); in place (out2 == ct, equal strides) polynomials
+ * 2 .. src_poly - 1 simply stay where they are, so the ciphertext has become one polynomial shorter.  src_poly == 2 is
+ * fhe_relinearize_to.  Same scratch. */
+int fhe_relinearize_poly(const fhe_ctx *ctx, const uint64_t *ct, uint64_t ct_stride_words, uint32_t src_poly, uint64_t *out2,
+                         uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,
+                         size_t scratch_bytes, fhe_stream stream);
+/* evaluator.relinearize(ct, evk) for ciphertexts of `size` >= 3 polynomials down to 2 (SEAL 2.3: size - 2 steps, the top
+ * polynomial first): d_evk_ntt holds the keys for s^2, s^3, .. s^(size-1) one after the other (fhe_evk_words(ctx, dbc) words
+ * each; KeyGenerator::generate_evaluation_keys(dbc, size - 2, keys)).  The steps above the last one run IN PLACE: ct's first two
+ * polynomials are overwritten with partial sums when size > 3 (ct is scratch after the call).  out2 as in fhe_relinearize_to. */
+size_t fhe_evk_words(const fhe_ctx *ctx, uint32_t dbc);
+int fhe_relinearize_n(const fhe_ctx *ctx, uint64_t *ct, uint32_t size, uint64_t ct_stride_words, uint64_t *out2,
+                      uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,
+                      size_t scratch_bytes, fhe_stream stream);
 
 /* ---- fused block circuit: encrypted_dct (homo/fhe_image.h:196-288) followed by quantize_fhe
  * (homo/fhe_image.h:294-305) on n_blocks independent 8x8 blocks.  in/out: [n_blocks][64][2][k][n].

@@ -378,6 +378,32 @@ int fhe_relinearize_to(const fhe_ctx *c, const uint64_t *ct3, uint64_t stride, u
     return FHE_OK;
 }
 
+int fhe_relinearize_poly(const fhe_ctx *c, const uint64_t *ct, uint64_t stride, uint32_t src_poly, uint64_t *out2, uint64_t out_stride,
+                         uint64_t count, const uint64_t *evk, uint32_t dbc, void *scr, size_t sbytes, fhe_stream s) {
+    (void)scr; (void)sbytes; (void)s;
+    if (src_poly < 2 || src_poly >= FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "key-switch source polynomial out of range");
+    uint64_t *tmp = (uint64_t *)malloc((src_poly + 1) * pw(c) * 8);
+    if (!tmp) return fail(FHE_ERR_NOMEM, "out of memory");
+    for (uint64_t i = 0; i < count; i++) {
+        memcpy(tmp, ct + i * stride, (src_poly + 1) * pw(c) * 8);
+        fo_relinearize_poly(c->o, tmp, src_poly, evk, dbc);
+        memcpy(out2 + i * out_stride, tmp, 2 * pw(c) * 8);
+    }
+    free(tmp);
+    return FHE_OK;
+}
+size_t fhe_evk_words(const fhe_ctx *c, uint32_t dbc) { return (size_t)c->k * fo_evk_digits(c->o, dbc) * 2 * pw(c); }
+int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
+                      const uint64_t *evk, uint32_t dbc, void *scr, size_t sbytes, fhe_stream s) {
+    if (size < 3 || size > FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "relinearize: size out of range");
+    const size_t ew = fhe_evk_words(c, dbc);
+    for (uint32_t p = size - 1; p >= 3; --p) {
+        int rc = fhe_relinearize_poly(c, ct, stride, p, ct, stride, count, evk + (size_t)(p - 2) * ew, dbc, scr, sbytes, s);
+        if (rc) return rc;
+    }
+    return fhe_relinearize_poly(c, ct, stride, 2, out2, out_stride, count, evk, dbc, scr, sbytes, s);
+}
+
 int fhe_dct_plan_create(const fhe_ctx *c, const double *quant64, int ic, int fc, fhe_stream s, fhe_dct_plan **out) {
     (void)c; (void)s;
     if (ic != 100 || fc != 100) return fail(FHE_ERR_PARAM, "the oracle fixes 100/100 coefficients");

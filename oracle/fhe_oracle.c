@@ -864,13 +864,21 @@ uint32_t fo_evk_digits(const fo_ctx *c, uint32_t dbc) {
     return mx;
 }
 
-void fo_evk_gen(const fo_ctx *c, const uint64_t *sk, uint32_t dbc, uint64_t seed, uint64_t *evk) {
+void fo_evk_gen(const fo_ctx *c, const uint64_t *sk, uint32_t dbc, uint64_t seed, uint64_t *evk) { fo_evk_gen_pow(c, sk, 2, dbc, seed, evk); }
+/* keys for s^power (SEAL 2.3 generate_evaluation_keys(dbc, count, keys) makes them for s^2 .. s^(count+1); the reference only
+ * ever asks for count = 1, tests/parameters.cpp:89): the same construction with s^power in the place of s^2; the sampler is
+ * seeded by (seed, power) so that the keys of different powers are independent and power = 2 is fo_evk_gen */
+void fo_evk_gen_pow(const fo_ctx *c, const uint64_t *sk, uint32_t power, uint32_t dbc, uint64_t seed, uint64_t *evk) {
     u32 n = c->n, k = c->k, nd = fo_evk_digits(c, dbc);
     size_t pq = (size_t)k * n;
-    rng r = {seed ^ 0xE7A1BEEF5ULL};
+    rng r = {(seed ^ 0xE7A1BEEF5ULL) + 0x9E3779B97F4A7C15ULL * (u64)(power - 2)};
     u64 *s2 = (u64 *)malloc(sizeof(u64) * pq), *a = (u64 *)malloc(sizeof(u64) * pq),
         *e = (u64 *)malloc(sizeof(u64) * pq), *as = (u64 *)malloc(sizeof(u64) * pq);
     ring_mul(c, sk, sk, s2);
+    for (u32 pw = 2; pw < power; pw++) {                     /* s^power */
+        ring_mul(c, s2, sk, as);
+        memcpy(s2, as, sizeof(u64) * pq);
+    }
     for (u32 i = 0; i < k; i++)
         for (u32 d = 0; d < nd; d++) {
             u64 *k0 = evk + (((size_t)i * nd + d) * 2 + 0) * pq;
@@ -898,14 +906,17 @@ void fo_evk_gen(const fo_ctx *c, const uint64_t *sk, uint32_t dbc, uint64_t seed
     free(s2); free(a); free(e); free(as);
 }
 
-void fo_relinearize3(const fo_ctx *c, uint64_t *ct, const uint64_t *evk, uint32_t dbc) {
+void fo_relinearize3(const fo_ctx *c, uint64_t *ct, const uint64_t *evk, uint32_t dbc) { fo_relinearize_poly(c, ct, 2, evk, dbc); }
+/* one key-switch step (SEAL 2.3 relinearize_one_step): the LAST polynomial `src_poly` of a ciphertext of src_poly + 1 polynomials is
+ * decomposed and folded into c0 / c1 with the keys for s^src_poly; the polynomials in between stay */
+void fo_relinearize_poly(const fo_ctx *c, uint64_t *ct, uint32_t src_poly, const uint64_t *evk, uint32_t dbc) {
     u32 n = c->n, k = c->k, nd = fo_evk_digits(c, dbc);
     size_t pq = (size_t)k * n;
     u64 mask = (dbc >= 64) ? ~0ULL : ((1ULL << dbc) - 1);
     u64 *acc0 = (u64 *)calloc(pq, sizeof(u64)), *acc1 = (u64 *)calloc(pq, sizeof(u64));
     u64 *dig = (u64 *)malloc(sizeof(u64) * n);
     for (u32 i = 0; i < k; i++) {
-        const u64 *c2 = POLY(ct, 2, i);
+        const u64 *c2 = POLY(ct, src_poly, i);
         for (u32 d = 0; d < nd; d++) {
             const u64 *k0 = evk + (((size_t)i * nd + d) * 2 + 0) * pq;
             const u64 *k1 = evk + (((size_t)i * nd + d) * 2 + 1) * pq;

@@ -129,6 +129,10 @@ uint32_t fo_evk_digits(const fo_ctx *c, uint32_t dbc);
 void fo_evk_gen(const fo_ctx *c, const uint64_t *sk, uint32_t dbc, uint64_t seed, uint64_t *evk);
 /* relinearise a size-3 ciphertext to size 2 (in place, first two polys) */
 void fo_relinearize3(const fo_ctx *c, uint64_t *ct, const uint64_t *evk, uint32_t dbc);
+/* keys for s^power (power >= 2; 2 == fo_evk_gen) and one key-switch step on the last polynomial `src_poly` of a ciphertext
+ * of src_poly + 1 polynomials with them (SEAL 2.3 generate_evaluation_keys(dbc, count, ..) / relinearize_one_step) */
+void fo_evk_gen_pow(const fo_ctx *c, const uint64_t *sk, uint32_t power, uint32_t dbc, uint64_t seed, uint64_t *evk);
+void fo_relinearize_poly(const fo_ctx *c, uint64_t *ct, uint32_t src_poly, const uint64_t *evk, uint32_t dbc);
 
 /* ---- circuits, op-at-a-time exactly as the reference issues them ------- */
 /* data: 64 ct(2), row-major 8x8 (homo/fhe_image.h:196-288) */

@@ -100,6 +100,8 @@ def lib(omp=False):
         L.fo_evk_digits.argtypes = [C.c_void_p, C.c_uint32]
         L.fo_evk_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.fo_relinearize3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fo_evk_gen_pow.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.fo_relinearize_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.fo_encrypted_dct.argtypes = [C.c_void_p, C.c_void_p]
         L.fo_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_dct_quant_blocks.restype = C.c_int
@@ -317,6 +319,23 @@ class Oracle:
         self.L.fo_relinearize3(self.h, _p(out), _p(evk), dbc)
         return out[:2].copy()
 
+    def evk_gen_powers(self, sk, dbc=30, count=2, seed=11):
+        """[count][k][nd][2][k][n]: keys for s^2 .. s^(count+1) (SEAL 2.3 generate_evaluation_keys(dbc, count, keys)); entry 0 is evk_gen's"""
+        nd = int(self.L.fo_evk_digits(self.h, dbc))
+        evk = np.zeros((count, self.k, nd, 2, self.k, self.n), dtype=np.uint64)
+        for j in range(count):
+            self.L.fo_evk_gen_pow(self.h, _p(sk), j + 2, dbc, seed, _p(evk[j]))
+        return evk
+
+    def relinearize_n(self, ct, evks, dbc=30):
+        """evaluator.relinearize of a ciphertext of any size >= 2 down to 2 (SEAL 2.3: one key-switch step per polynomial above the
+        second, the top one first, with the keys for s^(size-1)); evks: evk_gen_powers(..)"""
+        out = np.ascontiguousarray(ct).copy()
+        assert out.shape[0] - 2 <= evks.shape[0], "not enough evaluation keys for a ciphertext of this size"
+        for p in range(out.shape[0] - 1, 1, -1):
+            self.L.fo_relinearize_poly(self.h, _p(out), p, _p(evks[p - 2]), dbc)
+        return out[:2].copy()
+
     # -- circuits ---------------------------------------------------------
     def encrypted_dct(self, block):
         out = np.ascontiguousarray(block).copy()
@@ -473,6 +492,26 @@ class RelinOracle:
         return self._rl(self.orc.square(a))
 
 
+class TailRelinOracle:
+    """The second relinearised mode ("per Cubic"): the reference's call sequences UNCHANGED (products grow to 3 / 4 polynomials as
+    in homo/fhe_resize.h:174-179,196-199) and ONE evaluator.relinearize(result, evk) at the end of every Cubic / Linear, taking the
+    size-4 (Cubic) or size-3 (Linear) result to 2 with the keys for s^2 and s^3 -- two key switches per Cubic where RelinOracle
+    spends five.  An oracle-shaped object whose operations are the plain oracle's; `tail(x)` is that one call."""
+
+    def __init__(self, orc, evks, dbc):
+        self.orc, self.evks, self.dbc = orc, evks, int(dbc)
+
+    def __getattr__(self, name):
+        return getattr(self.orc, name)
+
+    def tail(self, x):
+        return self.orc.relinearize_n(x, self.evks, self.dbc) if x.shape[0] > 2 else x
+
+
+def _tail(orc, x):
+    return orc.tail(x) if hasattr(orc, "tail") else x
+
+
 def oracle_cubic_calls(orc, A, B, Cc, D, t):
     """Cubic (homo/fhe_resize.h:143-189) one Evaluator call per line -- fo_cubic restates the same sequence in C; this form
     takes any oracle-shaped object, so oracle_cubic_calls(RelinOracle(...), ...) is the relinearised Cubic."""
@@ -494,7 +533,7 @@ def oracle_cubic_calls(orc, A, B, Cc, D, t):
     a = orc.add(a, b)                                   # :181
     a = orc.add(a, c)                                   # :182
     a = orc.multiply_plain(a, E(0.5))                   # :183
-    return orc.add(a, B)                                # :184 (d = B)
+    return _tail(orc, orc.add(a, B))                    # :184 (d = B); TailRelinOracle: + one evaluator.relinearize(result, evk)
 
 
 def oracle_linear_calls(orc, A, B, t):
@@ -502,7 +541,7 @@ def oracle_linear_calls(orc, A, B, t):
     omt = orc.add_plain(orc.negate(t), orc.encode(1.0))     # :196
     x = orc.multiply(omt, A)                                # :197
     y = orc.multiply(B, t)                                  # :198
-    return orc.add(x, y)                                    # :199
+    return _tail(orc, orc.add(x, y))                        # :199
 
 
 def oracle_sample_bicubic_calls(orc, p, xfract, yfract):

@@ -319,3 +319,119 @@ def test_streaming_servers_in_the_relinearised_mode(fhe, oracle_mod, tmp_path):
     for i in range(width * height):
         for ch in range(3):
             assert got[i * 3 + ch].shape[0] == 2 and np.array_equal(got[i * 3 + ch], want[ch][i]), (i, ch)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the second placement: the reference's Cubic / Linear unchanged, ONE evaluator.relinearize at the end of each (FHE_RELIN_PER_CUBIC)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _setup_tail(fhe, om, name, dbc, key_seed=77):
+    """context + oracle + the keys for s^2 AND s^3 in both libraries' NTT slot orders"""
+    p = SMALL if name == "SMALL" else om.PRESETS[name]
+    ctx, orc = fhe.SEALContext(p["n"], p["q"], p["t"]), om.Oracle(p["n"], p["q"], p["t"])
+    sk, pk = orc.keygen(key_seed)
+    evks = orc.evk_gen_powers(sk, dbc=dbc, count=2)                 # [2][k][nd][2][k][n], oracle NTT form
+    coeff = np.zeros_like(evks)
+    for idx in np.ndindex(evks.shape[:4]):
+        for i in range(ctx.k):
+            coeff[idx + (i,)] = orc.ntt_inv(evks[idx + (i,)], i)
+    evk_dev = fhe.Evaluator(ctx).ntt_forward(fhe.to_device(coeff)).contiguous()
+    return ctx, orc, om.TailRelinOracle(orc, evks, dbc), (evk_dev, dbc, "cubic"), evks, sk, pk
+
+
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30), ("SEAL23_4096", 30), ("P8192", 60)])
+def test_relinearize_any_size_and_per_cubic_placement_vs_oracle(fhe, oracle_mod, preset, dbc):
+    """fhe_relinearize_n (sizes 3, 4, 5 -> 2: key switches for s^4, s^3, s^2, the top polynomial first, as SEAL's relinearize) and the
+    per-Cubic placement: fhe_cubic / fhe_linear == the op-by-op Evaluator calls + one relinearize == the oracle's composition
+    `oracle_cubic_calls -> relinearize_n` (TailRelinOracle), bit for bit, levels 1 and 2, an operand at q - 1."""
+    import torch
+    ctx, orc, torc, relin, evks, sk, pk = _setup_tail(fhe, oracle_mod, preset, dbc)
+    ev, pc, h = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), fhe.to_host
+    for size in (3, 4):
+        x = ctx.random_ct(3, size=size, seed=900 + size)
+        got = h(ev.relinearize(x, relin[0] if size > 3 else relin[0][0].contiguous(), dbc))
+        for i in range(3):
+            assert np.array_equal(got[i], orc.relinearize_n(h(x)[i], evks, dbc)), (size, i)
+    with pytest.raises(ValueError):
+        ev.relinearize(ctx.random_ct(1, size=5, seed=1), relin[0], dbc)           # needs the keys for s^4 as well
+    A, B, C, D = (ctx.random_ct(3, size=2, seed=400 + i) for i in range(4))
+    t = ctx.random_ct(3, size=2, seed=410)
+    A[1] = torch.tensor([q - 1 for q in ctx.q], dtype=torch.int64, device=A.device).view(1, ctx.k, 1).expand(2, ctx.k, ctx.n)
+    r1 = fhe.circuits.cubic(ev, pc, A, B, C, D, t, relin=relin)
+    assert r1.shape[-3] == 2
+    assert torch.equal(r1, fhe.circuits.cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin))
+    # the reference's result (4 polynomials) relinearised by one call is the same thing
+    assert torch.equal(r1, ev.relinearize(fhe.circuits.cubic(ev, pc, A, B, C, D, t), relin[0], dbc))
+    want1 = [oracle_mod.oracle_cubic_calls(torc, h(A)[i], h(B)[i], h(C)[i], h(D)[i], h(t)[i]) for i in range(3)]
+    for i in range(3):
+        assert want1[i].shape[0] == 2 and np.array_equal(h(r1)[i], want1[i]), i
+    r2 = fhe.circuits.cubic(ev, pc, r1, B, r1, D, t, relin=relin)
+    assert np.array_equal(h(r2)[2], oracle_mod.oracle_cubic_calls(torc, want1[2], h(B)[2], want1[2], h(D)[2], h(t)[2]))
+    l1 = fhe.circuits.linear(ev, pc, A, B, t, relin=relin)
+    l2 = fhe.circuits.linear(ev, pc, l1, r1, t, relin=relin)
+    assert l1.shape[-3] == 2 and l2.shape[-3] == 2
+    for i in (0, 1):
+        o1 = oracle_mod.oracle_linear_calls(torc, h(A)[i], h(B)[i], h(t)[i])
+        assert np.array_equal(h(l1)[i], o1)
+        assert np.array_equal(h(l2)[i], oracle_mod.oracle_linear_calls(torc, o1, want1[i], h(t)[i]))
+    # the decode circuits have no Cubic to end: refused for such a handle
+    with pytest.raises(fhe._lib.FheError):
+        fhe.circuits.homomorphic_sin(ev, pc, ctx.random_ct(1, size=2, seed=3), ctx.random_ct(1, size=2, seed=4), relin=relin)
+
+
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30)])
+def test_samplers_per_cubic_placement_vs_oracle_and_decrypt(fhe, oracle_mod, preset, dbc):
+    """SampleBicubic / SampleLinear / the shared-offset ResizeImage (+ a row shard) with ONE relinearize per Cubic / Linear on an
+    8x8 -> 4x4 image of real encryptions: library == oracle composition bit for bit, every output decrypts to the closed form, and
+    the remaining noise budget is printed beside the every-product placement's and the reference mode's"""
+    import torch
+    ctx, orc, torc, relin, evks, sk, pk = _setup_tail(fhe, oracle_mod, preset, dbc, key_seed=21)
+    each = (relin[0][0].contiguous(), dbc)
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    W = H = 8
+    w = h_ = 4
+    vals = [float((29 * x + 53 * y) % 256) for y in range(H) for x in range(W)]
+    pix = np.stack([orc.encrypt(pk, orc.encode(v), seed=500 + i) for i, v in enumerate(vals)])
+    d_pix = fhe.to_device(pix)
+
+    def plain_cubic(A, B, C, D, t):
+        a, b, c = -A + 3 * B - 3 * C + D, 2 * A - 5 * B + 4 * C - D, C - A
+        return 0.5 * (a * t * t + b * t * t + c * t) + B
+
+    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=True)
+    xf = np.stack([orc.encrypt(pk, orc.encode(f), seed=600 + i) for i, f in enumerate(fx)])
+    yf = np.stack([orc.encrypt(pk, orc.encode(f), seed=700 + i) for i, f in enumerate(fy)])
+    dx, dy = fhe.to_device(xf), fhe.to_device(yf)
+    out = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, dx, dy, relin=relin))
+    assert out.shape == (w * h_, 2, ctx.k, ctx.n)
+    for o in ((0, 5, 15) if preset == "SMALL" else (5,)):
+        assert np.array_equal(out[o], oracle_mod.oracle_sample_bicubic_calls(torc, [pix[i] for i in taps[o]], xf[o], yf[o])), o
+    if preset != "SMALL":
+        other = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, dx, dy, relin=each))
+        ref_mode = fhe.to_host(fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, dx, dy))
+        b_tail, b_each, b_ref = [], [], []
+        for o in range(w * h_):
+            v = [vals[i] for i in taps[o]]
+            cols = [plain_cubic(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3], fx[o]) for r in range(4)]
+            expect = plain_cubic(cols[0], cols[1], cols[2], cols[3], fy[o])
+            plain, budget = orc.decrypt(sk, out[o])
+            assert budget > 0 and abs(orc.decode(plain) - expect) < 1e-6
+            b_tail.append(budget)
+            b_each.append(orc.decrypt(sk, other[o])[1])
+            b_ref.append(orc.decrypt(sk, ref_mode[o])[1])
+        print("\n[relin %s dbc=%d] SampleBicubic noise budget left (min over 16 pixels): per-Cubic placement %d bits, every-product placement %d bits, "
+              "reference mode %d bits" % (preset, dbc, min(b_tail), min(b_each), min(b_ref)))
+    xs, ys = fhe.to_device(xf[:w].copy()), fhe.to_device(yf[::w].copy())
+    shared = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix, W, H, w, h_, xs, ys, batch=8, band_rows=2, relin=relin)
+    per_px = fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, xs.repeat(h_, 1, 1, 1).contiguous(), ys.repeat_interleave(w, dim=0).contiguous(), relin=relin)
+    assert shared.shape[-3] == 2 and torch.equal(shared, per_px)
+    first, cnt = fhe.circuits.resize_source_rows(H, h_, 1, 3)
+    part = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix[first * W:(first + cnt) * W].contiguous(), W, H, w, h_, xs, ys[1:3].contiguous(), batch=8, band_rows=2,
+                                              rows=(1, 3), src_rows=(first, cnt), relin=relin)
+    assert torch.equal(part, shared[w:3 * w])
+    tl, lx, ly = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=False)
+    xl = np.stack([orc.encrypt(pk, orc.encode(f), seed=800 + i) for i, f in enumerate(lx)])
+    yl = np.stack([orc.encrypt(pk, orc.encode(f), seed=850 + i) for i, f in enumerate(ly)])
+    lin = fhe.to_host(fhe.circuits.sample_linear(ev, pc, d_pix, tl, fhe.to_device(xl), fhe.to_device(yl), relin=relin))
+    assert lin.shape[1] == 2
+    for o in (0, 9):
+        assert np.array_equal(lin[o], oracle_mod.oracle_sample_linear_calls(torc, [pix[i] for i in tl[o]], xl[o], yl[o])), o
