@@ -81,6 +81,7 @@ SIGNATURES = {
     "fhe_relinearize_poly": (_i, [_vp, _vp, _u64, _u32, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_relinearize_n": (_i, [_vp, _vp, _u32, _u64, _vp, _u64, _u64, _vp, _u32, _vp, _sz, _vp]),
     "fhe_evk_words": (_sz, [_vp, _u32]),
+    "fhe_relinearize_n_scratch_bytes": (_sz, [_vp, _u32, _u32, _u64]),
     "fhe_dct_plan_create": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(_vp)]),
     "fhe_dct_plan_destroy": (_i, [_vp]),
     "fhe_dct8x8_scratch_bytes": (_sz, [_vp, _u64]),

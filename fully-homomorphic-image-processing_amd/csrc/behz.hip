@@ -925,14 +925,17 @@ __global__ __launch_bounds__(256) void k_relin_add(const u64 *ct, u64 stride, u6
 // modulo q_ii (the k workgroups of one digit sit next to each other: the repeated reads of c2_i hit L2); a digit of
 // dbc >= bits(q_ii) bits is folded first.  dig [count][k][nd][k][n], NTT form, canonical.
 template <int L, typename C>
-__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, RnsBase base, u32 nd, u32 dbc, u32 src_poly) {
+__global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *__restrict__ ct, u64 stride, u64 *__restrict__ dig, RnsBase base, u32 nd, u32 dbc, u32 src_poly, u32 npow) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N;
     const int tid = threadIdx.x;
-    const u32 k = base.count, ii = blockIdx.x % k;
-    const u64 u = blockIdx.x / k;                  // (c * k + i) * nd + d
-    const u32 d = (u32)(u % nd), i = (u32)((u / nd) % k);
-    const u64 c = u / ((u64)nd * k);
+    // npow > 1: the polynomials src_poly .. src_poly + npow - 1 at once (one evaluator.relinearize of a size src_poly + npow ciphertext:
+    // every step's source polynomial is untouched by the steps before it, fhe_relinearize_n); row i' = power * k + prime
+    const u32 k = base.count, ii = blockIdx.x % k, kk = k * npow;
+    const u64 u = blockIdx.x / k;                  // (c * kk + i') * nd + d
+    const u32 d = (u32)(u % nd), ip = (u32)((u / nd) % kk), i = ip % k;
+    src_poly += ip / k;
+    const u64 c = u / ((u64)nd * kk);
     const u64 mask = (1ULL << dbc) - 1;            // dbc <= 60
     const PmMod m = base.pm[ii];
     u64 x[1][16];
@@ -951,17 +954,17 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_fwd_pm(const u64 *
 // (2) acc[c][pp][ii][s] = sum_{i,d} dig * evk with mulvv_pm products summed as integers (k nd <= 20 terms of at most 6q), one fold
 template <typename C>
 __global__ __launch_bounds__(256) void k_relin_accum_pm(const u64 *__restrict__ dig, const u64 *__restrict__ evk, u64 *__restrict__ acc,
-                                                        RnsBase base, u32 n, u32 nd, u64 count) {
-    const u32 k = base.count;
+                                                        RnsBase base, u32 n, u32 nd, u64 count, u32 npow) {
+    const u32 k = base.count, kk = k * npow;      // rows (power, source prime): the key sets of consecutive powers follow each other
     for (u64 u = blockIdx.y; u < count * k; u += gridDim.y) {
         const u32 ii = (u32)(u % k);
         const u64 c = u / k;
         const PmMod m = base.pm[ii];
         for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
             u64 a0 = 0, a1 = 0;
-            for (u32 i = 0; i < k; i++)
+            for (u32 i = 0; i < kk; i++)
                 for (u32 d = 0; d < nd; d++) {
-                    const u64 x = dig[(((c * k + i) * nd + d) * k + ii) * n + s];
+                    const u64 x = dig[(((c * kk + i) * nd + d) * k + ii) * n + s];
                     const u64 *e = evk + ((((u64)i * nd + d) * 2) * k + ii) * n + s;
                     a0 += mulvv_pm(x, e[0], m);
                     a1 += mulvv_pm(x, e[(u64)k * n], m);
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 4) void k_relin_accum_inv_add_pm(c
     u64 acc[1][16], y[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][r] = 0;
-    const u32 terms = k * nd;                            // (i, d) pairs, at most 20: 20 x 6q < 2^62 on a 55-bit base
+    const u32 terms = k * nd;                            // (i, d) pairs, at most 20: 20 x 6q < 2^62 on a 55-bit base (the host passes nd x powers as nd)
     for (u32 t = 0; t < terms; t++) {
         const u64 *pa = dig + ((c * terms + t) * k + ii) * N + tid, *pb = evk + (((u64)t * 2 + pp) * k + ii) * N + tid;
         u64 xa[16], xb[16];
@@ -1534,11 +1537,35 @@ extern "C" size_t fhe_evk_words(const fhe_ctx *c, uint32_t dbc) {
     if (!c || !dbc) return 0;
     return (size_t)c->k * fhe_evk_digits(c, dbc) * 2 * c->k * c->n;
 }
+static bool relin_pm_ok(const fhe_ctx *c, u32 nd, u32 npow, u64 count);
+static int relin_pm(const fhe_ctx *c, const u64 *ct, u64 stride, u32 src_poly, u32 npow, u64 *out2, u64 out_stride, u64 count, const u64 *evk, u32 dbc, u64 *scratch,
+                    hipStream_t st);
+extern "C" size_t fhe_relinearize_n_scratch_bytes(const fhe_ctx *c, uint32_t size, uint32_t dbc, uint64_t count) {
+    if (!c || !dbc || size < 3) return 0;
+    const size_t kn = (size_t)c->k * c->n;
+    return (count * c->k * fhe_evk_digits(c, dbc) * kn * (size - 2) + count * 2 * kn) * sizeof(u64);
+}
 extern "C" int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
                                  const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
     if (!c || !ct || !evk || !out2) return fail(FHE_ERR_PARAM, "null argument");
     if (size < 3 || size > FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "relinearize: %u polynomials (3 .. %d)", size, FHE_MAX_POLYS);
     if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
+    // all size - 2 key switches as ONE pass where the lazy sums have room for their terms and the caller brought the digits' scratch
+    // (fhe_relinearize_n_scratch_bytes); FHE_RELIN_STEPS=1 keeps the sequential steps (A/B measurements, the parity test's second path)
+    if (size > 3 && count && !c->opt.relin_steps && scratch && scratch_bytes >= fhe_relinearize_n_scratch_bytes(c, size, dbc, count)) {
+        if (int erc = fhe_behz_ensure(c)) return erc;
+        const u32 nd = fhe_evk_digits(c, dbc);
+        if (relin_pm_ok(c, nd, size - 2, count)) {
+            if (stride < (u64)size * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-%u ciphertext", size);
+            if (out_stride < (u64)2 * c->k * c->n) return fail(FHE_ERR_PARAM, "output stride smaller than a size-2 ciphertext");
+            if (!(out2 == ct && out_stride == stride)) {
+                const uintptr_t i0 = (uintptr_t)ct, i1 = i0 + ((count - 1) * stride + (u64)size * c->k * c->n) * sizeof(u64);
+                const uintptr_t o0 = (uintptr_t)out2, o1 = o0 + ((count - 1) * out_stride + (u64)2 * c->k * c->n) * sizeof(u64);
+                if (o0 < i1 && i0 < o1) return fail(FHE_ERR_PARAM, "output range overlaps the input range (only out2 == ct with out_stride == stride may alias)");
+            }
+            return relin_pm(c, (const u64 *)ct, stride, 2, size - 2, (u64 *)out2, out_stride, count, (const u64 *)evk, dbc, (u64 *)scratch, (hipStream_t)s);
+        }
+    }
     const size_t ew = fhe_evk_words(c, dbc);
     for (uint32_t p = size - 1; p >= 3; --p)                 // the top polynomial first, with the keys for s^p, in place
         if (int rc = fhe_relinearize_poly(c, ct, stride, p, ct, stride, count, evk + (size_t)(p - 2) * ew, dbc, scratch, scratch_bytes, s)) return rc;
@@ -1548,6 +1575,36 @@ extern "C" int fhe_relinearize(const fhe_ctx *cc, uint64_t *ct3, uint64_t stride
                                void *scratch, size_t scratch_bytes, fhe_stream s) {
     return fhe_relinearize_to(cc, ct3, stride, ct3, stride, count, evk, dbc, scratch, scratch_bytes, s);
 }
+// The pseudo-Mersenne key switch: polynomials src_poly .. src_poly + npow - 1 with the keys for s^src_poly .. in ONE pass of three
+// launches.  npow > 1 is evaluator.relinearize of a size src_poly + npow ciphertext as one sum: SEAL's steps run top polynomial first,
+// but step j only ever writes c0 / c1, so the source polynomial of every step is the caller's own -- the result is c + sum over
+// the steps of their key-switch terms, and modular addition does not care about the order: the same bits as the sequential steps
+// (tests/test_gpu_relin.py compares them), with one inverse transform pair and one addition pass instead of npow.
+static bool relin_pm_ok(const fhe_ctx *c, u32 nd, u32 npow, u64 count) {
+    const bool f64 = fhe_rgb_f64_supported(c) && !c->opt.force_u64;      // the q-base transforms run on the FP64 kernels there
+    return c->qb.pm_class && !c->opt.ntt_nopm && !f64 && (u64)c->k * nd * npow <= 20 && count * c->k * nd * c->k * npow <= 0x7fffffffULL;
+}
+static int relin_pm(const fhe_ctx *c, const u64 *ct, u64 stride, u32 src_poly, u32 npow, u64 *out2, u64 out_stride, u64 count, const u64 *evk, u32 dbc, u64 *scratch,
+                    hipStream_t st) {
+    const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
+    u64 *dig = scratch, *acc = dig + count * k * nd * k * n * npow;
+    const RnsBase base = c->qb.dev();
+#define GO_PM(CC)                                                                                                                          \
+    DISPATCH_L(c->logn, {                                                                                                                  \
+        k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k * npow), NttShape<L>::TP, 0, st>>>(ct, stride, dig, base, nd, dbc, src_poly, npow); \
+        if (!c->opt.relin_fused) {                                                                                                        \
+            k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, evk, acc, base, n, nd, count, npow);                              \
+            k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>(ct, stride, out2, out_stride, acc, base);     \
+        } else {                                                                                                                           \
+            k_relin_accum_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>(ct, stride, out2, out_stride, dig, evk, base, nd * npow); \
+        }                                                                                                                                  \
+    })
+    if (c->qb.pm_class == 1) { GO_PM(PmA); } else { GO_PM(PmB); }
+#undef GO_PM
+    KERNEL_CHECK();
+    return FHE_OK;
+}
+
 extern "C" int fhe_relinearize_to(const fhe_ctx *cc, const uint64_t *ct3, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,
                                   const uint64_t *evk, uint32_t dbc, void *scratch, size_t scratch_bytes, fhe_stream s) {
     return fhe_relinearize_poly(cc, ct3, stride, 2, out2, out_stride, count, evk, dbc, scratch, scratch_bytes, s);
@@ -1577,25 +1634,7 @@ extern "C" int fhe_relinearize_poly(const fhe_ctx *cc, const uint64_t *ct3, uint
     const u32 k = c->k, n = c->n, nd = fhe_evk_digits(c, dbc);
     const BehzDev *T = c->behz->dev;
     u64 *dig = (u64 *)scratch, *acc = dig + count * k * nd * k * n;
-    const bool f64 = fhe_rgb_f64_supported(c) && !c->opt.force_u64;      // the q-base transforms run on the FP64 kernels there
-    if (c->qb.pm_class && !c->opt.ntt_nopm && !f64 && k * nd <= 20 && count * k * nd * k <= 0x7fffffffULL) {
-        const RnsBase base = c->qb.dev();
-#define GO_PM(CC)                                                                                                                          \
-    DISPATCH_L(c->logn, {                                                                                                                  \
-        k_relin_fwd_pm<L, CC><<<(unsigned)(count * k * nd * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, dig, base, nd, dbc, src_poly); \
-        if (!c->opt.relin_fused) {                                                                                                        \
-            k_relin_accum_pm<CC><<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, base, n, nd, count);                       \
-            k_relin_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, acc, base); \
-        } else {                                                                                                                           \
-            k_relin_accum_inv_add_pm<L, CC><<<(unsigned)(count * 2 * k), NttShape<L>::TP, 0, st>>>((const u64 *)ct3, stride, (u64 *)out2, out_stride, dig, \
-                                                                                                  (const u64 *)evk, base, nd);           \
-        }                                                                                                                                  \
-    })
-        if (c->qb.pm_class == 1) { GO_PM(PmA); } else { GO_PM(PmB); }
-#undef GO_PM
-        KERNEL_CHECK();
-        return FHE_OK;
-    }
+    if (relin_pm_ok(c, nd, 1, count)) return relin_pm(c, (const u64 *)ct3, stride, src_poly, 1, (u64 *)out2, out_stride, count, (const u64 *)evk, dbc, (u64 *)scratch, st);
     k_relin_digits<<<grid2(n, count * k * nd), 256, 0, st>>>((const u64 *)ct3, stride, dig, T, n, nd, dbc, count, src_poly);
     if ((rc = qbase_ntt(false, c, dig, dig, count * k * nd, st))) return rc;
     k_relin_accum<<<grid2(n, count * k), 256, 0, st>>>(dig, (const u64 *)evk, acc, T, n, nd, count);

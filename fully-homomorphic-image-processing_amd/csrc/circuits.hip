@@ -438,7 +438,7 @@ struct Run {
     // evaluator.relinearize(result, evk) at the end of a Cubic / Linear (placement per Cubic): raw [count][size] -> out [count][2], size - 2
     // key switches (keys for s^(size-1) .. s^2); raw is scratch afterwards
     int relin_n(u64 *raw, u32 size, u64 *out, u64 count) {
-        const size_t bytes = fhe_relinearize_scratch_bytes(c, cc->dbc, count);
+        const size_t bytes = fhe_relinearize_n_scratch_bytes(c, size, cc->dbc, count);
         const size_t m = mark();
         void *scr = alloc((bytes + 7) / 8);
         int rc = FHE_OK;

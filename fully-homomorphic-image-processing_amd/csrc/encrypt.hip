@@ -164,6 +164,141 @@ __global__ __launch_bounds__(256) void k_enc_finish(ChaChaKey key, u64 first_ind
     }
 }
 
+// ---- ONE launch per batch (round 6) ----------------------------------------------------------------------------------------------
+// One workgroup = one encryption, n / 16 threads, sixteen coefficients per thread in the transforms' pass-0 mapping (coefficient
+// r * TP + tid).  The three draws of the encryption (u, e1, e2: 3 n / 8 ChaCha20 blocks, the SAME blocks of the SAME (key, index)
+// stream the five-launch path reads, so the same ciphertext bits) are generated once, six blocks per thread in stream order, and
+// exchanged through the transform buffer as bytes: every thread ends up with its sixteen draws of each kind packed into four
+// registers (12 VGPRs, alive across the primes).  Then per prime: u's residues -> forward transform -> the two key products per
+// slot -> two inverse transforms -> + e1 / e2 (+ Delta m' on c0) -> 2 n residues written.  The only memory traffic is the public
+// key (k polynomial pairs, L2-resident across the batch), the plaintext coefficients and the ciphertext itself; u, its transform
+// and the products never exist in memory (the five launches moved 3.6 MB per 0.5 MB ciphertext at n = 8192, k = 4).
+// A = the arithmetic of the q-base: EncPm<L, C> (pseudo-Mersenne transforms, SEAL's 54 / 55-bit primes) or EncShoup<L> (lazy Shoup
+// transforms, any base of primes up to 58 bits).
+template <int L, typename C> struct EncPm {
+    using Mod = PmMod;
+    static constexpr int N = NttShape<L>::N;
+    static __device__ __forceinline__ Mod mod(const RnsBase &b, u32 p) { return b.pm[p]; }
+    static __device__ __forceinline__ u64 q(const Mod &m) { return m.q; }
+    static __device__ __forceinline__ void fwd(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_fwd_regs_pm<L, 1, 16, C::LIM, C::CS>(x, b.tw_pm + (size_t)p * N, m, lds, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[0][r] = fold_pm(x[0][r], m);
+    }
+    static __device__ __forceinline__ u64 mul(u64 x, u64 w, const Mod &m, const Modulus &) { return mulvv_pm(x, w, m); }      // below RQ / 16 q
+    static __device__ __forceinline__ void inv(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_inv_regs_pm<L, 1, C::RQ, C::XB, C::LIM, C::RQ>(x, b.itw_pm + (size_t)p * N, m, lds, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[0][r] = canon_rq_pm<C::RQ>(x[0][r], m);
+    }
+};
+template <int L> struct EncShoup {
+    struct Mod { NttMod m; float cs; };
+    static constexpr int N = NttShape<L>::N;
+    static __device__ __forceinline__ Mod mod(const RnsBase &b, u32 p) { Mod o; o.m = ntt_mod(b.mod[p].q); o.cs = canon_scale(o.m.q); return o; }
+    static __device__ __forceinline__ u64 q(const Mod &m) { return m.m.q; }
+    static __device__ __forceinline__ void fwd(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_fwd_regs4<L, true>(x[0], b.tw + (size_t)p * N, m.m, lds, tid);        // below (2 + 4 L) q <= 58 q
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[0][r] = canon_below_64q(x[0][r], m.m.q, m.cs);
+    }
+    static __device__ __forceinline__ u64 mul(u64 x, u64 w, const Mod &, const Modulus &md) { return mul_barrett(x, w, md); }  // canonical
+    static __device__ __forceinline__ void inv(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_inv_regs4<L, true>(x[0], b.itw + (size_t)p * N, m.m, lds, tid);       // [0, 4q) in and out
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[0][r] = csub(csub(x[0][r], 2 * m.m.q), m.m.q);
+    }
+};
+__device__ __forceinline__ int enc_byte(const u32 (&w)[4], int r) { return (int)(w[r >> 2] << (24 - 8 * (r & 3))) >> 24; }      // sign-extended byte r
+
+template <int L, typename A>
+__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key, u64 first_index, u64 *__restrict__ ct, const u64 *__restrict__ plain,
+                                                                   const u64 *__restrict__ pk_ntt, RnsBase base, EncLift Lf) {
+    __shared__ u64 lds[NttShape<L>::LDS_WORDS];
+    constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
+    const int tid = threadIdx.x;
+    const u64 e = blockIdx.x;
+    const u32 k = base.count;
+    // (1) the draws, in stream order: block g = role * (n / 8) + b of encryption e, eight draws as eight bytes in one LDS word
+    constexpr int PER = N / 8;
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const int g = tid + j * TP;                              // 6 TP = 3 PER blocks
+        u64 r[8];
+        chacha20_block(key, (u64)g, first_index + e, r);
+        u64 packed = 0;
+        if (g < PER) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) packed |= (u64)(unsigned char)draw_ternary(r[i]) << (8 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) packed |= (u64)(unsigned char)draw_noise(r[i]) << (8 * i);
+        }
+        lds[g] = packed;
+    }
+    __syncthreads();
+    u32 du[4], d1[4], d2[4];                                     // byte r of each: the draw at coefficient r * TP + tid
+    {
+        const signed char *bytes = (const signed char *)lds;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            u32 a = 0, b = 0, c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int coef = (4 * w + i) * TP + tid;
+                a |= (u32)(unsigned char)bytes[coef] << (8 * i);
+                b |= (u32)(unsigned char)bytes[N + coef] << (8 * i);
+                c |= (u32)(unsigned char)bytes[2 * N + coef] << (8 * i);
+            }
+            du[w] = a; d1[w] = b; d2[w] = c;
+        }
+    }
+    __syncthreads();                                             // the buffer goes back to the transforms
+    // (2) per prime
+#pragma unroll 1
+    for (u32 p = 0; p < k; ++p) {
+        const typename A::Mod m = A::mod(base, p);
+        const Modulus md = base.mod[p];
+        const u64 q = A::q(m);
+        u64 x[1][16], y[1][16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int v = enc_byte(du, r);
+            x[0][r] = v < 0 ? q - 1 : (u64)v;
+        }
+        A::fwd(x, base, p, m, lds, tid);                         // slot r of this thread: NTT-form word r * TP + tid
+        const u64 *p0 = pk_ntt + (size_t)p * N + tid, *p1 = pk_ntt + ((size_t)k + p) * N + tid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[0][r] = A::mul(x[0][r], p0[r * TP], m, md);
+        A::inv(y, base, p, m, lds, tid);                         // after a forward transform: no barrier needed (ntt_core.h, CONTRACT)
+        u64 *c0 = ct + ((e * 2) * k + p) * N + tid, *c1 = ct + ((e * 2 + 1) * k + p) * N + tid;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int nv = enc_byte(d1, r);
+            u64 v = addmod(y[0][r], nv < 0 ? q - (u64)(-nv) : (u64)nv, q);
+            if (plain) {
+                const u64 mm = plain[e * N + r * TP + tid];
+                if (mm) {
+                    u64 lift = mul_barrett(Lf.delta[p], mm % q, md);
+                    if (mm >= Lf.threshold) lift = addmod(lift, Lf.increment[p], q);
+                    v = addmod(v, lift, q);
+                }
+            }
+            c0[r * TP] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[0][r] = A::mul(x[0][r], p1[r * TP], m, md);
+        ntt_lds_release();                                       // the inverse transform above ended with a cross-wave read; this one starts wave-locally
+        A::inv(y, base, p, m, lds, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int nv = enc_byte(d2, r);
+            c1[r * TP] = addmod(y[0][r], nv < 0 ? q - (u64)(-nv) : (u64)nv, q);
+        }
+        ntt_lds_release();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_enc_draws(ChaChaKey key, u64 first_index, u64 count, signed char *__restrict__ out, u32 n) {
     const u64 per = n / 8, total = count * 3 * per;
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
@@ -376,6 +511,25 @@ extern "C" int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *d_pk_ntt, con
     if (c->n % 8) return fail(FHE_ERR_PARAM, "n must be a multiple of 8");
     hipStream_t st = (hipStream_t)s;
     const ChaChaKey k = load_key(key);
+    EncLift lift;
+    lift.threshold = c->upper_half_threshold;
+    for (u32 i = 0; i < FHE_MAX_K; ++i) { lift.delta[i] = i < c->k ? c->delta_mod[i] : 0; lift.increment[i] = i < c->k ? c->upper_half_increment[i] : 0; }
+    // one launch (k_enc_fused) where the base has register transforms this file instantiates: pseudo-Mersenne bases, and any other base of
+    // primes up to 58 bits on the lazy Shoup passes; FHE_ENC_UNFUSED=1 (and 59..61-bit primes) keeps the five launches below -- same bits
+    bool shoup_ok = c->max_prime_bits <= 58;                      // EncShoup: lazy passes (<= 58 bits) and the float quotient estimate of canon_below_64q (>= 2^33)
+    for (u32 i = 0; i < c->k; ++i) shoup_ok = shoup_ok && (c->qb.primes[i] >> 33);
+    if (!c->opt.enc_unfused && count <= 0x7fffffffULL && (shoup_ok || (c->qb.pm_class && !c->opt.ntt_nopm))) {
+        const RnsBase base = c->qb.dev();
+        if (c->qb.pm_class == 1 && !c->opt.ntt_nopm) {
+            DISPATCH_L(c->logn, (k_enc_fused<L, EncPm<L, PmA>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
+        } else if (c->qb.pm_class == 2 && !c->opt.ntt_nopm) {
+            DISPATCH_L(c->logn, (k_enc_fused<L, EncPm<L, PmB>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
+        } else {
+            DISPATCH_L(c->logn, (k_enc_fused<L, EncShoup<L>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
+        }
+        KERNEL_CHECK();
+        return FHE_OK;
+    }
     u64 *u = (u64 *)scratch;
     k_enc_sample_u<<<blocks_for(count * (c->n / 8)), 256, 0, st>>>(k, first_index, count, u, c->qb.d_mod, c->k, c->n);
     KERNEL_CHECK();
@@ -388,10 +542,7 @@ extern "C" int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *d_pk_ntt, con
         KERNEL_CHECK();
     }
     if ((rc = fhe_ntt_inverse(c, d_out, d_out, count * 2, s))) return rc;
-    EncLift L;
-    L.threshold = c->upper_half_threshold;
-    for (u32 i = 0; i < FHE_MAX_K; ++i) { L.delta[i] = i < c->k ? c->delta_mod[i] : 0; L.increment[i] = i < c->k ? c->upper_half_increment[i] : 0; }
-    k_enc_finish<<<blocks_for(count * 2 * (c->n / 8)), 256, 0, st>>>(k, first_index, count, (u64 *)d_out, (const u64 *)d_plain, c->qb.d_mod, c->k, c->n, L);
+    k_enc_finish<<<blocks_for(count * 2 * (c->n / 8)), 256, 0, st>>>(k, first_index, count, (u64 *)d_out, (const u64 *)d_plain, c->qb.d_mod, c->k, c->n, lift);
     KERNEL_CHECK();
     return FHE_OK;
 }

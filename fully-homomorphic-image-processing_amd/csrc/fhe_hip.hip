@@ -184,6 +184,11 @@ extern "C" int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out
     static const u64 s23_2048[] = {0x3fffffff000001ULL};
     static const u64 s23_4096[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL};
     static const u64 s23_8192[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x3fffffff000001ULL, 0x3ffffffef40001ULL};
+    // n = 16384 (the last column of the reference's benchmark grid, benchmark/benchmark.py:6): SEAL 2.3.1's 438-bit default, six
+    // 55-bit and two 54-bit primes -- the head of its tables of the largest primes = 1 (mod 2^18) of each width (the rule the entries
+    // above obey; recollection).  SEAL 3's default there has nine primes, more than FHE_MAX_K: both presets give this one
+    static const u64 s23_16384[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x7ffffffeac0001ULL, 0x7ffffffe700001ULL, 0x7ffffffe600001ULL, 0x7ffffffe4c0001ULL,
+                                    0x3fffffff000001ULL, 0x3ffffffef40001ULL};
     const u64 *src = nullptr;
     int cnt = 0;
 #define PICK(a) do { src = a; cnt = (int)(sizeof(a) / sizeof(a[0])); } while (0)
@@ -191,10 +196,12 @@ extern "C" int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out
         if (n == 4096) PICK(s3_4096);
         else if (n == 8192) PICK(s3_8192);
         else if (n == 2048 || n == 1024) PICK(s23_2048);
+        else if (n == 16384) PICK(s23_16384);
     } else if (preset == 1) {
         if (n == 2048 || n == 1024) PICK(s23_2048);
         else if (n == 4096) PICK(s23_4096);
         else if (n == 8192) PICK(s23_8192);
+        else if (n == 16384) PICK(s23_16384);
     }
 #undef PICK
     if (!src) return fail(FHE_ERR_PARAM, "no default coefficient modulus for n=%u preset=%d", n, preset);
@@ -236,6 +243,8 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.dct_u64_fused = !off("FHE_DCT_U64_FUSED");
         if (const char *e = getenv("FHE_DCT_ONE_LAUNCH")) o.dct_one_launch = (u32)atoi(e);
         o.relin_fused = env_on("FHE_RELIN_FUSED");
+        o.relin_steps = env_on("FHE_RELIN_STEPS");
+        o.enc_unfused = env_on("FHE_ENC_UNFUSED");
         o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
         o.ntt_single = env_on("FHE_NTT_SINGLE");
         o.ntt_nopm = env_on("FHE_NTT_NOPM");

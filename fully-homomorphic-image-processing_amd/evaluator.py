@@ -19,6 +19,8 @@ PRESETS = {
     "P8192": dict(n=8192, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),
     "SEAL23_4096": dict(n=4096, q=[0x7FFFFFFF380001, 0x3FFFFFFF000001], t=1 << 14),
     "SEAL23_2048": dict(n=2048, q=[0x3FFFFFFF000001], t=1 << 14),
+    "SEAL23_16384": dict(n=16384, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x7FFFFFFEAC0001, 0x7FFFFFFE700001, 0x7FFFFFFE600001, 0x7FFFFFFE4C0001,
+                                     0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),      # six 55-bit + two 54-bit primes, 438 bits
     "SEAL3_8192": dict(n=8192, q=[0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001, 0xFFFFFEBC001], t=1 << 14),
 }
 YQT = [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
@@ -371,7 +373,7 @@ class Evaluator:
         work = a.clone()                                   # the steps above the last one run in place
         count = work.numel() // (size * kn)
         out = torch.empty(tuple(a.shape[:-3]) + (2, self.ctx.k, self.ctx.n), dtype=a.dtype, device=a.device)
-        nbytes = _lib.load().fhe_relinearize_scratch_bytes(self.ctx.h, dbc, count)
+        nbytes = _lib.load().fhe_relinearize_n_scratch_bytes(self.ctx.h, size, dbc, count)
         scr = self._scratch_buf(nbytes)
         _lib.call("fhe_relinearize_n", self.ctx.h, _ptr(work), size, size * kn, _ptr(out), 2 * kn, count, _ptr(evk_ntt), dbc, _ptr(scr), nbytes, _stream())
         return out

@@ -1401,7 +1401,7 @@ public:
             throw std::invalid_argument("relinearize: a ciphertext of " + std::to_string(a.size()) + " polynomials needs " + std::to_string(a.size() - 2) +
                                         " evaluation keys (generate_evaluation_keys(dbc, count, keys)), these hold " + std::to_string(evk.count));
         const uint32_t sz = (uint32_t)a.size();
-        const size_t bytes = fhe_relinearize_scratch_bytes(st_->h, evk.dbc, 1);
+        const size_t bytes = fhe_relinearize_n_scratch_bytes(st_->h, sz, evk.dbc, 1);
         detail::DevBuf scratch_((bytes + 7) / 8);                              // per call: an Evaluator may be shared by threads
         const size_t pw = st_->poly_words();
         const uint64_t *keys = evk.device_keys();

@@ -53,9 +53,12 @@ int fhe_default_coeff_modulus(uint32_t n, int preset, uint64_t *q_out) {
     static const uint64_t s23_4096[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL};
     static const uint64_t s23_8192[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x3fffffff000001ULL,
                                         0x3ffffffef40001ULL};
+    static const uint64_t s23_16384[] = {0x7fffffff380001ULL, 0x7ffffffef00001ULL, 0x7ffffffeac0001ULL, 0x7ffffffe700001ULL,
+                                         0x7ffffffe600001ULL, 0x7ffffffe4c0001ULL, 0x3fffffff000001ULL, 0x3ffffffef40001ULL};
     const uint64_t *src = NULL;
     int cnt = 0;
     if (n == 2048 || n == 1024) { src = s23_2048; cnt = 1; }
+    else if (n == 16384) { src = s23_16384; cnt = 8; }
     else if (n == 4096) { src = preset ? s23_4096 : s3_4096; cnt = preset ? 2 : 3; }
     else if (n == 8192) { src = preset ? s23_8192 : s3_8192; cnt = preset ? 4 : 5; }
     if (!src || preset < 0 || preset > 1) return fail(FHE_ERR_PARAM, "no default coefficient modulus for n=%u", n);
@@ -391,6 +394,10 @@ int fhe_relinearize_poly(const fhe_ctx *c, const uint64_t *ct, uint64_t stride, 
     }
     free(tmp);
     return FHE_OK;
+}
+size_t fhe_relinearize_n_scratch_bytes(const fhe_ctx *c, uint32_t size, uint32_t dbc, uint64_t count) {
+    (void)c; (void)size; (void)dbc; (void)count;
+    return 8;
 }
 size_t fhe_evk_words(const fhe_ctx *c, uint32_t dbc) { return (size_t)c->k * fo_evk_digits(c->o, dbc) * 2 * pw(c); }
 int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, uint64_t stride, uint64_t *out2, uint64_t out_stride, uint64_t count,

@@ -21,6 +21,8 @@ PRESETS = {
     "P8192": dict(n=8192, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),
     "SEAL23_4096": dict(n=4096, q=[0x7FFFFFFF380001, 0x3FFFFFFF000001], t=1 << 14),
     "SEAL23_2048": dict(n=2048, q=[0x3FFFFFFF000001], t=1 << 14),
+    "SEAL23_16384": dict(n=16384, q=[0x7FFFFFFF380001, 0x7FFFFFFEF00001, 0x7FFFFFFEAC0001, 0x7FFFFFFE700001, 0x7FFFFFFE600001, 0x7FFFFFFE4C0001,
+                                     0x3FFFFFFF000001, 0x3FFFFFFEF40001], t=1 << 14),      # six 55-bit + two 54-bit primes, 438 bits
     "SEAL3_8192": dict(n=8192, q=[0x7FFFFFD8001, 0x7FFFFFC8001, 0xFFFFFFFC001, 0xFFFFFF6C001, 0xFFFFFEBC001], t=1 << 14),
 }
 

@@ -351,6 +351,10 @@ def test_relinearize_any_size_and_per_cubic_placement_vs_oracle(fhe, oracle_mod,
         got = h(ev.relinearize(x, relin[0] if size > 3 else relin[0][0].contiguous(), dbc))
         for i in range(3):
             assert np.array_equal(got[i], orc.relinearize_n(h(x)[i], evks, dbc)), (size, i)
+    # the one-pass form (all key switches as one sum, the default where the lazy sums have room) == the sequential steps (FHE_RELIN_STEPS=1)
+    x4 = ctx.random_ct(5, size=4, seed=950)
+    steps = fhe.Evaluator(fhe.SEALContext(ctx.n, ctx.q, ctx.t, switches={"FHE_RELIN_STEPS": 1}))
+    assert torch.equal(ev.relinearize(x4, relin[0], dbc), steps.relinearize(x4, relin[0], dbc))
     with pytest.raises(ValueError):
         ev.relinearize(ctx.random_ct(1, size=5, seed=1), relin[0], dbc)           # needs the keys for s^4 as well
     A, B, C, D = (ctx.random_ct(3, size=2, seed=400 + i) for i in range(4))
