@@ -186,10 +186,12 @@ template <int L, typename C> struct EncPm {
         for (int r = 0; r < 16; r++) x[0][r] = fold_pm(x[0][r], m);
     }
     static __device__ __forceinline__ u64 mul(u64 x, u64 w, const Mod &m, const Modulus &) { return mulvv_pm(x, w, m); }      // below RQ / 16 q
-    static __device__ __forceinline__ void inv(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
-        ntt_inv_regs_pm<L, 1, C::RQ, C::XB, C::LIM, C::RQ>(x, b.itw_pm + (size_t)p * N, m, lds, tid);
+    static __device__ __forceinline__ void inv(u64 (&x)[2][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_inv_regs_pm<L, 2, C::RQ, C::XB, C::LIM, C::RQ>(x, b.itw_pm + (size_t)p * N, m, lds, tid);
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[0][r] = canon_rq_pm<C::RQ>(x[0][r], m);
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[j][r] = canon_rq_pm<C::RQ>(x[j][r], m);
     }
 };
 template <int L> struct EncShoup {
@@ -203,27 +205,31 @@ template <int L> struct EncShoup {
         for (int r = 0; r < 16; r++) x[0][r] = canon_below_64q(x[0][r], m.m.q, m.cs);
     }
     static __device__ __forceinline__ u64 mul(u64 x, u64 w, const Mod &, const Modulus &md) { return mul_barrett(x, w, md); }  // canonical
-    static __device__ __forceinline__ void inv(u64 (&x)[1][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
-        ntt_inv_regs4<L, true>(x[0], b.itw + (size_t)p * N, m.m, lds, tid);       // [0, 4q) in and out
+    static __device__ __forceinline__ void inv(u64 (&x)[2][16], const RnsBase &b, u32 p, const Mod &m, u64 *lds, int tid) {
+        ntt_inv_regs4m<L, 2, true>(x, b.itw + (size_t)p * N, m.m, lds, tid);      // [0, 4q) in and out
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[0][r] = csub(csub(x[0][r], 2 * m.m.q), m.m.q);
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[j][r] = csub(csub(x[j][r], 2 * m.m.q), m.m.q);
     }
 };
+template <int L> using EncPmA = EncPm<L, PmA>;
+template <int L> using EncPmB = EncPm<L, PmB>;
 __device__ __forceinline__ int enc_byte(const u32 (&w)[4], int r) { return (int)(w[r >> 2] << (24 - 8 * (r & 3))) >> 24; }      // sign-extended byte r
 
-template <int L, typename A>
-__global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key, u64 first_index, u64 *__restrict__ ct, const u64 *__restrict__ plain,
+template <int L, typename A, int OCC>
+__global__ __launch_bounds__(NttShape<L>::TP, OCC) void k_enc_fused(ChaChaKey key, u64 first_index, u64 *__restrict__ ct, const u64 *__restrict__ plain,
                                                                    const u64 *__restrict__ pk_ntt, RnsBase base, EncLift Lf) {
     __shared__ u64 lds[NttShape<L>::LDS_WORDS];
     constexpr int N = NttShape<L>::N, TP = NttShape<L>::TP;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const u64 e = blockIdx.x;
     const u32 k = base.count;
     // (1) the draws, in stream order: block g = role * (n / 8) + b of encryption e, eight draws as eight bytes in one LDS word
     constexpr int PER = N / 8;
 #pragma unroll 1
     for (int j = 0; j < 6; ++j) {
-        const int g = tid + j * TP;                              // 6 TP = 3 PER blocks
+        const int g = tid0 + j * TP;                              // 6 TP = 3 PER blocks
         u64 r[8];
         chacha20_block(key, (u64)g, first_index + e, r);
         u64 packed = 0;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key,
             u32 a = 0, b = 0, c = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int coef = (4 * w + i) * TP + tid;
+                const int coef = (4 * w + i) * TP + tid0;
                 a |= (u32)(unsigned char)bytes[coef] << (8 * i);
                 b |= (u32)(unsigned char)bytes[N + coef] << (8 * i);
                 c |= (u32)(unsigned char)bytes[2 * N + coef] << (8 * i);
@@ -257,10 +263,16 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key,
     // (2) per prime
 #pragma unroll 1
     for (u32 p = 0; p < k; ++p) {
+        // the packed draws are loop-invariant: without this the compiler unpacks all 48 bytes ONCE, before the loop, and keeps them in
+        // 48 registers across the transforms (800 B of scratch per lane); declared modified here, they are unpacked where they are used
+#pragma unroll
+        for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(du[w]), "+v"(d1[w]), "+v"(d2[w]));
+        int tid = tid0;                                          // likewise the thread index: every LDS / global address of the transforms is a function of
+        asm volatile("" : "+v"(tid));                            // it, and hoisted out of the loop they cost another 60 spilled registers
         const typename A::Mod m = A::mod(base, p);
         const Modulus md = base.mod[p];
         const u64 q = A::q(m);
-        u64 x[1][16], y[1][16];
+        u64 x[1][16], y[2][16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int v = enc_byte(du, r);
@@ -269,7 +281,10 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key,
         A::fwd(x, base, p, m, lds, tid);                         // slot r of this thread: NTT-form word r * TP + tid
         const u64 *p0 = pk_ntt + (size_t)p * N + tid, *p1 = pk_ntt + ((size_t)k + p) * N + tid;
 #pragma unroll
-        for (int r = 0; r < 16; r++) y[0][r] = A::mul(x[0][r], p0[r * TP], m, md);
+        for (int r = 0; r < 16; r++) {                           // both key products per slot; x dies here: the two inverse transforms run as a
+            y[0][r] = A::mul(x[0][r], p0[r * TP], m, md);        // PAIR (one set of twiddle loads, the register budget of the pair kernels)
+            y[1][r] = A::mul(x[0][r], p1[r * TP], m, md);
+        }
         A::inv(y, base, p, m, lds, tid);                         // after a forward transform: no barrier needed (ntt_core.h, CONTRACT)
         u64 *c0 = ct + ((e * 2) * k + p) * N + tid, *c1 = ct + ((e * 2 + 1) * k + p) * N + tid;
 #pragma unroll
@@ -287,13 +302,9 @@ __global__ __launch_bounds__(NttShape<L>::TP, 2) void k_enc_fused(ChaChaKey key,
             c0[r * TP] = v;
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) y[0][r] = A::mul(x[0][r], p1[r * TP], m, md);
-        ntt_lds_release();                                       // the inverse transform above ended with a cross-wave read; this one starts wave-locally
-        A::inv(y, base, p, m, lds, tid);
-#pragma unroll
         for (int r = 0; r < 16; r++) {
             const int nv = enc_byte(d2, r);
-            c1[r * TP] = addmod(y[0][r], nv < 0 ? q - (u64)(-nv) : (u64)nv, q);
+            c1[r * TP] = addmod(y[1][r], nv < 0 ? q - (u64)(-nv) : (u64)nv, q);
         }
         ntt_lds_release();
     }
@@ -520,13 +531,16 @@ extern "C" int fhe_encrypt_batch(const fhe_ctx *c, const uint64_t *d_pk_ntt, con
     for (u32 i = 0; i < c->k; ++i) shoup_ok = shoup_ok && (c->qb.primes[i] >> 33);
     if (!c->opt.enc_unfused && count <= 0x7fffffffULL && (shoup_ok || (c->qb.pm_class && !c->opt.ntt_nopm))) {
         const RnsBase base = c->qb.dev();
-        if (c->qb.pm_class == 1 && !c->opt.ntt_nopm) {
-            DISPATCH_L(c->logn, (k_enc_fused<L, EncPm<L, PmA>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
-        } else if (c->qb.pm_class == 2 && !c->opt.ntt_nopm) {
-            DISPATCH_L(c->logn, (k_enc_fused<L, EncPm<L, PmB>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
-        } else {
-            DISPATCH_L(c->logn, (k_enc_fused<L, EncShoup<L>><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)));
-        }
+        // OCC = waves per SIMD asked of the register allocator: 2 (256 VGPRs, no scratch to speak of, one workgroup per CU at n = 8192; the default:
+        // 0.67 against 0.77 us per ciphertext at P8192, 0.38 against 0.50 at P4096) or 4 (128 VGPRs, 300-500 bytes of scratch per lane, two workgroups per
+        // CU; FHE_ENC_OCC=4) -- profiles/EXPERIMENTS.md section 13
+#define GO_ENC(AA, OCC) DISPATCH_L(c->logn, (k_enc_fused<L, AA<L>, OCC><<<(unsigned)count, NttShape<L>::TP, 0, st>>>(k, first_index, (u64 *)d_out, (const u64 *)d_plain, (const u64 *)d_pk_ntt, base, lift)))
+#define GO_ENC2(AA) do { if (c->opt.enc_occ4) { GO_ENC(AA, 4); } else { GO_ENC(AA, 2); } } while (0)
+        if (c->qb.pm_class == 1 && !c->opt.ntt_nopm) { GO_ENC2(EncPmA); }
+        else if (c->qb.pm_class == 2 && !c->opt.ntt_nopm) { GO_ENC2(EncPmB); }
+        else { GO_ENC2(EncShoup); }
+#undef GO_ENC2
+#undef GO_ENC
         KERNEL_CHECK();
         return FHE_OK;
     }

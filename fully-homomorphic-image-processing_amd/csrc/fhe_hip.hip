@@ -245,6 +245,7 @@ extern "C" int fhe_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_
         o.relin_fused = env_on("FHE_RELIN_FUSED");
         o.relin_steps = env_on("FHE_RELIN_STEPS");
         o.enc_unfused = env_on("FHE_ENC_UNFUSED");
+        { const char *e = std::getenv("FHE_ENC_OCC"); o.enc_occ4 = e && e[0] == '4'; }
         o.ntt_nolazy = env_on("FHE_NTT_NOLAZY");
         o.ntt_single = env_on("FHE_NTT_SINGLE");
         o.ntt_nopm = env_on("FHE_NTT_NOPM");

@@ -63,6 +63,7 @@ struct FheOptions {
     bool plain_sum_unfused = false;  // FHE_PLAIN_SUM_UNFUSED=1: the Taylor / harmonic sums as separate multiply_plain calls and additions (before k_mulplain_sum_pm)
     bool cubic_unfused = false;      // FHE_CUBIC_UNFUSED=1: Cubic's three products as three complete fhe_multiply calls + k_cubic_combine_g (before round 4's fused tail)
     bool enc_unfused = false;        // FHE_ENC_UNFUSED=1: fhe_encrypt_batch as the five launches of round 5 (k_enc_sample_u, transforms, k_enc_pk_mul, k_enc_finish) instead of k_enc_fused
+    bool enc_occ4 = false;           // FHE_ENC_OCC=4: k_enc_fused built for four waves per SIMD (128 VGPRs, scratch) instead of two
     bool relin_steps = false;        // FHE_RELIN_STEPS=1: fhe_relinearize_n runs its key switches one after the other (round 6: the default folds them into one pass, behz.hip relin_pm)
     bool relin_fused = false;        // FHE_RELIN_FUSED=1 (experiment, round 5): key-switch accumulation inside the inverse-transform kernel (k_relin_accum_inv_add_pm: one launch and
                                      // 4 MB of traffic per relinearisation less, same bits, 1-3 % SLOWER at dbc = 30 -- the digits are read twice and the kernels are issue-bound; profiles/EXPERIMENTS.md)

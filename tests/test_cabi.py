@@ -25,8 +25,8 @@ def test_library_exports_every_declared_symbol(fhe):
         assert hasattr(lib, name), "libfhe_hip.so does not export %s" % name
     # and the Python binding table covers the whole header
     assert set(names) == set(fhe._lib.SIGNATURES), set(names) ^ set(fhe._lib.SIGNATURES)
-    assert lib.fhe_abi_version() == fhe._lib.ABI_VERSION == 3
-    assert re.search(r"#define FHE_ABI_VERSION 3\b", open(fhe.HEADER_PATH).read())
+    assert lib.fhe_abi_version() == fhe._lib.ABI_VERSION == 4
+    assert re.search(r"#define FHE_ABI_VERSION 4\b", open(fhe.HEADER_PATH).read())
 
 
 def test_no_oracle_dependency_in_product(fhe):

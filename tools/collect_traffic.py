@@ -190,6 +190,43 @@ def circuits(f_read, f_write):
     print(json.dumps({k: (v if not isinstance(v, dict) else {x: v[x] for x in v if x != "per_kernel"}) for k, v in res.items()}))
 
 
+# ---- the servers' own encryptions (csrc/encrypt.hip): one batch of 8192 at P8192, fused (default) and as five launches ----------------
+ENC_BATCH, ENC_REPS = 8192, 3        # 8192 x 512 KiB = 4 GiB of ciphertexts per batch: far beyond the Infinity Cache
+ENC = [sys.executable, "-c",
+       "import sys; sys.path.insert(0, %r); import numpy as np, torch, fhip_amd as fhe; ctx = fhe.SEALContext.preset('P8192'); "
+       "der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx, seed=1).public_key()); v = np.linspace(0, 1, %d); "
+       "[der.encrypt_values(v) for _ in range(%d)]; torch.cuda.synchronize()" % (ROOT, ENC_BATCH, ENC_REPS)]
+ENC_KERNELS = ["k_enc_fused", "k_enc_sample_u", "k_enc_pk_mul", "k_enc_finish", "k_ntt_fwd", "k_ntt_inv", "k_frac_encode"]
+
+
+def encrypt(f_read, f_write):
+    k, n = 4, 8192
+    out_bytes = 2 * k * n * 8                                      # the ciphertext: 524,288 B (+ 64 KiB of plaintext coefficients read)
+    res = {"output_bytes_per_ciphertext": out_bytes, "ciphertexts_per_dispatch": ENC_BATCH, "read_factor": f_read, "write_factor": f_write,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), summed over every launch of %d x DeviceEncryptor.encrypt_values(%d values) "
+                     "at P8192, per ciphertext; factors as calibrated for pmc_traffic.json; tools/collect_traffic.py encrypt" % (ENC_REPS, ENC_BATCH)}
+    for tag, env in (("fused", {}), ("five_launches", {"FHE_ENC_UNFUSED": "1"})):
+        os.environ.update(env)
+        rd, calls = run_pass_sum(["FETCH_SIZE"], "enc_fetch_" + tag, ENC, ENC_KERNELS)
+        wr, _ = run_pass_sum(["WRITE_SIZE"], "enc_write_" + tag, ENC, ENC_KERNELS)
+        for name in env:
+            os.environ.pop(name)
+        cts = ENC_BATCH * ENC_REPS
+        per, total = {}, 0.0
+        for m in ENC_KERNELS:
+            if not calls.get(m):
+                continue
+            r, w = rd[m] * 1024 * f_read / cts, wr[m] * 1024 * f_write / cts
+            per[m] = {"read_bytes_per_ciphertext": r, "write_bytes_per_ciphertext": w, "launches_per_batch": calls[m] / ENC_REPS}
+            total += r + w
+        res[tag] = {"hbm_bytes_per_ciphertext": total, "ratio_to_output_bytes": total / out_bytes, "per_kernel": per}
+    for d in ("profiles", "gpurun_out"):
+        os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+        with open(os.path.join(ROOT, d, "pmc_traffic_encrypt.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
 def main():
     cal_bytes = CAL_CTS * 2 * 3 * 4096 * 8
     crd, cnames = run_pass(["FETCH_SIZE"], "cal_fetch", CAL, ["k_poly_f64"])
@@ -200,6 +237,8 @@ def main():
         return ctct(f_read, f_write)
     if "circuits" in sys.argv[1:]:
         return circuits(f_read, f_write)
+    if "encrypt" in sys.argv[1:]:
+        return encrypt(f_read, f_write)
     rd, names = run_pass(["FETCH_SIZE"], "fetch", CMD, ["k_dct_rows", "k_dct_cols"])
     wr, _ = run_pass(["WRITE_SIZE"], "write", CMD, ["k_dct_rows", "k_dct_cols"])
     per_kernel, total = {}, 0.0
