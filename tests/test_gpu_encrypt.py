@@ -58,7 +58,31 @@ def test_device_encoder_equals_host_encoder(fhe, oracle_mod):
         assert np.array_equal(got[i].cpu().numpy().view(np.uint64), fe.encode(float(many[i]))), i
 
 
-@pytest.mark.parametrize("preset", ["P4096", "SEAL23_4096", "SEAL23_2048", "P8192", "SEAL3_8192"])
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_4096", "SEAL23_2048", "P8192", "SEAL3_8192", "SEAL23_16384"])
+def test_fused_encryption_kernel_equals_the_five_launches(fhe, preset):
+    """fhe_encrypt_batch as ONE launch (k_enc_fused: draws, forward transform, both key products, the pair of inverse transforms, noise
+    and Delta m' per workgroup; pseudo-Mersenne arithmetic on SEAL's 54 / 55-bit primes, lazy Shoup arithmetic on the 36 / 43-bit sets),
+    built for two and for four waves per SIMD (FHE_ENC_OCC=4), against the five launches of round 5 (FHE_ENC_UNFUSED=1): the same
+    (key, index) stream, the same exact arithmetic, the same bits -- 70 ciphertexts (not a multiple of anything) with plaintexts in
+    both halves of [0, t), and encryptions of zero."""
+    ctx = fhe.SEALContext.preset(preset)
+    kg = fhe.KeyGenerator(ctx, seed=5)
+    vals = np.linspace(-300.0, 300.0, 70)
+    outs, zeros = [], []
+    for sw in ({}, {"FHE_ENC_OCC": 4}, {"FHE_ENC_UNFUSED": 1}):
+        c2 = fhe.SEALContext(ctx.n, ctx.q, ctx.t, switches=sw) if sw else ctx
+        der = fhe.DeviceEncryptor(c2, kg.public_key(), key=KEY, reproducible=True)
+        der.seek(1 << 40)
+        outs.append(der.encrypt_values(vals))
+        zeros.append(der.encrypt_zeros(3))
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(zeros[0], zeros[2]) and torch.equal(zeros[1], zeros[2])
+    dec, fe = fhe.Decryptor(ctx, kg.secret_key()), fhe.FractionalEncoder(ctx)
+    plains, budgets = dec.decrypt_batch(outs[0][:4], with_budget=True)
+    assert [fe.decode(p) for p in plains] == [fe.decode(fe.encode(v)) for v in vals[:4]] and min(budgets) > 20
+
+
+@pytest.mark.parametrize("preset", ["P4096", "SEAL23_4096", "SEAL23_2048", "P8192", "SEAL3_8192", "SEAL23_16384"])
 def test_encrypt_batch_equals_the_oracle_bit_for_bit(fhe, oracle_mod, preset):
     ctx, orc = _pair(fhe, oracle_mod, preset)
     kg = fhe.KeyGenerator(ctx, seed=11)

@@ -12,6 +12,7 @@ python tools/collect_traffic.py ctct > $O/collect_traffic_ctct.log 2>&1; cp gpur
 FHE_BEHZ_FUSED_PREPARE=1 python tools/collect_traffic.py ctct > $O/collect_traffic_ctct_fused.log 2>&1; cp gpurun_out/pmc_traffic_ctct.json $O/pmc_traffic_ctct_fused_prepare.json
 cp $O/pmc_traffic_ctct.json profiles/pmc_traffic_ctct.json
 python tools/collect_traffic.py circuits > $O/collect_traffic_circuits.log 2>&1; cp gpurun_out/pmc_traffic_circuits.json $O/pmc_traffic_circuits.json
+python tools/collect_traffic.py encrypt > $O/collect_traffic_encrypt.log 2>&1; cp gpurun_out/pmc_traffic_encrypt.json $O/pmc_traffic_encrypt.json
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --cpu-blocks 0 > $O/bench_default_with_traffic.json 2>/dev/null
@@ -27,6 +28,8 @@ python bench_circuits.py resize --shared --cpu-pixels 4 > $O/bench_circuits_resi
 python bench_circuits.py decode --cpu-terms 2 > $O/bench_circuits_decode.json 2> /dev/null
 # the relinearised mode: the same workloads with evaluator.relinearize after every product, dbc 30 (the reference's unused DBC) and 60
 for dbc in 30 60; do
+  python bench_circuits.py resize --relin $dbc --relin-placement cubic --cpu-pixels 2 > $O/bench_circuits_resize_relin${dbc}_cubic.json 2> /dev/null
+  python bench_circuits.py resize --shared --relin $dbc --relin-placement cubic > $O/bench_circuits_resize_shared_relin${dbc}_cubic.json 2> /dev/null
   python bench_circuits.py resize --relin $dbc > $O/bench_circuits_resize_relin$dbc.json 2> /dev/null
   python bench_circuits.py resize --shared --relin $dbc > $O/bench_circuits_resize_shared_relin$dbc.json 2> /dev/null
   python bench_circuits.py decode --relin $dbc > $O/bench_circuits_decode_relin$dbc.json 2> /dev/null
@@ -43,12 +46,23 @@ python tools/bench_encrypt.py P8192 8192 2>/dev/null | tail -1 >> $O/bench_encry
 for m in bank device host; do python tools/bench_server_resize.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_resize_encryptions.txt; done
 for m in device host; do python tools/bench_server_decode.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_decode_encryptions.txt; done
 fully-homomorphic-image-processing_amd/seal/multi_gpu_dct 1024 4 64 1 > $O/cpp_multi_gpu_dct.json 2>&1
+fully-homomorphic-image-processing_amd/seal/multi_gpu_dct 1024 1 256 0 resident 20 > $O/cpp_multi_gpu_dct_resident.json 2>&1
+# the one command the driver runs at N > 1, on this one device over gloo (schema + every leg; the physics needs N devices)
+FHE_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_world2_gloo_one_device.json 2>/dev/null
+FHE_BENCH_BACKEND=gloo python bench_circuits.py resize --shared --gpus 2 > $O/bench_circuits_resize_shared_world2_gloo.json 2>/dev/null
+python tools/results_table.py > $O/results_table.json 2>/dev/null
+FHE_ENC_UNFUSED=1 python tools/bench_encrypt.py P8192 512 2>/dev/null | tail -1 | sed 's/^/UNFUSED /' >> $O/bench_encrypt.txt
+FHE_ENC_OCC=4 python tools/bench_encrypt.py P8192 512 2>/dev/null | tail -1 | sed 's/^/OCC4 /' >> $O/bench_encrypt.txt
 fully-homomorphic-image-processing_amd/seal/bench_resize > $O/bench_resize_cpp_host.txt 2>&1
 python tools/run_ref_cli.py 48 48 --golden --pmod 3001 > $O/ref_cli_config0_lazy.txt 2>&1
 FHE_FACADE_EAGER=1 python tools/run_ref_cli.py 48 48 --golden --pmod 3001 > $O/ref_cli_config0_eager.txt 2>&1
 python tools/run_ref_resize.py bicubic 4096 101 > $O/ref_cli_resize.txt 2>&1
 python tools/run_ref_resize.py bilinear 4096 101 >> $O/ref_cli_resize.txt 2>&1
 FHE_FACADE_RELIN=30 python tools/run_ref_resize.py bicubic 4096 101 > $O/ref_cli_resize_relin30.txt 2>&1
+# the last two columns of the reference's grid end to end (benchmark/benchmark.py:6)
+for n in 8192 16384; do python oracle/pin_against_reference.py --gpu --n $n --pmod 101 1009 3001 --jobs 2 > $O/ref_grid_jpeg_$n.txt 2>&1; done
+python oracle/pin_against_reference.py --gpu --n 16384 --resize bicubic --pmod 31 100003 --jobs 2 > $O/ref_grid_bicubic_16384.txt 2>&1
+python oracle/pin_against_reference.py --gpu --n 16384 --resize bilinear --pmod 31 100003 --jobs 2 > $O/ref_grid_bilinear_16384.txt 2>&1
 tools/prof.sh ${1}_bench python $R/bench.py --cpu-blocks 0 --no-verify > $O/kernel_stats_bench_default.txt 2>&1
 tools/prof.sh ${1}_resize python $R/bench_circuits.py resize > $O/kernel_stats_resize.txt 2>&1
 tools/prof.sh ${1}_resize_shared python $R/bench_circuits.py resize --shared > $O/kernel_stats_resize_shared.txt 2>&1
