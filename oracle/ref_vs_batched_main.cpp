@@ -14,6 +14,10 @@
 // FHE_FACADE_RELIN=<dbc>: the RELINEARISED mode on both sides -- (1) the reference's unchanged functions with the facade relinearising
 // after every multiply / square, (2) seal::hip::Circuits built with the same keys (fhe_circuits_create_relin): every ciphertext has
 // two polynomials and the two evaluations must still agree bit for bit.
+// FHE_XCHECK_PER_CUBIC=<dbc>: the SECOND placement of the relinearised mode (include/fhe_circuits.h FHE_RELIN_PER_CUBIC): (1) the reference's
+// unchanged Cubic / Linear followed by ONE evaluator.relinearize(result, keys) of the facade (keys for s^2 and s^3 from
+// generate_evaluation_keys(dbc, 2, keys): a size-4 ciphertext to 2 in one call, as SEAL's relinearize), the samplers composed from those
+// calls exactly as homo/fhe_resize.h:237-248,293-303 compose them; (2) seal::hip::Circuits(context, keys, 100, 100, true).  Resize circuits only.
 // Built at -O0 with the stack scrubbed before the decode circuits: homomorphic_cos has no return statement
 // (homo/fhe_decode.h:200), see ref_decode_circuit_main.cpp.
 #include <cstdio>
@@ -79,11 +83,24 @@ int main(int argc, char **argv) {
         seal::detail::check(fhe_fill_random(st.h, b.ptr(), count * size, 0x5EA12026ULL + 977 * seed++, 0, nullptr), "fill");
         return b;
     };
-    const bool relin = std::getenv("FHE_FACADE_RELIN") != nullptr;
-    std::unique_ptr<seal::hip::Circuits> circ_p(relin ? new seal::hip::Circuits(context, seal::hip::Circuits::context_relin_keys(context), 100, 100)
-                                                      : new seal::hip::Circuits(context, 100, 100));
+    const int per_cubic = std::getenv("FHE_XCHECK_PER_CUBIC") ? std::atoi(std::getenv("FHE_XCHECK_PER_CUBIC")) : 0;
+    const bool relin = std::getenv("FHE_FACADE_RELIN") != nullptr || per_cubic;      // either way: every operand and result has two polynomials
+    EvaluationKeys evk2;
+    if (per_cubic) keygen.generate_evaluation_keys(per_cubic, 2, evk2);
+    std::unique_ptr<seal::hip::Circuits> circ_p(per_cubic ? new seal::hip::Circuits(context, evk2, 100, 100, true)
+                                                : relin ? new seal::hip::Circuits(context, seal::hip::Circuits::context_relin_keys(context), 100, 100)
+                                                        : new seal::hip::Circuits(context, 100, 100));
     seal::hip::Circuits &circ = *circ_p;
     if (relin != circ.relinearises()) { std::printf("MISMATCH: handle mode\n"); return 1; }
+    // the reference's function, then the one relinearize of the per-Cubic placement
+    auto ref_cubic = [&](Ciphertext &res, Ciphertext a, Ciphertext b, Ciphertext c, Ciphertext d, Ciphertext tt) {
+        Cubic(res, a, b, c, d, tt, evaluator, encoder, encryptor);                                  // homo/fhe_resize.h:143
+        if (per_cubic) evaluator.relinearize(res, evk2);
+    };
+    auto ref_linear = [&](Ciphertext &res, Ciphertext a, Ciphertext b, Ciphertext tt) {
+        Linear(res, a, b, tt, evaluator, encoder, encryptor);                                       // homo/fhe_resize.h:191
+        if (per_cubic) evaluator.relinearize(res, evk2);
+    };
 
     // ---- Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 and 3 -> 4 ----------------------------
     // (relinearised mode: every operand has two polynomials, so only the first of each)
@@ -92,8 +109,8 @@ int main(int argc, char **argv) {
         CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), C = random_batch(cnt, size), D = random_batch(cnt, size), T = random_batch(cnt, 2);
         CiphertextBatch got = circ.cubic(A, B, C, D, T);
         for (size_t i = 0; i < cnt; ++i) {
-            Ciphertext a = A.get(i), b = B.get(i), c = C.get(i), d = D.get(i), tt = T.get(i), res;
-            Cubic(res, a, b, c, d, tt, evaluator, encoder, encryptor);                              // homo/fhe_resize.h:143
+            Ciphertext res;
+            ref_cubic(res, A.get(i), B.get(i), C.get(i), D.get(i), T.get(i));
             expect_equal(size == 2 ? "Cubic(2)" : "Cubic(4)", i, res, got, i);
         }
     }
@@ -102,8 +119,8 @@ int main(int argc, char **argv) {
         CiphertextBatch A = random_batch(cnt, size), B = random_batch(cnt, size), T = random_batch(cnt, 2);
         CiphertextBatch got = circ.linear(A, B, T);
         for (size_t i = 0; i < cnt; ++i) {
-            Ciphertext a = A.get(i), b = B.get(i), tt = T.get(i), res;
-            Linear(res, a, b, tt, evaluator, encoder, encryptor);                                   // homo/fhe_resize.h:191
+            Ciphertext res;
+            ref_linear(res, A.get(i), B.get(i), T.get(i));
             expect_equal(size == 2 ? "Linear(2)" : "Linear(3)", i, res, got, i);
         }
     }
@@ -125,11 +142,28 @@ int main(int argc, char **argv) {
             float v = float(y) / float(h - 1) * float(H) - 0.5;                                     // :351
             for (int x = 0; x < w; ++x) {
                 float u = float(x) / float(w - 1) * float(W) - 0.5;                                 // :382
+                std::vector<Ciphertext> sample(3);
+                if (per_cubic) {            // the samplers' composition (:237-248, :293-303) with the relinearising Cubic / Linear above
+                    const uint32_t *tp = plan.taps.data() + (size_t)(y * w + x) * (bicubic ? 16 : 4);
+                    for (int ch = 0; ch < 3; ++ch) {
+                        Ciphertext xo = xf.get(y * w + x), yo = yf.get(y * w + x);
+                        if (bicubic) {
+                            Ciphertext col[4];
+                            for (int r = 0; r < 4; ++r) ref_cubic(col[r], chan[ch].get(tp[4 * r]), chan[ch].get(tp[4 * r + 1]), chan[ch].get(tp[4 * r + 2]), chan[ch].get(tp[4 * r + 3]), xo);
+                            ref_cubic(sample[ch], col[0], col[1], col[2], col[3], yo);
+                        } else {
+                            Ciphertext c0, c1;
+                            ref_linear(c0, chan[ch].get(tp[0]), chan[ch].get(tp[1]), xo);
+                            ref_linear(c1, chan[ch].get(tp[2]), chan[ch].get(tp[3]), xo);
+                            ref_linear(sample[ch], c0, c1, yo);
+                        }
+                    }
+                } else {
                 g_hook.push_back(xf.get(y * w + x));
                 g_hook.push_back(yf.get(y * w + x));
-                std::vector<Ciphertext> sample(3);
                 if (bicubic) SampleBicubic(sample, image, u, v, evaluator, encoder, encryptor);     // :386
                 else SampleLinear(sample, image, u, v, evaluator, encoder, encryptor);              // :384
+                }
                 for (int ch = 0; ch < 3; ++ch) expect_equal(bicubic ? "SampleBicubic" : "SampleLinear", (size_t)(y * w + x) * 3 + ch, sample[ch], got[ch], y * w + x);
             }
         }
@@ -144,17 +178,30 @@ int main(int argc, char **argv) {
             float v = float(y) / float(h - 1) * float(H) - 0.5;
             for (int x = 0; x < w; ++x) {
                 float u = float(x) / float(w - 1) * float(W) - 0.5;
+                std::vector<Ciphertext> sample(3);
+                if (per_cubic) {
+                    seal::hip::SamplePlan plan = seal::hip::resize_sample_plan(W, H, w, h, 1);
+                    const uint32_t *tp = plan.taps.data() + (size_t)(y * w + x) * 16;
+                    Ciphertext col[4];
+                    for (int r = 0; r < 4; ++r) ref_cubic(col[r], chan[1].get(tp[4 * r]), chan[1].get(tp[4 * r + 1]), chan[1].get(tp[4 * r + 2]), chan[1].get(tp[4 * r + 3]), xf.get(x));
+                    ref_cubic(sample[0], col[0], col[1], col[2], col[3], yf.get(y));
+                } else {
                 g_hook.push_back(xf.get(x));
                 g_hook.push_back(yf.get(y));
-                std::vector<Ciphertext> sample(3);
                 SampleBicubic(sample, one, u, v, evaluator, encoder, encryptor);
+                }
                 expect_equal("resize_bicubic(shared)", (size_t)y * w + x, sample[0], got, (size_t)y * w + x);
             }
         }
     }
     std::printf("\n");
 
-    // ---- decode path ----------------------------------------------------------------------------------------------------
+    // ---- decode path (not in the per-Cubic placement: no Cubic to end; the library refuses such a handle there) ------------
+    if (per_cubic) {
+        bool refused = false;
+        try { CiphertextBatch X = random_batch(1, 2), Z = random_batch(1, 2); circ.homomorphic_sin(X, Z); } catch (const std::exception &) { refused = true; }
+        if (!refused) { std::printf("MISMATCH: the per-Cubic handle evaluated a decode circuit\n"); ++g_fail; }
+    } else {
     {
         const size_t cnt = 2;
         CiphertextBatch X = random_batch(cnt, 2), Z = random_batch(cnt, 2);
@@ -206,6 +253,7 @@ int main(int argc, char **argv) {
         }
         for (size_t k = 0; k < npos; ++k) expect_equal("decode_channel", k, channel[k], got, k);
         if (host(index) != host(index_b)) { std::printf("MISMATCH decode_channel index\n"); ++g_fail; }
+    }
     }
     std::printf("\n");
     if (!g_hook.empty()) { std::printf("MISMATCH: %zu hook ciphertexts unused\n", g_hook.size()); ++g_fail; }

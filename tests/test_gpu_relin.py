@@ -439,3 +439,50 @@ def test_samplers_per_cubic_placement_vs_oracle_and_decrypt(fhe, oracle_mod, pre
     assert lin.shape[1] == 2
     for o in (0, 9):
         assert np.array_equal(lin[o], oracle_mod.oracle_sample_linear_calls(torc, [pix[i] for i in tl[o]], xl[o], yl[o])), o
+
+
+def test_streaming_server_resize_with_the_per_cubic_placement(fhe, oracle_mod, tmp_path):
+    """server.server_resize(relin=(keys, dbc, "cubic")), per-pixel offsets and shared offsets: records of size 2, each equal to the oracle's
+    composition `reference sequence -> relinearize` on the same stream (TailRelinOracle), bicubic and bilinear"""
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from refrun import clamp, read_records, sample_origins, write_record
+    ctx, orc, torc, relin, _, _, _ = _setup_tail(fhe, oracle_mod, "SEAL23_4096", 30)
+    W = H = 10
+    w = h = 6
+    pix = orc.random_ct(W * H * 3, seed=21).reshape(W * H, 3, 2, orc.k, orc.n)
+    fin, fout = tmp_path / "in.ct", tmp_path / "out.ct"
+    with open(fin, "wb") as f:
+        for p in range(W * H):
+            for c in range(3):
+                write_record(f, pix[p, c])
+    bank = orc.random_ct(w * h * 2, seed=22)
+    pos = [0]
+
+    def encrypt(values):
+        out = bank[pos[0]:pos[0] + len(values)]
+        pos[0] += len(values)
+        return fhe.to_device(np.ascontiguousarray(out))
+    origins = sample_origins(W, H, w, h)
+    for bicubic in (True, False):
+        pos[0] = 0
+        assert fhe.server.server_resize(ctx, str(fin), str(fout), W, H, w, h, bicubic, encrypt, rows_per_step=3, relin=relin) == w * h
+        out = read_records(str(fout), 2, orc.k, orc.n, w * h * 3)
+        for o in (0, 7, w * h - 1):
+            xi, yi = origins[o]
+            P = lambda dx, dy, ch: pix[clamp(yi + dy, 0, H - 1) * W + clamp(xi + dx, 0, W - 1), ch]
+            for ch in (0, 2):
+                if bicubic:
+                    want = oracle_mod.oracle_sample_bicubic_calls(torc, [P(dx, dy, ch) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)], bank[2 * o], bank[2 * o + 1])
+                else:
+                    want = oracle_mod.oracle_sample_linear_calls(torc, [P(0, 0, ch), P(1, 0, ch), P(0, 1, ch), P(1, 1, ch)], bank[2 * o], bank[2 * o + 1])
+                assert np.array_equal(out[o * 3 + ch], want), (bicubic, o, ch)
+    # shared offsets: the bank is read as one ciphertext per output column, then one per output row
+    pos[0] = 0
+    assert fhe.server.server_resize(ctx, str(fin), str(fout), W, H, w, h, True, encrypt, rows_per_step=3, relin=relin, shared_offsets=True) == w * h
+    out = read_records(str(fout), 2, orc.k, orc.n, w * h * 3)
+    for o in (0, 7, w * h - 1):
+        xi, yi = origins[o]
+        P = lambda dx, dy, ch: pix[clamp(yi + dy, 0, H - 1) * W + clamp(xi + dx, 0, W - 1), ch]
+        want = oracle_mod.oracle_sample_bicubic_calls(torc, [P(dx, dy, 1) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)], bank[o % w], bank[w + o // w])
+        assert np.array_equal(out[o * 3 + 1], want), o

@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n,env", [(4096, {}), (8192, {"FHE_SEAL23_MODULI": "1"}),
                                    # the RELINEARISED mode on both sides: the reference's unchanged functions under FHE_FACADE_RELIN against
                                    # seal::hip::Circuits built with the same keys (fhe_circuits_create_relin) -- size 2 everywhere, same bits
-                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_FACADE_RELIN": "30"}), (4096, {"FHE_FACADE_RELIN": "16"})])
+                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_FACADE_RELIN": "30"}), (4096, {"FHE_FACADE_RELIN": "16"}),
+                                   # the per-Cubic placement: the reference's unchanged Cubic / Linear + ONE facade relinearize (size 4 / 3 -> 2, keys for
+                                   # s^2 and s^3) against seal::hip::Circuits(context, keys, 100, 100, per_cubic = true): samplers and shared resize too
+                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "30"}), (4096, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "60"})])
 def test_reference_functions_equal_batched_cpp_api(n, env):
     exe = ref_bin("ref_vs_batched", True)
     if not exe:
