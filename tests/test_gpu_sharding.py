@@ -224,6 +224,12 @@ def test_bench_circuits_sharded_modes_on_one_gpu():
     """bench_circuits.py --shared resize and decode carry the BENCH-schema objects and a digest of everything produced"""
     a = _bench_circuits(["resize", "--preset", "P4096", "--src", "24", "--dst", "12", "--pixels", "48", "--shared", "--cpu-pixels", "1"], 1)
     assert a["n_gpus"] == 1 and a["roofline"]["bound"] == "hbm" and a["cpu_baseline"]["kind"] == "port" and a["output_digest"]
+    # both relinearised placements carry the CPU baseline too (the oracle's op-by-op composition of the mode), and say which mode they are
+    r1 = _bench_circuits(["resize", "--preset", "SEAL23_4096", "--src", "24", "--dst", "12", "--pixels", "48", "--relin", "30", "--cpu-pixels", "1"], 1)
+    r2 = _bench_circuits(["resize", "--preset", "SEAL23_4096", "--src", "24", "--dst", "12", "--pixels", "48", "--relin", "30", "--relin-placement", "cubic", "--cpu-pixels", "1"], 1)
+    for r in (r1, r2):
+        assert r["out_size"] == 2 and r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
+    assert "every multiply" in r1["config"]["mode"] and "ONE evaluator.relinearize" in r2["config"]["mode"] and r1["output_digest"] != r2["output_digest"]
     b = _bench_circuits(["decode", "--preset", "P4096", "--positions", "4", "--degree", "2"], 1)
     assert b["n_gpus"] == 1 and b["output_digest"] and b["roofline"]["frac"] > 0
 
@@ -236,6 +242,10 @@ def test_world2_paths_of_bench_circuits_on_one_gpu_over_gloo():
                  ["decode", "--preset", "P4096", "--positions", "4", "--degree", "2"]):
         one, two = _bench_circuits(base, 1), _bench_circuits(base, 2, FHE_BENCH_BACKEND="gloo")
         assert two["n_gpus"] == 2 and one["output_digest"] == two["output_digest"], base
+        # the fixed-size job's in-run N = 1 leg (rank 0 alone over the WHOLE job): speed-up and efficiency in the same line
+        ss = two["strong_scaling"]
+        assert ss["n1_seconds"] > 0 and abs(ss["speedup"] - ss["n1_seconds"] / two["seconds"]) < 1e-9 and abs(ss["efficiency"] - ss["speedup"] / 2) < 1e-12
+        assert "strong_scaling" not in one
 
 
 def test_two_gpus_resize_rows_and_decode_units_over_rccl():
