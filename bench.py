@@ -232,7 +232,6 @@ def cpu_baseline_all_cores(blocks_per_thread=1):
             "sample": "%d blocks, OpenMP over blocks, %d threads, same oracle" % (nb, threads)}
 
 
-OUT_BYTES_PER_CT_WORD = 8
 XGMI_LINK_GBS = 153.0                      # MI355X_MICROARCH.md: 7 xGMI links per GPU, ~153 GB/s each, point to point
 PCIE_GBS = 64.0                            # PCIe Gen5 x16 per direction (nominal); 55-60 GB/s is what pinned copies sustain
 
