@@ -23,10 +23,16 @@ ap.add_argument("--dir", default="/dev/shm")
 ap.add_argument("--encrypt", choices=["bank", "host", "device"], default="bank",
                 help="the circuit's server-side encryptions (two per output pixel): bank = pre-made ciphertexts (the circuit alone, rounds 2-4), "
                      "host = keys.Encryptor one at a time (numpy sampler), device = keys.DeviceEncryptor batches (fhe_encrypt_batch)")
+ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="the relinearised mode of the circuits (records of 2 polynomials instead of 6 / 4): decomposition bit count")
+ap.add_argument("--relin-placement", choices=["product", "cubic"], default="product", help="after every product, or once per Cubic / Linear (include/fhe_circuits.h)")
 a = ap.parse_args()
 ctx = fhe.SEALContext.preset(a.preset)
+relin = None
+if a.relin:
+    kg = fhe.KeyGenerator(ctx, seed=1)
+    relin = (kg.generate_evaluation_keys(a.relin, 2).contiguous(), a.relin, "cubic") if a.relin_placement == "cubic" else (kg.generate_evaluation_keys(a.relin).contiguous(), a.relin)
 fin, fout = os.path.join(a.dir, "fhe_rs_in.ct"), os.path.join(a.dir, "fhe_rs_out.ct")
-out_size = 4 if a.bilinear else 6
+out_size = 2 if relin else (4 if a.bilinear else 6)
 rec_in = fhe.server.RECORD_HEADER + 2 * ctx.k * ctx.n * 8
 rec_out = fhe.server.RECORD_HEADER + out_size * ctx.k * ctx.n * 8
 n_in, n_out = a.src * a.src * 3, a.dst * a.dst * 3
@@ -52,11 +58,11 @@ try:
     sin = fhe.server.StreamFile(fin)
     sout = fhe.server.StreamFile(fout, write=True, size=n_out * rec_out)
     fresh = {}
-    fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=fresh, shared_offsets=a.shared)   # first pass: page-locking, page allocation
+    fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=fresh, shared_offsets=a.shared, relin=relin)   # first pass: page-locking, page allocation
     torch.cuda.synchronize()
     stats = {}
     t0 = time.time()
-    done = fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=stats, shared_offsets=a.shared)
+    done = fhe.server.server_resize(ctx, sin, sout, a.src, a.src, a.dst, a.dst, not a.bilinear, fractions, rows_per_step=a.rows, io_threads=a.io_threads, stats=stats, shared_offsets=a.shared, relin=relin)
     torch.cuda.synchronize()
     dt = time.time() - t0
     sin.close()
@@ -64,7 +70,7 @@ try:
     # the same job from the C++ host (seal/server_resize_hip.cpp): three passes over its own mappings, the last one reported
     cpp = None
     exe = os.path.join(ROOT, "fully-homomorphic-image-processing_amd", "seal", "server_resize_hip")
-    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096"):
+    if os.path.exists(exe) and a.preset in ("P8192", "P4096", "SEAL23_4096") and not relin:      # the C++ host streams the reference's mode
         import subprocess
         fpk = os.path.join(a.dir, "fhe_rs_pk.txt")
         with open(fpk, "wb") as f:
@@ -81,6 +87,7 @@ finally:
         if os.path.exists(p):
             os.remove(p)
 print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s, files in %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset, a.dir),
+                  "mode": ("relinearised %s, dbc %d: records of 2 polynomials" % ("once per Cubic / Linear" if a.relin_placement == "cubic" else "after every product", a.relin)) if relin else "reference (no relinearisation)",
                   "output_pixels": done, "rows_per_step": a.rows, "server_side_encryptions": a.encrypt, "offsets": "shared (one per output column / row)" if a.shared else "per output pixel (the reference's)", "seconds": dt, "pixels_per_s": done / dt,
                   "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
                   "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
