@@ -159,10 +159,15 @@ def _relin(args, fhe, ctx):
     kg = fhe.KeyGenerator(ctx, seed=1)
     if args.relin_placement == "cubic":        # keys for s^2 and s^3: one evaluator.relinearize takes a Cubic's size-4 result to 2
         return (kg.generate_evaluation_keys(args.relin, 2).contiguous(), args.relin, "cubic")
+    if args.relin_placement == "sample":       # keys for s^2 .. s^5: one evaluator.relinearize takes an output pixel's size-6 ciphertext to 2
+        return (kg.generate_evaluation_keys(args.relin, 4).contiguous(), args.relin, "sample")
     return (kg.generate_evaluation_keys(args.relin).contiguous(), args.relin)
 
 
 def _mode(args):
+    if args.relin and args.relin_placement == "sample":
+        return ("the reference's SampleBicubic sequence unchanged (sizes 2 -> 4 -> 6) + ONE evaluator.relinearize of every output pixel (keys for s^2 .. s^5), "
+                "dbc = %d (NOT the reference's bits: the reference never relinearises)" % args.relin)
     if args.relin and args.relin_placement == "cubic":
         return ("the reference's Cubic sequence unchanged + ONE evaluator.relinearize of its size-4 result (keys for s^2, s^3: two key switches per Cubic), "
                 "dbc = %d (NOT the reference's bits: the reference never relinearises)" % args.relin)
@@ -172,7 +177,7 @@ def _mode(args):
 
 
 def _wl_suffix(args):
-    return ("_relin%d%s" % (args.relin, "_cubic" if args.relin_placement == "cubic" else "")) if args.relin else ""
+    return ("_relin%d%s" % (args.relin, {"cubic": "_cubic", "sample": "_sample"}.get(args.relin_placement, ""))) if args.relin else ""
 
 
 def _oracle_for_mode(args, om, orc):
@@ -182,6 +187,8 @@ def _oracle_for_mode(args, om, orc):
     sk, _ = orc.keygen(1)
     if args.relin_placement == "cubic":
         return om.TailRelinOracle(orc, orc.evk_gen_powers(sk, dbc=args.relin, count=2), args.relin)
+    if args.relin_placement == "sample":
+        return om.SampleRelinOracle(orc, orc.evk_gen_powers(sk, dbc=args.relin, count=4), args.relin)
     return om.RelinOracle(orc, orc.evk_gen(sk, dbc=args.relin), args.relin)
 
 
@@ -426,9 +433,10 @@ if __name__ == "__main__":
     ap.add_argument("--degree", type=int, default=12)
     ap.add_argument("--positions", type=int, default=16)
     ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="relinearised mode with this decomposition bit count (0 = the reference's mode)")
-    ap.add_argument("--relin-placement", choices=["product", "cubic"], default="product",
+    ap.add_argument("--relin-placement", choices=["product", "cubic", "sample"], default="product",
                     help="product: evaluator.relinearize after every multiply / square (five key switches per Cubic); cubic (resize only): the reference's "
-                         "Cubic unchanged and ONE relinearize of its size-4 result (two key switches, keys for s^2 and s^3) -- include/fhe_circuits.h FHE_RELIN_PER_CUBIC")
+                         "Cubic unchanged and ONE relinearize of its size-4 result (two key switches, keys for s^2 and s^3) -- include/fhe_circuits.h FHE_RELIN_PER_CUBIC; "
+                         "sample (resize only): SampleBicubic unchanged and ONE relinearize of every output pixel, 6 -> 2 (FHE_RELIN_PER_SAMPLE)")
     a = ap.parse_args()
     from bench import ensure_world
     ensure_world(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # `python bench_circuits.py <workload> --gpus N` starts its N ranks itself

@@ -69,7 +69,9 @@ class Circuits:
     polynomials.  evk_ntt as KeyGenerator.generate_evaluation_keys(dbc) returns it; the handle keeps it alive.
     relin=(evk_ntt, dbc, "cubic"): the second placement (FHE_RELIN_PER_CUBIC, include/fhe_circuits.h): the reference's Cubic /
     Linear sequences unchanged and ONE relinearize at the end of each (size 4 / 3 -> 2; two key switches per Cubic where the
-    first placement spends five); evk_ntt = generate_evaluation_keys(dbc, 2): the keys for s^2 and s^3.  Resize circuits only."""
+    first placement spends five); evk_ntt = generate_evaluation_keys(dbc, 2): the keys for s^2 and s^3.  Resize circuits only.
+    relin=(evk_ntt, dbc, "sample"): the third (FHE_RELIN_PER_SAMPLE): the samplers exactly as the reference evaluates them and ONE relinearize of
+    every output pixel (6 -> 2 / 4 -> 2); evk_ntt = generate_evaluation_keys(dbc, 4): the keys for s^2 .. s^5.  Resize circuits only."""
 
     def __init__(self, ctx, int_coeffs=100, frac_coeffs=100, relin=None):
         self.ctx = ctx
@@ -78,11 +80,13 @@ class Circuits:
             _lib.call("fhe_circuits_create", ctx.h, int_coeffs, frac_coeffs, C.byref(h))
         else:
             self._evk, dbc = relin[0], relin[1]
-            per_cubic = relin_placement(relin) == 1
+            placement = relin_placement(relin)
             assert self._evk.is_contiguous() and self._evk.dtype == torch.int64
-            if per_cubic:
+            if placement == 1:
                 assert self._evk.dim() == 6 and self._evk.shape[0] >= 2, "per-Cubic placement: keys for s^2 and s^3 (generate_evaluation_keys(dbc, 2))"
-            _lib.call("fhe_circuits_create_relin_at", ctx.h, int_coeffs, frac_coeffs, _ptr(self._evk), int(dbc), 1 if per_cubic else 0, C.byref(h))
+            if placement == 2:
+                assert self._evk.dim() == 6 and self._evk.shape[0] >= 4, "per-sample placement: keys for s^2 .. s^5 (generate_evaluation_keys(dbc, 4))"
+            _lib.call("fhe_circuits_create_relin_at", ctx.h, int_coeffs, frac_coeffs, _ptr(self._evk), int(dbc), placement, C.byref(h))
         self.h = h
         self._scratch = None
 
@@ -113,7 +117,9 @@ def relin_placement(relin):
         return 0
     if relin[2] in (1, "cubic"):
         return 1
-    raise ValueError("relin placement must be 'product' or 'cubic', got %r" % (relin[2],))
+    if relin[2] in (2, "sample"):
+        return 2
+    raise ValueError("relin placement must be 'product', 'cubic' or 'sample', got %r" % (relin[2],))
 
 
 def circuits_of(pc, relin=None):
@@ -169,7 +175,8 @@ def cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin=None):
     then differ from the reference path by construction (key-switching noise), the decrypted value does not."""
     M, P = ev.multiply_plain, pc.prepared
     each = relin is not None and relin_placement(relin) == 0     # relinearize after every product
-    tail = relin is not None and relin_placement(relin) == 1     # the reference's sequence, ONE relinearize of the result (relin=(evk, dbc, "cubic"))
+    tail = relin is not None and relin_placement(relin) in (1, 2)    # the reference's sequence, ONE relinearize of the result (relin=(evk, dbc, "cubic"); a
+    #                                                                  stand-alone Cubic of the "sample" placement is relinearised by its caller the same way)
 
     def mul(x, y):
         z = ev.multiply(x, y)

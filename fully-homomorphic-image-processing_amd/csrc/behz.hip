@@ -1550,12 +1550,16 @@ extern "C" int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, 
     if (!c || !ct || !evk || !out2) return fail(FHE_ERR_PARAM, "null argument");
     if (size < 3 || size > FHE_MAX_POLYS) return fail(FHE_ERR_PARAM, "relinearize: %u polynomials (3 .. %d)", size, FHE_MAX_POLYS);
     if (dbc < 1 || dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
-    // all size - 2 key switches as ONE pass where the lazy sums have room for their terms and the caller brought the digits' scratch
-    // (fhe_relinearize_n_scratch_bytes); FHE_RELIN_STEPS=1 keeps the sequential steps (A/B measurements, the parity test's second path)
+    // the size - 2 key switches in as FEW passes as the lazy sums allow (k x digits x powers <= 20 terms per pass: all of them at once for
+    // a Cubic's size-4 result, and for a sampler's size-6 result at dbc 60; two passes of two powers at dbc 30), the top powers first and in
+    // place, the last pass into out2 -- when the caller brought the digits' scratch (fhe_relinearize_n_scratch_bytes);
+    // FHE_RELIN_STEPS=1 keeps the sequential steps (A/B measurements, the parity test's second path)
     if (size > 3 && count && !c->opt.relin_steps && scratch && scratch_bytes >= fhe_relinearize_n_scratch_bytes(c, size, dbc, count)) {
         if (int erc = fhe_behz_ensure(c)) return erc;
         const u32 nd = fhe_evk_digits(c, dbc);
-        if (relin_pm_ok(c, nd, size - 2, count)) {
+        u32 gmax = size - 2;
+        while (gmax > 1 && !relin_pm_ok(c, nd, gmax, count)) --gmax;
+        if (gmax > 1 && relin_pm_ok(c, nd, gmax, count)) {
             if (stride < (u64)size * c->k * c->n) return fail(FHE_ERR_PARAM, "ciphertext stride smaller than a size-%u ciphertext", size);
             if (out_stride < (u64)2 * c->k * c->n) return fail(FHE_ERR_PARAM, "output stride smaller than a size-2 ciphertext");
             if (!(out2 == ct && out_stride == stride)) {
@@ -1563,7 +1567,16 @@ extern "C" int fhe_relinearize_n(const fhe_ctx *c, uint64_t *ct, uint32_t size, 
                 const uintptr_t o0 = (uintptr_t)out2, o1 = o0 + ((count - 1) * out_stride + (u64)2 * c->k * c->n) * sizeof(u64);
                 if (o0 < i1 && i0 < o1) return fail(FHE_ERR_PARAM, "output range overlaps the input range (only out2 == ct with out_stride == stride may alias)");
             }
-            return relin_pm(c, (const u64 *)ct, stride, 2, size - 2, (u64 *)out2, out_stride, count, (const u64 *)evk, dbc, (u64 *)scratch, (hipStream_t)s);
+            const size_t ew = fhe_evk_words(c, dbc);
+            u32 hi = size - 1;                                       // polynomials [lo, hi] per pass, from the top
+            while (hi >= 2) {
+                const u32 g = hi - 1 < gmax ? hi - 1 : gmax, lo = hi - g + 1;
+                const bool last = lo == 2;
+                if (int rc = relin_pm(c, (const u64 *)ct, stride, lo, g, last ? (u64 *)out2 : (u64 *)ct, last ? out_stride : stride, count,
+                                      (const u64 *)evk + (size_t)(lo - 2) * ew, dbc, (u64 *)scratch, (hipStream_t)s)) return rc;
+                hi = lo - 1;
+            }
+            return FHE_OK;
         }
     }
     const size_t ew = fhe_evk_words(c, dbc);

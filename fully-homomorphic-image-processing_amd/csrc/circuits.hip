@@ -323,6 +323,7 @@ struct Run {
     bool query = false;                    // a *_scratch_bytes query: placeholder scalars, so constants are neither required to fit the encoder nor to be non-zero
     bool relin;                            // the handle relinearises after every multiply / square: every ciphertext has two polynomials
     bool tail;                             // the handle relinearises ONCE at the end of every Cubic / Linear (size 4 / 3 -> 2): inside them the reference's sizes
+    bool stail;                            // ... ONCE per output of a sampler / of a stand-alone Cubic or Linear (FHE_RELIN_PER_SAMPLE): the reference's sizes until then
     uintptr_t base = 0;
     size_t cap = 0, top = 0, high = 0;     // bytes
     u32 k, n;
@@ -330,13 +331,28 @@ struct Run {
 
     Run(const fhe_circuits *circ, void *scratch, size_t bytes, fhe_stream s, bool dry_run)
         : cc(circ), c(circ->c), st((hipStream_t)s), dry(dry_run), relin(circ->dbc != 0 && circ->placement == FHE_RELIN_EVERY_PRODUCT),
-          tail(circ->dbc != 0 && circ->placement == FHE_RELIN_PER_CUBIC), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
+          tail(circ->dbc != 0 && circ->placement == FHE_RELIN_PER_CUBIC), stail(circ->dbc != 0 && circ->placement == FHE_RELIN_PER_SAMPLE), base((uintptr_t)scratch), cap(bytes), k(circ->c->k), n(circ->c->n),
           pw((size_t)circ->c->k * circ->c->n) {}
 
     // polynomials of a ciphertext that has `ref` of them in the reference's evaluation
     u32 S(u32 ref) const { return relin && ref > 2 ? 2 : ref; }
     // polynomials of a Cubic's / Linear's / sampler's RESULT (either relinearised mode: 2)
     u32 O(u32 ref) const { return (relin || tail) && ref > 2 ? 2 : ref; }
+    // ... of what a circuit hands to its caller (every relinearised placement: 2)
+    u32 F(u32 ref) const { return (relin || tail || stail) && ref > 2 ? 2 : ref; }
+    // FHE_RELIN_PER_SAMPLE: `produce(dst)` forms a batch of `ref`-polynomial results; they are relinearised into `out` (ref -> 2: all
+    // the key switches of one evaluator.relinearize, fhe_relinearize_n).  Other placements: produce(out).
+    template <typename P>
+    int finish_sample(u32 ref, u64 *out, u64 count, P &&produce) {
+        if (!stail || ref <= 2) return produce(out);
+        if (ref - 2 > 4) return fail(FHE_ERR_PARAM, "per-sample relinearisation: a result of %u polynomials needs keys beyond s^5", ref);
+        const size_t m = mark();
+        u64 *raw = alloc(count * ref * pw);
+        int rc = produce(raw);
+        if (!rc) rc = relin_n(raw, ref, out, count);
+        release(m);
+        return rc;
+    }
 
     // 256-byte aligned bump allocation; in a dry run only the high-water mark is real
     u64 *alloc(size_t words) {
@@ -632,7 +648,9 @@ int cubic_powers(Run &R, const u64 *t, u64 count, u64 **p2, u64 **p1) {
 int run_cubic(Run &R, const u64 *A, const u64 *B, const u64 *C, const u64 *D, u32 size, const u64 *t, u64 *out, u64 count) {
     u64 *p2, *p1;
     TRY(cubic_powers(R, t, count, &p2, &p1));
-    return cubic_core(R, Src{A, ident()}, Src{B, ident()}, Src{C, ident()}, Src{D, ident()}, size, p2, p1, ident(), out, ident(), count);
+    return R.finish_sample(size + 2, out, count, [&](u64 *dst) {
+        return cubic_core(R, Src{A, ident()}, Src{B, ident()}, Src{C, ident()}, Src{D, ident()}, size, p2, p1, ident(), dst, ident(), count);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -675,7 +693,7 @@ int linear_operands(Run &R, const u64 *t, u64 count, u64 **pomt, u64 **pt) {
 int run_linear(Run &R, const u64 *A, const u64 *B, u32 size, const u64 *t, u64 *out, u64 count) {
     u64 *pomt, *pt;
     TRY(linear_operands(R, t, count, &pomt, &pt));
-    return linear_core(R, A, B, size, pomt, pt, ident(), out, count);
+    return R.finish_sample(size + 1, out, count, [&](u64 *dst) { return linear_core(R, A, B, size, pomt, pt, ident(), dst, count); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -706,8 +724,10 @@ int run_sample_bicubic(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps,
     u64 *py2, *py1;
     TRY(cubic_powers(R, yfract, count, &py2, &py1));
     const size_t cw = count * sr * R.pw;
-    return cubic_core(R, Src{cols, ident()}, Src{cols + cw, ident()}, Src{cols + 2 * cw, ident()}, Src{cols + 3 * cw, ident()}, sr, py2, py1,
-                      ident(), out, ident(), count);
+    return R.finish_sample(R.O(6), out, count, [&](u64 *dst) {                // :303; FHE_RELIN_PER_SAMPLE: + one relinearize of the pixel, 6 -> 2
+        return cubic_core(R, Src{cols, ident()}, Src{cols + cw, ident()}, Src{cols + 2 * cw, ident()}, Src{cols + 3 * cw, ident()}, sr, py2, py1,
+                          ident(), dst, ident(), count);
+    });
 }
 
 int run_sample_linear(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps, const u64 *xfract, const u64 *yfract, u64 *out, u64 count) {
@@ -733,7 +753,7 @@ int run_sample_linear(Run &R, const u64 *pixels, u64 n_pixels, const u32 *taps, 
     TRY(linear_core(R, A, B, 2, pomx, ptx, periodic(1, count), cols, rows));
     u64 *pomy, *pty;
     TRY(linear_operands(R, yfract, count, &pomy, &pty));
-    return linear_core(R, cols, cols + count * sr * R.pw, sr, pomy, pty, ident(), out, count);
+    return R.finish_sample(R.O(4), out, count, [&](u64 *dst) { return linear_core(R, cols, cols + count * sr * R.pw, sr, pomy, pty, ident(), dst, count); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -800,7 +820,7 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
             band_need.push_back(need);
         }
     }
-    const u32 sr = R.O(4), sout = R.O(6);                               // polynomials of a row Cubic's result and of an output pixel
+    const u32 sr = R.O(4), sout = R.F(6);                               // polynomials of a row Cubic's result and of an output pixel
     const size_t slot_words = (size_t)dst_w * sr * R.pw;
     u64 *cache = R.alloc((size_t)max_live * slot_words);
     const u32 call_px = rows_per_call * dst_w;
@@ -849,8 +869,10 @@ int run_resize_shared(Run &R, const u64 *pixels, u32 src_w, u32 src_h, u32 dst_w
             TRY(R.stage(h.data(), (size_t)4 * cnt, d_idx));
             u64 *dst = out ? out + (size_t)(ya - sh.row0) * dst_w * sout * R.pw : band;
             // pixel c of the call sits in output row ya + c / dst_w: entry ya - row0 + c / dst_w of the prepared yfract batches
-            TRY(cubic_core(R, Src{cache, by_index(d_idx)}, Src{cache, by_index(d_idx + cnt)}, Src{cache, by_index(d_idx + 2 * (size_t)cnt)},
-                           Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, sr, py2, py1, periodic(dst_w, n_rows, ya - sh.row0), dst, ident(), cnt));
+            TRY(R.finish_sample(R.O(6), dst, cnt, [&](u64 *d6) {
+                return cubic_core(R, Src{cache, by_index(d_idx)}, Src{cache, by_index(d_idx + cnt)}, Src{cache, by_index(d_idx + 2 * (size_t)cnt)},
+                                  Src{cache, by_index(d_idx + 3 * (size_t)cnt)}, sr, py2, py1, periodic(dst_w, n_rows, ya - sh.row0), d6, ident(), cnt);
+            }));
             if (consume && !R.dry) {
                 const int rc = consume(user, (u64)ya * dst_w, cu(dst), cnt, (fhe_stream)R.st);
                 if (rc) return fail(rc < 0 ? rc : FHE_ERR_PARAM, "band consumer failed");
@@ -1090,8 +1112,9 @@ int run_decode_channel(Run &R, const u64 *runs, u32 pairs, u64 *index, const u64
 bool args_ok(const fhe_circuits *cc) { return cc && cc->c && cc->c->behz; }
 // the decode circuits have no Cubic / Linear whose end the per-Cubic placement could relinearise at
 int decode_mode_ok(const fhe_circuits *cc) {
-    if (cc && cc->dbc && cc->placement == FHE_RELIN_PER_CUBIC)
-        return fail(FHE_ERR_PARAM, "this handle relinearises per Cubic (FHE_RELIN_PER_CUBIC): the decode circuits take FHE_RELIN_EVERY_PRODUCT or the reference's mode");
+    if (cc && cc->dbc && cc->placement != FHE_RELIN_EVERY_PRODUCT)
+        return fail(FHE_ERR_PARAM, "this handle relinearises per Cubic / per sample (FHE_RELIN_PER_CUBIC, FHE_RELIN_PER_SAMPLE): the decode circuits take "
+                                   "FHE_RELIN_EVERY_PRODUCT or the reference's mode");
     return FHE_OK;
 }
 
@@ -1166,7 +1189,7 @@ extern "C" int fhe_circuits_create_relin_at(const fhe_ctx *ctx, int int_coeffs, 
                                             fhe_circuits **out) {
     if (!ctx || !out) return fail(FHE_ERR_PARAM, "null argument");
     *out = nullptr;
-    if (placement != FHE_RELIN_EVERY_PRODUCT && placement != FHE_RELIN_PER_CUBIC) return fail(FHE_ERR_PARAM, "unknown relinearisation placement %u", placement);
+    if (placement > FHE_RELIN_PER_SAMPLE) return fail(FHE_ERR_PARAM, "unknown relinearisation placement %u", placement);
     if ((d_evk_ntt != nullptr) != (dbc != 0)) return fail(FHE_ERR_PARAM, "evaluation keys and a decomposition bit count come together");
     if (dbc > 60) return fail(FHE_ERR_PARAM, "decomposition bit count out of range");
     if (int_coeffs < 1 || frac_coeffs < 0 || (u32)(int_coeffs + frac_coeffs) > ctx->n) return fail(FHE_ERR_PARAM, "encoder coefficient counts do not fit the polynomial");

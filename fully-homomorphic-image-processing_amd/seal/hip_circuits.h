@@ -221,11 +221,15 @@ public:
     // homo/client_resize.cpp:26,47,72), so every result below has TWO polynomials (out_size()).  The keys are copied.
     // per_cubic = true: the second placement (FHE_RELIN_PER_CUBIC): the reference's Cubic / Linear unchanged and ONE relinearize of each
     // result (size 4 / 3 -> 2); the keys then come from generate_evaluation_keys(dbc, 2, keys) (s^2 and s^3).  Resize circuits only.
-    Circuits(const SEALContext &ctx, const EvaluationKeys &evk, int int_coeffs = 100, int frac_coeffs = 100, bool per_cubic = false) : ctx_(ctx), h_(nullptr), evk_(evk.buf) {
+    // placement 2 (FHE_RELIN_PER_SAMPLE): the samplers unchanged and ONE relinearize of every output pixel (6 -> 2); keys from
+    // generate_evaluation_keys(dbc, 4, keys) (s^2 .. s^5).  `placement` takes the constants of include/fhe_circuits.h (or false / true).
+    Circuits(const SEALContext &ctx, const EvaluationKeys &evk, int int_coeffs = 100, int frac_coeffs = 100, int placement = FHE_RELIN_EVERY_PRODUCT) : ctx_(ctx), h_(nullptr), evk_(evk.buf) {
+        const bool per_cubic = placement == FHE_RELIN_PER_CUBIC;
         if (per_cubic && evk.count < 2) throw std::invalid_argument("per-Cubic relinearisation needs the keys for s^2 and s^3: generate_evaluation_keys(dbc, 2, keys)");
+        if (placement == FHE_RELIN_PER_SAMPLE && evk.count < 4) throw std::invalid_argument("per-sample relinearisation needs the keys for s^2 .. s^5: generate_evaluation_keys(dbc, 4, keys)");
         evk.device_keys();                                     // key objects handed out by mutable_data() are folded back first
         evk_ = evk.buf;
-        detail::check(fhe_circuits_create_relin_at(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, per_cubic ? FHE_RELIN_PER_CUBIC : FHE_RELIN_EVERY_PRODUCT, &h_),
+        detail::check(fhe_circuits_create_relin_at(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, (uint32_t)placement, &h_),
                       "circuits (relinearised)");
     }
     // the keys a context under FHE_FACADE_RELIN=<dbc> relinearises with (derived from the first secret key seen on it): a host that

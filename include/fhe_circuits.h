@@ -61,9 +61,18 @@ int fhe_circuits_create_relin(const fhe_ctx *ctx, int int_coeffs, int frac_coeff
  *                            fhe_linear / the samplers / the shared resize have two polynomials, as in the other placement; bit-identical
  *                            to the oracle's composition `reference sequence -> relinearize` (oracle/oracle.py TailRelinOracle).  The
  *                            decode circuits (sin / cos, approximated_step, decode_channel) have no Cubic to end: they return
- *                            FHE_ERR_PARAM for such a handle. */
+ *                            FHE_ERR_PARAM for such a handle.
+ *   FHE_RELIN_PER_SAMPLE     the SAMPLERS' call sequences unchanged -- SampleBicubic: five Cubics in the reference's mode, sizes 2 -> 4 -> 6
+ *                            (homo/fhe_resize.h:293-303); SampleLinear: three Linears, 2 -> 3 -> 4 (:237-248); the shared-offset resize the same --
+ *                            and ONE evaluator.relinearize of every OUTPUT pixel (6 -> 2: four key switches, keys for s^2 .. s^5; 4 -> 2 for
+ *                            bilinear), which fhe_relinearize_n runs as one pass at dbc 60 and as two at dbc 30.  d_evk_ntt holds FOUR key sets
+ *                            (generate_evaluation_keys(dbc, 4, keys)).  Costs one pass of key switches per output pixel where PER_CUBIC costs
+ *                            five: the device time of the reference's mode + 2-6 %, with records of two polynomials.  fhe_cubic / fhe_linear on
+ *                            their own relinearise their result (any operand size the keys reach: size + 2 <= 6).  Checker:
+ *                            oracle/oracle.py SampleRelinOracle.  Resize circuits only, like PER_CUBIC. */
 #define FHE_RELIN_EVERY_PRODUCT 0
 #define FHE_RELIN_PER_CUBIC 1
+#define FHE_RELIN_PER_SAMPLE 2
 int fhe_circuits_create_relin_at(const fhe_ctx *ctx, int int_coeffs, int frac_coeffs, const uint64_t *d_evk_ntt, uint32_t dbc,
                                  uint32_t placement, fhe_circuits **out);
 uint32_t fhe_circuits_relin_placement(const fhe_circuits *circ);

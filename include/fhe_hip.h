@@ -270,11 +270,12 @@ int fhe_relinearize_poly(const fhe_ctx *ctx, const uint64_t *ct, uint64_t ct_str
  * each; KeyGenerator::generate_evaluation_keys(dbc, size - 2, keys)).  The steps above the last one run IN PLACE: ct's first two
  * polynomials are overwritten with partial sums when size > 3 (ct is scratch after the call).  out2 as in fhe_relinearize_to. */
 size_t fhe_evk_words(const fhe_ctx *ctx, uint32_t dbc);
-/* scratch for fhe_relinearize_n: the digits of all size - 2 source polynomials at once.  With at least this much (and a base
- * whose lazy sums have room: k * digits * (size - 2) <= 20 on the pseudo-Mersenne kernels) the size - 2 key switches run as ONE
- * pass -- every step's source polynomial is the caller's own, so the result is the ciphertext plus the sum of the steps' terms,
- * the same bits in any order -- with one inverse transform pair instead of size - 2; with only fhe_relinearize_scratch_bytes
- * the steps run one after the other. */
+/* scratch for fhe_relinearize_n: the digits of all size - 2 source polynomials at once.  With at least this much the size - 2 key
+ * switches run in as few PASSES as the lazy sums of the pseudo-Mersenne kernels allow (k * digits * powers <= 20 terms per pass: one
+ * pass for a size-4 ciphertext at k = 4, dbc 30, and for a size-6 one at dbc 60; two passes of two powers for size 6 at dbc 30) --
+ * every step's source polynomial is the caller's own, so the result is the ciphertext plus the sum of the steps' terms, the same bits
+ * in any order -- with one inverse transform pair per pass instead of one per step; with only fhe_relinearize_scratch_bytes the steps
+ * run one after the other. */
 size_t fhe_relinearize_n_scratch_bytes(const fhe_ctx *ctx, uint32_t size, uint32_t dbc, uint64_t count);
 int fhe_relinearize_n(const fhe_ctx *ctx, uint64_t *ct, uint32_t size, uint64_t ct_stride_words, uint64_t *out2,
                       uint64_t out_stride_words, uint64_t count, const uint64_t *d_evk_ntt, uint32_t dbc, void *scratch,

@@ -510,8 +510,28 @@ class TailRelinOracle:
         return self.orc.relinearize_n(x, self.evks, self.dbc) if x.shape[0] > 2 else x
 
 
+class SampleRelinOracle:
+    """The third relinearised mode ("per sample", FHE_RELIN_PER_SAMPLE): SampleBicubic / SampleLinear exactly as the reference evaluates them
+    (homo/fhe_resize.h:237-248,293-303: sizes 2 -> 4 -> 6 and 2 -> 3 -> 4, no relinearisation inside) and ONE evaluator.relinearize of every
+    output (6 -> 2: keys for s^2 .. s^5; 4 -> 2).  `sample_tail(x)` is that call; a stand-alone Cubic / Linear is relinearised the same way by
+    its caller (`sample_tail(oracle_cubic_calls(orc.orc, ...))`)."""
+
+    def __init__(self, orc, evks, dbc):
+        self.orc, self.evks, self.dbc = orc, evks, int(dbc)
+
+    def __getattr__(self, name):
+        return getattr(self.orc, name)
+
+    def sample_tail(self, x):
+        return self.orc.relinearize_n(x, self.evks, self.dbc) if x.shape[0] > 2 else x
+
+
 def _tail(orc, x):
     return orc.tail(x) if hasattr(orc, "tail") else x
+
+
+def _sample_tail(orc, x):
+    return orc.sample_tail(x) if hasattr(orc, "sample_tail") else x
 
 
 def oracle_cubic_calls(orc, A, B, Cc, D, t):
@@ -549,11 +569,11 @@ def oracle_linear_calls(orc, A, B, t):
 def oracle_sample_bicubic_calls(orc, p, xfract, yfract):
     """SampleBicubic (homo/fhe_resize.h:293-303): p = the sixteen clamped taps, row-major 4 x 4"""
     cols = [oracle_cubic_calls(orc, p[4 * r], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3], xfract) for r in range(4)]
-    return oracle_cubic_calls(orc, cols[0], cols[1], cols[2], cols[3], yfract)
+    return _sample_tail(orc, oracle_cubic_calls(orc, cols[0], cols[1], cols[2], cols[3], yfract))      # SampleRelinOracle: + one relinearize of the pixel
 
 
 def oracle_sample_linear_calls(orc, p, xfract, yfract):
     """SampleLinear (homo/fhe_resize.h:237-248): p = p00, p10, p01, p11"""
     c0 = oracle_linear_calls(orc, p[0], p[1], xfract)
     c1 = oracle_linear_calls(orc, p[2], p[3], xfract)
-    return oracle_linear_calls(orc, c0, c1, yfract)
+    return _sample_tail(orc, oracle_linear_calls(orc, c0, c1, yfract))

@@ -18,6 +18,9 @@
 // unchanged Cubic / Linear followed by ONE evaluator.relinearize(result, keys) of the facade (keys for s^2 and s^3 from
 // generate_evaluation_keys(dbc, 2, keys): a size-4 ciphertext to 2 in one call, as SEAL's relinearize), the samplers composed from those
 // calls exactly as homo/fhe_resize.h:237-248,293-303 compose them; (2) seal::hip::Circuits(context, keys, 100, 100, true).  Resize circuits only.
+// FHE_XCHECK_PER_SAMPLE=<dbc>: the THIRD placement (FHE_RELIN_PER_SAMPLE): (1) the reference's UNCHANGED Cubic / Linear / SampleBicubic /
+// SampleLinear (sizes grow to 6 / 4 as in its own mode) followed by ONE evaluator.relinearize of each result (keys for s^2 .. s^5 from
+// generate_evaluation_keys(dbc, 4, keys)); (2) seal::hip::Circuits(context, keys, 100, 100, FHE_RELIN_PER_SAMPLE).
 // Built at -O0 with the stack scrubbed before the decode circuits: homomorphic_cos has no return statement
 // (homo/fhe_decode.h:200), see ref_decode_circuit_main.cpp.
 #include <cstdio>
@@ -84,22 +87,25 @@ int main(int argc, char **argv) {
         return b;
     };
     const int per_cubic = std::getenv("FHE_XCHECK_PER_CUBIC") ? std::atoi(std::getenv("FHE_XCHECK_PER_CUBIC")) : 0;
+    const int per_sample = std::getenv("FHE_XCHECK_PER_SAMPLE") ? std::atoi(std::getenv("FHE_XCHECK_PER_SAMPLE")) : 0;
     const bool relin = std::getenv("FHE_FACADE_RELIN") != nullptr || per_cubic;      // either way: every operand and result has two polynomials
     EvaluationKeys evk2;
     if (per_cubic) keygen.generate_evaluation_keys(per_cubic, 2, evk2);
-    std::unique_ptr<seal::hip::Circuits> circ_p(per_cubic ? new seal::hip::Circuits(context, evk2, 100, 100, true)
+    if (per_sample) keygen.generate_evaluation_keys(per_sample, 4, evk2);
+    std::unique_ptr<seal::hip::Circuits> circ_p(per_sample ? new seal::hip::Circuits(context, evk2, 100, 100, FHE_RELIN_PER_SAMPLE)
+                                                : per_cubic ? new seal::hip::Circuits(context, evk2, 100, 100, true)
                                                 : relin ? new seal::hip::Circuits(context, seal::hip::Circuits::context_relin_keys(context), 100, 100)
                                                         : new seal::hip::Circuits(context, 100, 100));
     seal::hip::Circuits &circ = *circ_p;
-    if (relin != circ.relinearises()) { std::printf("MISMATCH: handle mode\n"); return 1; }
+    if ((relin || per_sample) != circ.relinearises()) { std::printf("MISMATCH: handle mode\n"); return 1; }
     // the reference's function, then the one relinearize of the per-Cubic placement
     auto ref_cubic = [&](Ciphertext &res, Ciphertext a, Ciphertext b, Ciphertext c, Ciphertext d, Ciphertext tt) {
         Cubic(res, a, b, c, d, tt, evaluator, encoder, encryptor);                                  // homo/fhe_resize.h:143
-        if (per_cubic) evaluator.relinearize(res, evk2);
+        if (per_cubic || per_sample) evaluator.relinearize(res, evk2);
     };
     auto ref_linear = [&](Ciphertext &res, Ciphertext a, Ciphertext b, Ciphertext tt) {
         Linear(res, a, b, tt, evaluator, encoder, encryptor);                                       // homo/fhe_resize.h:191
-        if (per_cubic) evaluator.relinearize(res, evk2);
+        if (per_cubic || per_sample) evaluator.relinearize(res, evk2);
     };
 
     // ---- Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 and 3 -> 4 ----------------------------
@@ -163,6 +169,7 @@ int main(int argc, char **argv) {
                 g_hook.push_back(yf.get(y * w + x));
                 if (bicubic) SampleBicubic(sample, image, u, v, evaluator, encoder, encryptor);     // :386
                 else SampleLinear(sample, image, u, v, evaluator, encoder, encryptor);              // :384
+                if (per_sample) for (int ch = 0; ch < 3; ++ch) evaluator.relinearize(sample[ch], evk2);      // the ONE relinearize of the placement, 6 / 4 -> 2
                 }
                 for (int ch = 0; ch < 3; ++ch) expect_equal(bicubic ? "SampleBicubic" : "SampleLinear", (size_t)(y * w + x) * 3 + ch, sample[ch], got[ch], y * w + x);
             }
@@ -189,6 +196,7 @@ int main(int argc, char **argv) {
                 g_hook.push_back(xf.get(x));
                 g_hook.push_back(yf.get(y));
                 SampleBicubic(sample, one, u, v, evaluator, encoder, encryptor);
+                if (per_sample) evaluator.relinearize(sample[0], evk2);
                 }
                 expect_equal("resize_bicubic(shared)", (size_t)y * w + x, sample[0], got, (size_t)y * w + x);
             }
@@ -197,7 +205,7 @@ int main(int argc, char **argv) {
     std::printf("\n");
 
     // ---- decode path (not in the per-Cubic placement: no Cubic to end; the library refuses such a handle there) ------------
-    if (per_cubic) {
+    if (per_cubic || per_sample) {
         bool refused = false;
         try { CiphertextBatch X = random_batch(1, 2), Z = random_batch(1, 2); circ.homomorphic_sin(X, Z); } catch (const std::exception &) { refused = true; }
         if (!refused) { std::printf("MISMATCH: the per-Cubic handle evaluated a decode circuit\n"); ++g_fail; }

@@ -486,3 +486,85 @@ def test_streaming_server_resize_with_the_per_cubic_placement(fhe, oracle_mod, t
         P = lambda dx, dy, ch: pix[clamp(yi + dy, 0, H - 1) * W + clamp(xi + dx, 0, W - 1), ch]
         want = oracle_mod.oracle_sample_bicubic_calls(torc, [P(dx, dy, 1) for dy in (-1, 0, 1, 2) for dx in (-1, 0, 1, 2)], bank[o % w], bank[w + o // w])
         assert np.array_equal(out[o * 3 + 1], want), o
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the third placement: the samplers unchanged, ONE evaluator.relinearize of every output pixel (FHE_RELIN_PER_SAMPLE)
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,dbc", [("SMALL", 16), ("P8192", 30), ("P8192", 60), ("SEAL23_4096", 30)])
+def test_per_sample_placement_vs_oracle_and_decrypt(fhe, oracle_mod, preset, dbc):
+    """SampleBicubic / SampleLinear / the shared-offset resize (+ a row shard) / a stand-alone Cubic and Linear with ONE relinearize of every
+    result (6 / 4 -> 2: keys for s^2 .. s^5; one pass of key switches at dbc 60, two at dbc 30, sequential steps on the general kernels):
+    library == oracle composition `reference sequence -> relinearize_n` (SampleRelinOracle) bit for bit; equal to the reference mode's result
+    relinearised by one call; decrypts to the closed form with the budget printed beside the other modes'."""
+    import torch
+    p = SMALL if preset == "SMALL" else oracle_mod.PRESETS[preset]
+    ctx, orc = fhe.SEALContext(p["n"], p["q"], p["t"]), oracle_mod.Oracle(p["n"], p["q"], p["t"])
+    sk, pk = orc.keygen(21)
+    evks = orc.evk_gen_powers(sk, dbc=dbc, count=4)
+    coeff = np.zeros_like(evks)
+    for idx in np.ndindex(evks.shape[:4]):
+        for i in range(ctx.k):
+            coeff[idx + (i,)] = orc.ntt_inv(evks[idx + (i,)], i)
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    relin = (ev.ntt_forward(fhe.to_device(coeff)).contiguous(), dbc, "sample")
+    sorc = oracle_mod.SampleRelinOracle(orc, evks, dbc)
+    W = H = 8
+    w = h_ = 4
+    vals = [float((29 * x + 53 * y) % 256) for y in range(H) for x in range(W)]
+    pix = np.stack([orc.encrypt(pk, orc.encode(v), seed=500 + i) for i, v in enumerate(vals)])
+    d_pix = fhe.to_device(pix)
+    taps, fx, fy = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=True)
+    xf = np.stack([orc.encrypt(pk, orc.encode(f), seed=600 + i) for i, f in enumerate(fx)])
+    yf = np.stack([orc.encrypt(pk, orc.encode(f), seed=700 + i) for i, f in enumerate(fy)])
+    dx, dy = fhe.to_device(xf), fhe.to_device(yf)
+    got = fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, dx, dy, relin=relin)
+    assert got.shape[-3] == 2
+    # the reference mode's size-6 pixels relinearised by ONE call are the same thing
+    ref6 = fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, dx, dy)
+    assert ref6.shape[-3] == 6 and torch.equal(got, ev.relinearize(ref6, relin[0], dbc))
+    out = fhe.to_host(got)
+    for o in ((0, 5, 15) if preset == "SMALL" else (5,)):
+        assert np.array_equal(out[o], oracle_mod.oracle_sample_bicubic_calls(sorc, [pix[i] for i in taps[o]], xf[o], yf[o])), o
+    if preset == "P8192":
+        def plain_cubic(A, B, C, D, t):
+            a, b, c = -A + 3 * B - 3 * C + D, 2 * A - 5 * B + 4 * C - D, C - A
+            return 0.5 * (a * t * t + b * t * t + c * t) + B
+        budgets, ref_b = [], []
+        for o in range(w * h_):
+            v = [vals[i] for i in taps[o]]
+            cols = [plain_cubic(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3], fx[o]) for r in range(4)]
+            plain, budget = orc.decrypt(sk, out[o])
+            assert budget > 0 and abs(orc.decode(plain) - plain_cubic(cols[0], cols[1], cols[2], cols[3], fy[o])) < 1e-6
+            budgets.append(budget)
+            ref_b.append(orc.decrypt(sk, fhe.to_host(ref6[o:o + 1])[0])[1])
+        print("\n[relin %s dbc=%d] SampleBicubic noise budget left (min over 16 pixels): per-sample placement %d bits, reference mode %d bits" % (preset, dbc, min(budgets), min(ref_b)))
+    xs, ys = fhe.to_device(xf[:w].copy()), fhe.to_device(yf[::w].copy())
+    shared = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix, W, H, w, h_, xs, ys, batch=8, band_rows=2, relin=relin)
+    per_px = fhe.circuits.sample_bicubic(ev, pc, d_pix, taps, xs.repeat(h_, 1, 1, 1).contiguous(), ys.repeat_interleave(w, dim=0).contiguous(), relin=relin)
+    assert shared.shape[-3] == 2 and torch.equal(shared, per_px)
+    first, cnt = fhe.circuits.resize_source_rows(H, h_, 1, 3)
+    part = fhe.circuits.resize_bicubic_shared(ev, pc, d_pix[first * W:(first + cnt) * W].contiguous(), W, H, w, h_, xs, ys[1:3].contiguous(), batch=8, band_rows=2,
+                                              rows=(1, 3), src_rows=(first, cnt), relin=relin)
+    assert torch.equal(part, shared[w:3 * w])
+    tl, lx, ly = fhe.circuits.resize_sample_plan(W, H, w, h_, bicubic=False)
+    xl = np.stack([orc.encrypt(pk, orc.encode(f), seed=800 + i) for i, f in enumerate(lx)])
+    yl = np.stack([orc.encrypt(pk, orc.encode(f), seed=850 + i) for i, f in enumerate(ly)])
+    lin = fhe.to_host(fhe.circuits.sample_linear(ev, pc, d_pix, tl, fhe.to_device(xl), fhe.to_device(yl), relin=relin))
+    assert lin.shape[1] == 2
+    for o in (0, 9):
+        assert np.array_equal(lin[o], oracle_mod.oracle_sample_linear_calls(sorc, [pix[i] for i in tl[o]], xl[o], yl[o])), o
+    # stand-alone Cubic (operands of 2 and of 4 polynomials) and Linear: the reference's result, relinearised
+    A, B, C, D = (ctx.random_ct(3, size=2, seed=400 + i) for i in range(4))
+    t = ctx.random_ct(3, size=2, seed=410)
+    c2 = fhe.circuits.cubic(ev, pc, A, B, C, D, t, relin=relin)
+    r4 = fhe.circuits.cubic(ev, pc, A, B, C, D, t)
+    assert c2.shape[-3] == 2 and torch.equal(c2, ev.relinearize(r4, relin[0], dbc)) and torch.equal(c2, fhe.circuits.cubic_evaluator_calls(ev, pc, A, B, C, D, t, relin))
+    c6 = fhe.circuits.cubic(ev, pc, r4, r4, r4, r4, t, relin=relin)
+    assert c6.shape[-3] == 2 and torch.equal(c6, ev.relinearize(fhe.circuits.cubic(ev, pc, r4, r4, r4, r4, t), relin[0], dbc))
+    h = fhe.to_host
+    assert np.array_equal(h(c2)[1], sorc.sample_tail(oracle_mod.oracle_cubic_calls(orc, h(A)[1], h(B)[1], h(C)[1], h(D)[1], h(t)[1])))
+    l2 = fhe.circuits.linear(ev, pc, A, B, t, relin=relin)
+    assert l2.shape[-3] == 2 and np.array_equal(h(l2)[2], sorc.sample_tail(oracle_mod.oracle_linear_calls(orc, h(A)[2], h(B)[2], h(t)[2])))
+    with pytest.raises(fhe._lib.FheError):
+        fhe.circuits.homomorphic_sin(ev, pc, ctx.random_ct(1, size=2, seed=3), ctx.random_ct(1, size=2, seed=4), relin=relin)

@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
                                    (8192, {"FHE_SEAL23_MODULI": "1", "FHE_FACADE_RELIN": "30"}), (4096, {"FHE_FACADE_RELIN": "16"}),
                                    # the per-Cubic placement: the reference's unchanged Cubic / Linear + ONE facade relinearize (size 4 / 3 -> 2, keys for
                                    # s^2 and s^3) against seal::hip::Circuits(context, keys, 100, 100, per_cubic = true): samplers and shared resize too
-                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "30"}), (4096, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "60"})])
+                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "30"}), (4096, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_CUBIC": "60"}),
+                                   # the per-sample placement: the reference's UNCHANGED SampleBicubic / SampleLinear / Cubic / Linear (sizes up to 6) + ONE facade
+                                   # relinearize of each result (keys for s^2 .. s^5) against seal::hip::Circuits(context, keys, 100, 100, FHE_RELIN_PER_SAMPLE)
+                                   (8192, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_SAMPLE": "60"}), (8192, {"FHE_SEAL23_MODULI": "1", "FHE_XCHECK_PER_SAMPLE": "30"})])
 def test_reference_functions_equal_batched_cpp_api(n, env):
     exe = ref_bin("ref_vs_batched", True)
     if not exe:

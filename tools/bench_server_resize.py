@@ -24,13 +24,14 @@ ap.add_argument("--encrypt", choices=["bank", "host", "device"], default="bank",
                 help="the circuit's server-side encryptions (two per output pixel): bank = pre-made ciphertexts (the circuit alone, rounds 2-4), "
                      "host = keys.Encryptor one at a time (numpy sampler), device = keys.DeviceEncryptor batches (fhe_encrypt_batch)")
 ap.add_argument("--relin", type=int, default=0, metavar="DBC", help="the relinearised mode of the circuits (records of 2 polynomials instead of 6 / 4): decomposition bit count")
-ap.add_argument("--relin-placement", choices=["product", "cubic"], default="product", help="after every product, or once per Cubic / Linear (include/fhe_circuits.h)")
+ap.add_argument("--relin-placement", choices=["product", "cubic", "sample"], default="product", help="after every product, or once per Cubic / Linear (include/fhe_circuits.h)")
 a = ap.parse_args()
 ctx = fhe.SEALContext.preset(a.preset)
 relin = None
 if a.relin:
     kg = fhe.KeyGenerator(ctx, seed=1)
-    relin = (kg.generate_evaluation_keys(a.relin, 2).contiguous(), a.relin, "cubic") if a.relin_placement == "cubic" else (kg.generate_evaluation_keys(a.relin).contiguous(), a.relin)
+    relin = ((kg.generate_evaluation_keys(a.relin, 2).contiguous(), a.relin, "cubic") if a.relin_placement == "cubic" else
+             (kg.generate_evaluation_keys(a.relin, 4).contiguous(), a.relin, "sample") if a.relin_placement == "sample" else (kg.generate_evaluation_keys(a.relin).contiguous(), a.relin))
 fin, fout = os.path.join(a.dir, "fhe_rs_in.ct"), os.path.join(a.dir, "fhe_rs_out.ct")
 out_size = 2 if relin else (4 if a.bilinear else 6)
 rec_in = fhe.server.RECORD_HEADER + 2 * ctx.k * ctx.n * 8
@@ -87,7 +88,7 @@ finally:
         if os.path.exists(p):
             os.remove(p)
 print(json.dumps({"workload": "server_resize stream %dx%d -> %dx%d %s, three channels, %s, files in %s" % (a.src, a.src, a.dst, a.dst, "bilinear" if a.bilinear else "bicubic", a.preset, a.dir),
-                  "mode": ("relinearised %s, dbc %d: records of 2 polynomials" % ("once per Cubic / Linear" if a.relin_placement == "cubic" else "after every product", a.relin)) if relin else "reference (no relinearisation)",
+                  "mode": ("relinearised %s, dbc %d: records of 2 polynomials" % ({"cubic": "once per Cubic / Linear", "sample": "once per output pixel"}.get(a.relin_placement, "after every product"), a.relin)) if relin else "reference (no relinearisation)",
                   "output_pixels": done, "rows_per_step": a.rows, "server_side_encryptions": a.encrypt, "offsets": "shared (one per output column / row)" if a.shared else "per output pixel (the reference's)", "seconds": dt, "pixels_per_s": done / dt,
                   "stream_GB_in": stats["bytes_in"] / 1e9, "stream_GB_out": stats["bytes_out"] / 1e9, "stream_GB_per_s_in_plus_out": (stats["bytes_in"] + stats["bytes_out"]) / dt / 1e9,
                   "device_compute_seconds": stats["device_compute_seconds"], "device_compute_share": stats["device_compute_seconds"] / dt,
