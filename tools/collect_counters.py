@@ -50,6 +50,7 @@ WORKLOADS = {
     "decode_relin30": ([PY, os.path.join(ROOT, "bench_circuits.py"), "decode", "--relin", "30"], ["k_"]),
     "resize_relin30": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--relin", "30", "--max-pixels", "512"], ["k_"]),
     "resize_relin30_cubic": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--relin", "30", "--relin-placement", "cubic", "--max-pixels", "512"], ["k_"]),
+    "resize_relin60_sample": ([PY, os.path.join(ROOT, "bench_circuits.py"), "resize", "--relin", "60", "--relin-placement", "sample", "--max-pixels", "512"], ["k_"]),
     "encrypt": ([PY, os.path.join(ROOT, "tools", "bench_encrypt.py"), "P8192", "512"], ["k_enc_fused", "k_frac_encode", "k_dec_"]),
     "seal23": ([PY, os.path.join(ROOT, "bench.py"), "--preset", "SEAL23_4096", "--steps", "2", "--warmup", "1", "--blocks", "256", "--cpu-blocks", "0", "--no-verify"],
                ["k_dct_rows_u64", "k_dct_cols_u64"]),

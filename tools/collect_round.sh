@@ -30,6 +30,8 @@ python bench_circuits.py decode --cpu-terms 2 > $O/bench_circuits_decode.json 2>
 for dbc in 30 60; do
   python bench_circuits.py resize --relin $dbc --relin-placement cubic --cpu-pixels 2 > $O/bench_circuits_resize_relin${dbc}_cubic.json 2> /dev/null
   python bench_circuits.py resize --shared --relin $dbc --relin-placement cubic > $O/bench_circuits_resize_shared_relin${dbc}_cubic.json 2> /dev/null
+  python bench_circuits.py resize --relin $dbc --relin-placement sample --cpu-pixels 2 > $O/bench_circuits_resize_relin${dbc}_sample.json 2> /dev/null
+  python bench_circuits.py resize --shared --relin $dbc --relin-placement sample > $O/bench_circuits_resize_shared_relin${dbc}_sample.json 2> /dev/null
   python bench_circuits.py resize --relin $dbc > $O/bench_circuits_resize_relin$dbc.json 2> /dev/null
   python bench_circuits.py resize --shared --relin $dbc > $O/bench_circuits_resize_shared_relin$dbc.json 2> /dev/null
   python bench_circuits.py decode --relin $dbc > $O/bench_circuits_decode_relin$dbc.json 2> /dev/null
@@ -44,6 +46,9 @@ python tools/bench_encrypt.py P8192 512 2>/dev/null | tail -1 > $O/bench_encrypt
 python tools/bench_encrypt.py P4096 512 2>/dev/null | tail -1 >> $O/bench_encrypt.txt
 python tools/bench_encrypt.py P8192 8192 2>/dev/null | tail -1 >> $O/bench_encrypt.txt
 for m in bank device host; do python tools/bench_server_resize.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_resize_encryptions.txt; done
+# the streaming server end to end in every mode (records of 6 polynomials against 2)
+for sh in "" "--shared"; do for mode in "" "--relin 30" "--relin 30 --relin-placement cubic" "--relin 60 --relin-placement cubic" "--relin 30 --relin-placement sample" "--relin 60 --relin-placement sample"; do
+  python tools/bench_server_resize.py --encrypt device $sh $mode 2>/dev/null | tail -1 >> $O/bench_server_resize_modes.txt; done; done
 for m in device host; do python tools/bench_server_decode.py --encrypt $m 2>/dev/null | tail -1 >> $O/bench_server_decode_encryptions.txt; done
 fully-homomorphic-image-processing_amd/seal/multi_gpu_dct 1024 4 64 1 > $O/cpp_multi_gpu_dct.json 2>&1
 fully-homomorphic-image-processing_amd/seal/multi_gpu_dct 1024 1 256 0 resident 20 > $O/cpp_multi_gpu_dct_resident.json 2>&1
