@@ -568,3 +568,41 @@ def test_per_sample_placement_vs_oracle_and_decrypt(fhe, oracle_mod, preset, dbc
     assert l2.shape[-3] == 2 and np.array_equal(h(l2)[2], sorc.sample_tail(oracle_mod.oracle_linear_calls(orc, h(A)[2], h(B)[2], h(t)[2])))
     with pytest.raises(fhe._lib.FheError):
         fhe.circuits.homomorphic_sin(ev, pc, ctx.random_ct(1, size=2, seed=3), ctx.random_ct(1, size=2, seed=4), relin=relin)
+
+
+def test_relinearize_n_argument_errors_and_empty_batches(fhe, oracle_mod):
+    """fhe_relinearize_n / fhe_relinearize_poly / fhe_circuits_create_relin_at: sizes below 3 and above FHE_MAX_POLYS, null pointers, strides
+    smaller than the ciphertext, a decomposition bit count out of range, an unknown placement and partially overlapping ranges return
+    FHE_ERR_PARAM with a message; an empty batch is a no-op; nothing is launched on a refusal (the output keeps its bytes)."""
+    import ctypes as C
+    import torch
+    ctx = fhe.SEALContext.preset("SEAL23_4096")
+    L, kn = fhe._lib.load(), ctx.k * ctx.n
+    kg = fhe.KeyGenerator(ctx, seed=3)
+    evk = kg.generate_evaluation_keys(30, 2).contiguous()
+    ct = ctx.random_ct(2, size=4, seed=1)
+    out = torch.full((2, 2, ctx.k, ctx.n), 7, dtype=torch.int64, device=ct.device)
+    nbytes = L.fhe_relinearize_n_scratch_bytes(ctx.h, 4, 30, 2)
+    assert nbytes > L.fhe_relinearize_scratch_bytes(ctx.h, 30, 2) > 0 and L.fhe_relinearize_n_scratch_bytes(ctx.h, 2, 30, 2) == 0
+    scr = torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=ct.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    args = lambda size=4, stride=4 * kn, o=out, ostride=2 * kn, count=2, dbc=30, e=evk: (ctx.h, p(ct), size, stride, p(o) if o is not None else None, ostride, count, p(e) if e is not None else None, dbc, p(scr), nbytes, None)
+    assert L.fhe_relinearize_n(*args(size=2)) == -1 and b"polynomials" in L.fhe_last_error()
+    assert L.fhe_relinearize_n(*args(size=65)) == -1
+    assert L.fhe_relinearize_n(*args(dbc=61)) == -1 and L.fhe_relinearize_n(*args(dbc=0)) == -1
+    assert L.fhe_relinearize_n(*args(o=None)) == -1 and L.fhe_relinearize_n(*args(e=None)) == -1
+    assert L.fhe_relinearize_n(*args(stride=3 * kn)) == -1 and b"stride" in L.fhe_last_error()
+    assert L.fhe_relinearize_n(*args(ostride=kn)) == -1
+    inside = C.c_void_p(ct.data_ptr() + 8 * kn)                       # output inside the input range with another stride
+    assert L.fhe_relinearize_n(ctx.h, p(ct), 4, 4 * kn, inside, 2 * kn, 2, p(evk), 30, p(scr), nbytes, None) == -1 and b"overlaps" in L.fhe_last_error()
+    assert L.fhe_relinearize_poly(ctx.h, p(ct), 4 * kn, 1, p(out), 2 * kn, 2, p(evk), 30, p(scr), nbytes, None) == -1           # source polynomial below 2
+    assert L.fhe_relinearize_poly(ctx.h, p(ct), 4 * kn, 4, p(out), 2 * kn, 2, p(evk), 30, p(scr), nbytes, None) == -1           # ... beyond the ciphertext
+    torch.cuda.synchronize()
+    assert bool((out == 7).all())                                        # no refusal launched anything
+    assert L.fhe_relinearize_n(*args(count=0)) == 0 and bool((out == 7).all())
+    h = C.c_void_p()
+    assert L.fhe_circuits_create_relin_at(ctx.h, 100, 100, p(evk), 30, 3, C.byref(h)) == -1 and b"placement" in L.fhe_last_error()
+    assert L.fhe_circuits_create_relin_at(ctx.h, 100, 100, None, 30, 1, C.byref(h)) == -1
+    # and the good call: the same bits as the Evaluator wrapper
+    assert L.fhe_relinearize_n(*args()) == 0
+    assert torch.equal(out, fhe.Evaluator(ctx).relinearize(ctx.random_ct(2, size=4, seed=1), evk, 30))
