@@ -985,6 +985,47 @@ class EvaluationKeys {
 public:
     int decomposition_bit_count() const { return (int)dbc; }
     int size() const { return (int)count; }
+    // SEAL 2.3 EvaluationKeys::save / load (what a client that honoured the reference's parsed-and-unused `--dbc`, homo/client_resize.cpp:26,47,72,
+    // would send along with its public key).  Self-consistent record like the other streams: magic "FHEHIPK\0", u32 dbc, digits, count, k, n,
+    // reserved, then count * k * digits * 2 * k * n words (NTT form, the library's slot order); every field bounded and every residue checked.
+    void save(std::ostream &os) const {
+        const uint64_t *dev = device_keys();
+        const size_t words = (size_t)count * k * digits * 2 * k * n;
+        const char magic[8] = {'F', 'H', 'E', 'H', 'I', 'P', 'K', 0};
+        const uint32_t hdr[6] = {dbc, digits, count, k, n, 0};
+        os.write(magic, 8);
+        os.write((const char *)hdr, sizeof hdr);
+        std::vector<uint64_t> h(words);
+        if (words) {
+            detail::check(fhe_download(h.data(), dev, words * 8, nullptr), "download");
+            detail::check(fhe_stream_sync(nullptr), "sync");
+        }
+        os.write((const char *)h.data(), (std::streamsize)(words * 8));
+    }
+    void load(std::istream &is) {
+        char magic[8];
+        uint32_t hdr[6];
+        is.read(magic, 8);
+        is.read((char *)hdr, sizeof hdr);
+        if (!is || std::memcmp(magic, "FHEHIPK", 8) != 0) throw std::invalid_argument("stream does not hold evaluation keys");
+        if (hdr[0] < 1 || hdr[0] > 60 || hdr[1] < 1 || hdr[1] > 61 || hdr[2] < 1 || hdr[2] > FHE_MAX_POLYS - 2 || hdr[3] < 1 || hdr[3] > FHE_MAX_K ||
+            hdr[4] < 1024 || hdr[4] > 16384 || (hdr[4] & (hdr[4] - 1)))
+            throw std::invalid_argument("evaluation key header out of range");
+        const detail::KnownModuli *km = nullptr;
+        const std::vector<detail::KnownModuli> known = detail::known_moduli();
+        for (const auto &m : known) if (m.k == hdr[3] && m.n == hdr[4]) km = &m;
+        if (!km) throw std::invalid_argument("evaluation keys do not match any context of this process");
+        const size_t words = (size_t)hdr[2] * hdr[3] * hdr[1] * 2 * hdr[3] * hdr[4];
+        std::vector<uint64_t> h(words);
+        is.read((char *)h.data(), (std::streamsize)(words * 8));
+        if (!is) throw std::invalid_argument("truncated evaluation key stream");
+        for (size_t i = 0; i < words; ++i)
+            if (h[i] >= km->q[(i / hdr[4]) % hdr[3]]) throw std::invalid_argument("evaluation key residue not reduced");
+        *this = EvaluationKeys();
+        dbc = hdr[0]; digits = hdr[1]; count = hdr[2]; k = hdr[3]; n = hdr[4];
+        buf.resize(words);
+        buf.upload(h.data(), words);
+    }
     inline std::vector<std::vector<Ciphertext>> &mutable_data();
     inline const std::vector<std::vector<Ciphertext>> &data() const { return const_cast<EvaluationKeys *>(this)->expand(); }
     inline const uint64_t *device_keys() const;       // facade internal: `buf`, reassembled from the key objects when they were handed out

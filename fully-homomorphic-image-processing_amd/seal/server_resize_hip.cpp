@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <deque>
 #include <fstream>
 #include <mutex>
@@ -68,7 +69,7 @@ struct Step { uint32_t y0, y1; uint32_t lo, hi; uint32_t first, cnt; };      // 
 
 int main(int argc, char **argv) {
     if (argc < 9) {
-        std::fprintf(stderr, "usage: %s in.ct out.ct pubkey src_w src_h dst_w dst_h bicubic [rows_per_step=4] [io_threads=16] [n=8192] [plain_modulus=16384] [key hex | -] [passes=1]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s in.ct out.ct pubkey src_w src_h dst_w dst_h bicubic [rows_per_step=4] [io_threads=16] [n=8192] [plain_modulus=16384] [key hex | -] [passes=1] [shared=0] [evaluation keys | -] [relin placement 0|1|2]\n", argv[0]);
         return 2;
     }
     const char *in_path = argv[1], *out_path = argv[2], *pk_path = argv[3];
@@ -80,6 +81,10 @@ int main(int argc, char **argv) {
     const uint64_t t = argc > 12 ? std::strtoull(argv[12], nullptr, 10) : 16384;
     const int passes = argc > 14 ? std::atoi(argv[14]) : 1;
     const bool shared = argc > 15 && std::atoi(argv[15]) != 0;
+    // the relinearised modes (include/fhe_circuits.h): an evaluation-key file (seal::EvaluationKeys::save: what a client that honoured the reference's
+    // parsed-and-unused --dbc would send) and where to relinearise: 0 after every product, 1 once per Cubic / Linear (keys s^2, s^3), 2 once per pixel (s^2 .. s^5)
+    const char *evk_path = argc > 16 && std::strcmp(argv[16], "-") != 0 ? argv[16] : nullptr;
+    const int placement = argc > 17 ? std::atoi(argv[17]) : 0;
     uint8_t key[32];
     const bool have_key = argc > 13 && std::strlen(argv[13]) == 64;
     for (int i = 0; have_key && i < 32; ++i) { unsigned v = 0; std::sscanf(argv[13] + 2 * i, "%2x", &v); key[i] = (uint8_t)v; }
@@ -104,7 +109,14 @@ int main(int argc, char **argv) {
             if (!kf) throw Fail{"cannot open the public key file"};
             pk.load(kf);
         }
-        hip::Circuits circ(context, 100, 100);
+        EvaluationKeys evk;
+        if (evk_path) {
+            std::ifstream ef(evk_path, std::ios::binary);
+            if (!ef) throw Fail{"cannot open the evaluation key file"};
+            evk.load(ef);
+        }
+        std::unique_ptr<hip::Circuits> circ_p(evk_path ? new hip::Circuits(context, evk, 100, 100, placement) : new hip::Circuits(context, 100, 100));
+        hip::Circuits &circ = *circ_p;
         hip::DeviceEncryptor enc(context, pk, 100, 100, have_key ? key : nullptr, 0);
         const uint32_t so = circ.out_size(bicubic ? FHE_CIRC_SAMPLE_BICUBIC : FHE_CIRC_SAMPLE_LINEAR);
         const size_t ct_in = (size_t)2 * k * n, ct_out = (size_t)so * k * n;

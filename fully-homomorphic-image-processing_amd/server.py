@@ -32,6 +32,17 @@ def write_ciphertext(f, ct):
     f.write(np.ascontiguousarray(ct, dtype="<u8").tobytes())
 
 
+def write_evaluation_keys(f, evk_ntt, dbc):
+    """evk_ntt: KeyGenerator.generate_evaluation_keys(dbc[, count]) ([k][digits][2][k][n] or [count][k][digits][2][k][n], device or host) -> the record
+    seal::EvaluationKeys::load reads (seal/seal.h: magic "FHEHIPK", u32 dbc, digits, count, k, n, reserved, then the words, NTT form)"""
+    import struct
+    t = evk_ntt if evk_ntt.dim() == 6 else evk_ntt[None]
+    count, k, digits, two, k2, n = t.shape
+    assert two == 2 and k2 == k
+    f.write(b"FHEHIPK\0" + struct.pack("<6I", int(dbc), digits, count, k, n, 0))
+    f.write(np.ascontiguousarray(t.cpu().numpy().view(np.uint64), dtype="<u8").tobytes())
+
+
 def read_ciphertext_into(f, out):
     """Read one record into out (numpy uint64 [size, k, n], e.g. a view of a pinned buffer)."""
     hdr = f.read(HEADER.size)

@@ -444,6 +444,43 @@ def test_cpp_server_resize_writes_the_python_servers_bytes(fhe, tmp_path, bicubi
         assert a == b
 
 
+@pytest.mark.parametrize("placement,shared,bicubic", [("product", False, True), ("cubic", False, True), ("sample", False, True), ("cubic", True, True), ("sample", False, False)])
+def test_cpp_server_resize_in_the_relinearised_modes_writes_the_python_servers_bytes(fhe, tmp_path, placement, shared, bicubic):
+    """The C++ host with an evaluation-key FILE (seal::EvaluationKeys::load; written here by server.write_evaluation_keys -- what a client that
+    honoured the reference's parsed-and-unused --dbc would send, homo/client_resize.cpp:26,47,72) and a relinearisation placement (after every
+    product / once per Cubic / once per output pixel) against server.server_resize(relin=(keys, dbc[, placement])) with the same sampler key:
+    records of two polynomials, the same stream byte for byte."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fully-homomorphic-image-processing_amd", "seal", "server_resize_hip")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    ctx = fhe.SEALContext.preset("SEAL23_4096")
+    kg = fhe.KeyGenerator(ctx, seed=12)
+    enc = fhe.FractionalEncoder(ctx)
+    W, H, w, h, dbc = 7, 9, 5, 6, 30
+    rgb = np.random.default_rng(7).integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    fin, f_py, f_cpp, f_pk, f_evk = (str(tmp_path / x) for x in ("in.ct", "py.ct", "cpp.ct", "pubkey.txt", "evk.txt"))
+    assert fhe.client.send_resize(ctx, fhe.DeviceEncryptor(ctx, kg.public_key()), enc, rgb, fin) == (W, H)
+    with open(f_pk, "wb") as f:
+        fhe.server.write_ciphertext(f, fhe.to_host(kg.public_key()))
+    count = {"product": 1, "cubic": 2, "sample": 4}[placement]
+    keys = kg.generate_evaluation_keys(dbc, count).contiguous()
+    with open(f_evk, "wb") as f:
+        fhe.server.write_evaluation_keys(f, keys, dbc)
+    relin = (keys, dbc) if placement == "product" else (keys, dbc, placement)
+    fractions = fhe.server.make_fraction_encryptor(ctx, kg.public_key(), enc, seed=5, device=True)
+    assert fhe.server.server_resize(ctx, fin, f_py, W, H, w, h, bicubic, fractions, rows_per_step=2, shared_offsets=shared, relin=relin) == w * h
+    rec = fhe.server.RECORD_HEADER + 2 * ctx.k * ctx.n * 8
+    assert os.path.getsize(f_py) == w * h * 3 * rec                    # two polynomials per record
+    argv = [exe, fin, f_cpp, f_pk, str(W), str(H), str(w), str(h), "1" if bicubic else "0", "2", "4", str(ctx.n), str(ctx.t), fhe.server._sampler_key(5).hex(), "1",
+            "1" if shared else "0", f_evk, str({"product": 0, "cubic": 1, "sample": 2}[placement])]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=dict(os.environ, FHE_SEAL23_MODULI="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert open(f_cpp, "rb").read() == open(f_py, "rb").read()
+    # a truncated key file is refused before anything is computed
+    open(f_evk, "r+b").truncate(os.path.getsize(f_evk) - 8)
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=dict(os.environ, FHE_SEAL23_MODULI="1"))
+    assert r.returncode != 0 and "truncated evaluation key stream" in r.stderr
+
+
 def test_server_resize_with_shared_offsets(fhe, tmp_path):
     """server_resize(shared_offsets=True): one offset ciphertext per output column and row instead of two per output pixel.  Not the
     reference's ciphertexts -- but the bytes equal the shared-offset circuit called on the whole image with the same encryptions, two row
