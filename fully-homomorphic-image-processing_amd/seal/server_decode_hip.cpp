@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <fstream>
 
 #include <unistd.h>
@@ -31,7 +32,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char **argv) {
     if (argc < 9) {
-        std::fprintf(stderr, "usage: %s in.ct out.ct pubkey width height pairsR pairsG pairsB [order=64] [degree=12] [delta=0.5] [n=8192] [plain_modulus=16384] [key hex]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s in.ct out.ct pubkey width height pairsR pairsG pairsB [order=64] [degree=12] [delta=0.5] [n=8192] [plain_modulus=16384] [key hex | -] [evaluation keys]\n", argv[0]);
         return 2;
     }
     const char *in_path = argv[1], *out_path = argv[2], *pk_path = argv[3];
@@ -61,7 +62,17 @@ int main(int argc, char **argv) {
             if (!kf) throw std::invalid_argument("cannot open the public key file");
             pk.load(kf);
         }
-        hip::Circuits circ(context, 100, 100);                                   // FractionalEncoder(t, poly, 100, 100, 2): homo/server_decode.cpp
+        // argv[15]: an evaluation-key file (seal::EvaluationKeys::save) -> the RELINEARISED mode (relinearize after every product: records of two
+        // polynomials instead of 22; the decode circuits take that placement only, include/fhe_circuits.h)
+        EvaluationKeys evk;
+        const char *evk_path = argc > 15 && std::strcmp(argv[15], "-") != 0 ? argv[15] : nullptr;
+        if (evk_path) {
+            std::ifstream ef(evk_path, std::ios::binary);
+            if (!ef) throw std::invalid_argument("cannot open the evaluation key file");
+            evk.load(ef);
+        }
+        std::unique_ptr<hip::Circuits> circ_p(evk_path ? new hip::Circuits(context, evk, 100, 100) : new hip::Circuits(context, 100, 100));   // FractionalEncoder(t, poly, 100, 100, 2): homo/server_decode.cpp
+        hip::Circuits &circ = *circ_p;
         hip::DeviceEncryptor enc(context, pk, 100, 100, have_key ? key : nullptr, 0);
         std::ifstream in(in_path, std::ios::binary);
         if (!in) throw std::invalid_argument("cannot open the input stream");

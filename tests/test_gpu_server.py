@@ -393,6 +393,15 @@ def test_cpp_server_decode_writes_the_python_servers_bytes(fhe, tmp_path):
     r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert open(f_cpp, "rb").read() == open(f_py, "rb").read()
+    # the relinearised mode from an evaluation-key file: records of two polynomials, the Python server's bytes again
+    f_evk, f_py2, f_cpp2 = (str(tmp_path / x) for x in ("evk.txt", "py_relin.ct", "cpp_relin.ct"))
+    keys = kg.generate_evaluation_keys(16).contiguous()
+    with open(f_evk, "wb") as f:
+        fhe.server.write_evaluation_keys(f, keys, 16)
+    fhe.server.server_decode(ctx, fin, f_py2, w, h, pairs, fhe.server.make_zero_encryptor(ctx, kg.public_key(), seed=77, device=True), order=64, degree=degree, relin=(keys, 16))
+    r = subprocess.run([exe, fin, f_cpp2] + argv[3:] + [f_evk], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert open(f_cpp2, "rb").read() == open(f_py2, "rb").read() and os.path.getsize(f_cpp2) < os.path.getsize(f_cpp)
     # without a key argument: fresh randomness (at this small n the circuit's noise budget is gone, so the decrypted values are not compared)
     r = subprocess.run(argv[:-1], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and open(f_cpp, "rb").read() != open(f_py, "rb").read() and os.path.getsize(f_cpp) == os.path.getsize(f_py)
