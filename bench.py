@@ -560,7 +560,7 @@ def main():
                 res["roofline"]["frac_of"] = "hbm peak (the metric's roofline; the binding resource is VALU issue: issue_roofline.frac %.2f, %.2f at the nominal clock)" % (
                     ir["frac"], ir["frac_at_nominal_clock"])
             res["roofline"]["limiter"] = ("valu-issue at the package power limit (see issue_roofline; 1.37 kW and sclk 2.13-2.20 GHz measured under this pair, "
-                                          "profiles/r04_power_clocks_headline.txt); the HBM fraction is reported because BASELINE.json's metric asks for it")
+                                          "profiles/r04_power_clocks_headline.txt, again in round 6: profiles/r06_power_clocks_headline.txt); the HBM fraction is reported because BASELINE.json's metric asks for it")
         # SEAL's own CPU path "in the same run" (north_star): rank 0's host, every N; the other ranks wait at the barrier below
         if args.cpu_blocks > 0 and args.preset == "P4096":
             res["cpu_baseline"] = cpu_baseline(args.cpu_blocks)
