@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .evaluator import FractionalEncoder, PreparedPlain, _ptr, _stream
+from .evaluator import FractionalEncoder, PreparedPlain, _ptr, _stream, check_evaluation_keys
 
 
 class PlainCache:
@@ -81,7 +81,7 @@ class Circuits:
         else:
             self._evk, dbc = relin[0], relin[1]
             placement = relin_placement(relin)
-            assert self._evk.is_contiguous() and self._evk.dtype == torch.int64
+            check_evaluation_keys(ctx, self._evk, dbc, (1, 2, 4)[placement], "Circuits")
             if placement == 1:
                 assert self._evk.dim() == 6 and self._evk.shape[0] >= 2, "per-Cubic placement: keys for s^2 and s^3 (generate_evaluation_keys(dbc, 2))"
             if placement == 2:

@@ -213,6 +213,24 @@ class DctPlan:
             self.h = None
 
 
+def check_evaluation_keys(ctx, evk_ntt, dbc, need, who):
+    """The library takes the keys as a bare pointer and reads need * fhe_evk_words(ctx, dbc) words behind it (include/fhe_hip.h): the host
+    checks that the tensor it hands over holds them -- a key tensor made for another decomposition bit count (fewer digits), another context or
+    fewer powers must be an error here, not a read behind the allocation."""
+    if not 1 <= int(dbc) <= 60:
+        raise ValueError("%s: decomposition bit count %r (1 .. 60)" % (who, dbc))
+    if evk_ntt.dtype != torch.int64 or not evk_ntt.is_contiguous() or evk_ntt.device != ctx.device:
+        raise ValueError("%s: evaluation keys must be a contiguous int64 tensor on the context's device" % who)
+    words = int(_lib.load().fhe_evk_words(ctx.h, int(dbc)))
+    if evk_ntt.numel() < need * words:
+        raise ValueError("%s: %d key set(s) at dbc %d take %d words on this context, the tensor holds %d (keys generated with another "
+                         "decomposition bit count, for another context, or for fewer powers)" % (who, need, dbc, need * words, evk_ntt.numel()))
+    nd = int(_lib.load().fhe_evk_digits(ctx.h, int(dbc)))
+    if evk_ntt.dim() >= 5 and tuple(evk_ntt.shape[-5:]) != (ctx.k, nd, 2, ctx.k, ctx.n):
+        raise ValueError("%s: evaluation keys of shape %r, this context at dbc %d has [k = %d][digits = %d][2][k][n = %d]"
+                         % (who, tuple(evk_ntt.shape), dbc, ctx.k, nd, ctx.n))
+
+
 class Evaluator:
     """seal::Evaluator over batches.  In-place semantics of SEAL are expressed functionally:
     every method returns a new tensor unless `out=` is given (which may alias an input)."""
@@ -370,6 +388,7 @@ class Evaluator:
         have = evk_ntt.shape[0] if evk_ntt.dim() == 6 else 1
         if have < size - 2:
             raise ValueError("relinearize: a ciphertext of %d polynomials needs the keys for s^2 .. s^%d (got %d key set(s))" % (size, size - 1, have))
+        check_evaluation_keys(self.ctx, evk_ntt, dbc, size - 2, "relinearize")
         work = a.clone()                                   # the steps above the last one run in place
         count = work.numel() // (size * kn)
         out = torch.empty(tuple(a.shape[:-3]) + (2, self.ctx.k, self.ctx.n), dtype=a.dtype, device=a.device)

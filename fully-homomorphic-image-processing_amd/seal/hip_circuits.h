@@ -227,6 +227,7 @@ public:
         const bool per_cubic = placement == FHE_RELIN_PER_CUBIC;
         if (per_cubic && evk.count < 2) throw std::invalid_argument("per-Cubic relinearisation needs the keys for s^2 and s^3: generate_evaluation_keys(dbc, 2, keys)");
         if (placement == FHE_RELIN_PER_SAMPLE && evk.count < 4) throw std::invalid_argument("per-sample relinearisation needs the keys for s^2 .. s^5: generate_evaluation_keys(dbc, 4, keys)");
+        evk.require_for(*ctx.state(), placement == FHE_RELIN_PER_SAMPLE ? 4u : per_cubic ? 2u : 1u, "Circuits");        // the fields may come from a stream
         evk.device_keys();                                     // key objects handed out by mutable_data() are folded back first
         evk_ = evk.buf;
         detail::check(fhe_circuits_create_relin_at(ctx.state()->h, int_coeffs, frac_coeffs, evk_.ptr(), evk.dbc, (uint32_t)placement, &h_),

@@ -1016,15 +1016,41 @@ public:
         for (const auto &m : known) if (m.k == hdr[3] && m.n == hdr[4]) km = &m;
         if (!km) throw std::invalid_argument("evaluation keys do not match any context of this process");
         const size_t words = (size_t)hdr[2] * hdr[3] * hdr[1] * 2 * hdr[3] * hdr[4];
-        std::vector<uint64_t> h(words);
-        is.read((char *)h.data(), (std::streamsize)(words * 8));
-        if (!is) throw std::invalid_argument("truncated evaluation key stream");
-        for (size_t i = 0; i < words; ++i)
-            if (h[i] >= km->q[(i / hdr[4]) % hdr[3]]) throw std::invalid_argument("evaluation key residue not reduced");
+        // the header alone must not size an allocation (62 keys of 61 digits at k = 16, n = 16384 would be 250 GB): the payload is taken in
+        // pieces, so that memory follows the bytes the stream really holds
+        std::vector<uint64_t> h;
+        const size_t piece = (size_t)1 << 20;
+        while (h.size() < words) {
+            const size_t at = h.size(), take = std::min(piece, words - at);
+            h.resize(at + take);
+            is.read((char *)(h.data() + at), (std::streamsize)(take * 8));
+            if (!is) throw std::invalid_argument("truncated evaluation key stream");
+        }
+        bool fits = false;                         // several contexts may share (k, n): accept if one of them fits (load_host does the same)
+        for (const auto &m : known) {
+            if (m.k != hdr[3] || m.n != hdr[4] || fits) continue;
+            uint64_t bad = 0;
+            for (size_t p = 0; p < words / hdr[4]; ++p) {
+                const uint64_t q = m.q[p % hdr[3]], *v = h.data() + p * hdr[4];
+                for (uint32_t c = 0; c < hdr[4]; ++c) bad |= (uint64_t)(v[c] >= q);
+            }
+            fits = !bad;
+        }
+        if (!fits) throw std::invalid_argument("evaluation key residue not reduced");
         *this = EvaluationKeys();
         dbc = hdr[0]; digits = hdr[1]; count = hdr[2]; k = hdr[3]; n = hdr[4];
         buf.resize(words);
         buf.upload(h.data(), words);
+    }
+    // what every consumer checks before it hands `buf` to the library (the fields may come from a stream): the keys belong to this context's
+    // (k, n), hold the digit count the library derives from dbc for this context's moduli, and at least `need` powers -- the library reads
+    // need * fhe_evk_words(ctx, dbc) words from the pointer and cannot see the allocation behind it
+    void require_for(const detail::CtxState &s, uint32_t need, const char *who) const {
+        if (!count || k != s.k || n != s.n) throw std::invalid_argument(std::string(who) + ": the evaluation keys are empty or belong to another context");
+        if (dbc < 1 || dbc > 60 || digits != fhe_evk_digits(s.h, dbc))
+            throw std::invalid_argument(std::string(who) + ": the evaluation keys' digit count does not fit their decomposition bit count on this context");
+        if (count < need) throw std::invalid_argument(std::string(who) + ": needs " + std::to_string(need) + " evaluation keys (generate_evaluation_keys(dbc, count, keys)), these hold " + std::to_string(count));
+        if (buf.words() < (size_t)count * fhe_evk_words(s.h, dbc)) throw std::invalid_argument(std::string(who) + ": the evaluation keys are shorter than their header says");
     }
     inline std::vector<std::vector<Ciphertext>> &mutable_data();
     inline const std::vector<std::vector<Ciphertext>> &data() const { return const_cast<EvaluationKeys *>(this)->expand(); }
@@ -1438,9 +1464,7 @@ public:
     void relinearize(Ciphertext &a, const EvaluationKeys &evk) {
         need(a);
         if (a.size() < 3) return;
-        if ((int)evk.count < a.size() - 2)
-            throw std::invalid_argument("relinearize: a ciphertext of " + std::to_string(a.size()) + " polynomials needs " + std::to_string(a.size() - 2) +
-                                        " evaluation keys (generate_evaluation_keys(dbc, count, keys)), these hold " + std::to_string(evk.count));
+        evk.require_for(*st_, (uint32_t)a.size() - 2, "relinearize");
         const uint32_t sz = (uint32_t)a.size();
         const size_t bytes = fhe_relinearize_n_scratch_bytes(st_->h, sz, evk.dbc, 1);
         detail::DevBuf scratch_((bytes + 7) / 8);                              // per call: an Evaluator may be shared by threads

@@ -43,6 +43,34 @@ def write_evaluation_keys(f, evk_ntt, dbc):
     f.write(np.ascontiguousarray(t.cpu().numpy().view(np.uint64), dtype="<u8").tobytes())
 
 
+def read_evaluation_keys(ctx, f):
+    """One record of write_evaluation_keys / seal::EvaluationKeys::save -> (evk_ntt [count][k][digits][2][k][n] on the context's device, dbc),
+    what Evaluator.relinearize and Circuits(relin=...) take.  The stream is untrusted: the header must name THIS context's (k, n) and the digit count
+    its moduli give at the stated dbc (so the payload size is fixed by the context and the number of powers, not by the stream), the payload must be
+    complete and every residue reduced -- the checks of seal::EvaluationKeys::load plus the consumer's (seal/seal.h require_for)."""
+    import struct
+    hdr = f.read(32)
+    if len(hdr) != 32 or hdr[:8] != b"FHEHIPK\0":
+        raise ValueError("stream does not hold evaluation keys")
+    dbc, digits, count, k, n, _ = struct.unpack("<6I", hdr[8:])
+    if not (1 <= dbc <= 60 and 1 <= count <= 62):
+        raise ValueError("evaluation key header out of range")
+    if (k, n) != (ctx.k, ctx.n):
+        raise ValueError("evaluation keys for (k, n) = %r, the context has %r" % ((k, n), (ctx.k, ctx.n)))
+    want = max((int(q).bit_length() + dbc - 1) // dbc for q in ctx.q)
+    if digits != want:
+        raise ValueError("evaluation keys with %d digit(s) at dbc %d: this context's moduli take %d" % (digits, dbc, want))
+    words = count * k * digits * 2 * k * n
+    body = f.read(words * 8)
+    if len(body) != words * 8:
+        raise EOFError("truncated evaluation key stream")
+    evk = np.frombuffer(body, dtype="<u8").reshape(count, k, digits, 2, k, n)
+    for i, q in enumerate(ctx.q):
+        if int(evk[:, :, :, :, i, :].max()) >= int(q):
+            raise ValueError("evaluation key residue not reduced")
+    return torch.from_numpy(evk.view(np.int64).copy()).to(ctx.device), dbc
+
+
 def read_ciphertext_into(f, out):
     """Read one record into out (numpy uint64 [size, k, n], e.g. a view of a pinned buffer)."""
     hdr = f.read(HEADER.size)

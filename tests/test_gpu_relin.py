@@ -606,3 +606,49 @@ def test_relinearize_n_argument_errors_and_empty_batches(fhe, oracle_mod):
     # and the good call: the same bits as the Evaluator wrapper
     assert L.fhe_relinearize_n(*args()) == 0
     assert torch.equal(out, fhe.Evaluator(ctx).relinearize(ctx.random_ct(2, size=4, seed=1), evk, 30))
+
+
+def test_host_checks_evaluation_keys_before_the_library_reads_behind_them(fhe, tmp_path):
+    """The C ABI takes evaluation keys as a bare pointer (include/fhe_hip.h): Evaluator.relinearize, Circuits(relin=...) and server.read_evaluation_keys
+    refuse keys made for another decomposition bit count (fewer digits than the call will read), another context, too few powers, or a stream that is
+    short / unreduced / foreign; write_evaluation_keys -> read_evaluation_keys returns the tensor and the bit count it was given."""
+    import io
+    import struct
+    import torch
+    ctx = fhe.SEALContext.preset("SEAL23_4096")
+    other = fhe.SEALContext.preset("SEAL23_2048")
+    ev, kg = fhe.Evaluator(ctx), fhe.KeyGenerator(ctx, seed=3)
+    keys60 = kg.generate_evaluation_keys(60, 2).contiguous()           # one digit per prime
+    keys30 = kg.generate_evaluation_keys(30, 2).contiguous()           # two
+    ct = ctx.random_ct(2, size=4, seed=1)
+    with pytest.raises(ValueError, match="another decomposition bit count"):
+        ev.relinearize(ct, keys60, 30)                                 # the call at dbc 30 reads twice what keys60 holds
+    with pytest.raises(ValueError, match="shape"):
+        ev.relinearize(ct, keys30, 60)                                 # enough words, but not this context's layout at dbc 60
+    with pytest.raises(ValueError, match="needs the keys"):
+        ev.relinearize(ctx.random_ct(1, size=5, seed=2), keys30, 30)
+    with pytest.raises(ValueError, match="1 .. 60"):
+        ev.relinearize(ct, keys30, 61)
+    with pytest.raises(ValueError, match="contiguous int64"):
+        ev.relinearize(ct, keys30.cpu(), 30)
+    with pytest.raises(ValueError, match="another decomposition bit count"):
+        fhe.circuits.Circuits(ctx, relin=(keys60, 30, "cubic"))
+    with pytest.raises(ValueError, match="Circuits"):
+        fhe.circuits.Circuits(ctx, relin=(keys30[:1].contiguous().view(-1), 30, "cubic"))      # one power where the placement takes two
+    good = ev.relinearize(ct, keys30, 30)
+    # the key file of the C++ hosts, read back
+    f = io.BytesIO()
+    fhe.server.write_evaluation_keys(f, keys30, 30)
+    raw = f.getvalue()
+    back, dbc = fhe.server.read_evaluation_keys(ctx, io.BytesIO(raw))
+    assert dbc == 30 and torch.equal(back, keys30) and back.device == keys30.device
+    assert torch.equal(ev.relinearize(ct, back, dbc), good)
+    hdr = lambda **kw: raw[:8] + struct.pack("<6I", *[kw.get(name, v) for name, v in zip(("dbc", "digits", "count", "k", "n", "r"), struct.unpack("<6I", raw[8:32]))])
+    for bad, exc, what in ((raw[:-8], EOFError, "truncated"), (b"FHEHIP1\0" + raw[8:], ValueError, "does not hold"), (raw[:20], ValueError, "does not hold"),
+                           (hdr(dbc=60) + raw[32:], ValueError, "digit"), (hdr(digits=1) + raw[32:], ValueError, "digit"), (hdr(count=0) + raw[32:], ValueError, "out of range"),
+                           (hdr(count=63) + raw[32:], ValueError, "out of range"), (hdr(count=3) + raw[32:], EOFError, "truncated"), (hdr(n=8192) + raw[32:], ValueError, "context has"),
+                           (raw[:32] + b"\xff" * 8 + raw[40:], ValueError, "not reduced")):
+        with pytest.raises(exc, match=what):
+            fhe.server.read_evaluation_keys(ctx, io.BytesIO(bad))
+    with pytest.raises(ValueError, match="context has"):
+        fhe.server.read_evaluation_keys(other, io.BytesIO(raw))

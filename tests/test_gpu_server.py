@@ -488,6 +488,14 @@ def test_cpp_server_resize_in_the_relinearised_modes_writes_the_python_servers_b
     open(f_evk, "r+b").truncate(os.path.getsize(f_evk) - 8)
     r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=dict(os.environ, FHE_SEAL23_MODULI="1"))
     assert r.returncode != 0 and "truncated evaluation key stream" in r.stderr
+    # a self-consistent key file whose digit count cannot belong to its decomposition bit count on this context (ONE digit of 30 bits for primes
+    # of 54 / 55 bits; the library would read two digits' worth behind the pointer): refused by the consumer, EvaluationKeys::require_for
+    import struct
+    one_digit = count * ctx.k * 1 * 2 * ctx.k * ctx.n
+    with open(f_evk, "wb") as f:
+        f.write(struct.pack("<8sIIIIII", b"FHEHIPK\0", dbc, 1, count, ctx.k, ctx.n, 0) + bytes(one_digit * 8))
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=dict(os.environ, FHE_SEAL23_MODULI="1"))
+    assert r.returncode != 0 and "digit count does not fit" in r.stderr, r.stderr[-1000:]
 
 
 def test_server_resize_with_shared_offsets(fhe, tmp_path):

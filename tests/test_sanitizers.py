@@ -103,6 +103,13 @@ def _record(polys, k, n, rng, magic=b"FHEHIP1\0", reduce=True):
     return struct.pack("<8sIIII", magic, polys, k, n, 0) + body.tobytes()
 
 
+def _evk_record(dbc, digits, count, k, n, rng, magic=b"FHEHIPK\0", reduce=True, words=None):
+    """seal::EvaluationKeys::save's record (seal/seal.h): magic, u32 dbc, digits, count, k, n, reserved, then count*k*digits*2*k*n words"""
+    w = count * k * digits * 2 * k * n if words is None else words
+    body = rng.integers(0, Q54 if reduce else 1 << 63, size=w, dtype=np.uint64)
+    return struct.pack("<8sIIIIII", magic, dbc, digits, count, k, n, 0) + body.tobytes()
+
+
 def _bundle(cases):
     out = [struct.pack("<I", len(cases))]
     for (polys, k, n, first, count, threads, data) in cases:
@@ -122,6 +129,7 @@ def test_stream_loaders_fuzz_under_asan(san_bins, tmp_path):
     good2 = _record(2, 1, 1024, rng) + _record(2, 1, 1024, rng) + _record(2, 1, 1024, rng)
     good1 = _record(1, 1, 1024, rng)
     rec2 = len(good2) // 3
+    goodk = _evk_record(16, 4, 1, 1, 1024, rng)               # one 54-bit prime at dbc 16: four digits
     bundles = []
 
     mutation = st.one_of(
@@ -130,7 +138,7 @@ def test_stream_loaders_fuzz_under_asan(san_bins, tmp_path):
         st.tuples(st.just("field"), st.integers(0, 4), st.integers(0, 2 ** 32 - 1)),
         st.tuples(st.just("splice"), st.integers(0, 10 ** 9), st.integers(0, 64)),
         st.tuples(st.just("none"), st.just(0), st.just(0)))
-    case = st.tuples(st.sampled_from([0, 1]), st.lists(mutation, min_size=0, max_size=3),
+    case = st.tuples(st.sampled_from([0, 1, 2]), st.lists(mutation, min_size=0, max_size=3),
                      st.integers(0, 5), st.integers(0, 3), st.sampled_from([0, 1, 512, 1024, 1000, 2048, 4096]),      # polys, k, n of the transfer
                      st.integers(0, 6), st.integers(0, 6), st.integers(0, 5))                                       # first record, count, threads
 
@@ -139,14 +147,14 @@ def test_stream_loaders_fuzz_under_asan(san_bins, tmp_path):
     def collect(cases):
         out = []
         for which, muts, polys, k, n, first, count, threads in cases:
-            data = bytearray(good1 if which else good2)
+            data = bytearray((good2, good1, goodk)[which])
             for kind, a, b in muts:
                 if kind == "flip" and data:
                     data[a % len(data)] ^= 1 << b
                 elif kind == "trunc":
                     data = data[:a % (len(data) + 1)]
                 elif kind == "field" and len(data) >= 24:
-                    struct.pack_into("<I", data, 8 + 4 * (a % 4), b)
+                    struct.pack_into("<I", data, 8 + 4 * (a % (6 if which == 2 else 4)), b)
                 elif kind == "splice" and data:
                     at = a % len(data)
                     data[at:at] = bytes(b)
@@ -157,7 +165,14 @@ def test_stream_loaders_fuzz_under_asan(san_bins, tmp_path):
     fixed = [(2, 1, 1024, 0, 3, 2, good2), (2, 1, 1024, 1, 2, 1, good2), (1, 1, 1024, 0, 1, 1, good1),
              (2, 1, 1024, 0, 3, 2, good2[:-8]), (2, 1, 1024, 0, 4, 1, good2), (2, 1, 1024, 0xFFFFFFFF, 2, 1, good2),
              (2, 1, 1024, 0, 3, 3, good2[:rec2] + _record(2, 1, 1024, rng, magic=b"NOTHIP1\0") + good2[2 * rec2:]),
-             (2, 1, 1024, 0, 1, 1, _record(2, 1, 1024, rng, reduce=False)), (2, 1, 1024, 0, 1, 1, b"")]
+             (2, 1, 1024, 0, 1, 1, _record(2, 1, 1024, rng, reduce=False)), (2, 1, 1024, 0, 1, 1, b""),
+             # evaluation-key streams (seal::EvaluationKeys::load + Evaluator::relinearize of a size-3 ciphertext with what loaded)
+             (0, 0, 0, 0, 0, 0, goodk), (0, 0, 0, 0, 0, 0, goodk[:-8]), (0, 0, 0, 0, 0, 0, _evk_record(16, 4, 1, 1, 1024, rng, reduce=False)),
+             (0, 0, 0, 0, 0, 0, _evk_record(16, 1, 1, 1, 1024, rng)),               # self-consistent, but ONE digit cannot hold 54 bits at dbc 16
+             (0, 0, 0, 0, 0, 0, _evk_record(60, 1, 1, 1, 2048, rng)),               # another degree than the Evaluator's context
+             (0, 0, 0, 0, 0, 0, _evk_record(1, 61, 62, 1, 1024, rng, words=4096)),  # a header worth 62 MB on 32 KB of payload
+             (0, 0, 0, 0, 0, 0, _evk_record(16, 4, 1, 16, 16384, rng, words=16)),   # (k, n) no context of the process has
+             (0, 0, 0, 0, 0, 0, _evk_record(0, 4, 1, 1, 1024, rng)), (0, 0, 0, 0, 0, 0, _evk_record(16, 4, 0, 1, 1024, rng, words=8))]
     total = 0
     for i, cases in enumerate([fixed] + bundles):
         bpath, scratch = str(tmp_path / ("bundle%d.bin" % i)), str(tmp_path / "scratch.bin")
@@ -168,13 +183,18 @@ def test_stream_loaders_fuzz_under_asan(san_bins, tmp_path):
         total += len(lines)
         if i == 0:
             v = [dict(kv.split("=") for kv in ln.split()[2:]) for ln in lines]
-            assert v[0] == {"load": "1", "pk": "1", "sk": "0", "transfer": "0", "read": "0"}      # three size-2 records: the first loads as a ciphertext or a public key
+            assert v[0] == {"load": "1", "pk": "1", "sk": "0", "evk": "0", "transfer": "0", "read": "0"}      # three size-2 records: the first loads as a ciphertext or a public key
             assert v[1]["transfer"] == "0" and v[1]["read"] == "0"
-            assert v[2] == {"load": "1", "pk": "0", "sk": "1", "transfer": "0", "read": "0"}
+            assert v[2] == {"load": "1", "pk": "0", "sk": "1", "evk": "0", "transfer": "0", "read": "0"}
             assert v[3]["transfer"] == "-1" and v[3]["read"] == "-1" and v[3]["load"] == "1"      # the LAST record is truncated: the first still loads
             assert v[4]["transfer"] == "-1" and v[4]["read"] == "-1"                              # more records than the stream holds
             assert v[5]["transfer"] == "-1" and v[5]["read"] == "-1"                              # a record number that would wrap the byte offset
             assert v[6]["transfer"] == "-1" and v[6]["read"] == "-1"                              # a foreign record in the middle
             assert v[7]["load"] == "0" and v[7]["transfer"] == "0"                                # unreduced residues: load() checks payloads, the raw transfer does not (fhe_count_unreduced does)
-            assert v[8] == {"load": "0", "pk": "0", "sk": "0", "transfer": "-1", "read": "-1"}
+            assert v[8] == {"load": "0", "pk": "0", "sk": "0", "evk": "0", "transfer": "-1", "read": "-1"}
+            assert [x["evk"] for x in v[:8]] == ["0"] * 8                                         # no ciphertext / key record passes for evaluation keys
+            assert v[9]["evk"] == "2" and v[9]["load"] == "0"                                     # loads AND relinearises
+            assert v[10]["evk"] == "0" and v[11]["evk"] == "0"                                    # truncated; unreduced residues
+            assert v[12]["evk"] == "1" and v[13]["evk"] == "1"                                    # load, but relinearize refuses them on this context
+            assert [x["evk"] for x in v[14:18]] == ["0"] * 4
     assert total >= 300
