@@ -72,6 +72,13 @@ class _Sampler:
         return np.stack([self.rng.integers(0, q, size=self.ctx.n, dtype=np.uint64) for q in self.ctx.q])
 
 
+def _check_key(ctx, key, polys, what):
+    """a key of another context (other degree / number of primes) would be read with THIS context's strides: refuse it here"""
+    if tuple(key.shape) != ((polys, ctx.k, ctx.n) if polys > 1 else (ctx.k, ctx.n)) or key.dtype != torch.int64 or key.device != ctx.device:
+        raise ValueError("%s: expected an int64 tensor of shape %r on %s, got %r (%s, %s) -- a key of another context?"
+                         % (what, (polys, ctx.k, ctx.n) if polys > 1 else (ctx.k, ctx.n), ctx.device, tuple(key.shape), key.dtype, key.device))
+
+
 def _ntt(ctx, a):
     out = torch.empty_like(a)
     polys = a.numel() // (ctx.k * ctx.n)
@@ -140,6 +147,7 @@ class KeyGenerator:
 class Encryptor:
     def __init__(self, ctx, public_key, seed=None):
         self.ctx = ctx
+        _check_key(ctx, public_key, 2, "Encryptor: public key")
         self._pk_ntt = _ntt(ctx, public_key.contiguous())
         self._smp = _Sampler(ctx, seed)
 
@@ -174,6 +182,7 @@ class DeviceEncryptor:
 
     def __init__(self, ctx, public_key, key=None, int_coeffs=None, frac_coeffs=None, reproducible=False):
         self.ctx = ctx
+        _check_key(ctx, public_key, 2, "DeviceEncryptor: public key")
         self._pk_ntt = _ntt(ctx, public_key.contiguous())
         if reproducible and key is None:
             raise ValueError("reproducible=True needs an explicit key (the OS generator's key is never reused)")
@@ -229,6 +238,7 @@ class DeviceEncryptor:
 class Decryptor:
     def __init__(self, ctx, secret_key):
         self.ctx = ctx
+        _check_key(ctx, secret_key, 1, "Decryptor: secret key")
         self._sk_ntt = _ntt(ctx, secret_key[None].contiguous())[0]
         self.Q = reduce(lambda a, b: a * b, ctx.q, 1)
         self._crt = [(self.Q // q) * pow(self.Q // q, -1, q) for q in ctx.q]

@@ -76,3 +76,15 @@ def test_relinearised_cubic_mode(fhe, oracle_mod):
     b_ref, b_rel = dec.invariant_noise_budget(ref[0]), dec.invariant_noise_budget(rel[0])
     print("\n[relin n=4096 Q3 dbc=30] Cubic noise budget left: reference mode %d bits, relinearised %d bits" % (b_ref, b_rel))
     assert b_rel > 0 and b_ref > 0
+
+
+def test_keys_of_another_context_are_refused(fhe):
+    """Encryptor / DeviceEncryptor / Decryptor read their key with the context's strides: a key of another degree or another number of
+    primes, a host tensor or a wrong polynomial count is an error at construction, not a read behind the allocation"""
+    ctx, other = fhe.SEALContext.preset("SEAL23_4096"), fhe.SEALContext.preset("SEAL23_2048")
+    kg, kg2 = fhe.KeyGenerator(ctx, seed=1), fhe.KeyGenerator(other, seed=1)
+    for make in (lambda: fhe.Encryptor(ctx, kg2.public_key()), lambda: fhe.DeviceEncryptor(ctx, kg2.public_key()), lambda: fhe.Decryptor(ctx, kg2.secret_key()),
+                 lambda: fhe.DeviceEncryptor(ctx, kg.secret_key()), lambda: fhe.Decryptor(ctx, kg.public_key()), lambda: fhe.DeviceEncryptor(ctx, kg.public_key().cpu())):
+        with pytest.raises(ValueError, match="another context"):
+            make()
+    fhe.DeviceEncryptor(ctx, kg.public_key()), fhe.Encryptor(ctx, kg.public_key()), fhe.Decryptor(ctx, kg.secret_key())
