@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver; before torch / HIP load
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -188,6 +190,90 @@ def ensure_world(gpus, script, argv):
     os.execvpe(sys.executable, cmd, env)
 
 
+_RCCL_PROBE_CHILD = r"""
+import datetime, os, sys
+if os.environ.get("FHE_BENCH_PROBE_FAIL") == "1":        # test hook: the fall-back path of open_process_group
+    sys.exit(3)
+import torch, torch.distributed as dist
+r, w, lr = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(lr)
+dist.init_process_group("nccl", rank=r, world_size=w, timeout=datetime.timedelta(seconds=float(sys.argv[1])), device_id=torch.device("cuda", lr))
+ok = 1
+t = torch.ones(1, dtype=torch.int64, device="cuda")
+dist.all_reduce(t)
+torch.cuda.synchronize()
+ok &= int(int(t.item()) == w)
+if w > 1:                                                # the point-to-point pattern of parallel.WaveGather, once around the ring
+    a = torch.full((1 << 20,), r, dtype=torch.int64, device="cuda")
+    b = torch.empty_like(a)
+    for x in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, (r + 1) % w), dist.P2POp(dist.irecv, b, (r - 1) % w)]):
+        x.wait()
+    torch.cuda.synchronize()
+    ok &= int(int(b[0].item()) == (r - 1) % w and int(b[-1].item()) == (r - 1) % w)
+f = torch.tensor([ok], dtype=torch.int64, device="cuda")
+dist.all_reduce(f, op=dist.ReduceOp.MIN)                 # every rank learns whether EVERY rank passed: the parents decide alike
+torch.cuda.synchronize()
+print("RCCL PROBE OK" if int(f.item()) == 1 else "RCCL PROBE MISMATCH", flush=True)
+os._exit(0)
+"""
+
+
+def rccl_probe(limit):
+    """No box this repository ever ran on had two devices: the first RCCL rendezvous between two GPUs happens on the driver's node.  So that a
+    fabric / IPC problem there cannot hang the measurement, every rank first runs RCCL's initialisation, an all-reduce, one send/recv around the
+    ring and a closing all-reduce of the verdicts in a CHILD process (its own store: MASTER_PORT + 29, rank 0's child hosts it), bounded by
+    `limit` seconds.  All children pass or none does (the closing all-reduce), so every rank takes the same branch in open_process_group."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)            # the children rendezvous among themselves, not on the launcher's store
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    base = int(env.get("MASTER_PORT", "29500"))
+    env["MASTER_PORT"] = str(base + 29 if base + 29 < 65536 else base - 29)
+    t0 = time.perf_counter()
+    child = subprocess.Popen([sys.executable, "-c", _RCCL_PROBE_CHILD, str(limit)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    detail = None
+    try:
+        out, err = child.communicate(timeout=limit + 30)
+    except subprocess.TimeoutExpired:
+        child.kill()                                         # the process this function started, by its own handle
+        out, err = child.communicate()
+        detail = "no completion within %.0f s" % (limit + 30)
+    ok = "RCCL PROBE OK" in (out or "")
+    if not ok and detail is None:
+        lines = [ln for ln in ((out or "") + "\n" + (err or "")).splitlines() if ln.strip()]
+        detail = ("exit code %s: %s" % (child.returncode, lines[-1] if lines else "no output"))[:300]
+    return {"ok": ok, "seconds": time.perf_counter() - t0, "detail": detail}
+
+
+def open_process_group(world, local_rank, requested):
+    """-> (torch.distributed, backend in use, probe record or None).  requested == "nccl" with more than one rank: RCCL after rccl_probe passed
+    on every rank; otherwise the SAME job continues with gloo for its control plane (barrier, max over ranks, digests, per-rank times on host
+    tensors; parallel.WaveGather stages through pinned host memory) -- every rank still computes on its own GPU, the compute-only `value` has no
+    data-path collective either way, and the line says which backend ran.  FHE_BENCH_RCCL_PROBE=0 skips the probe."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend, probe = requested, None
+    probing = world > 1 or os.environ.get("FHE_BENCH_PROBE_FORCE") == "1"          # the second: tests on a one-GPU box
+    if requested == "nccl" and probing and os.environ.get("FHE_BENCH_RCCL_PROBE", "1") != "0":
+        probe = rccl_probe(float(os.environ.get("FHE_BENCH_RCCL_PROBE_TIMEOUT", "180")))
+        if not probe["ok"]:
+            backend = "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist, backend, probe
+
+
+def backend_label(backend, requested, shared_devices):
+    if backend == "nccl":
+        return "rccl"
+    if requested == "nccl":
+        return "gloo (FALL-BACK: the RCCL probe between this job's devices failed; control plane on host tensors, every rank computes on its own GPU)"
+    return backend + (" (test mode: ranks share devices)" if shared_devices else " (requested with FHE_BENCH_BACKEND)")
+
+
 def cpu_baseline(n_blocks_sample):
     """The CPU oracle (op-at-a-time port of the SEAL path) timed on this host, 1 thread."""
     from oracle import oracle as om
@@ -301,17 +387,13 @@ def main():
         shared_devices = world > torch.cuda.device_count()
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    requested_backend, rccl_probe_record = backend, None
     dist = None
     # FHE_BENCH_FORCE_DIST=1: a process group even for ONE rank -- the RCCL initialisation, barrier, all-reduce and all-gather of the
     # multi-GPU path execute (trivially) on a one-GPU box; tests/test_gpu_multi.py uses it so that the collective code has run on RCCL
     if world > 1 or os.environ.get("FHE_BENCH_FORCE_DIST") == "1":
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist, backend, rccl_probe_record = open_process_group(world, local_rank, backend)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     ctx = fhe.SEALContext.preset(args.preset, device=local_rank)
     ev = fhe.Evaluator(ctx)
@@ -514,7 +596,7 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if path == 1 else "u64", "data": "synthetic",
-            "rccl_ranks": rccl_ranks, "collective_backend": ("rccl" if backend == "nccl" else backend + " (test mode: ranks share devices)") if dist is not None else None,
+            "rccl_ranks": rccl_ranks, "collective_backend": backend_label(backend, requested_backend, shared_devices) if dist is not None else None, "rccl_probe": rccl_probe_record,
             "ms_per_step_per_rank": rank_ms,
             "config": {"workload": "homomorphic 8x8 DCT+quant, %d ciphertext blocks per GPU, n=%d, %d coeff moduli, t=2^14" % (B, ctx.n, ctx.k),
                        "blocks_per_gpu": B, "poly_modulus_degree": ctx.n, "coeff_moduli": [hex(x) for x in ctx.q],
@@ -619,7 +701,7 @@ def main():
                            "~%.1f k blocks/s of %.0f MiB outputs while it computes ~%.0f k), overlapped with the next wave's compute; rank 0 drains every wave by digest.  "
                            "The ceiling of this consumer is the links into ONE root, not a defect of the overlap" % (
                                wave, XGMI_LINK_GBS, link_blocks / 1e3, out_bytes_per_block / 2 ** 20, (res["value"] / world / 1e3) if res else 0.0) +
-                           ("; TEST MODE (gloo, shared device): the transfer is a host copy" if backend != "nccl" else "")}
+                           ("; NOT RCCL (%s): the transfer is staged through pinned host memory" % backend_label(backend, requested_backend, shared_devices) if backend != "nccl" else "")}
 
         def local_done(sec):
             per_gpu = B * out_bytes_per_block / sec / 1e9

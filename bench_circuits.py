@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver; before torch / HIP load
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
@@ -47,13 +49,14 @@ def _dist_setup(args):
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        # RCCL after a bounded probe in a child process, else the same job on gloo (bench.open_process_group); the line's `collective_backend` says which
+        from bench import backend_label, open_process_group
+        dist, used, probe = open_process_group(world, local, backend)
+        _DIST_INFO.update(collective_backend=backend_label(used, backend, backend == "gloo" and world > torch.cuda.device_count()), rccl_probe=probe)
     return rank, world, local, dist
+
+
+_DIST_INFO = {}                         # what _dist_setup found out; _strong_scaling adds it to the N > 1 lines
 
 
 def _timed(fn, dist, reps=1):
@@ -308,6 +311,7 @@ def resize(args):
                "output_digest": "%016x" % digest}
         if n1_seconds is not None:
             res["strong_scaling"] = _strong_scaling(n1_seconds, wall, world, "all %d destination rows" % h)
+        res.update(_DIST_INFO)
         if world == 1 and not args.max_pixels:
             _, fxs, fys = fhe.circuits.resize_sample_plan(W, H, w, h, bicubic=True)
             vals = ([fxs[x] for x in range(w)] + [fys[y * w] for y in range(h)]) if args.shared else [v for pair in zip(fxs, fys) for v in pair]
@@ -399,6 +403,7 @@ def decode(args):
                "output_digest": "%016x" % digest}
         if n1_seconds is not None:
             res["strong_scaling"] = _strong_scaling(n1_seconds, wall, world, "all %d output positions" % npos)
+        res.update(_DIST_INFO)
         if world == 1 and degree:
             res["server_side_encryptions"] = _server_side_encryptions(fhe, ctx, npos * degree * 2, None, wall, 1, "Enc(encode(0)) per (position, harmonic) for homomorphic_sin and homomorphic_cos")
         if args.cpu_terms:

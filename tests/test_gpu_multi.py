@@ -162,3 +162,32 @@ def test_one_rank_process_group_runs_the_collectives_on_rccl():
     one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert one["collective_backend"] == "rccl" and one["rccl_ranks"] == 1 and one["n_gpus"] == 1 and len(one["ms_per_step_per_rank"]) == 1
     assert one["output_digest"] == plain["output_digest"] and one["verified_bit_exact_vs_oracle"]
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_rccl_probe_and_its_gloo_fall_back_under_the_launcher(fail):
+    """bench.open_process_group: before the job's own RCCL initialisation every rank runs RCCL's rendezvous, an all-reduce, the send/recv ring and
+    a closing verdict all-reduce in a CHILD process on its own store (bench.rccl_probe) -- the first RCCL contact between two devices will happen
+    on the driver's node, and a fabric problem there must not hang the measurement.  On a one-GPU box the probe is forced (FHE_BENCH_PROBE_FORCE=1)
+    on a one-rank job under the real launcher (agent store in the environment): it passes and the job runs on RCCL; with the child made to fail
+    (FHE_BENCH_PROBE_FAIL=1) the SAME job continues on gloo, says so, and computes the same digest."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FHE_BENCH_FORCE_DIST="1", FHE_BENCH_PROBE_FORCE="1", FHE_BENCH_RCCL_PROBE_TIMEOUT="240")
+    env.pop("FHE_BENCH_BACKEND", None)
+    if fail:
+        env["FHE_BENCH_PROBE_FAIL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "128", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    probe = one["rccl_probe"]
+    assert probe["ok"] == (not fail) and probe["seconds"] < 240
+    if fail:
+        assert one["collective_backend"].startswith("gloo (FALL-BACK") and "exit code 3" in probe["detail"]
+    else:
+        assert one["collective_backend"] == "rccl" and probe["detail"] is None
+    assert one["rccl_ranks"] == 1 and one["verified_bit_exact_vs_oracle"] and one["value"] > 0
