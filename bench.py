@@ -256,7 +256,7 @@ def open_process_group(world, local_rank, requested):
     backend, probe = requested, None
     probing = world > 1 or os.environ.get("FHE_BENCH_PROBE_FORCE") == "1"          # the second: tests on a one-GPU box
     if requested == "nccl" and probing and os.environ.get("FHE_BENCH_RCCL_PROBE", "1") != "0":
-        probe = rccl_probe(float(os.environ.get("FHE_BENCH_RCCL_PROBE_TIMEOUT", "180")))
+        probe = rccl_probe(float(os.environ.get("FHE_BENCH_RCCL_PROBE_TIMEOUT", "120")))
         if not probe["ok"]:
             backend = "gloo"
     if backend == "nccl":
