@@ -34,3 +34,31 @@ def test_gpus_flag_is_checked_against_launcher_and_devices(script, extra):
     if have == 0:                           # without a device the one-rank run refuses too: there is no CPU path
         r = _run(script, extra + ["--gpus", "1"])
         assert r.returncode != 0 and "needs a HIP device" in r.stderr
+
+
+def test_rccl_probe_host_logic_without_a_device(monkeypatch):
+    """bench.rccl_probe / backend_label: the child program parses; a child that exits before touching a device is reported as a failed probe with
+    its exit code (the fall-back branch of open_process_group); a child that does not finish is killed by its own handle at the limit; the
+    children get their own store port and never the launcher's agent store"""
+    sys.path.insert(0, ROOT)
+    import bench
+    compile(bench._RCCL_PROBE_CHILD, "rccl_probe_child", "exec")
+    monkeypatch.setenv("FHE_BENCH_PROBE_FAIL", "1")
+    monkeypatch.setenv("MASTER_PORT", "65530")
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    rec = bench.rccl_probe(5.0)
+    assert rec["ok"] is False and "exit code 3" in rec["detail"] and rec["seconds"] < 30
+    seen = {}
+    real = subprocess.Popen
+
+    class Hung(real):                                       # a child that never finishes: sleeps instead of probing
+        def __init__(self, cmd, **kw):
+            seen["env"] = kw["env"]
+            super().__init__([sys.executable, "-c", "import time; time.sleep(600)"], **kw)
+    monkeypatch.setattr(subprocess, "Popen", Hung)
+    rec = bench.rccl_probe(-29.0)                           # limit + 30 = 1 s
+    assert rec["ok"] is False and "no completion" in rec["detail"] and rec["seconds"] < 20
+    assert seen["env"]["MASTER_PORT"] == "65501" and "TORCHELASTIC_USE_AGENT_STORE" not in seen["env"]      # 65530 + 29 would leave the port range
+    assert bench.backend_label("nccl", "nccl", False) == "rccl"
+    assert bench.backend_label("gloo", "nccl", False).startswith("gloo (FALL-BACK")
+    assert "test mode" in bench.backend_label("gloo", "gloo", True)
