@@ -718,6 +718,7 @@ def main():
                 dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
             return {"drained_bytes_equal_in_hbm_result_on_every_rank": bool(ok_all.item())}
 
+        barrier()                       # rank 0 comes from its CPU baseline: every rank arms a leg's watchdog at the same moment
         run_leg("local", step_local, local_done, local_check)
         run_leg("wave", step_wave, wave_done)
 
