@@ -252,7 +252,13 @@ class Evaluator:
 
     def _binary(self, name, a, b, out):
         sa, sb = a.shape[-3], b.shape[-3]
+        kn = self.ctx.k * self.ctx.n
+        if tuple(a.shape[-2:]) != (self.ctx.k, self.ctx.n) or tuple(b.shape[-2:]) != (self.ctx.k, self.ctx.n) or a.numel() // (sa * kn) != b.numel() // (sb * kn):
+            raise ValueError("%s: operands of shapes %r and %r are not the same number of ciphertexts of this context (the library reads both with the first one's count)"
+                             % (name, tuple(a.shape), tuple(b.shape)))
         if sa == sb:
+            if out is not None and (out.numel() != a.numel() or out.dtype != a.dtype or not out.is_contiguous()):
+                raise ValueError("%s: `out` must be a contiguous int64 tensor of %d words, got %r" % (name, a.numel(), tuple(out.shape)))
             out = torch.empty_like(a) if out is None else out
             _lib.call(name, self.ctx.h, _ptr(a), _ptr(b), _ptr(out), self._npolys(a), _stream())
             return out

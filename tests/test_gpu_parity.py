@@ -1157,3 +1157,24 @@ def test_add_sub_of_unequal_sizes_batched(fhe, oracle_mod, preset):
         assert np.array_equal(fhe.to_host(alias)[2], orc.add(fhe.to_host(big)[2], fhe.to_host(small)[2]))
     with pytest.raises(fhe._lib.FheError):
         L.call("fhe_add_sizes", ctx.h, C.c_void_p(a.data_ptr()), 0, C.c_void_p(b.data_ptr()), 2, C.c_void_p(a.data_ptr()), 1, 0, None)
+
+
+def test_add_sub_refuse_operands_of_different_counts(fhe):
+    """Evaluator.add / sub hand the library two pointers and ONE count: operands that are not the same number of ciphertexts of this context,
+    or an `out` of another size, are an error in the host -- not a read or write behind the shorter tensor"""
+    import torch
+    ctx = fhe.SEALContext.preset("SEAL23_2048")
+    ev = fhe.Evaluator(ctx)
+    a, b = ctx.random_ct(4, size=2, seed=1), ctx.random_ct(3, size=2, seed=2)
+    for op in (ev.add, ev.sub):
+        with pytest.raises(ValueError, match="same number of ciphertexts"):
+            op(a, b)
+        with pytest.raises(ValueError, match="same number of ciphertexts"):
+            op(a, ctx.random_ct(3, size=3, seed=2))
+        with pytest.raises(ValueError, match="same number of ciphertexts"):
+            op(a, a[..., : ctx.n // 2].contiguous())
+        with pytest.raises(ValueError, match="out"):
+            op(a, a, out=torch.empty_like(b))
+    one = ctx.random_ct(1, size=2, seed=3)
+    assert torch.equal(ev.add(one, one[0]), ev.add(one, one))              # [1, 2, k, n] with [2, k, n]: the same single ciphertext
+    assert ev.add(a, ctx.random_ct(4, size=3, seed=5)).shape[-3] == 3
