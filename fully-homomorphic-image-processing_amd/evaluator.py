@@ -440,6 +440,8 @@ class Evaluator:
     def dct8x8_quant(self, plan, blocks, out=None):
         """encrypted_dct + quantize_fhe on [n_blocks, 64, 2, k, n] (homo/fhe_image.h:196-305)."""
         assert blocks.shape[-4:] == (64, 2, self.ctx.k, self.ctx.n) and blocks.is_contiguous()
+        if out is not None and (out.shape != blocks.shape or out.dtype != blocks.dtype or not out.is_contiguous() or out.device != blocks.device):
+            raise ValueError("dct8x8_quant: `out` must be a contiguous tensor like `blocks` (%r), got %r" % (tuple(blocks.shape), tuple(out.shape)))
         out = torch.empty_like(blocks) if out is None else out
         n_blocks = blocks.numel() // (64 * 2 * self.ctx.k * self.ctx.n)
         nbytes = _lib.load().fhe_dct8x8_scratch_bytes(self.ctx.h, n_blocks)
@@ -449,6 +451,8 @@ class Evaluator:
 
     def rgb_to_ycc(self, r, g, b, int_coeffs=100, frac_coeffs=100):
         """rgb_to_ycc_fhe on [count, 2, k, n] tensors, in place (homo/fhe_image.h:310-325)."""
+        if not (r.shape == g.shape == b.shape and tuple(r.shape[-3:]) == (2, self.ctx.k, self.ctx.n) and r.is_contiguous() and g.is_contiguous() and b.is_contiguous()):
+            raise ValueError("rgb_to_ycc: three contiguous tensors of one shape [..., 2, k, n], got %r, %r, %r" % (tuple(r.shape), tuple(g.shape), tuple(b.shape)))
         count = r.numel() // (2 * self.ctx.k * self.ctx.n)
         _lib.call("fhe_rgb_to_ycc", self.ctx.h, _ptr(r), _ptr(g), _ptr(b), count, int_coeffs, frac_coeffs, _stream())
         return r, g, b

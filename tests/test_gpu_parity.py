@@ -1178,3 +1178,21 @@ def test_add_sub_refuse_operands_of_different_counts(fhe):
     one = ctx.random_ct(1, size=2, seed=3)
     assert torch.equal(ev.add(one, one[0]), ev.add(one, one))              # [1, 2, k, n] with [2, k, n]: the same single ciphertext
     assert ev.add(a, ctx.random_ct(4, size=3, seed=5)).shape[-3] == 3
+
+
+def test_fused_ops_refuse_mismatched_tensors(fhe):
+    """dct8x8_quant with an `out` of another shape, rgb_to_ycc with channels of different counts: refused by the host (one count goes to the library)"""
+    import torch
+    ctx = fhe.SEALContext.preset("SEAL23_2048")
+    ev = fhe.Evaluator(ctx)
+    blocks = ctx.random_ct(2, 64, seed=1)
+    plan = fhe.DctPlan(ctx, fhe.YQT)
+    with pytest.raises(ValueError, match="out"):
+        ev.dct8x8_quant(plan, blocks, out=torch.empty_like(blocks[:1]))
+    r, g, b = ctx.random_ct(4, seed=1), ctx.random_ct(4, seed=2), ctx.random_ct(3, seed=3)
+    with pytest.raises(ValueError, match="one shape"):
+        ev.rgb_to_ycc(r, g, b)
+    with pytest.raises(ValueError, match="one shape"):
+        ev.rgb_to_ycc(r, g, ctx.random_ct(4, size=3, seed=3))
+    ev.rgb_to_ycc(r, g, ctx.random_ct(4, seed=3))
+    assert ev.dct8x8_quant(plan, blocks, out=torch.empty_like(blocks)).shape == blocks.shape
