@@ -33,7 +33,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_EMPTY = {}
+
+
 def _ptr(t):
+    """device pointer of a tensor for the C ABI.  An EMPTY tensor has no storage (data_ptr() == 0) while the library refuses null pointers before it
+    looks at the count: an empty batch (a rank whose shard of a small image holds no block, a channel without runs) gets the address of a
+    one-word placeholder on the same device instead -- the call is then the no-op the C ABI defines for count == 0."""
+    if t.numel() == 0:
+        key = (t.device.type, t.device.index)
+        if key not in _EMPTY:
+            _EMPTY[key] = torch.zeros(2, dtype=torch.int64, device=t.device)
+        return C.c_void_p(_EMPTY[key].data_ptr())
     return C.c_void_p(t.data_ptr())
 
 

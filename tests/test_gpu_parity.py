@@ -1196,3 +1196,43 @@ def test_fused_ops_refuse_mismatched_tensors(fhe):
         ev.rgb_to_ycc(r, g, ctx.random_ct(4, size=3, seed=3))
     ev.rgb_to_ycc(r, g, ctx.random_ct(4, seed=3))
     assert ev.dct8x8_quant(plan, blocks, out=torch.empty_like(blocks)).shape == blocks.shape
+
+
+def test_empty_batches_through_the_python_host_are_no_ops(fhe):
+    """An empty torch tensor has no storage (data_ptr() == 0) and the C ABI refuses null pointers before it looks at the count: the host hands
+    the library a placeholder address for empty tensors (evaluator._ptr), so a rank whose shard of a small image is empty, a channel without runs or
+    a zero-pixel band goes through every entry point as the no-op the C ABI defines for count == 0 -- with outputs of the right (empty) shape."""
+    import torch
+    ctx = fhe.SEALContext.preset("SEAL23_4096")
+    ev, pc = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx)
+    kg = fhe.KeyGenerator(ctx, seed=1)
+    evk = kg.generate_evaluation_keys(30, 2).contiguous()
+    e2, e3, e4 = ctx.empty(0), ctx.empty(0, size=3), ctx.empty(0, size=4)
+    k, n = ctx.k, ctx.n
+    assert ev.add(e2, e2).shape == ev.sub(e2, e2).shape == ev.negate(e2).shape == (0, 2, k, n)
+    assert ev.multiply(e2, e2).shape == ev.square(e2).shape == (0, 3, k, n)
+    assert ev.multiply(e3, e2).shape == (0, 4, k, n)
+    assert ev.relinearize(e3, evk, 30).shape == ev.relinearize(e4, evk, 30).shape == (0, 2, k, n)
+    assert ev.multiply_plain(e2, pc.prepared(0.5)).shape == ev.add_plain(e2, pc.plain(3.0)).shape == (0, 2, k, n)
+    assert ev.rgb_to_ycc(ctx.empty(0), ctx.empty(0), ctx.empty(0))[0].shape == (0, 2, k, n)
+    assert ev.ntt_inverse(ev.ntt_forward(e2)).shape == (0, 2, k, n)
+    assert ev.dct8x8_quant(fhe.DctPlan(ctx, fhe.YQT), ctx.empty(0, 64)).shape == (0, 64, 2, k, n)
+    assert ctx.digest(e2.view(-1)) == 0
+    for relin in (None, (evk, 30), (evk, 30, "cubic")):
+        want = 2 if relin else 4
+        assert fhe.circuits.cubic(ev, pc, e2, e2, e2, e2, e2, relin=relin).shape == (0, want, k, n)
+        assert fhe.circuits.linear(ev, pc, e2, e2, e2, relin=relin).shape == (0, 2 if relin else 3, k, n)
+    pix = ctx.random_ct(16, seed=1)
+    taps, _, _ = fhe.circuits.resize_sample_plan(4, 4, 2, 2, bicubic=True)
+    assert fhe.circuits.sample_bicubic(ev, pc, pix, taps[:0], e2, e2).shape == (0, 6, k, n)
+    assert fhe.circuits.homomorphic_sin(ev, pc, e2, e2).shape == (0, 11, k, n)
+    der, dec = fhe.DeviceEncryptor(ctx, kg.public_key()), fhe.Decryptor(ctx, kg.secret_key())
+    assert der.encrypt_values(np.zeros(0)).shape == der.encrypt_zeros(0).shape == (0, 2, k, n)
+    assert dec.decrypt_batch(e2).shape == (0, n)
+    torch.cuda.synchronize()
+    assert fhe._lib.load().fhe_last_error() == b""
+    # and a shard loop in which one rank owns nothing: three blocks over a world of four
+    plan, blocks = fhe.DctPlan(ctx, fhe.YQT), ctx.random_ct(3, 64, seed=5)
+    whole = ev.dct8x8_quant(plan, blocks)
+    parts = [ev.dct8x8_quant(plan, blocks[s:e].contiguous()) for s, e in (fhe.parallel.block_range(r, 4, 3) for r in range(4))]
+    assert parts[3].shape[0] == 0 and torch.equal(torch.cat(parts), whole)
