@@ -1236,3 +1236,43 @@ def test_empty_batches_through_the_python_host_are_no_ops(fhe):
     whole = ev.dct8x8_quant(plan, blocks)
     parts = [ev.dct8x8_quant(plan, blocks[s:e].contiguous()) for s, e in (fhe.parallel.block_range(r, 4, 3) for r in range(4))]
     assert parts[3].shape[0] == 0 and torch.equal(torch.cat(parts), whole)
+
+
+def test_buffers_beyond_2_to_the_32_words(fhe, oracle_mod):
+    """Maximum sizes: 288 GB of HBM holds batches whose WORD offsets pass 2^32 (3,072 blocks of the headline configuration = 4.8e9 words, 39 GB in and
+    39 GB out).  The fused DCT pair on the whole batch equals the oracle on blocks either side of the 2^31 / 2^32 word boundaries and at the end, equals
+    itself evaluated in three 1,024-block pieces, the position-keyed digest of the whole equals the sum over the pieces, and add / NTT round trips over
+    the same 196,608 ciphertexts are exact at the far end -- a 32-bit index anywhere in a kernel would show here."""
+    import torch
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free HBM")
+    om = oracle_mod
+    ctx = fhe.SEALContext.preset("P4096")
+    ev, plan, orc = fhe.Evaluator(ctx), fhe.DctPlan(ctx, fhe.YQT), om.Oracle.preset("P4096")
+    B, wpb = 3072, 64 * 2 * ctx.k * ctx.n
+    assert B * wpb > 2 ** 32
+    blocks = ctx.random_ct(B, 64, seed=fhe.SEED)
+    out = ev.dct8x8_quant(plan, blocks)
+    for b in (1365, 2730, 2731, B - 1):                       # word offsets 2^31 - 5e5, 2^32 - 1e6, 2^32 + 5e5, 4.83e9
+        assert np.array_equal(fhe.to_host(out[b]), orc.dct_quant(fhe.to_host(blocks[b]), om.YQT)), b
+    piece = torch.empty_like(blocks[:1024])
+    parts = 0
+    for c in range(3):
+        ev.dct8x8_quant(plan, blocks[c * 1024:(c + 1) * 1024], out=piece)
+        assert torch.equal(piece, out[c * 1024:(c + 1) * 1024])
+        parts += ctx.digest(piece.view(-1), index0=c * 1024 * wpb)
+    assert ctx.digest(out.view(-1)) == parts % (1 << 64)
+    del piece
+    a, o = blocks.view(-1, 2, ctx.k, ctx.n), out.view(-1, 2, ctx.k, ctx.n)
+    last = a.shape[0] - 1
+    ev.add(a, a, out=o)
+    ha = fhe.to_host(a[last])
+    want = np.stack([[(ha[j, i].astype(object) * 2 % int(ctx.q[i])).astype(np.uint64) for i in range(ctx.k)] for j in range(2)])
+    assert np.array_equal(fhe.to_host(o[last]), want)
+    ev.ntt_forward(a, out=o)
+    ev.ntt_inverse(o, out=o)
+    assert torch.equal(o, a)
+    del blocks, out, a, o
+    torch.cuda.empty_cache()
