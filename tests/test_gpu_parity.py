@@ -1276,3 +1276,29 @@ def test_buffers_beyond_2_to_the_32_words(fhe, oracle_mod):
     assert torch.equal(o, a)
     del blocks, out, a, o
     torch.cuda.empty_cache()
+
+
+def test_ctct_scratch_beyond_2_to_the_32_words(fhe):
+    """The same for the BEHZ pipeline: 9,216 products at n = 8192 take 35 GB of scratch (4.7e9 words); multiply, square and a relinearize of the
+    products equal the same calls on 1,024-ciphertext pieces, bit for bit (the pieces' scratch stays far below 2^31 words)."""
+    import torch
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free HBM")
+    ctx = fhe.SEALContext.preset("P8192")
+    ev, L, N = fhe.Evaluator(ctx), fhe._lib.load(), 9216
+    assert L.fhe_multiply_scratch_bytes(ctx.h, 2, 2, N) // 8 > 2 ** 32
+    a, b = ctx.random_ct(N, seed=1), ctx.random_ct(N, seed=2)
+    whole, sq = ev.multiply(a, b), ev.square(a)
+    evk = fhe.KeyGenerator(ctx, seed=3).generate_evaluation_keys(30, 1).contiguous()
+    rel = ev.relinearize(whole, evk, 30)
+    small = fhe.Evaluator(ctx)                                 # its own (small) scratch buffer
+    for c in range(N // 1024):
+        s = slice(c * 1024, (c + 1) * 1024)
+        pa, pb = a[s].contiguous(), b[s].contiguous()
+        assert torch.equal(small.multiply(pa, pb), whole[s]) and torch.equal(small.square(pa), sq[s])
+        assert torch.equal(small.relinearize(whole[s].contiguous(), evk, 30), rel[s])
+    del whole, sq, rel, a, b
+    ev._scratch = None
+    torch.cuda.empty_cache()
