@@ -1302,3 +1302,25 @@ def test_ctct_scratch_beyond_2_to_the_32_words(fhe):
     del whole, sq, rel, a, b
     ev._scratch = None
     torch.cuda.empty_cache()
+
+
+def test_cubic_scratch_beyond_2_to_the_32_words(fhe):
+    """... and for the batched circuits: 4,096 Cubics at n = 8192 take 46 GB of scratch (6.2e9 words); equal to four 1,024-tuple pieces, bit for bit"""
+    import torch
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free HBM")
+    ctx = fhe.SEALContext.preset("P8192")
+    ev, pc, K, M = fhe.Evaluator(ctx), fhe.circuits.PlainCache(ctx), fhe.circuits, 4096
+    assert fhe._lib.load().fhe_cubic_scratch_bytes(K.circuits_of(pc).h, 2, M) // 8 > 2 ** 32
+    ops = [ctx.random_ct(M, seed=10 + i) for i in range(5)]
+    whole = K.cubic(ev, pc, *ops)
+    K.circuits_of(pc)._scratch = None
+    torch.cuda.empty_cache()
+    for c in range(M // 1024):
+        s = slice(c * 1024, (c + 1) * 1024)
+        assert torch.equal(K.cubic(ev, pc, *[o[s].contiguous() for o in ops]), whole[s])
+    K.circuits_of(pc)._scratch = None
+    del whole, ops
+    torch.cuda.empty_cache()
