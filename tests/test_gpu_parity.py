@@ -1324,3 +1324,29 @@ def test_cubic_scratch_beyond_2_to_the_32_words(fhe):
     K.circuits_of(pc)._scratch = None
     del whole, ops
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("preset,B,P,path", [("SEAL23_4096", 4224, 1056, 2), ("P8192", 1100, 275, 2), ("SEAL23_16384", 288, 96, 0)])
+def test_other_dct_paths_beyond_2_to_the_32_words(fhe, preset, B, P, path):
+    """the u64 fused pair (SEAL 2.3.1's 54 / 55-bit primes at n = 4096 and 8192) and the general three-launch path (n = 16384) on batches of more than
+    2^32 words: equal to the same call on quarter-size pieces, digests add up"""
+    import torch
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free HBM")
+    ctx = fhe.SEALContext.preset(preset)
+    ev, plan = fhe.Evaluator(ctx), fhe.DctPlan(ctx, fhe.YQT)
+    wpb = 64 * 2 * ctx.k * ctx.n
+    assert B * wpb > 2 ** 32 and fhe._lib.load().fhe_dct_path(ctx.h) == path
+    blocks = ctx.random_ct(B, 64, seed=fhe.SEED)
+    out = ev.dct8x8_quant(plan, blocks)
+    piece, parts = torch.empty_like(blocks[:P]), 0
+    for c in range(B // P):
+        ev.dct8x8_quant(plan, blocks[c * P:(c + 1) * P], out=piece)
+        assert torch.equal(piece, out[c * P:(c + 1) * P]), c
+        parts += ctx.digest(piece.view(-1), index0=c * P * wpb)
+    assert ctx.digest(out.view(-1)) == parts % (1 << 64)
+    del blocks, out, piece
+    ev._scratch = None
+    torch.cuda.empty_cache()
