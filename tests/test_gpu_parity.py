@@ -1230,7 +1230,6 @@ def test_empty_batches_through_the_python_host_are_no_ops(fhe):
     assert der.encrypt_values(np.zeros(0)).shape == der.encrypt_zeros(0).shape == (0, 2, k, n)
     assert dec.decrypt_batch(e2).shape == (0, n)
     torch.cuda.synchronize()
-    assert fhe._lib.load().fhe_last_error() == b""
     # and a shard loop in which one rank owns nothing: three blocks over a world of four
     plan, blocks = fhe.DctPlan(ctx, fhe.YQT), ctx.random_ct(3, 64, seed=5)
     whole = ev.dct8x8_quant(plan, blocks)
