@@ -149,20 +149,21 @@ def test_wave_gather_delivers_every_wave_in_order(n_waves, slots):
             assert np.array_equal(t, np.arange(12).reshape(4, 3) + 1000 * src + 100 * w + 7 * rep)
 
 
-@pytest.mark.parametrize("method", ["wave", "collective"])
-def test_gather_outputs_in_single_block_waves(method):
+@pytest.mark.parametrize("method,nb", [("wave", NB), ("collective", NB), ("wave", 1), ("collective", 1)])
+def test_gather_outputs_in_single_block_waves(method, nb):
     """ragged shards (3 + 2 blocks): moved one block per wave through WaveGather (both sides batched point-to-point, the
-    pass's receives posted by its first acquire), and through the dist.gather fallback with padding"""
+    pass's receives posted by its first acquire), and through the dist.gather fallback with padding; nb = 1: ONE block over two
+    ranks -- the second rank's shard is empty and still takes part in every transfer"""
     fhe, om, orc = _setup()
     make_inputs, compute, digest = _pipeline(fhe, om, orc)
-    ref = compute(make_inputs(0, NB))
+    ref = compute(make_inputs(0, nb))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q, method)) for r in range(2)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q, method, nb)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in range(2))
@@ -172,13 +173,13 @@ def test_gather_outputs_in_single_block_waves(method):
     assert res[1] is None and np.array_equal(res[0], ref.numpy())
 
 
-def _gather_worker(rank, world, port, q, method):
+def _gather_worker(rank, world, port, q, method, nb=NB):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fhe, om, orc = _setup()
     make_inputs, compute, _ = _pipeline(fhe, om, orc)
-    s, e = fhe.parallel.block_range(rank, world, NB)
-    g = fhe.parallel.gather_outputs(compute(make_inputs(s, e)), NB, wave_blocks=1, method=method)
+    s, e = fhe.parallel.block_range(rank, world, nb)
+    g = fhe.parallel.gather_outputs(compute(make_inputs(s, e)), nb, wave_blocks=1, method=method)
     q.put((rank, None if g is None else g.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
