@@ -35,10 +35,14 @@ public:
     size_t count() const { return count_; }
     uint32_t size() const { return size_; }
     size_t ct_words() const { return (size_t)size_ * k_ * n_; }
-    uint64_t *ptr() { return buf_.ptr(); }
-    const uint64_t *ptr() const { return buf_.ptr(); }
+    // an EMPTY batch has no allocation, and the C ABI refuses null pointers before it looks at the count: it gets the address of a two-word
+    // placeholder, so that count == 0 is the no-op include/fhe_hip.h defines (the Python host does the same, evaluator._ptr)
+    uint64_t *ptr() { return buf_.ptr() ? buf_.ptr() : placeholder(); }
+    const uint64_t *ptr() const { return buf_.ptr() ? buf_.ptr() : placeholder(); }
     uint64_t *at(size_t i) { return buf_.ptr() + i * ct_words(); }
     const uint64_t *at(size_t i) const { return buf_.ptr() + i * ct_words(); }
+
+    static uint64_t *placeholder() { static detail::DevBuf *p = new detail::DevBuf(2); return p->ptr(); }      // never freed: no destruction-order questions at exit
 
     // gather / scatter between one-allocation-per-ciphertext objects and the batch (device copies)
     static CiphertextBatch from(const SEALContext &ctx, const std::vector<Ciphertext> &v) {

@@ -108,6 +108,14 @@ int main(int argc, char **argv) {
         if (per_cubic || per_sample) evaluator.relinearize(res, evk2);
     };
 
+    {   // an EMPTY batch (a shard that owns nothing) is a no-op with an empty result of the circuit's output size, not a "null argument"
+        CiphertextBatch E(context, 0, 2);
+        CiphertextBatch c0 = circ.cubic(E, E, E, E, E), l0 = circ.linear(E, E, E);
+        if (c0.count() != 0 || l0.count() != 0 || c0.size() != circ.out_size(FHE_CIRC_CUBIC, 2) || l0.size() != circ.out_size(FHE_CIRC_LINEAR, 2)) {
+            std::printf("MISMATCH: empty batch\n");
+            return 1;
+        }
+    }
     // ---- Cubic at level 1 (size 2 -> 4) and level 2 (size 4 -> 6), Linear 2 -> 3 and 3 -> 4 ----------------------------
     // (relinearised mode: every operand has two polynomials, so only the first of each)
     for (uint32_t size : relin ? std::vector<uint32_t>{2u} : std::vector<uint32_t>{2u, 4u}) {
