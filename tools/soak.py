@@ -60,6 +60,21 @@ def relin_digests():
 
 
 ref_relin = relin_digests()
+# round 6: the other two placements (one relinearize per Cubic / per output pixel: fhe_relinearize_n's one-pass key switches for s^2 .. s^5, the
+# scatter of the tail results) and the shared-offset resize with its bands
+keys4 = fhe.KeyGenerator(ctx, seed=1).generate_evaluation_keys(30, 4).contiguous()
+sxf, syf = ctx.random_ct(w, seed=34), ctx.random_ct(h, seed=35)
+
+
+def placement_digests():
+    oc = fhe.circuits.sample_bicubic(ev, pc, pix, taps[:half], xf[:half].contiguous(), yf[:half].contiguous(), relin=(keys4[:2].contiguous(), 30, "cubic"))
+    os_ = fhe.circuits.sample_bicubic(ev, pc, pix, taps[half:], xf[half:].contiguous(), yf[half:].contiguous(), relin=(keys4, 30, "sample"))
+    sh = fhe.circuits.resize_bicubic_shared(ev, pc, pix, W, H, w, h, sxf, syf, batch=16, band_rows=2)
+    rl = ev.relinearize(ctx.random_ct(8, size=6, seed=36), keys4, 30)
+    return [ctx.digest(t.reshape(-1)) for t in (oc, os_, sh, rl)]
+
+
+ref_place = placement_digests()
 # the servers' own encryptions as device batches (csrc/encrypt.hip): the staging ring of the encoder's values, the scratch reuse, the
 # keyed sampler -- the same (key, index) range must give the same ciphertexts every time
 der = fhe.DeviceEncryptor(ctx, fhe.KeyGenerator(ctx, seed=2).public_key(), key=bytes(range(32)), reproducible=True)
@@ -114,6 +129,9 @@ for i in range(iters):
         if relin_digests() != ref_relin:
             bad += 1
             print("relinearised circuits digest mismatch at iteration", i, flush=True)
+    if i % 16 == 8 and placement_digests() != ref_place:
+        bad += 1
+        print("relinearisation placements / shared resize digest mismatch at iteration", i, flush=True)
     if i % 8 == 0 and enc_digest() != ref_enc:
         bad += 1
         print("device encryption digest mismatch at iteration", i, flush=True)
